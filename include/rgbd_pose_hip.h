@@ -1,0 +1,180 @@
+/* rgbd_pose_hip.h -- C ABI of librgbdpose_hip.so, the MI355X (gfx950) backend of the RGB-D absolute-pose
+ * hot path of ShudaLi/rgbd_pose_estimation.  Plain pointers and sizes only; no C++ / torch types.
+ *
+ * Part 1 is the reference's own FFI, byte for byte (reference Library.cpp:15-82 -> libabsolute.so).
+ * Part 2 is additive: a handle-based API over correspondence arrays that stay resident in HBM, one entry
+ * point per hot loop of the reference plus the Gauss-Newton formulation the north
+ * star asks for.  Every function returns 0 on success or a negative rpe_status; rpe_last_error() explains.
+ *
+ * Conventions (same as the reference): Xc = R_cw * Xw + t (pose/AbsoluteOrientation.hpp:51); 3 x N arrays
+ * are column-major = N packed xyz triples (Eigen Map<MatrixXf>(p,3,n), Library.cpp:20-22); rotation
+ * matrices cross this boundary ROW-major (Library.cpp:35-39); masks are short 0/1 (N x cols column-major,
+ * column 0 = 2D-3D, 1 = 3D-3D, 2 = normal-normal: pose/NormalAOPoseAdapter.hpp:179-195).
+ */
+#ifndef RGBD_POSE_HIP_H
+#define RGBD_POSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1 -- drop-in replacements for libabsolute.so
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces ao() (Library.cpp:17-45): closed-form 3D-3D absolute orientation over ALL n correspondences
+ * (AOOnlyPoseAdapter + shinji_ls2, pose/AbsoluteOrientation.hpp:322-342).  x_w_, x_c_: n xyz float triples
+ * (host).  R_cw_[9] row-major, t_[3].  The moment sums run on the GPU with fp64 accumulation; the 3x3 SVD
+ * on the host.  Prints "ao()" like the reference unless RPE_QUIET=1.  Aborts like the reference
+ * (SOPHUS_ENSURE) only if no HIP device is usable: then it prints the reason and calls abort(). */
+void ao(float* x_w_, float* x_c_, int n_, float* R_cw_, float* t_);
+
+/* Replaces ao_ransac() (Library.cpp:47-75): shinji_ransac2 (Iter=1000, thre_3d=0.1, confidence=0.99999,
+ * pose/AbsoluteOrientation.hpp:158-213) with the vote loop scored on the GPU in hypothesis batches, then
+ * shinji_ls1 over the inliers (:298-320).  Sampling uses the documented Rand31 stream (seed RPE_SEED, default 1)
+ * instead of the reference's unseeded rand(). */
+void ao_ransac(float* x_w_, float* x_c_, int n_, float* R_cw_, float* t_);
+
+/* Replaces py2c() (Library.cpp:77-81): prints N floats, one per line. */
+void py2c(float* array, int N);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2 -- additive handle-based API
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef enum {
+  RPE_OK = 0,
+  RPE_ERR_NO_DEVICE = -1,     /* no HIP device / HIP runtime error: the product has NO CPU fallback */
+  RPE_ERR_HIP = -2,
+  RPE_ERR_ARG = -3,
+  RPE_ERR_STATE = -4,         /* a required array was never uploaded / bound */
+  RPE_ERR_DEGENERATE = -5,    /* normal equations not positive definite, or NaN result */
+  RPE_ERR_ALIGN = -6          /* bound device pointer not 16-byte aligned */
+} rpe_status;
+
+typedef struct rpe_context rpe_context;
+
+int rpe_abi_version(void);
+const char* rpe_last_error(void);
+int rpe_device_count(void);            /* number of usable HIP devices (0 on a CPU-only host) */
+
+/* stream: a hipStream_t the caller owns (e.g. torch's current stream), or NULL for a private stream. */
+int rpe_create(rpe_context** out, int device, void* stream);
+void rpe_destroy(rpe_context* ctx);
+int rpe_synchronize(rpe_context* ctx);
+
+/* dtype of the correspondence arrays: Tp of the reference's templates */
+enum { RPE_F32 = 0, RPE_F64 = 1 };
+/* array slots.  Names follow the adapters' members. */
+enum {
+  RPE_XW = 0,   /* points_g       world points         PnPPoseAdapter.hpp:100        */
+  RPE_XC = 1,   /* points_c       camera points        AOPoseAdapter.hpp:95 (NaN column = invalid, :147-152) */
+  RPE_BV = 2,   /* bearingVectors unit bearings        PnPPoseAdapter.hpp:98         */
+  RPE_NW = 3,   /* normal_g       world normals        NormalAOPoseAdapter.hpp:95    */
+  RPE_NC = 4,   /* normal_c       camera normals       NormalAOPoseAdapter.hpp:94    */
+  RPE_NUM_ARRAYS = 5
+};
+/* per-modality inlier masks (short) and weights (Tp), index = mask column */
+enum { RPE_MOD_23 = 0, RPE_MOD_33 = 1, RPE_MOD_NN = 2 };
+
+/* Declare the correspondence count and dtype; (re)allocates nothing until an upload. */
+int rpe_set_problem(rpe_context* ctx, int64_t n, int dtype);
+/* Copy a host array (3 x n, dtype of the problem) into HBM.  Asynchronous on the context stream. */
+int rpe_upload(rpe_context* ctx, int slot, const void* host);
+/* Use a buffer that already lives in HBM (must be 16-byte aligned, 3*n elements); no copy, not owned. */
+int rpe_bind(rpe_context* ctx, int slot, const void* device_ptr);
+/* n shorts (0/1) / n weights for one modality; host pointers, NULL clears. */
+int rpe_upload_mask(rpe_context* ctx, int modality, const short* host_mask);
+int rpe_upload_weight(rpe_context* ctx, int modality, const void* host_weight);
+/* Copy the device mask written by rpe_inlier_mask back to the host (n shorts). */
+int rpe_download_mask(rpe_context* ctx, int modality, short* host_mask);
+
+/* ---- K1' closed-form moments: the two passes of shinji() (AbsoluteOrientation.hpp:56-73) fused into ONE
+ * pass.  out[17] = { sum w, sum w*Xw (3), sum w*Xc (3), sum w*Xc*Xw^T (9, row-major), sum w*|Xc|^2 }.
+ * flags: RPE_USE_MASK -> only mask33 == 1 (shinji_ls/shinji_ls1 inlier set, :279-288); RPE_USE_WEIGHT ->
+ * w = weight33 (nl_shinji_kneip_ls centroid pass, AbsoluteOrientationNormal.hpp:457-469);
+ * RPE_SKIP_INVALID -> skip NaN columns (isValid).  fp32 inputs are widened, all arithmetic is fp64. */
+enum { RPE_USE_MASK = 1, RPE_USE_WEIGHT = 2, RPE_SKIP_INVALID = 4 };
+int rpe_p2p_moments(rpe_context* ctx, int flags, double* out17);
+/* Closed-form pose from the moments (host: 3x3 SVD, det fix, t = Cc - R*Cw; AbsoluteOrientation.hpp:75-95). */
+int rpe_pose_from_moments(const double* m17, double* R9, double* t3);
+
+/* ---- K1/K2/K3 Gauss-Newton normal equations (new formulation; objective of K1 == shinji()).
+ * kind: residual.  pose12 = R row-major (9) | t (3).  out32: H upper triangle row-major (21) | g (6) |
+ * sum w r^2 | sum w | 3 pad.  Tangent order (upsilon, omega), update T <- exp(delta)*T (sophus/se3.hpp:314-342).
+ * The pose enters the kernel in fp64; p = R*Xw + t and the residual are formed in fp64 (the subtraction
+ * cancels ~3 digits), the products in the array dtype, the sums in fp64. */
+enum {
+  RPE_RES_P2P = 0,      /* r = R*Xw + t - Xc                         (3)  arrays XW, XC      24 B/corr fp32 */
+  RPE_RES_P2PLANE = 1,  /* r = Nc . (R*Xw + t - Xc)                  (1)  arrays XW, XC, NC  36 B/corr      */
+  RPE_RES_BEARING = 2   /* r = normalize(R*Xw + t) x bv  (P3P.hpp:482-485) (3)  arrays XW, BV  24 B/corr      */
+};
+int rpe_normal_eq(rpe_context* ctx, int kind, int flags, const double* pose12, double* out32);
+/* Same, result left in HBM at d_out32 (32 doubles) for a caller-side collective (RCCL all-reduce); no sync. */
+int rpe_normal_eq_device(rpe_context* ctx, int kind, int flags, const double* pose12, double* d_out32);
+/* Host: solve H*delta = -g (Cholesky); RPE_ERR_DEGENERATE if H is not positive definite. */
+int rpe_gn_solve(const double* ne32, double* delta6);
+/* Host: pose <- exp(delta) * pose  (Sophus SE3::exp, sophus/se3.hpp:321-342). */
+int rpe_gn_apply(const double* delta6, double* pose12);
+/* Whole refinement loop on one GPU: up to 3 residual kinds summed with scales; stops when |delta| < tol.
+ * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */
+int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
+                  double tol, int* iters_out, double* last_step, double* final_cost);
+
+/* ---- K4 batched hypothesis scoring: the vote loops V1..V8.
+ * kind selects the modality set exactly as the reference's loops combine them. */
+enum {
+  RPE_VOTE_33 = 0,        /* shinji_ransac / ransac2 / prosac      AbsoluteOrientation.hpp:133-143,190-200,248-258 */
+  RPE_VOTE_23 = 1,        /* kneip_ransac / prosac                 P3P.hpp:362-376,439-453                         */
+  RPE_VOTE_33_23 = 2,     /* shinji_kneip_ransac / prosac          AbsoluteOrientation.hpp:403-422,480-499         */
+  RPE_VOTE_NN_23 = 3,     /* nl_kneip_ransac                       AbsoluteOrientationNormal.hpp:245-264           */
+  RPE_VOTE_NN_33 = 4,     /* nl_shinji_ransac                      :322-337                                        */
+  RPE_VOTE_NN_33_23 = 5,  /* nl_shinji_kneip_ransac                :397-423                                        */
+  RPE_VOTE_23_MATRIX = 6  /* kneip_ransac multiplies by so3().matrix() (P3P.hpp:365) where kneip_prosac uses so3()*x (:442):
+                             differs from RPE_VOTE_23 only in RPE_SCORE_EXACT arithmetic                     */
+};
+/* arithmetic: RPE_SCORE_FAST = rotation-matrix FMA form, squared-distance compare (results can differ from
+ * the reference only for correspondences within rounding of a threshold); RPE_SCORE_EXACT = the reference's
+ * own operation sequence in Tp (quaternion rotate, sqrt, divide, no FMA contraction): votes bit-identical
+ * to the CPU path. */
+enum { RPE_SCORE_FAST = 0, RPE_SCORE_EXACT = 1 };
+/* poses7: H x (qw qx qy qz tx ty tz) doubles holding Tp-representable values (a Sophus::SE3<Tp>).
+ * thre_3d in metres; cos_thr = cos(atan(thre_2d/f)); cos_nl = cos(nl_thre), already evaluated in Tp.
+ * votes_out[H]: total votes per hypothesis (sum over the modalities of `kind`). */
+int rpe_score(rpe_context* ctx, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl,
+              int* votes_out);
+/* K4b: write the winner's inlier masks into the context's device masks (all modalities of `kind`; others
+ * untouched) -- what setInlier() stores; returns the vote total. */
+int rpe_inlier_mask(rpe_context* ctx, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,
+                    int* votes_out);
+
+/* ---- K5 one round of nl_shinji_kneip_ls (AbsoluteOrientationNormal.hpp:484-505) + find_opt_cc (:24-39),
+ * fused into one pass over up to 60 B/corr.  in: c_opt[3], Cw[3], Cc[3], Rwc9 (row-major, rotation used by
+ * find_opt_cc).  out44: M23 (9) TW K | M33 (9) sigma | MNN (9) TL M | AA (6: xx xy xz yy yz zz) bb (3) | pad.
+ * Sums are the FRESH contributions of this round; the host applies the reference's accumulate-across-rounds
+ * recurrences.  Masks/weights of all three modalities are honoured (weights optional, scaled as the adapters do). */
+int rpe_nl_round(rpe_context* ctx, const double* c_opt3, const double* Cw3, const double* Cc3, const double* Rwc9, double* out44);
+
+/* ---- adapter-level pipelines, for hosts that cannot include the C++ headers (and for the parity tests):
+ * runs the named solver of pose/ *.hpp on a freshly built adapter.  Same ids as oracle/oracle_capi.cpp. */
+typedef struct {
+  int n;
+  int dtype;              /* RPE_F32 / RPE_F64 */
+  const void* bv;         /* host pointers, 3 x n, or NULL */
+  const void* xc;
+  const void* nc;
+  const void* xw;
+  const void* nw;
+  const void* weights;    /* n x wcols column-major or NULL */
+  int wcols;
+  double fx, fy;
+} rpe_problem;
+int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
+            uint64_t seed, int ls, int score_mode, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBD_POSE_HIP_H */

@@ -1,0 +1,59 @@
+"""Compile the HIP backend for gfx950 in-tree: rgbd_pose_estimation_amd/lib/librgbdpose_hip.so.
+
+hipcc cross-compiles without a GPU.  Sources: csrc/rpe_kernels.hip (kernels), csrc/rpe_capi.hip (C-ABI shim),
+csrc/library.cpp (reference-compatible ao / ao_ransac / py2c and the adapter-level pipelines)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "librgbdpose_hip.so")
+SOURCES = ["rpe_kernels.hip", "rpe_capi.hip", "library.cpp"]
+ARCH = "gfx950"
+
+
+def _deps():
+    out = []
+    for root in (CSRC, os.path.join(PKG, "include"), os.path.join(os.path.dirname(PKG), "include")):
+        for d, _, fs in os.walk(root):
+            out += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".cpp", ".h", ".hpp"))]
+    return out
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: the HIP backend cannot be built (there is no CPU fallback)")
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

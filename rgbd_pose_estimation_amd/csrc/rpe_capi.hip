@@ -1,0 +1,433 @@
+// extern "C" shim of librgbdpose_hip.so, Part 2 of include/rgbd_pose_hip.h: context, HBM-resident
+// correspondence arrays, kernel launches, the small host-side solves.  There is NO CPU fallback: every entry
+// point that computes fails with RPE_ERR_NO_DEVICE when no HIP device is usable.
+#include "../../include/rgbd_pose_hip.h"
+#include "rpe_kernels.h"
+#include "../include/rpe/linalg.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RPE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+size_t elem_size(int dtype) { return dtype == RPE_F64 ? 8 : 4; }
+
+}  // namespace
+
+struct rpe_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int64_t n = 0;
+  int dtype = RPE_F32;
+  void* arr[RPE_NUM_ARRAYS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool own[RPE_NUM_ARRAYS] = {false, false, false, false, false};
+  size_t cap[RPE_NUM_ARRAYS] = {0, 0, 0, 0, 0};
+  short* mask[3] = {nullptr, nullptr, nullptr};
+  size_t mask_cap[3] = {0, 0, 0};
+  void* weight[3] = {nullptr, nullptr, nullptr};
+  size_t weight_cap[3] = {0, 0, 0};
+  int max_blocks = 1024;
+  double* d_partials = nullptr;  // max_blocks * kNlLd doubles
+  double* d_out = nullptr;       // 64 doubles
+  double* h_out = nullptr;       // pinned, 64 doubles
+  void* d_poses = nullptr;       // kMaxScoreH * 12 doubles
+  void* h_poses = nullptr;       // pinned staging
+  int* d_votes = nullptr;        // kMaxScoreH ints
+  int* h_votes = nullptr;        // pinned
+
+  rpe::DeviceArrays arrays() const {
+    rpe::DeviceArrays A;
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) A.a[i] = arr[i];
+    for (int i = 0; i < 3; i++) { A.mask[i] = mask[i]; A.weight[i] = weight[i]; }
+    A.n = n; A.dtype = dtype;
+    return A;
+  }
+};
+
+namespace {
+
+int ensure_mask(rpe_context* c, int mod, bool fill_ones) {
+  const size_t need = (size_t)c->n * sizeof(short);
+  if (c->mask[mod] && c->mask_cap[mod] >= need) return RPE_OK;
+  if (c->mask[mod]) { HIP_TRY(hipFree(c->mask[mod])); c->mask[mod] = nullptr; }
+  HIP_TRY(hipMalloc((void**)&c->mask[mod], need ? need : 2));
+  c->mask_cap[mod] = need;
+  if (fill_ones && c->n) {  // adapters start with all-ones masks (e.g. AOPoseAdapter.hpp:103-106)
+    std::vector<short> ones((size_t)c->n, 1);
+    HIP_TRY(hipMemcpyAsync(c->mask[mod], ones.data(), need, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return RPE_OK;
+}
+
+int need_arrays(rpe_context* c, std::initializer_list<int> slots) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (c->n <= 0) return fail(RPE_ERR_STATE, "rpe_set_problem was not called (n = %lld)", (long long)c->n);
+  static const char* names[] = {"XW (points_g)", "XC (points_c)", "BV (bearingVectors)", "NW (normal_g)", "NC (normal_c)"};
+  for (int s : slots) if (!c->arr[s]) return fail(RPE_ERR_STATE, "array %s was never uploaded or bound", names[s]);
+  return RPE_OK;
+}
+
+int kind_arrays(rpe_context* c, int kind) {
+  switch (kind) {
+    case RPE_RES_P2P: return need_arrays(c, {RPE_XW, RPE_XC});
+    case RPE_RES_P2PLANE: return need_arrays(c, {RPE_XW, RPE_XC, RPE_NC});
+    case RPE_RES_BEARING: return need_arrays(c, {RPE_XW, RPE_BV});
+  }
+  return fail(RPE_ERR_ARG, "unknown residual kind %d", kind);
+}
+
+int check_flags(rpe_context* c, int kind, int flags) {
+  const int mod = kind == RPE_RES_BEARING ? RPE_MOD_23 : RPE_MOD_33;
+  if ((flags & RPE_USE_MASK) && !c->mask[mod]) return fail(RPE_ERR_STATE, "RPE_USE_MASK but no mask for modality %d", mod);
+  if ((flags & RPE_USE_WEIGHT) && !c->weight[mod]) return fail(RPE_ERR_STATE, "RPE_USE_WEIGHT but no weight for modality %d", mod);
+  return RPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpe_abi_version(void) { return 1; }
+const char* rpe_last_error(void) { return g_err.c_str(); }
+
+int rpe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int rpe_create(rpe_context** out, int device, void* stream) {
+  if (!out) return fail(RPE_ERR_ARG, "null out");
+  *out = nullptr;
+  const int nd = rpe_device_count();
+  if (nd <= 0) return fail(RPE_ERR_NO_DEVICE, "no HIP device is visible; librgbdpose_hip has no CPU fallback");
+  if (device < 0 || device >= nd) return fail(RPE_ERR_ARG, "device %d out of range (have %d)", device, nd);
+  HIP_TRY(hipSetDevice(device));
+  rpe_context* c = new rpe_context();
+  c->device = device;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return fail(RPE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
+  if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->max_blocks = v; }
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)c->max_blocks * rpe::kNlLd * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, (size_t)rpe::kMaxScoreH * sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) { rpe_destroy(c); return fail(RPE_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e)); }
+  *out = c;
+  return RPE_OK;
+}
+
+void rpe_destroy(rpe_context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < RPE_NUM_ARRAYS; i++) if (c->own[i] && c->arr[i]) (void)hipFree(c->arr[i]);
+  for (int i = 0; i < 3; i++) { if (c->mask[i]) (void)hipFree(c->mask[i]); if (c->weight[i]) (void)hipFree(c->weight[i]); }
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->d_poses) (void)hipFree(c->d_poses);
+  if (c->h_poses) (void)hipHostFree(c->h_poses);
+  if (c->d_votes) (void)hipFree(c->d_votes);
+  if (c->h_votes) (void)hipHostFree(c->h_votes);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rpe_synchronize(rpe_context* c) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RPE_OK;
+}
+
+int rpe_set_problem(rpe_context* c, int64_t n, int dtype) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (n < 0 || (dtype != RPE_F32 && dtype != RPE_F64)) return fail(RPE_ERR_ARG, "bad n (%lld) or dtype (%d)", (long long)n, dtype);
+  HIP_TRY(hipSetDevice(c->device));
+  if (n != c->n || dtype != c->dtype) {
+    // a new problem invalidates every array, mask and weight of the old one
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) {
+      if (c->own[i] && c->arr[i]) (void)hipFree(c->arr[i]);
+      c->arr[i] = nullptr; c->cap[i] = 0; c->own[i] = false;
+    }
+    for (int i = 0; i < 3; i++) {
+      if (c->mask[i]) { (void)hipFree(c->mask[i]); c->mask[i] = nullptr; c->mask_cap[i] = 0; }
+      if (c->weight[i]) { (void)hipFree(c->weight[i]); c->weight[i] = nullptr; c->weight_cap[i] = 0; }
+    }
+  }
+  c->n = n; c->dtype = dtype;
+  return RPE_OK;
+}
+
+int rpe_upload(rpe_context* c, int slot, const void* host) {
+  if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS || !host) return fail(RPE_ERR_ARG, "rpe_upload: bad argument");
+  if (c->n <= 0) return fail(RPE_ERR_STATE, "rpe_set_problem first");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = (size_t)c->n * 3 * elem_size(c->dtype);
+  if (!c->own[slot] || c->cap[slot] < bytes) {
+    if (c->own[slot] && c->arr[slot]) HIP_TRY(hipFree(c->arr[slot]));
+    c->arr[slot] = nullptr; c->own[slot] = false;
+    HIP_TRY(hipMalloc(&c->arr[slot], bytes));
+    c->own[slot] = true; c->cap[slot] = bytes;
+  }
+  HIP_TRY(hipMemcpyAsync(c->arr[slot], host, bytes, hipMemcpyHostToDevice, c->stream));
+  return RPE_OK;
+}
+
+int rpe_bind(rpe_context* c, int slot, const void* device_ptr) {
+  if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS) return fail(RPE_ERR_ARG, "rpe_bind: bad argument");
+  if (device_ptr && ((uintptr_t)device_ptr & 15u)) return fail(RPE_ERR_ALIGN, "device pointer %p is not 16-byte aligned", device_ptr);
+  if (c->own[slot] && c->arr[slot]) { HIP_TRY(hipFree(c->arr[slot])); }
+  c->arr[slot] = const_cast<void*>(device_ptr); c->own[slot] = false; c->cap[slot] = 0;
+  return RPE_OK;
+}
+
+int rpe_upload_mask(rpe_context* c, int mod, const short* host_mask) {
+  if (!c || mod < 0 || mod > 2) return fail(RPE_ERR_ARG, "rpe_upload_mask: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!host_mask) { if (c->mask[mod]) { HIP_TRY(hipFree(c->mask[mod])); c->mask[mod] = nullptr; c->mask_cap[mod] = 0; } return RPE_OK; }
+  int rc = ensure_mask(c, mod, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->mask[mod], host_mask, (size_t)c->n * sizeof(short), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RPE_OK;
+}
+
+int rpe_upload_weight(rpe_context* c, int mod, const void* host_weight) {
+  if (!c || mod < 0 || mod > 2) return fail(RPE_ERR_ARG, "rpe_upload_weight: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!host_weight) { if (c->weight[mod]) { HIP_TRY(hipFree(c->weight[mod])); c->weight[mod] = nullptr; c->weight_cap[mod] = 0; } return RPE_OK; }
+  const size_t need = (size_t)c->n * elem_size(c->dtype);
+  if (!c->weight[mod] || c->weight_cap[mod] < need) {
+    if (c->weight[mod]) HIP_TRY(hipFree(c->weight[mod]));
+    c->weight[mod] = nullptr;
+    HIP_TRY(hipMalloc(&c->weight[mod], need ? need : 8));
+    c->weight_cap[mod] = need;
+  }
+  HIP_TRY(hipMemcpyAsync(c->weight[mod], host_weight, need, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RPE_OK;
+}
+
+int rpe_download_mask(rpe_context* c, int mod, short* host_mask) {
+  if (!c || mod < 0 || mod > 2 || !host_mask) return fail(RPE_ERR_ARG, "rpe_download_mask: bad argument");
+  if (!c->mask[mod]) return fail(RPE_ERR_STATE, "no mask for modality %d", mod);
+  HIP_TRY(hipMemcpyAsync(host_mask, c->mask[mod], (size_t)c->n * sizeof(short), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- K1'
+int rpe_p2p_moments(rpe_context* c, int flags, double* out17) {
+  int rc = need_arrays(c, {RPE_XW, RPE_XC});
+  if (rc) return rc;
+  if (!out17) return fail(RPE_ERR_ARG, "null out17");
+  if ((rc = check_flags(c, RPE_RES_P2P, flags))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(rpe::launch_moments(c->arrays(), flags, c->d_partials, c->max_blocks, c->d_out, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 17; i++) out17[i] = c->h_out[i];
+  return RPE_OK;
+}
+
+int rpe_pose_from_moments(const double* m, double* R9, double* t3) {
+  if (!m || !R9 || !t3) return fail(RPE_ERR_ARG, "null argument");
+  const double n = m[0];
+  if (!(n > 0)) return fail(RPE_ERR_DEGENERATE, "moment record has total weight %g", n);
+  rpe::Vec3d Cw(m[1] / n, m[2] / n, m[3] / n), Cc(m[4] / n, m[5] / n, m[6] / n);
+  rpe::Mat3d M;  // sum w (Xc - Cc)(Xw - Cw)^T / n  ==  S/n - Cc Cw^T
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = m[7 + 3 * i + j] / n - Cc[i] * Cw[j];
+  rpe::Mat3d R = rpe::rotation_from_covariance(M);
+  rpe::Vec3d t = Cc - rpe::mul(R, Cw);
+  for (int i = 0; i < 9; i++) { if (!std::isfinite(R.a[i])) return fail(RPE_ERR_DEGENERATE, "non-finite rotation"); R9[i] = R.a[i]; }
+  for (int i = 0; i < 3; i++) t3[i] = t[i];
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- K1/K2/K3
+int rpe_normal_eq_device(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
+  int rc = kind_arrays(c, kind);
+  if (rc) return rc;
+  if (!pose12 || !d_out32) return fail(RPE_ERR_ARG, "null argument");
+  if ((rc = check_flags(c, kind, flags))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, c->d_partials, c->max_blocks, d_out32, c->stream));
+  return RPE_OK;
+}
+
+int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, double* out32) {
+  if (!out32) return fail(RPE_ERR_ARG, "null out32");
+  int rc = rpe_normal_eq_device(c, kind, flags, pose12, c ? c->d_out : nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
+  return RPE_OK;
+}
+
+int rpe_gn_solve(const double* ne32, double* delta6) {
+  if (!ne32 || !delta6) return fail(RPE_ERR_ARG, "null argument");
+  if (!rpe::solve_normal_eq6(ne32, delta6)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite");
+  return RPE_OK;
+}
+
+int rpe_gn_apply(const double* delta6, double* pose12) {
+  if (!delta6 || !pose12) return fail(RPE_ERR_ARG, "null argument");
+  rpe::se3_left_update(delta6, pose12);
+  return RPE_OK;
+}
+
+int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter, double tol,
+                  int* iters_out, double* last_step, double* final_cost) {
+  if (!c || nterms < 1 || nterms > 3 || !kinds || !pose12) return fail(RPE_ERR_ARG, "rpe_gn_refine: bad argument");
+  int it = 0;
+  double step = 0, cost = 0;
+  for (; it < max_iter; it++) {
+    double tot[32];
+    for (int k = 0; k < 32; k++) tot[k] = 0.0;
+    for (int t = 0; t < nterms; t++) {
+      double ne[32];
+      int rc = rpe_normal_eq(c, kinds[t], flags, pose12, ne);
+      if (rc) return rc;
+      const double s = scales ? scales[t] : 1.0;
+      for (int k = 0; k < 28; k++) tot[k] += s * ne[k];
+      tot[28] += ne[28];
+    }
+    cost = tot[27];
+    double d[6];
+    if (!rpe::solve_normal_eq6(tot, d)) {
+      if (iters_out) *iters_out = it;
+      return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, tot[28]);
+    }
+    rpe::se3_left_update(d, pose12);
+    step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    if (step < tol) { it++; break; }
+  }
+  if (iters_out) *iters_out = it;
+  if (last_step) *last_step = step;
+  if (final_cost) *final_cost = cost;
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- K4
+static int vote_arrays(rpe_context* c, int kind) {
+  switch (kind) {
+    case RPE_VOTE_33: return need_arrays(c, {RPE_XW, RPE_XC});
+    case RPE_VOTE_23: case RPE_VOTE_23_MATRIX: return need_arrays(c, {RPE_XW, RPE_BV});
+    case RPE_VOTE_33_23: return need_arrays(c, {RPE_XW, RPE_XC, RPE_BV});
+    case RPE_VOTE_NN_23: return need_arrays(c, {RPE_XW, RPE_XC, RPE_BV, RPE_NW, RPE_NC});
+    case RPE_VOTE_NN_33: return need_arrays(c, {RPE_XW, RPE_XC, RPE_NW, RPE_NC});
+    case RPE_VOTE_NN_33_23: return need_arrays(c, {RPE_XW, RPE_XC, RPE_BV, RPE_NW, RPE_NC});
+  }
+  return fail(RPE_ERR_ARG, "unknown vote kind %d", kind);
+}
+
+// host -> staging in the kernel's layout.  fast: R(9) t(3) ; exact: q(4) t(3) pad
+static void stage_poses(int dtype, int exact, const double* poses7, int H, void* dst) {
+  for (int h = 0; h < H; h++) {
+    const double* p = poses7 + 7 * h;
+    double v[12];
+    int cnt;
+    if (exact) { for (int k = 0; k < 7; k++) v[k] = p[k]; v[7] = 0; cnt = 8; }
+    else {
+      rpe::Quat<double> q{p[0], p[1], p[2], p[3]};
+      rpe::quat_to_R(q, v);
+      v[9] = p[4]; v[10] = p[5]; v[11] = p[6]; cnt = 12;
+    }
+    if (dtype == RPE_F64) std::memcpy((double*)dst + (size_t)h * cnt, v, cnt * sizeof(double));
+    else { float* f = (float*)dst + (size_t)h * cnt; for (int k = 0; k < cnt; k++) f[k] = (float)v[k]; }
+  }
+}
+static void stage_thresholds(int dtype, int exact, double thre_3d, double cos_thr, double cos_nl, double thr[3]) {
+  if (exact) thr[0] = thre_3d;
+  else thr[0] = dtype == RPE_F64 ? thre_3d * thre_3d : (double)((float)thre_3d * (float)thre_3d);
+  thr[1] = cos_thr; thr[2] = cos_nl;
+}
+
+int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
+  int rc = vote_arrays(c, kind);
+  if (rc) return rc;
+  if (!poses7 || !votes_out || H < 0) return fail(RPE_ERR_ARG, "rpe_score: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const int exact = mode == RPE_SCORE_EXACT;
+  double thr[3];
+  stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
+  const size_t per = (exact ? 8 : 12) * elem_size(c->dtype);
+  for (int h0 = 0; h0 < H; h0 += rpe::kMaxScoreH) {
+    const int hb = std::min(rpe::kMaxScoreH, H - h0);
+    stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
+    HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->max_blocks, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, (size_t)hb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
+  }
+  return RPE_OK;
+}
+
+int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
+  int rc = vote_arrays(c, kind);
+  if (rc) return rc;
+  if (!pose7) return fail(RPE_ERR_ARG, "null pose");
+  HIP_TRY(hipSetDevice(c->device));
+  const bool m33 = kind == RPE_VOTE_33 || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
+  const bool m23 = kind == RPE_VOTE_23 || kind == RPE_VOTE_23_MATRIX || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33_23;
+  const bool mnn = kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
+  if (m23 && (rc = ensure_mask(c, RPE_MOD_23, true))) return rc;
+  if (m33 && (rc = ensure_mask(c, RPE_MOD_33, true))) return rc;
+  if (mnn && (rc = ensure_mask(c, RPE_MOD_NN, true))) return rc;
+  const int exact = mode == RPE_SCORE_EXACT;
+  double thr[3];
+  stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
+  stage_poses(c->dtype, exact, pose7, 1, c->h_poses);
+  HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, (exact ? 8 : 12) * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, c->d_poses, thr, c->d_votes, c->max_blocks, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (votes_out) *votes_out = c->h_votes[0];
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- K5
+int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const double* Cc3, const double* Rwc9, double* out44) {
+  int rc = need_arrays(c, {RPE_XW});
+  if (rc) return rc;
+  if (!c_opt3 || !Cw3 || !Cc3 || !Rwc9 || !out44) return fail(RPE_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  // masks default to all ones, exactly as a freshly constructed adapter
+  if ((rc = ensure_mask(c, RPE_MOD_23, true))) return rc;
+  if ((rc = ensure_mask(c, RPE_MOD_33, true))) return rc;
+  if (c->arr[RPE_NW] && (rc = ensure_mask(c, RPE_MOD_NN, true))) return rc;
+  double prm[24];
+  for (int i = 0; i < 3; i++) { prm[i] = c_opt3[i]; prm[3 + i] = Cw3[i]; prm[6 + i] = Cc3[i]; }
+  for (int i = 0; i < 9; i++) prm[9 + i] = Rwc9[i];
+  for (int i = 18; i < 24; i++) prm[i] = 0;
+  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, c->d_partials, c->max_blocks, c->d_out, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, 64 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 44; i++) out44[i] = c->h_out[i];
+  return RPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Internal launcher interface between the C-ABI shim (rpe_capi.hip) and the gfx950 kernels (rpe_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rpe {
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup
+constexpr int kNeLd = 32;            // doubles per normal-equation / moment partial record
+constexpr int kNlLd = 64;            // doubles per nl_round partial record
+constexpr int kMaxScoreH = 8192;     // hypotheses per scoring launch (LDS vote table = 32 KiB)
+
+// Correspondence arrays resident in HBM.  3 x n column-major (xyz interleaved), dtype 0 = f32, 1 = f64.
+struct DeviceArrays {
+  const void* a[5];        // RPE_XW, RPE_XC, RPE_BV, RPE_NW, RPE_NC
+  short* mask[3];          // RPE_MOD_23 / 33 / NN (n shorts each) or null
+  const void* weight[3];   // n Tp each or null
+  int64_t n;
+  int dtype;
+};
+
+// stage 1 + stage 2 of the normal-equation reduction.  d_partials: max_blocks * kNeLd doubles.
+hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, double* d_partials, int max_blocks,
+                            double* d_out32, hipStream_t s);
+hipError_t launch_moments(const DeviceArrays& A, int flags, double* d_partials, int max_blocks, double* d_out32, hipStream_t s);
+// d_poses: H x 12 (fast: R row-major, t) or H x 8 (exact: qw qx qy qz tx ty tz pad) values of the array dtype.
+// thr: {thre_3d (fast: squared), cos_thr, cos_nl} as doubles holding values of the array dtype.
+hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
+                        int max_blocks, hipStream_t s);
+hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d_pose, const double* thr3, int* d_votes, int max_blocks,
+                       hipStream_t s);
+// d_params: 24 doubles = c_opt(3) Cw(3) Cc(3) Rwc(9) pad;  d_partials: max_blocks * kNlLd doubles; d_out: 64 doubles
+hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, double* d_partials, int max_blocks, double* d_out64,
+                           hipStream_t s);
+
+}  // namespace rpe

@@ -1,0 +1,721 @@
+// gfx950 (MI355X, CDNA4) kernels of the RGB-D absolute-pose hot path.  Hand-written HIP, wave64.
+//
+// All kernels are streaming reductions / counts over the correspondence index c of the reference's O(N)
+// loops.  They are HBM-bandwidth bound (about 2.5 flop/B), so there is no MFMA here:
+// the design rules are (1) 16-byte vector loads of the reference's native xyz-interleaved 3 x N arrays --
+// a thread owns P consecutive correspondences (P = 4 for fp32 = three float4, P = 2 for fp64 = three
+// double2), so every byte of every 128-B line is consumed by one lane within three back-to-back loads;
+// (2) per-thread fp64 accumulators, wave64 __shfl_down tree, one LDS hop across the 4 waves of a workgroup,
+// one 256-B partial record per workgroup; (3) a single-workgroup second stage that sums the records in a
+// fixed order (deterministic, no float atomics) and expands them to the 6x6 / 6x1 normal equations;
+// (4) grids of at most a few workgroups per CU with a grid-stride loop, so a launch covers all 8 XCDs and a
+// workgroup re-reads the same slice every Gauss-Newton iteration (slice stays in its XCD's L2 when it fits).
+#include "rpe_kernels.h"
+
+namespace rpe {
+
+enum { KIND_P2P = 0, KIND_P2PLANE = 1, KIND_BEARING = 2 };
+enum { F_USE_MASK = 1, F_USE_WEIGHT = 2, F_SKIP_INVALID = 4 };
+
+template <class T> struct Pk;
+template <> struct Pk<float> { enum { P = 4 }; typedef float4 V; };
+template <> struct Pk<double> { enum { P = 2 }; typedef double2 V; };
+
+template <class T> struct PoseK { T R[9]; T t[3]; };
+
+__device__ __forceinline__ void unpack3(const float4& a, const float4& b, const float4& c, float (&v)[12]) {
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+}
+__device__ __forceinline__ void unpack3(const double2& a, const double2& b, const double2& c, double (&v)[6]) {
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+}
+
+// group g = correspondences [P*g, P*g + P).  Entries past n read as zero.
+template <class T>
+__device__ __forceinline__ void load_group(const T* __restrict__ a, int64_t g, int64_t n, T (&v)[3 * Pk<T>::P]) {
+  constexpr int P = Pk<T>::P;
+  if ((g + 1) * P <= n) {
+    const typename Pk<T>::V* q = reinterpret_cast<const typename Pk<T>::V*>(a) + 3 * g;
+    typename Pk<T>::V v0 = q[0], v1 = q[1], v2 = q[2];
+    unpack3(v0, v1, v2, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3 * P; i++) { int64_t idx = g * (3 * P) + i; v[i] = idx < 3 * n ? a[idx] : T(0); }
+  }
+}
+template <class T, class S>
+__device__ __forceinline__ void load_scalars(const S* __restrict__ a, int64_t g, int64_t n, S (&v)[Pk<T>::P], S fill) {
+  constexpr int P = Pk<T>::P;
+#pragma unroll
+  for (int i = 0; i < P; i++) { int64_t idx = g * P + i; v[i] = idx < n ? a[idx] : fill; }
+}
+template <class T> __device__ __forceinline__ bool all_nan(T x, T y, T z) { return x != x && y != y && z != z; }
+
+// ---- wave64 shuffle tree + one LDS hop; writes NACC doubles of this workgroup to row[]
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ row) {
+  __shared__ double red[kBlock / 64][NACC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double s = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) s += red[w][threadIdx.x];
+    row[threadIdx.x] = s;
+  }
+}
+
+// ================================================================================================
+// K1 / K2 / K3 : Gauss-Newton normal equations
+// ================================================================================================
+// p2p keeps 17 structured sums: w | w p (3) | w p p^T (6) | w r (3) | w p x r (3) | w r^2
+// The pose stays fp64 and p = R x + t, r = p - Xc are formed in fp64: the subtraction cancels ~3 digits
+// (|p| ~ 10 m, |r| ~ 5 cm), so doing it in fp32 would dominate the error budget.  p and r are then rounded
+// to the compute type C for the products (fp32 for fp32 arrays), and the sums are widened to fp64 per group.
+template <class C>
+__device__ __forceinline__ void transform(const PoseK<double>& T, C x, C y, C z, double& px, double& py, double& pz) {
+  const double xd = x, yd = y, zd = z;
+  px = fma(T.R[0], xd, fma(T.R[1], yd, fma(T.R[2], zd, T.t[0])));
+  py = fma(T.R[3], xd, fma(T.R[4], yd, fma(T.R[5], zd, T.t[1])));
+  pz = fma(T.R[6], xd, fma(T.R[7], yd, fma(T.R[8], zd, T.t[2])));
+}
+template <class C>
+__device__ __forceinline__ void p2p_point(const PoseK<double>& T, C x, C y, C z, C cx, C cy, C cz, C w, C (&s)[17]) {
+  double pxd, pyd, pzd;
+  transform<C>(T, x, y, z, pxd, pyd, pzd);
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
+  const C rx = (C)(pxd - (double)cx), ry = (C)(pyd - (double)cy), rz = (C)(pzd - (double)cz);
+  const C wpx = w * px, wpy = w * py, wpz = w * pz;
+  const C wrx = w * rx, wry = w * ry, wrz = w * rz;
+  s[0] += w;
+  s[1] += wpx; s[2] += wpy; s[3] += wpz;
+  s[4] = fma(wpx, px, s[4]); s[5] = fma(wpx, py, s[5]); s[6] = fma(wpx, pz, s[6]);
+  s[7] = fma(wpy, py, s[7]); s[8] = fma(wpy, pz, s[8]); s[9] = fma(wpz, pz, s[9]);
+  s[10] += wrx; s[11] += wry; s[12] += wrz;
+  s[13] += py * wrz - pz * wry;
+  s[14] += pz * wrx - px * wrz;
+  s[15] += px * wry - py * wrx;
+  s[16] = fma(wrx, rx, fma(wry, ry, fma(wrz, rz, s[16])));
+}
+// general packed record: H upper triangle (21) | g (6) | w r^2 | w
+template <class C> __device__ __forceinline__ void add_row(const C (&J)[6], C r, C w, C (&s)[29]) {
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const C wa = w * J[a];
+#pragma unroll
+    for (int b = a; b < 6; b++) { s[k] = fma(wa, J[b], s[k]); k++; }
+    s[21 + a] = fma(wa, r, s[21 + a]);
+  }
+  s[27] = fma(w * r, r, s[27]);
+}
+template <class C>
+__device__ __forceinline__ void p2plane_point(const PoseK<double>& T, C x, C y, C z, C cx, C cy, C cz, C nx, C ny, C nz, C w, C (&s)[29]) {
+  double pxd, pyd, pzd;
+  transform<C>(T, x, y, z, pxd, pyd, pzd);
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
+  const C r = (C)((double)nx * (pxd - (double)cx) + (double)ny * (pyd - (double)cy) + (double)nz * (pzd - (double)cz));
+  const C J[6] = {nx, ny, nz, py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx};  // [n ; p x n]
+  add_row(J, r, w, s);
+  s[28] += w;
+}
+template <class C>
+__device__ __forceinline__ void bearing_point(const PoseK<double>& T, C x, C y, C z, C bx, C by, C bz, C w, C (&s)[29]) {
+  double pxd, pyd, pzd;
+  transform<C>(T, x, y, z, pxd, pyd, pzd);
+  const double invd = 1.0 / sqrt(pxd * pxd + pyd * pyd + pzd * pzd);
+  const double hxd = pxd * invd, hyd = pyd * invd, hzd = pzd * invd;
+  // sine residual p^ x bv: near the optimum p^ ~ bv, so this too is a cancelling difference -> fp64
+  const C r[3] = {(C)(hyd * (double)bz - hzd * (double)by), (C)(hzd * (double)bx - hxd * (double)bz), (C)(hxd * (double)by - hyd * (double)bx)};
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd, inv = (C)invd;
+  const C hx = (C)hxd, hy = (C)hyd, hz = (C)hzd;
+  // A = -[bv]x (I - h h^T) * inv ; row u of A = -(e_u^T [bv]x) (I - h h^T) inv
+  const C Bx[3][3] = {{C(0), -bz, by}, {bz, C(0), -bx}, {-by, bx, C(0)}};
+  const C h[3] = {hx, hy, hz};
+#pragma unroll
+  for (int u = 0; u < 3; u++) {
+    const C bh = Bx[u][0] * h[0] + Bx[u][1] * h[1] + Bx[u][2] * h[2];
+    const C a0 = -(Bx[u][0] - bh * h[0]) * inv, a1 = -(Bx[u][1] - bh * h[1]) * inv, a2 = -(Bx[u][2] - bh * h[2]) * inv;
+    // J = a^T [I | -[p]x] : translation part a, rotation part (p x a)
+    const C J[6] = {a0, a1, a2, py * a2 - pz * a1, pz * a0 - px * a2, px * a1 - py * a0};
+    add_row(J, r[u], w, s);
+  }
+  s[28] += w;
+}
+
+template <class T, int KIND>
+__global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
+                                                           const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
+                                                           PoseK<double> pose, double* __restrict__ partials) {
+  constexpr int P = Pk<T>::P;
+  constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    T vw[3 * P], vb[3 * P], vc[3 * P];
+    load_group<T>(xw, g, n, vw);
+    load_group<T>(b, g, n, vb);
+    if (KIND == KIND_P2PLANE) load_group<T>(c, g, n, vc);
+    T w[P];
+    if (weight) load_scalars<T, T>(weight, g, n, w, T(0));
+    else {
+#pragma unroll
+      for (int i = 0; i < P; i++) w[i] = (g * P + i) < n ? T(1) : T(0);
+    }
+    if (mask) {
+      short m[P];
+      load_scalars<T, short>(mask, g, n, m, (short)0);
+#pragma unroll
+      for (int i = 0; i < P; i++) w[i] = m[i] == 1 ? w[i] : T(0);
+    }
+    T s[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) s[k] = T(0);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      T bx = vb[3 * i], by = vb[3 * i + 1], bz = vb[3 * i + 2];
+      T wi = all_nan(bx, by, bz) ? T(0) : w[i];
+      if (wi == T(0)) { x = y = z = T(0); bx = by = T(0); bz = T(1); }  // keeps NaN / inf of skipped columns out of the sums
+      if (KIND == KIND_P2P) p2p_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[17]>(s));
+      else if (KIND == KIND_P2PLANE) {
+        T nx = vc[3 * i], ny = vc[3 * i + 1], nz = vc[3 * i + 2];
+        if (wi == T(0)) { nx = ny = nz = T(0); }
+        p2plane_point<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, reinterpret_cast<T(&)[29]>(s));
+      } else {
+        if (wi == T(0)) { z = T(1); }  // p != 0 so that normalisation stays finite
+        bearing_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[29]>(s));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] += (double)s[k];
+  }
+  block_reduce_store<NACC>(acc, partials + (size_t)blockIdx.x * kNeLd);
+}
+
+// ---- stage 2: one workgroup sums the G partial records in a fixed order and writes the final record.
+// MODE 0: copy ncols values; MODE 1: expand the 17 structured p2p sums into the packed 29-value record.
+template <int LD, int MODE>
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restrict__ partials, int G, int ncols, double* __restrict__ out) {
+  constexpr int RG = kBlock / LD;  // row groups
+  __shared__ double part[RG][LD];
+  __shared__ double tot[LD];
+  const int j = threadIdx.x % LD, rg = threadIdx.x / LD;
+  double s = 0.0;
+  if (j < ncols) {
+    int r = rg;
+    for (; r + 3 * RG < G; r += 4 * RG) {  // 4 independent loads in flight, summed in row order
+      double a0 = partials[(size_t)r * LD + j], a1 = partials[(size_t)(r + RG) * LD + j];
+      double a2 = partials[(size_t)(r + 2 * RG) * LD + j], a3 = partials[(size_t)(r + 3 * RG) * LD + j];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; r < G; r += RG) s += partials[(size_t)r * LD + j];
+  }
+  part[rg][j] = s;
+  __syncthreads();
+  if (threadIdx.x < LD) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < RG; k++) t += part[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (MODE == 0) {
+    if (threadIdx.x < LD) out[threadIdx.x] = threadIdx.x < ncols ? tot[threadIdx.x] : 0.0;
+  } else if (threadIdx.x == 0) {
+    const double nn = tot[0], Sx = tot[1], Sy = tot[2], Sz = tot[3];
+    const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
+    double o[32];
+    for (int k = 0; k < 32; k++) o[k] = 0.0;
+    o[0] = nn; o[4] = Sz; o[5] = -Sy;            // row 0: (0,0) (0,1) (0,2) (0,3) (0,4) (0,5)
+    o[6] = nn; o[8] = -Sz; o[10] = Sx;           // row 1: (1,1) (1,2) (1,3) (1,4) (1,5)
+    o[11] = nn; o[12] = Sy; o[13] = -Sx;         // row 2: (2,2) (2,3) (2,4) (2,5)
+    o[15] = yy + zz; o[16] = -xy; o[17] = -xz;   // row 3
+    o[18] = xx + zz; o[19] = -yz;                // row 4
+    o[20] = xx + yy;                             // row 5
+    for (int k = 0; k < 6; k++) o[21 + k] = tot[10 + k];
+    o[27] = tot[16]; o[28] = nn;
+    for (int k = 0; k < 32; k++) out[k] = o[k];
+  }
+}
+
+// ================================================================================================
+// K1' : closed-form moments (both passes of shinji() in one): w | w Xw | w Xc | w Xc Xw^T | w |Xc|^2
+// fp32 x fp32 products are exact in fp64, so only the fp64 summation rounds.
+// ================================================================================================
+template <class T>
+__global__ __launch_bounds__(kBlock) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const short* __restrict__ mask,
+                                                         const T* __restrict__ weight, int64_t n, int skip_invalid,
+                                                         double* __restrict__ partials) {
+  constexpr int P = Pk<T>::P;
+  double acc[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) acc[k] = 0.0;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    T vw[3 * P], vc[3 * P];
+    load_group<T>(xw, g, n, vw);
+    load_group<T>(xc, g, n, vc);
+    T w[P];
+    if (weight) load_scalars<T, T>(weight, g, n, w, T(0));
+    else {
+#pragma unroll
+      for (int i = 0; i < P; i++) w[i] = (g * P + i) < n ? T(1) : T(0);
+    }
+    if (mask) {
+      short m[P];
+      load_scalars<T, short>(mask, g, n, m, (short)0);
+#pragma unroll
+      for (int i = 0; i < P; i++) w[i] = m[i] == 1 ? w[i] : T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      double x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      double cx = vc[3 * i], cy = vc[3 * i + 1], cz = vc[3 * i + 2];
+      double wi = w[i];
+      if (skip_invalid && all_nan(cx, cy, cz)) wi = 0.0;
+      if (wi == 0.0) { x = y = z = cx = cy = cz = 0.0; }
+      const double wcx = wi * cx, wcy = wi * cy, wcz = wi * cz;
+      acc[0] += wi;
+      acc[1] = fma(wi, x, acc[1]); acc[2] = fma(wi, y, acc[2]); acc[3] = fma(wi, z, acc[3]);
+      acc[4] += wcx; acc[5] += wcy; acc[6] += wcz;
+      acc[7] = fma(wcx, x, acc[7]); acc[8] = fma(wcx, y, acc[8]); acc[9] = fma(wcx, z, acc[9]);
+      acc[10] = fma(wcy, x, acc[10]); acc[11] = fma(wcy, y, acc[11]); acc[12] = fma(wcy, z, acc[12]);
+      acc[13] = fma(wcz, x, acc[13]); acc[14] = fma(wcz, y, acc[14]); acc[15] = fma(wcz, z, acc[15]);
+      acc[16] = fma(wcx, cx, fma(wcy, cy, fma(wcz, cz, acc[16])));
+    }
+  }
+  block_reduce_store<17>(acc, partials + (size_t)blockIdx.x * kNeLd);
+}
+
+// ================================================================================================
+// K4 : batched hypothesis scoring (vote loops V1..V8) and K4b : winner mask
+// ================================================================================================
+enum { VOTE_33 = 0, VOTE_23 = 1, VOTE_33_23 = 2, VOTE_NN_23 = 3, VOTE_NN_33 = 4, VOTE_NN_33_23 = 5, VOTE_23_MATRIX = 6 };
+template <int KIND> struct VoteMods {
+  static constexpr bool m33 = KIND == VOTE_33 || KIND == VOTE_33_23 || KIND == VOTE_NN_33 || KIND == VOTE_NN_33_23;
+  static constexpr bool m23 = KIND == VOTE_23 || KIND == VOTE_33_23 || KIND == VOTE_NN_23 || KIND == VOTE_NN_33_23 || KIND == VOTE_23_MATRIX;
+  static constexpr bool mnn = KIND == VOTE_NN_23 || KIND == VOTE_NN_33 || KIND == VOTE_NN_33_23;
+  static constexpr bool need_xc = m33 || mnn;  // isValid() gates the N-N vote too
+};
+
+// one hypothesis in registers (wave-uniform -> SGPRs)
+template <class T, bool EXACT> struct Hyp;
+template <class T> struct Hyp<T, false> {
+  T R[9], t[3];
+  enum { STRIDE = 12 };
+  __device__ __forceinline__ void load(const T* __restrict__ p, bool) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = p[k];
+    t[0] = p[9]; t[1] = p[10]; t[2] = p[11];
+  }
+  __device__ __forceinline__ void rot(T x, T y, T z, T& ox, T& oy, T& oz) const {
+    ox = fma(R[0], x, fma(R[1], y, R[2] * z));
+    oy = fma(R[3], x, fma(R[4], y, R[5] * z));
+    oz = fma(R[6], x, fma(R[7], y, R[8] * z));
+  }
+  // fast forms: squared distance / squared cosine compares (no sqrt, no divide)
+  __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T thr_sq) const {
+    const T ex = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0] - cx)));
+    const T ey = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1] - cy)));
+    const T ez = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2] - cz)));
+    return fma(ex, ex, fma(ey, ey, ez * ez)) < thr_sq;
+  }
+  __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool) const {
+    const T px = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0])));
+    const T py = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1])));
+    const T pz = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2])));
+    const T d = fma(px, bx, fma(py, by, pz * bz));
+    const T n2 = fma(px, px, fma(py, py, pz * pz));
+    const T lhs = d * d, rhs = c * c * n2;
+    return c >= T(0) ? (d > T(0) && lhs > rhs) : (d >= T(0) || lhs < rhs);
+  }
+  __device__ __forceinline__ bool innn(T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T cnl) const {
+    T rx, ry, rz;
+    rot(nwx, nwy, nwz, rx, ry, rz);
+    return fma(ncx, rx, fma(ncy, ry, ncz * rz)) > cnl;
+  }
+};
+// exact form: the reference's own operation sequence in Tp, no FMA contraction.
+//   R*x     = Eigen _transformVector (sophus/so3.hpp:238-240): uv = 2 (u x v); v + w uv + u x uv
+//   3D test = |Xc - (R Xw + t)| < thre_3d with norm = sqrt(x^2 + y^2 + z^2)      (AbsoluteOrientation.hpp:137-138)
+//   2D test = normalize(R Xw + t) . bv > cos_thr, normalisation by division        (:413-418)
+//   N-N     = Nc . (R Nw) > cos_nl                                                  (AbsoluteOrientationNormal.hpp:248-249)
+template <class T> struct Hyp<T, true> {
+  T qw, qx, qy, qz, t[3];
+  T M[9];  // toRotationMatrix(), only for the kneip_ransac variant that multiplies by so3().matrix() (P3P.hpp:365)
+  enum { STRIDE = 8 };
+  __device__ __forceinline__ void load(const T* __restrict__ p, bool need_matrix) {
+#pragma clang fp contract(off)
+    qw = p[0]; qx = p[1]; qy = p[2]; qz = p[3]; t[0] = p[4]; t[1] = p[5]; t[2] = p[6];
+    if (!need_matrix) return;
+    const T tx = T(2) * qx, ty = T(2) * qy, tz = T(2) * qz;
+    const T twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const T tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    M[0] = T(1) - (tyy + tzz); M[1] = txy - twz; M[2] = txz + twy;
+    M[3] = txy + twz; M[4] = T(1) - (txx + tzz); M[5] = tyz - twx;
+    M[6] = txz - twy; M[7] = tyz + twx; M[8] = T(1) - (txx + tyy);
+  }
+  __device__ __forceinline__ void rot(T x, T y, T z, T& ox, T& oy, T& oz) const {
+#pragma clang fp contract(off)
+    T ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const T cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
+  }
+  __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T thr) const {
+#pragma clang fp contract(off)
+    T rx, ry, rz;
+    rot(x, y, z, rx, ry, rz);
+    const T ex = cx - (rx + t[0]), ey = cy - (ry + t[1]), ez = cz - (rz + t[2]);
+    return sqrt(ex * ex + ey * ey + ez * ez) < thr;
+  }
+  __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool use_matrix) const {
+#pragma clang fp contract(off)
+    T rx, ry, rz;
+    if (use_matrix) {
+      rx = M[0] * x + M[1] * y + M[2] * z; ry = M[3] * x + M[4] * y + M[5] * z; rz = M[6] * x + M[7] * y + M[8] * z;
+    } else {
+      rot(x, y, z, rx, ry, rz);
+    }
+    T px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+    const T len = sqrt(px * px + py * py + pz * pz);
+    px = px / len; py = py / len; pz = pz / len;
+    return (px * bx + py * by + pz * bz) > c;
+  }
+  __device__ __forceinline__ bool innn(T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T cnl) const {
+#pragma clang fp contract(off)
+    T rx, ry, rz;
+    rot(nwx, nwy, nwz, rx, ry, rz);
+    return (ncx * rx + ncy * ry + ncz * rz) > cnl;
+  }
+};
+
+template <class T, int KIND, bool EXACT>
+__global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                       const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                       const T* __restrict__ poses, int H, T thr33, T cthr, T cnl, int* __restrict__ votes) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  extern __shared__ int lds_votes[];
+  for (int i = threadIdx.x; i < H; i += kBlock) lds_votes[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  // loop bound is workgroup-uniform so that every lane of a wave takes part in the per-hypothesis ballots
+  for (int64_t gb = (int64_t)blockIdx.x * kBlock; gb < groups; gb += stride) {
+    const int64_t g = gb + threadIdx.x;
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    bool present[P], valid[P];
+    load_group<T>(xw, g, n, vw);
+    if (MD::need_xc) load_group<T>(xc, g, n, vc);
+    if (MD::m23) load_group<T>(bv, g, n, vb);
+    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      present[i] = (g * P + i) < n;
+      valid[i] = present[i] && (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+    }
+    for (int h0 = 0; h0 < H; h0 += 64) {
+      const int hmax = min(64, H - h0);
+      int mine = 0;
+      for (int hl = 0; hl < hmax; hl++) {
+        Hyp<T, EXACT> hyp;
+        hyp.load(poses + (size_t)(h0 + hl) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+          const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+          if (MD::mnn) {
+            const bool v = valid[i] && hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
+            cnt += __popcll(__ballot(v));
+          }
+          if (MD::m33) {
+            const bool v = valid[i] && hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
+            cnt += __popcll(__ballot(v));
+          }
+          if (MD::m23) {
+            const bool v = present[i] && hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
+            cnt += __popcll(__ballot(v));
+          }
+        }
+        mine += (lane == hl) ? cnt : 0;
+      }
+      if (lane < hmax && mine != 0) atomicAdd(&lds_votes[h0 + lane], mine);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += kBlock) {
+    const int v = lds_votes[i];
+    if (v != 0) atomicAdd(&votes[i], v);
+  }
+}
+
+template <class T, int KIND, bool EXACT>
+__global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                      const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                      const T* __restrict__ pose, T thr33, T cthr, T cnl, short* __restrict__ m23,
+                                                      short* __restrict__ m33, short* __restrict__ mnn, int* __restrict__ votes) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  Hyp<T, EXACT> hyp;
+  hyp.load(pose, KIND == VOTE_23_MATRIX);
+  int cnt = 0;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    load_group<T>(xw, g, n, vw);
+    if (MD::need_xc) load_group<T>(xc, g, n, vc);
+    if (MD::m23) load_group<T>(bv, g, n, vb);
+    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const int64_t idx = g * P + i;
+      if (idx >= n) continue;
+      const bool valid = !MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]);
+      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      if (MD::mnn) {
+        const bool v = valid && hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
+        mnn[idx] = v ? 1 : 0; cnt += v;
+      }
+      if (MD::m33) {
+        const bool v = valid && hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
+        m33[idx] = v ? 1 : 0; cnt += v;
+      }
+      if (MD::m23) {
+        const bool v = hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
+        m23[idx] = v ? 1 : 0; cnt += v;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((threadIdx.x & 63) == 0 && cnt != 0) atomicAdd(votes, cnt);
+}
+
+// ================================================================================================
+// K5 : one round of nl_shinji_kneip_ls + find_opt_cc  (AbsoluteOrientationNormal.hpp:484-505, :24-39)
+// record (44): M23 (9) TW K | M33 (9) sigma | MNN (9) TL M | AA xx xy xz yy yz zz | bb (3) | pad
+// ================================================================================================
+struct NlParams { double c_opt[3], Cw[3], Cc[3], Rwc[9]; };
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void nl_round_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                          const T* __restrict__ nw, const T* __restrict__ nc,
+                                                          const short* __restrict__ k23, const short* __restrict__ k33,
+                                                          const short* __restrict__ knn, const T* __restrict__ w23,
+                                                          const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n, NlParams prm,
+                                                          double* __restrict__ partials) {
+  constexpr int P = Pk<T>::P;
+  double acc[44];
+#pragma unroll
+  for (int k = 0; k < 44; k++) acc[k] = 0.0;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    short a23[P], a33[P], ann[P];
+    load_group<T>(xw, g, n, vw);
+    load_scalars<T, short>(k23, g, n, a23, (short)0);
+    load_scalars<T, short>(k33, g, n, a33, (short)0);
+    if (knn) load_scalars<T, short>(knn, g, n, ann, (short)0);
+    else {
+#pragma unroll
+      for (int i = 0; i < P; i++) ann[i] = 0;
+    }
+    if (bv) load_group<T>(bv, g, n, vb);
+    if (xc) load_group<T>(xc, g, n, vc);
+    if (nw) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const int64_t idx = g * P + i;
+      const double x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      if (bv && a23[i] == 1) {
+        const double w = w23 ? (double)w23[idx] : 1.0;
+        double ax = x - prm.c_opt[0], ay = y - prm.c_opt[1], az = z - prm.c_opt[2];
+        const double inv = 1.0 / sqrt(ax * ax + ay * ay + az * az);
+        ax *= inv; ay *= inv; az *= inv;
+        const double bx = vb[3 * i], by = vb[3 * i + 1], bz = vb[3 * i + 2];
+        acc[0] = fma(w * bx, ax, acc[0]); acc[1] = fma(w * bx, ay, acc[1]); acc[2] = fma(w * bx, az, acc[2]);
+        acc[3] = fma(w * by, ax, acc[3]); acc[4] = fma(w * by, ay, acc[4]); acc[5] = fma(w * by, az, acc[5]);
+        acc[6] = fma(w * bz, ax, acc[6]); acc[7] = fma(w * bz, ay, acc[7]); acc[8] = fma(w * bz, az, acc[8]);
+        acc[9] += w; acc[10] += 1.0;
+        // find_opt_cc: v = Rwc * bv ; A = I - v v^T ; AA += A ; bb += A * Xw
+        const double vx = prm.Rwc[0] * bx + prm.Rwc[1] * by + prm.Rwc[2] * bz;
+        const double vy = prm.Rwc[3] * bx + prm.Rwc[4] * by + prm.Rwc[5] * bz;
+        const double vz = prm.Rwc[6] * bx + prm.Rwc[7] * by + prm.Rwc[8] * bz;
+        const double Axx = 1 - vx * vx, Axy = -vx * vy, Axz = -vx * vz, Ayy = 1 - vy * vy, Ayz = -vy * vz, Azz = 1 - vz * vz;
+        acc[32] += Axx; acc[33] += Axy; acc[34] += Axz; acc[35] += Ayy; acc[36] += Ayz; acc[37] += Azz;
+        acc[38] += Axx * x + Axy * y + Axz * z;
+        acc[39] += Axy * x + Ayy * y + Ayz * z;
+        acc[40] += Axz * x + Ayz * y + Azz * z;
+      }
+      if (xc && a33[i] == 1) {
+        const double v = w33 ? (double)w33[idx] : 1.0;
+        const double ax = x - prm.Cw[0], ay = y - prm.Cw[1], az = z - prm.Cw[2];
+        const double cx = vc[3 * i] - prm.Cc[0], cy = vc[3 * i + 1] - prm.Cc[1], cz = vc[3 * i + 2] - prm.Cc[2];
+        acc[20] += v * (cx * cx + cy * cy + cz * cz);
+        acc[11] = fma(v * cx, ax, acc[11]); acc[12] = fma(v * cx, ay, acc[12]); acc[13] = fma(v * cx, az, acc[13]);
+        acc[14] = fma(v * cy, ax, acc[14]); acc[15] = fma(v * cy, ay, acc[15]); acc[16] = fma(v * cy, az, acc[16]);
+        acc[17] = fma(v * cz, ax, acc[17]); acc[18] = fma(v * cz, ay, acc[18]); acc[19] = fma(v * cz, az, acc[19]);
+      }
+      if (nw && ann[i] == 1) {
+        const double l = wnn ? (double)wnn[idx] : 1.0;
+        const double ax = vnw[3 * i], ay = vnw[3 * i + 1], az = vnw[3 * i + 2];
+        const double cx = vnc[3 * i], cy = vnc[3 * i + 1], cz = vnc[3 * i + 2];
+        acc[21] = fma(l * cx, ax, acc[21]); acc[22] = fma(l * cx, ay, acc[22]); acc[23] = fma(l * cx, az, acc[23]);
+        acc[24] = fma(l * cy, ax, acc[24]); acc[25] = fma(l * cy, ay, acc[25]); acc[26] = fma(l * cy, az, acc[26]);
+        acc[27] = fma(l * cz, ax, acc[27]); acc[28] = fma(l * cz, ay, acc[28]); acc[29] = fma(l * cz, az, acc[29]);
+        acc[30] += l; acc[31] += 1.0;
+      }
+    }
+  }
+  block_reduce_store<44>(acc, partials + (size_t)blockIdx.x * kNlLd);
+}
+
+// ================================================================================================
+// launchers
+// ================================================================================================
+static inline int grid_for(int64_t n, int P, int max_blocks) {
+  int64_t groups = (n + P - 1) / P;
+  int64_t g = (groups + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+template <class T> static PoseK<T> make_pose(const double* p12) {
+  PoseK<T> k;
+  for (int i = 0; i < 9; i++) k.R[i] = (T)p12[i];
+  for (int i = 0; i < 3; i++) k.t[i] = (T)p12[9 + i];
+  return k;
+}
+
+template <class T>
+static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, double* d_partials, int max_blocks,
+                              double* d_out32, hipStream_t s) {
+  const T* xw = (const T*)A.a[0];
+  const T* b = (const T*)(kind == KIND_BEARING ? A.a[2] : A.a[1]);
+  const T* c = (const T*)A.a[4];
+  const int mod = kind == KIND_BEARING ? 0 : 1;
+  const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
+  const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
+  const int G = grid_for(A.n, Pk<T>::P, max_blocks);
+  PoseK<double> pose = make_pose<double>(pose12);
+  if (kind == KIND_P2P) {
+    hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2P>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, d_partials);
+    hipLaunchKernelGGL((finalize_kernel<kNeLd, 1>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 17, d_out32);
+  } else if (kind == KIND_P2PLANE) {
+    hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2PLANE>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, d_partials);
+    hipLaunchKernelGGL((finalize_kernel<kNeLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 29, d_out32);
+  } else {
+    hipLaunchKernelGGL((normal_eq_kernel<T, KIND_BEARING>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, d_partials);
+    hipLaunchKernelGGL((finalize_kernel<kNeLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 29, d_out32);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, double* d_partials, int max_blocks,
+                            double* d_out32, hipStream_t s) {
+  return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, d_partials, max_blocks, d_out32, s)
+                 : normal_eq_t<float>(A, kind, flags, pose12, d_partials, max_blocks, d_out32, s);
+}
+
+template <class T>
+static hipError_t moments_t(const DeviceArrays& A, int flags, double* d_partials, int max_blocks, double* d_out32, hipStream_t s) {
+  const short* mask = (flags & F_USE_MASK) ? A.mask[1] : nullptr;
+  const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[1] : nullptr;
+  const int G = grid_for(A.n, Pk<T>::P, max_blocks);
+  hipLaunchKernelGGL((moments_kernel<T>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], mask, weight, A.n,
+                     (flags & F_SKIP_INVALID) ? 1 : 0, d_partials);
+  hipLaunchKernelGGL((finalize_kernel<kNeLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 17, d_out32);
+  return hipGetLastError();
+}
+hipError_t launch_moments(const DeviceArrays& A, int flags, double* d_partials, int max_blocks, double* d_out32, hipStream_t s) {
+  return A.dtype ? moments_t<double>(A, flags, d_partials, max_blocks, d_out32, s) : moments_t<float>(A, flags, d_partials, max_blocks, d_out32, s);
+}
+
+template <class T, int KIND, bool EXACT>
+static void score_launch(const DeviceArrays& A, const void* d_poses, int H, const double* thr, int* d_votes, int G, hipStream_t s) {
+  hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), (size_t)H * sizeof(int), s, (const T*)A.a[0], (const T*)A.a[1],
+                     (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
+}
+template <class T, int KIND, bool EXACT>
+static void mask_launch(const DeviceArrays& A, const void* d_pose, const double* thr, int* d_votes, int G, hipStream_t s) {
+  hipLaunchKernelGGL((mask_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
+                     (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_pose, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2],
+                     d_votes);
+}
+#define RPE_KIND_SWITCH(FN, T, EX, ...)                                    \
+  switch (kind) {                                                          \
+    case VOTE_33: FN<T, VOTE_33, EX>(__VA_ARGS__); break;                  \
+    case VOTE_23: FN<T, VOTE_23, EX>(__VA_ARGS__); break;                  \
+    case VOTE_33_23: FN<T, VOTE_33_23, EX>(__VA_ARGS__); break;            \
+    case VOTE_NN_23: FN<T, VOTE_NN_23, EX>(__VA_ARGS__); break;            \
+    case VOTE_NN_33: FN<T, VOTE_NN_33, EX>(__VA_ARGS__); break;            \
+    case VOTE_NN_33_23: FN<T, VOTE_NN_33_23, EX>(__VA_ARGS__); break;      \
+    case VOTE_23_MATRIX: FN<T, VOTE_23_MATRIX, EX>(__VA_ARGS__); break;    \
+    default: return hipErrorInvalidValue;                                  \
+  }
+
+hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
+                        int max_blocks, hipStream_t s) {
+  if (H < 1 || H > kMaxScoreH) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(d_votes, 0, (size_t)H * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  if (A.dtype) {
+    const int G = grid_for(A.n, 2, max_blocks);
+    if (exact) { RPE_KIND_SWITCH(score_launch, double, true, A, d_poses, H, thr3, d_votes, G, s) }
+    else { RPE_KIND_SWITCH(score_launch, double, false, A, d_poses, H, thr3, d_votes, G, s) }
+  } else {
+    const int G = grid_for(A.n, 4, max_blocks);
+    if (exact) { RPE_KIND_SWITCH(score_launch, float, true, A, d_poses, H, thr3, d_votes, G, s) }
+    else { RPE_KIND_SWITCH(score_launch, float, false, A, d_poses, H, thr3, d_votes, G, s) }
+  }
+  return hipGetLastError();
+}
+hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d_pose, const double* thr3, int* d_votes, int max_blocks,
+                       hipStream_t s) {
+  hipError_t e = hipMemsetAsync(d_votes, 0, sizeof(int), s);
+  if (e != hipSuccess) return e;
+  if (A.dtype) {
+    const int G = grid_for(A.n, 2, max_blocks);
+    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, d_pose, thr3, d_votes, G, s) }
+    else { RPE_KIND_SWITCH(mask_launch, double, false, A, d_pose, thr3, d_votes, G, s) }
+  } else {
+    const int G = grid_for(A.n, 4, max_blocks);
+    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, d_pose, thr3, d_votes, G, s) }
+    else { RPE_KIND_SWITCH(mask_launch, float, false, A, d_pose, thr3, d_votes, G, s) }
+  }
+  return hipGetLastError();
+}
+
+template <class T>
+static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, double* d_partials, int max_blocks, double* d_out64, hipStream_t s) {
+  NlParams prm;
+  for (int i = 0; i < 3; i++) { prm.c_opt[i] = params24[i]; prm.Cw[i] = params24[3 + i]; prm.Cc[i] = params24[6 + i]; }
+  for (int i = 0; i < 9; i++) prm.Rwc[i] = params24[9 + i];
+  const int G = grid_for(A.n, Pk<T>::P, max_blocks);
+  hipLaunchKernelGGL((nl_round_kernel<T>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], (const T*)A.a[3],
+                     (const T*)A.a[4], (const short*)A.mask[0], (const short*)A.mask[1], (const short*)A.mask[2], (const T*)A.weight[0],
+                     (const T*)A.weight[1], (const T*)A.weight[2], A.n, prm, d_partials);
+  hipLaunchKernelGGL((finalize_kernel<kNlLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 44, d_out64);
+  return hipGetLastError();
+}
+hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, double* d_partials, int max_blocks, double* d_out64, hipStream_t s) {
+  return A.dtype ? nl_round_t<double>(A, params24, d_partials, max_blocks, d_out64, s) : nl_round_t<float>(A, params24, d_partials, max_blocks, d_out64, s);
+}
+
+}  // namespace rpe
