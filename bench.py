@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+A "step" is ONE Gauss-Newton iteration of the point-to-point absolute-orientation refinement over one batch of
+synthetic correspondences resident in HBM: stage-1 normal-equation kernel (K1) + stage-2 reduction, [all-reduce
+of the 32-double record over RCCL when --gpus > 1], D2H of the record, 6x6 solve and SE(3) exp-map update on the
+host.  Workload at N=1 = BASELINE.json configs[1]: 640x480 dense depth = 307 200 3D-3D correspondences, fp32.
+Weak scaling: every rank holds its own 307 200-correspondence shard (global problem = N x 307 200), same pose.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 307200           # 640 x 480
+BYTES_PER_CORR = 24 + 2      # Xw 12 + Xc 12 + short inlier mask 2 (p2p fp32 + mask)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+THRE_3D = 0.2                # Parameters.yml thre_3d
+
+
+def make_shard(rank: int, n: int):
+    """Same ground-truth pose on every rank, different points per rank (Simulator.hpp model, Parameters.yml values)."""
+    from rgbd_pose_estimation_amd import simulator as S
+    R, t = S.random_pose(np.random.default_rng(20260101))
+    rng = np.random.default_rng(1000 + rank)
+    return S.simulate_3d_3d_correspondences(rng, R, t, n, 0.05, 0.1).astype(np.float32)
+
+
+def initial_pose(sc):
+    """Start 0.02 rad / 5 cm away from the truth (what a RANSAC winner looks like)."""
+    w = np.array([0.012, -0.010, 0.0125]); th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    dR = np.eye(3) + math.sin(th) / th * K + (1 - math.cos(th)) / th ** 2 * K @ K
+    return dR @ sc.R, sc.t + np.array([0.03, -0.03, 0.03])
+
+
+def rot_err(Ra, Rb):
+    D = Ra @ Rb.T
+    s = np.linalg.norm([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]]) / 2
+    return math.atan2(s, (np.trace(D) - 1) / 2)
+
+
+def cpu_baseline(sc, seconds: float):
+    """Oracle (CPU restatement of the reference) timed on this host: shinji_ls2<float> through AOOnlyPoseAdapter's
+    virtual getters, exactly what Library.cpp ao() runs; 1 thread because the reference is single-threaded."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import oracle_lib as O
+        lib = O.lib()
+        xw, xc = np.ascontiguousarray(sc.Q, np.float32), np.ascontiguousarray(sc.P, np.float32)
+        R, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        n = len(xw)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib.orc_time_ao(p(xw), p(xc), n, 1, p(R), p(t))
+        reps, spent = 0, 0.0
+        while spent < seconds:
+            spent += lib.orc_time_ao(p(xw), p(xc), n, 20, p(R), p(t)); reps += 20
+        pose = np.concatenate([np.eye(3).reshape(9), np.zeros(3)])
+        out = np.zeros(29)
+        g = lib.orc_time_gn_p2p(p(xw), p(xc), C.c_long(n), 20, p(pose), p(out)) / 20
+        return {"value": n * reps / spent, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port",
+                "sample": f"{reps} calls of the oracle's shinji_ls2<float> (AOOnlyPoseAdapter virtual getters, gather + centroid + covariance "
+                          f"passes + 3x3 SVD = Library.cpp ao()) on the same {n}-correspondence scene, g++ -O2, 1 thread, {spent:.1f} s",
+                "gn_pass_fp64_value": n / g, "host_cpus": os.cpu_count()}
+    except Exception as e:  # the baseline is a reported number, never a dependency of the GPU path
+        return {"value": None, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e!r}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8, help="record a HIP event pair around every k-th K1 launch of the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dist = os.environ.get("RPE_BENCH_FORCE_DIST") == "1"   # exercise the collective path with one rank
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from rgbd_pose_estimation_amd import _lib as L, api
+    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton
+
+    if not torch.cuda.is_available() or L.device_count() < 1:
+        sys.exit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1 or force_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n_per_gpu
+    sc = make_shard(rank, n)
+    dist_path = world > 1 or force_dist
+    # the collective needs the kernel on the stream torch orders the all-reduce after; one GPU uses the library's own stream
+    stream = torch.cuda.Stream(device=local_rank) if dist_path else None
+    import contextlib
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        shard = HipShard(local_rank, stream)
+        ctx = shard.ctx
+        ctx.load(L.F32, xw=sc.Q, xc=sc.P)
+        R0, t0 = initial_pose(sc)
+        from rgbd_pose_estimation_amd.api import pose12, pose7_from_Rt
+        # untimed prologue: one scoring pass at the initial pose writes the 3D-3D inlier mask (K4b), as RANSAC would
+        q0 = pose7_from_Rt(R0, t0, L.F32)
+        inl = ctx.inlier_mask(L.VOTE_33, q0, thre_3d=THRE_3D)
+        shard.kind, shard.flags = L.RES_P2P, L.USE_MASK
+        gn = ShardedGaussNewton(shard.normal_eq)
+        pose = pose12(R0, t0)
+
+        def one_step(p):
+            if world == 1 and not force_dist:
+                ctx.gn_step(L.RES_P2P, p, L.USE_MASK)   # in place: kernel + D2H + solve + exp-map
+                return p
+            return gn.step(p)[0]
+
+        for _ in range(args.warmup):
+            pose = one_step(pose)
+        ctx.timing_enable(args.steps, args.time_every)   # HIP events around every time_every-th kernel launch
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            pose = one_step(pose)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        cnt, k_total_ms, k_min_ms = ctx.timing_collect()
+        ctx.timing_enable(0, 1)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        total = float(n) * world * args.steps
+        k_avg_s = (k_total_ms / max(cnt, 1)) * 1e-3
+        achieved = BYTES_PER_CORR * n / k_avg_s / 1e9 if k_avg_s > 0 else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("normal_eq_p2p_f32_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "correspondence-residuals/sec", "value": total / elapsed, "unit": "correspondence-residuals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: 640x480 dense depth, {n} 3D-3D correspondences per GPU, point-to-point absolute "
+                                   "orientation, Gauss-Newton step (K1 normal equations + host SE3 exp-map update) over the RANSAC inlier mask",
+                       "corr_per_gpu": n, "global_corr": n * world, "inliers_rank0": int(inl), "accumulate": "fp64",
+                       "collective": "all-reduce(sum) of 32 fp64 per step over RCCL" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
+                         "avg_launch_us": k_avg_s * 1e6, "min_launch_us": k_min_ms * 1e3, "launches_timed": cnt,
+                         "note": "HIP events on the kernel's own stream around every stage-1 launch of the timed region; 7.99 MB working set is "
+                                 "L2/Infinity-Cache resident after the first step, so this is not an HBM-streaming figure (see DESIGN.md)"},
+        }
+        # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)
+        if world == 1:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                m = ctx.download_mask(L.MOD_33)
+                Ro, to, _ = O.shinji_f32in_f64(sc.Q[m == 1], sc.P[m == 1])
+                out["pose_error_vs_cpu"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), Ro),
+                                            "trans_rel": float(np.linalg.norm(pose[9:] - to) / np.linalg.norm(to)),
+                                            "tolerance": {"rot_rad": 1e-5, "trans_rel": 1e-4},
+                                            "reference": "oracle shinji() fp64 on the same fp32 inputs and inlier set"}
+            except Exception as e:
+                out["pose_error_vs_cpu"] = {"error": repr(e)}
+            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(sc, args.cpu_seconds)
+        else:
+            out["pose_error_vs_truth"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), sc.R), "trans_abs_m": float(np.linalg.norm(pose[9:] - sc.t))}
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1 or force_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,14 +92,15 @@ int rpe_upload_weight(rpe_context* ctx, int modality, const void* host_weight);
 int rpe_download_mask(rpe_context* ctx, int modality, short* host_mask);
 
 /* ---- K1' closed-form moments: the two passes of shinji() (AbsoluteOrientation.hpp:56-73) fused into ONE
- * pass.  out[17] = { sum w, sum w*Xw (3), sum w*Xc (3), sum w*Xc*Xw^T (9, row-major), sum w*|Xc|^2 }.
+ * pass.  out[18] = { sum w, sum w*Xw (3), sum w*Xc (3), sum w*Xc*Xw^T (9, row-major), sum w*|Xc|^2, count of
+ * contributing correspondences }.
  * flags: RPE_USE_MASK -> only mask33 == 1 (shinji_ls/shinji_ls1 inlier set, :279-288); RPE_USE_WEIGHT ->
  * w = weight33 (nl_shinji_kneip_ls centroid pass, AbsoluteOrientationNormal.hpp:457-469);
  * RPE_SKIP_INVALID -> skip NaN columns (isValid).  fp32 inputs are widened, all arithmetic is fp64. */
 enum { RPE_USE_MASK = 1, RPE_USE_WEIGHT = 2, RPE_SKIP_INVALID = 4 };
-int rpe_p2p_moments(rpe_context* ctx, int flags, double* out17);
+int rpe_p2p_moments(rpe_context* ctx, int flags, double* out18);
 /* Closed-form pose from the moments (host: 3x3 SVD, det fix, t = Cc - R*Cw; AbsoluteOrientation.hpp:75-95). */
-int rpe_pose_from_moments(const double* m17, double* R9, double* t3);
+int rpe_pose_from_moments(const double* m18, double* R9, double* t3);
 
 /* ---- K1/K2/K3 Gauss-Newton normal equations (new formulation; objective of K1 == shinji()).
  * kind: residual.  pose12 = R row-major (9) | t (3).  out32: H upper triangle row-major (21) | g (6) |
@@ -112,16 +113,26 @@ enum {
   RPE_RES_BEARING = 2   /* r = normalize(R*Xw + t) x bv  (P3P.hpp:482-485) (3)  arrays XW, BV  24 B/corr      */
 };
 int rpe_normal_eq(rpe_context* ctx, int kind, int flags, const double* pose12, double* out32);
-/* Same, result left in HBM at d_out32 (32 doubles) for a caller-side collective (RCCL all-reduce); no sync. */
+/* Same, result left in HBM at d_out32 (32 doubles, must not be NULL) for a caller-side collective (RCCL
+ * all-reduce); asynchronous on the context's stream. */
 int rpe_normal_eq_device(rpe_context* ctx, int kind, int flags, const double* pose12, double* d_out32);
 /* Host: solve H*delta = -g (Cholesky); RPE_ERR_DEGENERATE if H is not positive definite. */
 int rpe_gn_solve(const double* ne32, double* delta6);
 /* Host: pose <- exp(delta) * pose  (Sophus SE3::exp, sophus/se3.hpp:321-342). */
 int rpe_gn_apply(const double* delta6, double* pose12);
+/* One Gauss-Newton step on one GPU (kernel -> D2H of the 32-double record -> solve -> exp-map update of pose12).
+ * ne32_out / step_norm may be NULL. */
+int rpe_gn_step(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
 /* Whole refinement loop on one GPU: up to 3 residual kinds summed with scales; stops when |delta| < tol.
  * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */
 int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
                   double tol, int* iters_out, double* last_step, double* final_cost);
+
+/* HIP-event timing of the normal-equation kernel, on the context's stream: after enable(max_records, stride)
+ * every stride-th rpe_normal_eq* call records an event pair around that one kernel launch; collect() synchronises,
+ * returns the number of pairs and their total / minimum elapsed milliseconds, and rearms.  enable(0, 1) = off. */
+int rpe_timing_enable(rpe_context* ctx, int max_records, int stride);
+int rpe_timing_collect(rpe_context* ctx, int* count, double* total_ms, double* min_ms);
 
 /* ---- K4 batched hypothesis scoring: the vote loops V1..V8.
  * kind selects the modality set exactly as the reference's loops combine them. */

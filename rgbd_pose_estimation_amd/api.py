@@ -21,6 +21,31 @@ def pose12(R, t):
     return np.concatenate([np.asarray(R, np.float64).reshape(9), np.asarray(t, np.float64).reshape(3)])
 
 
+def pose7_from_Rt(R, t, dtype=L.F32) -> np.ndarray:
+    """(qw qx qy qz tx ty tz) of the Sophus::SE3<Tp> a caller would build from R, t: the quaternion is extracted
+    from the Tp-rounded matrix in Tp arithmetic (Eigen's Quaternion(Matrix3) branches, sophus/so3.hpp:561).
+    Host-side input preparation only."""
+    dt = _np_dtype(dtype)
+    m = np.asarray(R, dt).reshape(3, 3)
+    one, half = dt(1), dt(0.5)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    q = np.zeros(4, dt)
+    if tr > 0:
+        s = np.sqrt(tr + one); q[0] = half * s; s = half / s
+        q[1] = (m[2, 1] - m[1, 2]) * s; q[2] = (m[0, 2] - m[2, 0]) * s; q[3] = (m[1, 0] - m[0, 1]) * s
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(m[i, i] - m[j, j] - m[k, k] + one)
+        q[1 + i] = half * s; s = half / s
+        q[0] = (m[k, j] - m[j, k]) * s; q[1 + j] = (m[j, i] + m[i, j]) * s; q[1 + k] = (m[k, i] + m[i, k]) * s
+    return np.concatenate([q.astype(np.float64), np.asarray(t, dt).astype(np.float64)])
+
+
 class Context:
     """One GPU context holding a correspondence set resident in HBM (rpe_context)."""
 
@@ -88,7 +113,7 @@ class Context:
 
     # ---- kernels
     def p2p_moments(self, flags: int = 0) -> np.ndarray:
-        out = np.zeros(17)
+        out = np.zeros(18)
         L.check(L.lib().rpe_p2p_moments(self._h, flags, _p(out)))
         return out
 
@@ -103,6 +128,20 @@ class Context:
         p = np.array(pose, np.float64).reshape(12).copy()
         L.check(L.lib().rpe_normal_eq_device(self._h, kind, flags, _p(p), C.c_void_p(d_out_ptr)))
         return p
+
+    def gn_step(self, kind: int, pose12_inout: np.ndarray, flags: int = 0) -> float:
+        """One GN step in place on a float64[12] array; returns |delta|."""
+        step = C.c_double(0)
+        L.check(L.lib().rpe_gn_step(self._h, kind, flags, _p(pose12_inout), None, C.byref(step)))
+        return step.value
+
+    def timing_enable(self, max_records: int, stride: int = 1):
+        L.check(L.lib().rpe_timing_enable(self._h, max_records, stride))
+
+    def timing_collect(self):
+        cnt, tot, mn = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.check(L.lib().rpe_timing_collect(self._h, C.byref(cnt), C.byref(tot), C.byref(mn)))
+        return cnt.value, tot.value, mn.value
 
     def gn_refine(self, kinds, pose, scales=None, flags: int = 0, max_iter: int = 20, tol: float = 1e-9):
         kinds = np.ascontiguousarray(kinds, np.int32)
@@ -169,3 +208,33 @@ def ao_ransac(xw, xc):
     R, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
     L.lib().ao_ransac(_p(xw), _p(xc), len(xw), _p(R), _p(t))
     return R.reshape(3, 3), t
+
+
+# ---- adapter-level pipelines (rpe_run): method / ls ids shared with the oracle's C API
+M_SHINJI_RANSAC, M_SHINJI_RANSAC2, M_SHINJI_PROSAC, M_KNEIP_RANSAC, M_KNEIP_PROSAC = 0, 1, 2, 3, 4
+M_SK_RANSAC, M_SK_PROSAC, M_NL_KNEIP_RANSAC, M_NL_SHINJI_RANSAC, M_NL_SK_RANSAC, M_NONE = 5, 6, 7, 8, 9, 10
+LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL, LS_GN_P2P, LS_GN_JOINT, LS_GN_P2PLANE, LS_GN_BEARING = range(9)
+
+
+def run(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weights=None, f=585.0, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0,
+        iters=0, confidence=0.99, seed=1, ls=LS_NONE, score_mode=L.SCORE_FAST, mask_in=None, pose_in=None, max_votes_in=1):
+    """Run one solver of pose/*.hpp on a freshly built adapter (AOOnly / PnP / AO / NormalAO chosen like the
+    reference's demos do).  Returns dict(R, t, iters, max_votes, masks[3, n])."""
+    dt = _np_dtype(dtype)
+    arrs = {k: (None if a is None else np.ascontiguousarray(a, dtype=dt)) for k, a in dict(xw=xw, xc=xc, bv=bv, nw=nw, nc=nc).items()}
+    n = len(arrs["xw"])
+    w = None if weights is None else np.asfortranarray(weights, dtype=dt)
+    prob = L.RpeProblem(n, dtype, _p(arrs["bv"]), _p(arrs["xc"]), _p(arrs["nc"]), _p(arrs["xw"]), _p(arrs["nw"]), _p(w),
+                        0 if w is None else w.shape[1], f, f)
+    R, t = np.zeros(9), np.zeros(3)
+    if pose_in is not None:
+        R[:] = np.asarray(pose_in[0], float).reshape(9)
+        t[:] = np.asarray(pose_in[1], float)
+    else:
+        R[:] = np.eye(3).reshape(9)
+    it, mv = C.c_int(iters), C.c_int(max_votes_in)
+    mi = None if mask_in is None else np.ascontiguousarray(mask_in, dtype=np.int16)
+    mo = np.zeros((3, n), np.int16)
+    L.check(L.lib().rpe_run(method, C.byref(prob), thre_3d, thre_2d, thre_nl, C.byref(it), confidence, seed, ls, score_mode, _p(mi), _p(R),
+                            _p(t), C.byref(mv), _p(mo)))
+    return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mo)

@@ -27,6 +27,11 @@ size_t elem_size(int dtype) { return dtype == RPE_F64 ? 8 : 4; }
 
 }  // namespace
 
+namespace rpe {
+// lets library.cpp (adapter-level pipelines) report through the same rpe_last_error() channel
+int set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
+}  // namespace rpe
+
 struct rpe_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -43,11 +48,19 @@ struct rpe_context {
   int max_blocks = 1024;
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
   double* d_out = nullptr;       // 64 doubles
-  double* h_out = nullptr;       // pinned, 64 doubles
+  double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
+  unsigned int* d_ticket = nullptr;
+  unsigned long long seq = 0;
   void* d_poses = nullptr;       // kMaxScoreH * 12 doubles
   void* h_poses = nullptr;       // pinned staging
   int* d_votes = nullptr;        // kMaxScoreH ints
   int* h_votes = nullptr;        // pinned
+  // optional HIP-event timing of the stage-1 normal-equation kernel (bench.py roofline leg)
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t ev_used = 0;
+  bool timing = false;
+  int timing_stride = 1;
+  unsigned long long timing_calls = 0;
 
   rpe::DeviceArrays arrays() const {
     rpe::DeviceArrays A;
@@ -80,6 +93,33 @@ int need_arrays(rpe_context* c, std::initializer_list<int> slots) {
   static const char* names[] = {"XW (points_g)", "XC (points_c)", "BV (bearingVectors)", "NW (normal_g)", "NC (normal_c)"};
   for (int s : slots) if (!c->arr[s]) return fail(RPE_ERR_STATE, "array %s was never uploaded or bound", names[s]);
   return RPE_OK;
+}
+
+rpe::ReduceTarget host_target(rpe_context* c) {
+  rpe::ReduceTarget rt;
+  rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks;
+  rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
+  return rt;
+}
+rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
+  rpe::ReduceTarget rt;
+  rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks;
+  rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
+  return rt;
+}
+// Spin on the sequence word the kernel's last workgroup stores after the record (pinned, coherent host memory).
+int wait_host(rpe_context* c, int ld) {
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out + ld);
+  const unsigned long long want = c->seq;
+  for (unsigned long long spins = 0;; spins++) {
+    if (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) == want) return RPE_OK;
+    if ((spins & 0xFFFFF) == 0xFFFFF) {  // every ~1M polls: has the stream died?
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+      if (q == hipSuccess && __atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != want)
+        return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu)", want);
+    }
+  }
 }
 
 int kind_arrays(rpe_context* c, int kind) {
@@ -126,7 +166,9 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)c->max_blocks * rpe::kNlLd * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 64 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 64); }
+  if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 64);
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
@@ -144,11 +186,14 @@ void rpe_destroy(rpe_context* c) {
   for (int i = 0; i < 3; i++) { if (c->mask[i]) (void)hipFree(c->mask[i]); if (c->weight[i]) (void)hipFree(c->weight[i]); }
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_out) (void)hipFree(c->d_out);
+  if (c->d_ticket) (void)hipFree(c->d_ticket);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->h_poses) (void)hipHostFree(c->h_poses);
   if (c->d_votes) (void)hipFree(c->d_votes);
   if (c->h_votes) (void)hipHostFree(c->h_votes);
+  for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -238,16 +283,15 @@ int rpe_download_mask(rpe_context* c, int mod, short* host_mask) {
 }
 
 // ---------------------------------------------------------------------------------------------- K1'
-int rpe_p2p_moments(rpe_context* c, int flags, double* out17) {
+int rpe_p2p_moments(rpe_context* c, int flags, double* out18) {
   int rc = need_arrays(c, {RPE_XW, RPE_XC});
   if (rc) return rc;
-  if (!out17) return fail(RPE_ERR_ARG, "null out17");
+  if (!out18) return fail(RPE_ERR_ARG, "null out18");
   if ((rc = check_flags(c, RPE_RES_P2P, flags))) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_moments(c->arrays(), flags, c->d_partials, c->max_blocks, c->d_out, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < 17; i++) out17[i] = c->h_out[i];
+  HIP_TRY(rpe::launch_moments(c->arrays(), flags, host_target(c), c->stream));
+  if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  for (int i = 0; i < 18; i++) out18[i] = c->h_out[i];
   return RPE_OK;
 }
 
@@ -266,22 +310,71 @@ int rpe_pose_from_moments(const double* m, double* R9, double* t3) {
 }
 
 // ---------------------------------------------------------------------------------------------- K1/K2/K3
-int rpe_normal_eq_device(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
+static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
   int rc = kind_arrays(c, kind);
   if (rc) return rc;
-  if (!pose12 || !d_out32) return fail(RPE_ERR_ARG, "null argument");
+  if (!pose12) return fail(RPE_ERR_ARG, "null argument");
   if ((rc = check_flags(c, kind, flags))) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, c->d_partials, c->max_blocks, d_out32, c->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : host_target(c), c->stream, e0, e1));
+  return RPE_OK;
+}
+
+int rpe_normal_eq_device(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
+  if (!d_out32) return fail(RPE_ERR_ARG, "null d_out32");
+  return normal_eq_launch(c, kind, flags, pose12, d_out32);
+}
+
+int rpe_timing_enable(rpe_context* c, int max_records, int stride) {
+  if (!c || max_records < 0 || stride < 1) return fail(RPE_ERR_ARG, "rpe_timing_enable: bad argument");
+  c->timing_stride = stride; c->timing_calls = 0;
+  HIP_TRY(hipSetDevice(c->device));
+  while ((int)c->ev0.size() < max_records) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    c->ev0.push_back(a); c->ev1.push_back(b);
+  }
+  c->ev_used = 0;
+  c->timing = max_records > 0;
+  return RPE_OK;
+}
+
+int rpe_timing_collect(rpe_context* c, int* count, double* total_ms, double* min_ms) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double tot = 0, mn = 1e30;
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+    tot += ms; if (ms < mn) mn = ms;
+  }
+  if (count) *count = (int)c->ev_used;
+  if (total_ms) *total_ms = tot;
+  if (min_ms) *min_ms = c->ev_used ? mn : 0.0;
+  c->ev_used = 0;
+  return RPE_OK;
+}
+
+// One Gauss-Newton step on one GPU: normal equations (device) -> solve -> pose <- exp(delta) * pose (host).
+int rpe_gn_step(rpe_context* c, int kind, int flags, double* pose12, double* ne32_out, double* step_norm) {
+  double ne[32], d[6];
+  int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
+  if (rc) return rc;
+  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
+  rpe::se3_left_update(d, pose12);
+  if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
+  if (step_norm) *step_norm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
   return RPE_OK;
 }
 
 int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, double* out32) {
   if (!out32) return fail(RPE_ERR_ARG, "null out32");
-  int rc = rpe_normal_eq_device(c, kind, flags, pose12, c ? c->d_out : nullptr);
+  int rc = normal_eq_launch(c, kind, flags, pose12, nullptr);  // null device target = publish to pinned host memory
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
   return RPE_OK;
 }
@@ -423,9 +516,8 @@ int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const 
   for (int i = 0; i < 3; i++) { prm[i] = c_opt3[i]; prm[3 + i] = Cw3[i]; prm[6 + i] = Cc3[i]; }
   for (int i = 0; i < 9; i++) prm[9 + i] = Rwc9[i];
   for (int i = 18; i < 24; i++) prm[i] = 0;
-  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, c->d_partials, c->max_blocks, c->d_out, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, 64 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, host_target(c), c->stream));
+  if ((rc = wait_host(c, rpe::kNlLd))) return rc;
   for (int i = 0; i < 44; i++) out44[i] = c->h_out[i];
   return RPE_OK;
 }

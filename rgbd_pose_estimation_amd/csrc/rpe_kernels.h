@@ -19,18 +19,26 @@ struct DeviceArrays {
   int dtype;
 };
 
-// stage 1 + stage 2 of the normal-equation reduction.  d_partials: max_blocks * kNeLd doubles.
-hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, double* d_partials, int max_blocks,
-                            double* d_out32, hipStream_t s);
-hipError_t launch_moments(const DeviceArrays& A, int flags, double* d_partials, int max_blocks, double* d_out32, hipStream_t s);
+// Where a reduction kernel leaves its result (both stages run inside one launch, see reduce_and_finish).
+struct ReduceTarget {
+  double* d_partials;          // max_blocks * kNlLd doubles of scratch
+  unsigned int* d_ticket;      // arrival counter, zero between launches
+  int max_blocks;
+  double* d_out;               // record in HBM (for a collective), or null
+  double* h_out;               // record in pinned host memory + sequence word at [LD], or null
+  unsigned long long seq;      // sequence value published after the record
+};
+// ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
+hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
+                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s);
 // d_poses: H x 12 (fast: R row-major, t) or H x 8 (exact: qw qx qy qz tx ty tz pad) values of the array dtype.
 // thr: {thre_3d (fast: squared), cos_thr, cos_nl} as doubles holding values of the array dtype.
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s);
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d_pose, const double* thr3, int* d_votes, int max_blocks,
                        hipStream_t s);
-// d_params: 24 doubles = c_opt(3) Cw(3) Cc(3) Rwc(9) pad;  d_partials: max_blocks * kNlLd doubles; d_out: 64 doubles
-hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, double* d_partials, int max_blocks, double* d_out64,
-                           hipStream_t s);
+// params24 = c_opt(3) Cw(3) Cc(3) Rwc(9) pad; record = 64 doubles
+hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s);
 
 }  // namespace rpe

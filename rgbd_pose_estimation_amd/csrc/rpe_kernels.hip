@@ -50,26 +50,176 @@ __device__ __forceinline__ void load_scalars(const S* __restrict__ a, int64_t g,
 #pragma unroll
   for (int i = 0; i < P; i++) { int64_t idx = g * P + i; v[i] = idx < n ? a[idx] : fill; }
 }
+// P inlier flags (short) of group g with one 8-byte (fp32, P = 4) or 4-byte (fp64, P = 2) load
+__device__ __forceinline__ void load_mask_group(const short* __restrict__ m, int64_t g, int64_t n, short (&v)[4]) {
+  if ((g + 1) * 4 <= n) {
+    const uint2 u = *reinterpret_cast<const uint2*>(m + 4 * g);
+    v[0] = (short)(u.x & 0xffffu); v[1] = (short)(u.x >> 16); v[2] = (short)(u.y & 0xffffu); v[3] = (short)(u.y >> 16);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { int64_t idx = g * 4 + i; v[i] = idx < n ? m[idx] : (short)0; }
+  }
+}
+__device__ __forceinline__ void load_mask_group(const short* __restrict__ m, int64_t g, int64_t n, short (&v)[2]) {
+  if ((g + 1) * 2 <= n) {
+    const unsigned int u = *reinterpret_cast<const unsigned int*>(m + 2 * g);
+    v[0] = (short)(u & 0xffffu); v[1] = (short)(u >> 16);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { int64_t idx = g * 2 + i; v[i] = idx < n ? m[idx] : (short)0; }
+  }
+}
+__device__ __forceinline__ void load_weight_group(const float* __restrict__ w, int64_t g, int64_t n, float (&v)[4]) {
+  if ((g + 1) * 4 <= n) { const float4 u = *reinterpret_cast<const float4*>(w + 4 * g); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
+  else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { int64_t idx = g * 4 + i; v[i] = idx < n ? w[idx] : 0.f; }
+  }
+}
+__device__ __forceinline__ void load_weight_group(const double* __restrict__ w, int64_t g, int64_t n, double (&v)[2]) {
+  if ((g + 1) * 2 <= n) { const double2 u = *reinterpret_cast<const double2*>(w + 2 * g); v[0] = u.x; v[1] = u.y; }
+  else {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { int64_t idx = g * 2 + i; v[i] = idx < n ? w[idx] : 0.0; }
+  }
+}
 template <class T> __device__ __forceinline__ bool all_nan(T x, T y, T z) { return x != x && y != y && z != z; }
 
-// ---- wave64 shuffle tree + one LDS hop; writes NACC doubles of this workgroup to row[]
-template <int NACC>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ row) {
-  __shared__ double red[kBlock / 64][NACC];
+// ---- two-stage reduction inside ONE launch.
+// Stage 1 (every workgroup): wave64 __shfl_down tree, one LDS hop across the 4 waves, one LD-double partial record
+// in HBM.  Stage 2 (the workgroup whose ticket is last): sums the G records IN ROW ORDER -- the result does not
+// depend on which workgroup happens to be last, so it is bitwise reproducible -- expands it to the packed
+// normal-equation record and publishes it to HBM (for a collective) and/or to pinned host memory followed by a
+// sequence word the host spins on (no D2H copy kernel, no stream synchronise on the critical path).
+// Hand-off protocol = cdna_hip_programming.md Guideline 16: plain stores -> storing wave's vmcnt(0) -> barrier ->
+// lane-0 agent release -> vmcnt(0) -> relaxed agent ticket add; last arriver: agent acquire -> vmcnt(0) -> barrier.
+// wave64 sum by DPP cross-lane moves (no LDS traffic): butterfly inside each row of 16 lanes (quad_perm, row_ror),
+// then row_bcast:15 / row_bcast:31 fold the four rows; the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_move<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v += dpp_move<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v += dpp_move<0x124, 0xf>(v);   // row_ror:4
+  v += dpp_move<0x128, 0xf>(v);   // row_ror:8
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+struct Finish {
+  double* partials;            // gridDim.x * LD doubles
+  unsigned int* ticket;        // zero before the launch; the last workgroup rearms it
+  double* out_dev;             // LD doubles in HBM, or null
+  double* out_host;            // LD doubles + 1 sequence word in pinned host memory, or null
+  unsigned long long seq;      // value published after the record
+};
+
+template <int NACC, int LD, int MODE>
+__device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Finish& fin) {
+  constexpr int NW = kBlock / 64;
+  constexpr int RG = kBlock / LD;
+  __shared__ double red[NW][NACC];
+  __shared__ double part[RG][LD];
+  __shared__ double tot[LD];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NACC; k++) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) red[wave][k] = v;
+    const double v = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) red[wave][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < NACC) {
-    double s = red[0][threadIdx.x];
+  const int G = gridDim.x;
+  if (G > 1) {
+    // Hand-off without fences (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms"): EVERY byte of
+    // the partial records is stored write-through (relaxed agent-scope atomic store = global_store sc1) and loaded
+    // L1-bypassing (relaxed agent-scope atomic load = global_load sc1); the storing wave drains vmcnt before the
+    // workgroup barrier, one lane then adds to the ticket, and the workgroup whose add returned G-1 reads after a barrier.
+    if (threadIdx.x < NACC) {
+      double s = red[0][threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < kBlock / 64; w++) s += red[w][threadIdx.x];
-    row[threadIdx.x] = s;
+      for (int w = 1; w < NW; w++) s += red[w][threadIdx.x];
+      __hip_atomic_store(fin.partials + (size_t)blockIdx.x * LD + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int prev = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = prev == (unsigned int)(G - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // fixed-order column sums: thread (j, rg) takes rows rg, rg + RG, ... ; U independent loads in flight
+    const int j = threadIdx.x % LD, rg = threadIdx.x / LD;
+    double s = 0.0;
+    if (j < NACC) {
+      constexpr int U = 16;
+      for (int r0 = rg; r0 < G; r0 += RG * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int r = r0 + u * RG;
+          v[u] = r < G ? __hip_atomic_load(fin.partials + (size_t)r * LD + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) s += v[u];
+      }
+    }
+    part[rg][j] = s;
+    __syncthreads();
+    if (threadIdx.x < LD) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < RG; k++) t += part[k][threadIdx.x];
+      tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rearm
+  } else {
+    if (threadIdx.x < LD) {
+      double t = 0.0;
+      if (threadIdx.x < NACC) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) t += red[w][threadIdx.x];
+      }
+      tot[threadIdx.x] = t;
+    }
+  }
+  __syncthreads();
+  // publish
+  double val = 0.0;
+  if (threadIdx.x < LD) {
+    if (MODE == 0) val = tot[threadIdx.x];
+    else {  // expand the 17 structured p2p sums into the packed record (H upper triangle 21 | g 6 | cost | weight)
+      const double nn = tot[0], Sx = tot[1], Sy = tot[2], Sz = tot[3];
+      const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
+      switch (threadIdx.x) {
+        case 0: case 6: case 11: case 28: val = nn; break;  // (0,0) (1,1) (2,2) ; weight sum
+        case 4: val = Sz; break;    case 5: val = -Sy; break;    // (0,4) (0,5)
+        case 8: val = -Sz; break;   case 10: val = Sx; break;    // (1,3) (1,5)
+        case 12: val = Sy; break;   case 13: val = -Sx; break;   // (2,3) (2,4)
+        case 15: val = yy + zz; break; case 16: val = -xy; break; case 17: val = -xz; break;  // row 3
+        case 18: val = xx + zz; break; case 19: val = -yz; break;                              // row 4
+        case 20: val = xx + yy; break;                                                         // row 5
+        case 21: case 22: case 23: case 24: case 25: case 26: val = tot[threadIdx.x - 11]; break;  // g = (sum r, sum p x r)
+        case 27: val = tot[16]; break;
+        default: val = 0.0;
+      }
+    }
+    if (fin.out_dev) fin.out_dev[threadIdx.x] = val;
+    // pinned, coherent host memory: system-scope stores go straight out over PCIe (posted, ordered)
+    if (fin.out_host) __hip_atomic_store(fin.out_host + threadIdx.x, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (fin.out_host) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -154,7 +304,7 @@ __device__ __forceinline__ void bearing_point(const PoseK<double>& T, C x, C y, 
 template <class T, int KIND>
 __global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                                                            const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
-                                                           PoseK<double> pose, double* __restrict__ partials) {
+                                                           PoseK<double> pose, Finish fin) {
   constexpr int P = Pk<T>::P;
   constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
   double acc[NACC];
@@ -168,14 +318,14 @@ __global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__
     load_group<T>(b, g, n, vb);
     if (KIND == KIND_P2PLANE) load_group<T>(c, g, n, vc);
     T w[P];
-    if (weight) load_scalars<T, T>(weight, g, n, w, T(0));
+    if (weight) load_weight_group(weight, g, n, w);
     else {
 #pragma unroll
       for (int i = 0; i < P; i++) w[i] = (g * P + i) < n ? T(1) : T(0);
     }
     if (mask) {
       short m[P];
-      load_scalars<T, short>(mask, g, n, m, (short)0);
+      load_mask_group(mask, g, n, m);
 #pragma unroll
       for (int i = 0; i < P; i++) w[i] = m[i] == 1 ? w[i] : T(0);
     }
@@ -201,67 +351,20 @@ __global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < NACC; k++) acc[k] += (double)s[k];
   }
-  block_reduce_store<NACC>(acc, partials + (size_t)blockIdx.x * kNeLd);
-}
-
-// ---- stage 2: one workgroup sums the G partial records in a fixed order and writes the final record.
-// MODE 0: copy ncols values; MODE 1: expand the 17 structured p2p sums into the packed 29-value record.
-template <int LD, int MODE>
-__global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restrict__ partials, int G, int ncols, double* __restrict__ out) {
-  constexpr int RG = kBlock / LD;  // row groups
-  __shared__ double part[RG][LD];
-  __shared__ double tot[LD];
-  const int j = threadIdx.x % LD, rg = threadIdx.x / LD;
-  double s = 0.0;
-  if (j < ncols) {
-    int r = rg;
-    for (; r + 3 * RG < G; r += 4 * RG) {  // 4 independent loads in flight, summed in row order
-      double a0 = partials[(size_t)r * LD + j], a1 = partials[(size_t)(r + RG) * LD + j];
-      double a2 = partials[(size_t)(r + 2 * RG) * LD + j], a3 = partials[(size_t)(r + 3 * RG) * LD + j];
-      s += a0; s += a1; s += a2; s += a3;
-    }
-    for (; r < G; r += RG) s += partials[(size_t)r * LD + j];
-  }
-  part[rg][j] = s;
-  __syncthreads();
-  if (threadIdx.x < LD) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < RG; k++) t += part[k][threadIdx.x];
-    tot[threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (MODE == 0) {
-    if (threadIdx.x < LD) out[threadIdx.x] = threadIdx.x < ncols ? tot[threadIdx.x] : 0.0;
-  } else if (threadIdx.x == 0) {
-    const double nn = tot[0], Sx = tot[1], Sy = tot[2], Sz = tot[3];
-    const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
-    double o[32];
-    for (int k = 0; k < 32; k++) o[k] = 0.0;
-    o[0] = nn; o[4] = Sz; o[5] = -Sy;            // row 0: (0,0) (0,1) (0,2) (0,3) (0,4) (0,5)
-    o[6] = nn; o[8] = -Sz; o[10] = Sx;           // row 1: (1,1) (1,2) (1,3) (1,4) (1,5)
-    o[11] = nn; o[12] = Sy; o[13] = -Sx;         // row 2: (2,2) (2,3) (2,4) (2,5)
-    o[15] = yy + zz; o[16] = -xy; o[17] = -xz;   // row 3
-    o[18] = xx + zz; o[19] = -yz;                // row 4
-    o[20] = xx + yy;                             // row 5
-    for (int k = 0; k < 6; k++) o[21 + k] = tot[10 + k];
-    o[27] = tot[16]; o[28] = nn;
-    for (int k = 0; k < 32; k++) out[k] = o[k];
-  }
+  reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0>(acc, fin);
 }
 
 // ================================================================================================
-// K1' : closed-form moments (both passes of shinji() in one): w | w Xw | w Xc | w Xc Xw^T | w |Xc|^2
+// K1' : closed-form moments (both passes of shinji() in one): w | w Xw | w Xc | w Xc Xw^T | w |Xc|^2 | count
 // fp32 x fp32 products are exact in fp64, so only the fp64 summation rounds.
 // ================================================================================================
 template <class T>
 __global__ __launch_bounds__(kBlock) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const short* __restrict__ mask,
-                                                         const T* __restrict__ weight, int64_t n, int skip_invalid,
-                                                         double* __restrict__ partials) {
+                                                         const T* __restrict__ weight, int64_t n, int skip_invalid, Finish fin) {
   constexpr int P = Pk<T>::P;
-  double acc[17];
+  double acc[18];
 #pragma unroll
-  for (int k = 0; k < 17; k++) acc[k] = 0.0;
+  for (int k = 0; k < 18; k++) acc[k] = 0.0;
   const int64_t groups = (n + P - 1) / P;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
@@ -269,24 +372,24 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const T* __restrict__ x
     load_group<T>(xw, g, n, vw);
     load_group<T>(xc, g, n, vc);
     T w[P];
-    if (weight) load_scalars<T, T>(weight, g, n, w, T(0));
-    else {
+    bool on[P];
 #pragma unroll
-      for (int i = 0; i < P; i++) w[i] = (g * P + i) < n ? T(1) : T(0);
-    }
+    for (int i = 0; i < P; i++) { on[i] = (g * P + i) < n; w[i] = T(1); }
+    if (weight) load_weight_group(weight, g, n, w);
     if (mask) {
       short m[P];
-      load_scalars<T, short>(mask, g, n, m, (short)0);
+      load_mask_group(mask, g, n, m);
 #pragma unroll
-      for (int i = 0; i < P; i++) w[i] = m[i] == 1 ? w[i] : T(0);
+      for (int i = 0; i < P; i++) on[i] = on[i] && m[i] == 1;
     }
 #pragma unroll
     for (int i = 0; i < P; i++) {
       double x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
       double cx = vc[3 * i], cy = vc[3 * i + 1], cz = vc[3 * i + 2];
-      double wi = w[i];
-      if (skip_invalid && all_nan(cx, cy, cz)) wi = 0.0;
-      if (wi == 0.0) { x = y = z = cx = cy = cz = 0.0; }
+      const bool use = on[i] && !(skip_invalid && all_nan(cx, cy, cz));
+      const double wi = use ? (double)w[i] : 0.0;
+      if (!use) { x = y = z = cx = cy = cz = 0.0; }
+      acc[17] += use ? 1.0 : 0.0;
       const double wcx = wi * cx, wcy = wi * cy, wcz = wi * cz;
       acc[0] += wi;
       acc[1] = fma(wi, x, acc[1]); acc[2] = fma(wi, y, acc[2]); acc[3] = fma(wi, z, acc[3]);
@@ -297,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const T* __restrict__ x
       acc[16] = fma(wcx, cx, fma(wcy, cy, fma(wcz, cz, acc[16])));
     }
   }
-  block_reduce_store<17>(acc, partials + (size_t)blockIdx.x * kNeLd);
+  reduce_and_finish<18, kNeLd, 0>(acc, fin);
 }
 
 // ================================================================================================
@@ -519,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void nl_round_kernel(const T* __restrict__ 
                                                           const short* __restrict__ k23, const short* __restrict__ k33,
                                                           const short* __restrict__ knn, const T* __restrict__ w23,
                                                           const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n, NlParams prm,
-                                                          double* __restrict__ partials) {
+                                                          Finish fin) {
   constexpr int P = Pk<T>::P;
   double acc[44];
 #pragma unroll
@@ -584,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void nl_round_kernel(const T* __restrict__ 
       }
     }
   }
-  block_reduce_store<44>(acc, partials + (size_t)blockIdx.x * kNlLd);
+  reduce_and_finish<44, kNlLd, 0>(acc, fin);
 }
 
 // ================================================================================================
@@ -604,47 +707,47 @@ template <class T> static PoseK<T> make_pose(const double* p12) {
   return k;
 }
 
+static Finish make_finish(const ReduceTarget& rt) {
+  Finish f;
+  f.partials = rt.d_partials; f.ticket = rt.d_ticket; f.out_dev = rt.d_out; f.out_host = rt.h_out; f.seq = rt.seq;
+  return f;
+}
+
 template <class T>
-static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, double* d_partials, int max_blocks,
-                              double* d_out32, hipStream_t s) {
+static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
+                              hipEvent_t ev0, hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
   const T* b = (const T*)(kind == KIND_BEARING ? A.a[2] : A.a[1]);
   const T* c = (const T*)A.a[4];
   const int mod = kind == KIND_BEARING ? 0 : 1;
   const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
-  const int G = grid_for(A.n, Pk<T>::P, max_blocks);
+  const int G = grid_for(A.n, Pk<T>::P, rt.max_blocks);
   PoseK<double> pose = make_pose<double>(pose12);
-  if (kind == KIND_P2P) {
-    hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2P>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, d_partials);
-    hipLaunchKernelGGL((finalize_kernel<kNeLd, 1>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 17, d_out32);
-  } else if (kind == KIND_P2PLANE) {
-    hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2PLANE>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, d_partials);
-    hipLaunchKernelGGL((finalize_kernel<kNeLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 29, d_out32);
-  } else {
-    hipLaunchKernelGGL((normal_eq_kernel<T, KIND_BEARING>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, d_partials);
-    hipLaunchKernelGGL((finalize_kernel<kNeLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 29, d_out32);
-  }
+  const Finish fin = make_finish(rt);
+  if (ev0) (void)hipEventRecord(ev0, s);
+  if (kind == KIND_P2P) hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2P>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, fin);
+  else if (kind == KIND_P2PLANE) hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2PLANE>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, fin);
+  else hipLaunchKernelGGL((normal_eq_kernel<T, KIND_BEARING>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, fin);
+  if (ev1) (void)hipEventRecord(ev1, s);
   return hipGetLastError();
 }
-hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, double* d_partials, int max_blocks,
-                            double* d_out32, hipStream_t s) {
-  return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, d_partials, max_blocks, d_out32, s)
-                 : normal_eq_t<float>(A, kind, flags, pose12, d_partials, max_blocks, d_out32, s);
+hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
+                            hipEvent_t ev0, hipEvent_t ev1) {
+  return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s, ev0, ev1);
 }
 
 template <class T>
-static hipError_t moments_t(const DeviceArrays& A, int flags, double* d_partials, int max_blocks, double* d_out32, hipStream_t s) {
+static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
   const short* mask = (flags & F_USE_MASK) ? A.mask[1] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[1] : nullptr;
-  const int G = grid_for(A.n, Pk<T>::P, max_blocks);
+  const int G = grid_for(A.n, Pk<T>::P, rt.max_blocks);
   hipLaunchKernelGGL((moments_kernel<T>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], mask, weight, A.n,
-                     (flags & F_SKIP_INVALID) ? 1 : 0, d_partials);
-  hipLaunchKernelGGL((finalize_kernel<kNeLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 17, d_out32);
+                     (flags & F_SKIP_INVALID) ? 1 : 0, make_finish(rt));
   return hipGetLastError();
 }
-hipError_t launch_moments(const DeviceArrays& A, int flags, double* d_partials, int max_blocks, double* d_out32, hipStream_t s) {
-  return A.dtype ? moments_t<double>(A, flags, d_partials, max_blocks, d_out32, s) : moments_t<float>(A, flags, d_partials, max_blocks, d_out32, s);
+hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
+  return A.dtype ? moments_t<double>(A, flags, rt, s) : moments_t<float>(A, flags, rt, s);
 }
 
 template <class T, int KIND, bool EXACT>
@@ -703,19 +806,18 @@ hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d
 }
 
 template <class T>
-static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, double* d_partials, int max_blocks, double* d_out64, hipStream_t s) {
+static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s) {
   NlParams prm;
   for (int i = 0; i < 3; i++) { prm.c_opt[i] = params24[i]; prm.Cw[i] = params24[3 + i]; prm.Cc[i] = params24[6 + i]; }
   for (int i = 0; i < 9; i++) prm.Rwc[i] = params24[9 + i];
-  const int G = grid_for(A.n, Pk<T>::P, max_blocks);
+  const int G = grid_for(A.n, Pk<T>::P, rt.max_blocks);
   hipLaunchKernelGGL((nl_round_kernel<T>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], (const T*)A.a[3],
                      (const T*)A.a[4], (const short*)A.mask[0], (const short*)A.mask[1], (const short*)A.mask[2], (const T*)A.weight[0],
-                     (const T*)A.weight[1], (const T*)A.weight[2], A.n, prm, d_partials);
-  hipLaunchKernelGGL((finalize_kernel<kNlLd, 0>), dim3(1), dim3(kBlock), 0, s, (const double*)d_partials, G, 44, d_out64);
+                     (const T*)A.weight[1], (const T*)A.weight[2], A.n, prm, make_finish(rt));
   return hipGetLastError();
 }
-hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, double* d_partials, int max_blocks, double* d_out64, hipStream_t s) {
-  return A.dtype ? nl_round_t<double>(A, params24, d_partials, max_blocks, d_out64, s) : nl_round_t<float>(A, params24, d_partials, max_blocks, d_out64, s);
+hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s) {
+  return A.dtype ? nl_round_t<double>(A, params24, rt, s) : nl_round_t<float>(A, params24, rt, s);
 }
 
 }  // namespace rpe

@@ -1,0 +1,93 @@
+// pose/AOOnlyPoseAdapter.hpp -- drop-in for /root/reference/pose/AOOnlyPoseAdapter.hpp:26-255 (3D-3D only).
+// Differences, all additive or fixes of undefined behaviour:
+//   * inlier index lists are int, not short (the reference's `for (short r...)` loop never runs for N > 32767,
+//     :222-231, so RANSAC -> LS breaks at 640x480 = 307200 points)
+//   * the referenced matrices may be any type with data()/rows()/cols() (column-major 3 x N)
+//   * pointsCurrData()/pointsGlobData() expose the contiguous arrays to the device backend
+#ifndef RPE_AO_ONLY_POSE_ADAPTER_HEADER
+#define RPE_AO_ONLY_POSE_ADAPTER_HEADER
+
+#include <algorithm>
+#include <iostream>
+#include <numeric>
+#include "PoseAdapterBase.hpp"
+#include "Utility.hpp"
+
+template <typename Tp>
+class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
+ protected:
+  using PoseAdapterBase<Tp>::_t_w;
+  using PoseAdapterBase<Tp>::_R_cw;
+
+ public:
+  typedef typename PoseAdapterBase<Tp>::Vector3 Vector3;
+  typedef typename PoseAdapterBase<Tp>::SO3_T SO3_T;
+  typedef typename PoseAdapterBase<Tp>::Point3 Point3;
+  typedef rpe::MatrixX<Tp> MatrixX;
+
+  template <class M> AOOnlyPoseAdapter(const M& points_c, const M& points_g)
+      : PoseAdapterBase<Tp>(), _points_c(points_c), _points_g(points_g) { init(); }
+  template <class M> AOOnlyPoseAdapter(const M& points_c, const M& points_g, const SO3_T& R)
+      : PoseAdapterBase<Tp>(R), _points_c(points_c), _points_g(points_g) { init(); }
+  template <class M> AOOnlyPoseAdapter(const M& points_c, const M& points_g, const Vector3& t, const SO3_T& R)
+      : PoseAdapterBase<Tp>(t, R), _points_c(points_c), _points_g(points_g) { init(); }
+  virtual ~AOOnlyPoseAdapter() {}
+
+  bool isInlier33(int index) const { return _inliers_3d[index] == 1; }
+  Tp weight33(int index) const { return _weights_3d.empty() ? Tp(1.0) : _weights_3d[index]; }  // raw weight (reference :175-183)
+  virtual Point3 getBearingVector(int) const { return Point3(); }
+  virtual Point3 getPointCurr(int index) const { return _points_c.col(index); }
+  virtual Point3 getPointGlob(int index) const { return _points_g.col(index); }
+  virtual Tp getWeight(int) const { return Tp(1.); }
+  virtual int getNumberCorrespondences() const { return _points_g.cols(); }
+
+  void setMaxVotes(int votes) { _max_votes = votes; }
+  int getMaxVotes() { return _max_votes; }
+
+  // a column is invalid only when ALL THREE coordinates are NaN (reference :147-152 uses ||)
+  virtual bool isValid(int index) const { Point3 p = _points_c.col(index); return p[0] == p[0] || p[1] == p[1] || p[2] == p[2]; }
+  // N x 2 mask: column 1 is the 3D-3D inlier flag; an N x 1 mask is ignored (reference :185-198)
+  virtual void setInlier(const rpe::MatrixXs& inliers) {
+    if (inliers.cols() != 1) {
+      for (int i = 0; i < inliers.rows(); i++) _inliers_3d[i] = inliers(i, 1);
+      this->device().mask_changed_on_host(RPE_MOD_33);
+    }
+  }
+  // N x 3 weights: column 1 (reference :200-212 tests rows() == 1)
+  template <class M> void setWeights(const M& weights) {
+    if (weights.rows() != 1) {
+      _weights_3d.resize(weights.rows());
+      for (int i = 0; i < (int)weights.rows(); i++) _weights_3d[i] = weights(i, 1);
+      this->device().weight_changed_on_host(RPE_MOD_33);
+    }
+  }
+  virtual void printInlier() const { for (short v : _inliers_3d) std::cout << v << " "; std::cout << std::endl; }
+  const std::vector<int>& getInlierIdx() const { return _vInliersAO; }
+  void cvtInlier() {
+    _vInliersAO.clear();
+    for (int r = 0; r < (int)_inliers_3d.size(); r++) if (1 == _inliers_3d[r]) _vInliersAO.push_back(r);
+  }
+  void sortIdx() { _idx = sortIndexes<Tp>(_weights_3d); }
+  void getSortedIdx(std::vector<int>& select_) const {
+    for (size_t i = 0; i < select_.size(); ++i) { const int j = select_[i]; if (j < (int)_idx.size()) select_[i] = _idx[j]; }
+  }
+
+  // ---- additive accessors for the device backend
+  const Tp* pointsCurrData() const { return _points_c.p; }
+  const Tp* pointsGlobData() const { return _points_g.p; }
+  std::vector<short>& inlierMask33() { return _inliers_3d; }
+  const std::vector<short>& inlierMask33() const { return _inliers_3d; }
+  const std::vector<Tp>& weights33() const { return _weights_3d; }
+  Tp weightScale33() const { return Tp(1); }
+
+ protected:
+  void init() { _inliers_3d.assign((size_t)_points_c.cols(), (short)1); _max_votes = 0; }
+  rpe::ColumnView<Tp> _points_c, _points_g;
+  std::vector<short> _inliers_3d;
+  std::vector<Tp> _weights_3d;
+  std::vector<int> _idx;
+  std::vector<int> _vInliersAO;
+  int _max_votes;
+};
+
+#endif

@@ -1,0 +1,78 @@
+// pose/AOPoseAdapter.hpp -- drop-in for /root/reference/pose/AOPoseAdapter.hpp:26-217 (2D-3D + 3D-3D; a NaN
+// points_c column means "no 3-D measurement", :147-152).
+#ifndef RPE_AO_POSE_ADAPTER_HEADER
+#define RPE_AO_POSE_ADAPTER_HEADER
+
+#include <limits>
+#include "PnPPoseAdapter.hpp"
+
+template <typename Tp>
+class AOPoseAdapter : public PnPPoseAdapter<Tp> {
+ protected:
+  using PoseAdapterBase<Tp>::_t_w;
+  using PoseAdapterBase<Tp>::_R_cw;
+  using PnPPoseAdapter<Tp>::_bearingVectors;
+  using PnPPoseAdapter<Tp>::_points_g;
+
+ public:
+  typedef typename PoseAdapterBase<Tp>::Vector3 Vector3;
+  typedef typename PoseAdapterBase<Tp>::SO3_T SO3_T;
+  typedef typename PoseAdapterBase<Tp>::Point3 Point3;
+  typedef typename PnPPoseAdapter<Tp>::MatrixX MatrixX;
+
+  template <class M> AOPoseAdapter(const M& bearingVectors, const M& points_c, const M& points_g)
+      : PnPPoseAdapter<Tp>(bearingVectors, points_g), _points_c(points_c) { init3(); }
+  template <class M> AOPoseAdapter(const M& bearingVectors, const M& points_c, const M& points_g, const SO3_T& R)
+      : PnPPoseAdapter<Tp>(bearingVectors, points_g, R), _points_c(points_c) { init3(); }
+  template <class M> AOPoseAdapter(const M& bearingVectors, const M& points_c, const M& points_g, const Vector3& t, const SO3_T& R)
+      : PnPPoseAdapter<Tp>(bearingVectors, points_g, t, R), _points_c(points_c) { init3(); }
+  virtual ~AOPoseAdapter() {}
+
+  bool isInlier33(int index) const { return _inliers_3d[index] == 1; }
+  // NB divides by SHRT_MAX, unlike AOOnlyPoseAdapter (reference :161-169)
+  Tp weight33(int index) const { return _weights_3d.empty() ? Tp(1.0) : Tp(_weights_3d[index]) / std::numeric_limits<short>::max(); }
+  virtual Point3 getPointCurr(int index) const { return _points_c.col(index); }
+  virtual bool isValid(int index) const { Point3 p = _points_c.col(index); return p[0] == p[0] || p[1] == p[1] || p[2] == p[2]; }
+  virtual void setInlier(const rpe::MatrixXs& inliers) {  // reference :171-184
+    PnPPoseAdapter<Tp>::setInlier(inliers);
+    if (inliers.cols() != 1) {
+      for (int i = 0; i < inliers.rows(); i++) _inliers_3d[i] = inliers(i, 1);
+      this->device().mask_changed_on_host(RPE_MOD_33);
+    }
+  }
+  template <class M> void setWeights(const M& weights) {  // reference :186-199
+    this->setWeights23(weights);
+    if (weights.rows() != 1) setWeights33(weights);
+  }
+  virtual void printInlier() const {
+    PnPPoseAdapter<Tp>::printInlier();
+    for (short v : _inliers_3d) std::cout << v << " ";
+    std::cout << std::endl;
+  }
+  const std::vector<int>& getInlierIdx() const { return _vInliersAO; }
+  void cvtInlier() {
+    _vInliersAO.clear();
+    for (int r = 0; r < (int)_inliers_3d.size(); r++) if (1 == _inliers_3d[r]) _vInliersAO.push_back(r);
+  }
+
+  // ---- additive accessors for the device backend
+  const Tp* pointsCurrData() const { return _points_c.p; }
+  std::vector<short>& inlierMask33() { return _inliers_3d; }
+  const std::vector<short>& inlierMask33() const { return _inliers_3d; }
+  const std::vector<Tp>& weights33() const { return _weights_3d; }
+  Tp weightScale33() const { return (Tp)std::numeric_limits<short>::max(); }
+
+ protected:
+  void init3() { _inliers_3d.assign((size_t)_bearingVectors.cols(), (short)1); }
+  template <class M> void setWeights33(const M& weights) {
+    _weights_3d.resize(weights.rows());
+    for (int i = 0; i < (int)weights.rows(); i++) _weights_3d[i] = weights(i, 1);
+    this->device().weight_changed_on_host(RPE_MOD_33);
+  }
+  rpe::ColumnView<Tp> _points_c;
+  std::vector<short> _inliers_3d;
+  std::vector<Tp> _weights_3d;
+  std::vector<int> _vInliersAO;
+};
+
+#endif

@@ -1,0 +1,190 @@
+// pose/AbsoluteOrientation.hpp -- drop-in for /root/reference/pose/AbsoluteOrientation.hpp.
+//
+// Same free functions, same argument meaning, results delivered by mutating the adapter:
+//   calc_percentage_err, calc_err, shinji, shinji_ransac, shinji_ransac2, shinji_prosac, shinji_ls, shinji_ls1,
+//   shinji_ls2, assign_sample, shinji_kneip_ransac, shinji_kneip_prosac
+// What moved to the GPU (everything that is O(N)):
+//   * the least-squares sums of shinji_ls / _ls1 / _ls2 (reference :279-290, :303-314, :327-336 gather + the two
+//     passes of shinji :56-73) -> ONE streaming pass, kernel K1' (rpe_p2p_moments), fp64 accumulation
+//   * the vote loops :133-143, :190-200, :248-258, :403-422, :480-499 -> batched scoring, kernel K4 (RansacEngine.hpp)
+// What stays on the host (O(1)): sampling, the 3-point shinji(), P3P, the 3x3 SVD, RANSACUpdateNumIters.
+#ifndef RPE_AO_POSE_HEADER
+#define RPE_AO_POSE_HEADER
+
+#include <vector>
+#include "AOPoseAdapter.hpp"
+#include "AOOnlyPoseAdapter.hpp"
+#include "P3P.hpp"
+#include "RansacEngine.hpp"
+
+// percentage errors of the adapter's pose against (R_cw_, t_w_)  (reference :11-27; not quaternion-sign invariant)
+template <typename Tp>
+rpe::Point3<Tp> calc_percentage_err(const rpe::SO3<Tp>& R_cw_, const rpe::Point3<Tp>& t_w_, const PoseAdapterBase<Tp>* p_ad) {
+  const rpe::Point3<Tp> te = R_cw_ * t_w_ - p_ad->getRcw() * p_ad->gettw();
+  const Tp t_e = te.norm() / p_ad->gettw().norm() * 100;
+  const rpe::Quat<Tp> a = R_cw_.unit_quaternion(), b = p_ad->getRcw().unit_quaternion();
+  const Tp dw = a.w - b.w, dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  const Tp r_e = std::sqrt(dw * dw + dx * dx + dy * dy + dz * dz) / std::sqrt(b.w * b.w + b.x * b.x + b.y * b.y + b.z * b.z) * 100;
+  return rpe::Point3<Tp>(t_e, r_e, Tp(0));  // (t_e, r_e); third entry unused
+}
+
+// (|t|, angle) of SE * GT^-1  (reference :29-43): the "rad / relative-t" parity metric
+template <typename Tp>
+rpe::Point3<Tp> calc_err(const rpe::SE3<Tp>& GT_cw_, const rpe::SE3<Tp>& SE_cw_) {
+  const rpe::Matrix3<Tp> Rd = SE_cw_.so3().matrix() * GT_cw_.so3().matrix().transpose();
+  const rpe::Point3<Tp> td = SE_cw_.translation() - Rd * GT_cw_.translation();
+  const rpe::Quat<Tp> q = rpe::quat_from_R<Tp>(Rd.a);
+  const Tp n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+  const Tp angle = n != Tp(0) ? Tp(2) * std::atan2(n, std::fabs(q.w)) : Tp(0);
+  return rpe::Point3<Tp>(td.norm(), angle, Tp(0));
+}
+
+// Closed-form rigid fit on the first K columns (Umeyama 1991 without scale; reference :47-99).  Host code: inside
+// RANSAC K = 3; the O(N) uses go through rpe::pose_from_device_moments instead.
+template <typename Tp>
+rpe::SE3<Tp> shinji(const rpe::MatrixX<Tp>& X_w_, const rpe::MatrixX<Tp>& X_c_, int K) {
+  rpe::Vec3d Cw, Cc;
+  for (int i = 0; i < K; i++) for (int k = 0; k < 3; k++) { Cw[k] += X_w_(k, i); Cc[k] += X_c_(k, i); }
+  for (int k = 0; k < 3; k++) { Cw[k] /= K; Cc[k] /= K; }
+  rpe::Mat3d M;
+  for (int i = 0; i < K; i++)
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M(r, c) += (X_c_(r, i) - Cc[r]) * (X_w_(c, i) - Cw[c]);
+  const rpe::Mat3d R = rpe::rotation_from_covariance(M);
+  const rpe::Vec3d t = Cc - rpe::mul(R, Cw);
+  rpe::Matrix3<Tp> Rt;
+  for (int i = 0; i < 9; i++) Rt.a[i] = (Tp)R.a[i];
+  // Tp-rounded entries are orthogonal only to Tp precision: take the quaternion and renormalise, as SO3(quaternion) does
+  const rpe::Quat<Tp> q = rpe::quat_from_R<Tp>(Rt.a);
+  return rpe::SE3<Tp>(rpe::SO3<Tp>::fromQuaternion(q.w, q.x, q.y, q.z), rpe::Point3<Tp>((Tp)t[0], (Tp)t[1], (Tp)t[2]));
+}
+
+namespace rpe {
+// closed-form pose from one pass of kernel K1' over the adapter's HBM-resident arrays
+template <typename Tp, class Adapter>
+void pose_from_device_moments(Adapter& adapter, int flags) {
+  const int N = adapter.getNumberCorrespondences();
+  DeviceSet& dev = adapter.device();
+  dev.template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
+  dev.template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
+  if (flags & RPE_USE_MASK) dev.upload_mask(RPE_MOD_33, adapter.inlierMask33());
+  double m[18], R[9], t[3];
+  check(rpe_p2p_moments(dev.ctx(), flags, m), "rpe_p2p_moments");
+  check(rpe_pose_from_moments(m, R, t), "rpe_pose_from_moments");
+  Matrix3<Tp> Rt;
+  for (int i = 0; i < 9; i++) Rt.a[i] = (Tp)R[i];
+  const Quat<Tp> q = quat_from_R<Tp>(Rt.a);
+  adapter.setRcw(SO3<Tp>::fromQuaternion(q.w, q.x, q.y, q.z));
+  adapter.sett(Point3<Tp>((Tp)t[0], (Tp)t[1], (Tp)t[2]));
+}
+
+template <typename Tp, class Adapter>
+void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence, bool prosac) {
+  const int N = adapter.getNumberCorrespondences();
+  const int K = 3;
+  RandomElements<int> re(N);
+  if (prosac) adapter.sortIdx();
+  ProsacSampler<Tp> ps(K, N);
+  VoteSpec<Tp> spec;
+  spec.kind = RPE_VOTE_33; spec.thre_3d = dist_thre_3d_; spec.modalities = 1; spec.model_points = K;
+  adapter.device().template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
+  adapter.device().template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
+  MatrixX<Tp> Xw(3, K), Xc(3, K);
+  auto gen = [&](std::vector<SE3<Tp> >& out) {
+    std::vector<int> sel;
+    if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K, &sel);
+    for (int s = 0; s < K; s++) {
+      if (!adapter.isValid(sel[s])) return;  // invalid sample: the reference 'continue's
+      Xw.setCol(s, adapter.getPointGlob(sel[s]));
+      Xc.setCol(s, adapter.getPointCurr(sel[s]));
+    }
+    out.push_back(shinji<Tp>(Xw, Xc, K));
+  };
+  auto commit = [&](const MatrixXs& m) { adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_33); };
+  ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+  adapter.cvtInlier();
+}
+}  // namespace rpe
+
+template <typename Tp>
+void shinji_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99) {  // reference :101-156
+  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, false);
+}
+template <typename Tp>
+void shinji_ransac2(AOOnlyPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99) {  // reference :158-213
+  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, false);
+}
+template <typename Tp>
+void shinji_prosac(AOOnlyPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99) {  // reference :215-271
+  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, true);
+}
+
+// least squares over the 3D-3D inliers (reference :273-296 / :298-320)
+template <typename Tp>
+void shinji_ls(AOPoseAdapter<Tp>& adapter) { rpe::pose_from_device_moments<Tp>(adapter, RPE_USE_MASK); }
+template <typename Tp>
+void shinji_ls1(AOOnlyPoseAdapter<Tp>& adapter) { rpe::pose_from_device_moments<Tp>(adapter, RPE_USE_MASK); }
+// least squares over ALL correspondences, no validity test (reference :322-342): what Library.cpp ao() runs
+template <typename Tp>
+void shinji_ls2(AOOnlyPoseAdapter<Tp>& adapter) { rpe::pose_from_device_moments<Tp>(adapter, 0); }
+
+// fill the 4-sample matrices; true when the first three have valid camera points (reference :344-365)
+template <typename Tp>
+bool assign_sample(const AOPoseAdapter<Tp>& adapter, const std::vector<int>& selected_cols_, rpe::MatrixX<Tp>* p_X_w_,
+                   rpe::MatrixX<Tp>* p_X_c_, rpe::MatrixX<Tp>* p_bv_) {
+  const int K = (int)selected_cols_.size() - 1;
+  int nValid = 0;
+  for (int s = 0; s < K; s++) {
+    p_X_w_->setCol(s, adapter.getPointGlob(selected_cols_[s]));
+    p_bv_->setCol(s, adapter.getBearingVector(selected_cols_[s]));
+    if (adapter.isValid(selected_cols_[s])) { p_X_c_->setCol(s, adapter.getPointCurr(selected_cols_[s])); nValid++; }
+  }
+  p_X_w_->setCol(3, adapter.getPointGlob(selected_cols_[3]));
+  p_bv_->setCol(3, adapter.getBearingVector(selected_cols_[3]));
+  return nValid == K;
+}
+
+namespace rpe {
+template <typename Tp>
+void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence, bool prosac) {
+  const int N = adapter.getNumberCorrespondences();
+  const int K = 3;
+  RandomElements<int> re(N);
+  if (prosac) adapter.sortIdx();
+  ProsacSampler<Tp> ps(K + 1, N);
+  VoteSpec<Tp> spec;
+  spec.kind = RPE_VOTE_33_23; spec.thre_3d = dist_thre_3d_;
+  spec.cos_thr = std::cos(std::atan(thre_2d_ / adapter.getFocal()));
+  spec.modalities = 2; spec.model_points = K;
+  DeviceSet& dev = adapter.device();
+  dev.template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
+  dev.template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
+  dev.template ensure<Tp>(RPE_BV, adapter.bearingData(), N);
+  MatrixX<Tp> X_w(3, K + 1), X_c(3, K + 1), bv(3, K + 1);
+  auto gen = [&](std::vector<SE3<Tp> >& out) {
+    std::vector<int> sel;
+    if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K + 1, &sel);
+    if (assign_sample<Tp>(adapter, sel, &X_w, &X_c, &bv)) out.push_back(shinji<Tp>(X_w, X_c, K));
+    SE3<Tp> sk;
+    if (kneip<Tp>(X_w, bv, &sk)) out.push_back(sk);
+  };
+  auto commit = [&](const MatrixXs& m) {
+    adapter.setInlier(m);
+    dev.mask_written_on_device(RPE_MOD_23); dev.mask_written_on_device(RPE_MOD_33);
+  };
+  ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+  PnPPoseAdapter<Tp>* pAdapter = &adapter;
+  pAdapter->cvtInlier();
+  adapter.cvtInlier();
+}
+}  // namespace rpe
+
+template <typename Tp>
+void shinji_kneip_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {  // :367-438
+  rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, false);
+}
+template <typename Tp>
+void shinji_kneip_prosac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {  // :440-515
+  rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, true);
+}
+
+#endif

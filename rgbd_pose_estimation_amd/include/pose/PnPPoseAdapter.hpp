@@ -1,0 +1,83 @@
+// pose/PnPPoseAdapter.hpp -- drop-in for /root/reference/pose/PnPPoseAdapter.hpp:27-255 (2D-3D: bearings + world points).
+#ifndef RPE_PNP_POSE_ADAPTER_HEADER
+#define RPE_PNP_POSE_ADAPTER_HEADER
+
+#include <iostream>
+#include "PoseAdapterBase.hpp"
+#include "Utility.hpp"
+
+template <typename Tp>
+class PnPPoseAdapter : public PoseAdapterBase<Tp> {
+ protected:
+  using PoseAdapterBase<Tp>::_t_w;
+  using PoseAdapterBase<Tp>::_R_cw;
+
+ public:
+  typedef typename PoseAdapterBase<Tp>::Vector3 Vector3;
+  typedef typename PoseAdapterBase<Tp>::SO3_T SO3_T;
+  typedef typename PoseAdapterBase<Tp>::Point3 Point3;
+  typedef rpe::MatrixX<Tp> MatrixX;
+
+  template <class M> PnPPoseAdapter(const M& bearingVectors, const M& points)
+      : PoseAdapterBase<Tp>(), _bearingVectors(bearingVectors), _points_g(points) { init(); }
+  template <class M> PnPPoseAdapter(const M& bearingVectors, const M& points, const SO3_T& R)
+      : PoseAdapterBase<Tp>(R), _bearingVectors(bearingVectors), _points_g(points) { init(); }
+  template <class M> PnPPoseAdapter(const M& bearingVectors, const M& points, const Vector3& t, const SO3_T& R)
+      : PoseAdapterBase<Tp>(t, R), _bearingVectors(bearingVectors), _points_g(points) { init(); }
+  virtual ~PnPPoseAdapter() {}
+
+  virtual Point3 getBearingVector(int index) const { return _bearingVectors.col(index); }
+  virtual Tp getWeight(int) const { return Tp(1.); }
+  virtual Point3 getPointGlob(int index) const { return _points_g.col(index); }
+  virtual int getNumberCorrespondences() const { return _bearingVectors.cols(); }
+
+  // column 0 of the mask (reference :196-202 memcpy's rows()*2 bytes = column 0 of a column-major short matrix)
+  virtual void setInlier(const rpe::MatrixXs& inliers) {
+    for (int i = 0; i < inliers.rows(); i++) _inliers[i] = inliers(i, 0);
+    this->device().mask_changed_on_host(RPE_MOD_23);
+  }
+  template <class M> void setWeights(const M& weights) { setWeights23(weights); }
+  virtual void printInlier() const { for (short v : _inliers) std::cout << v << " "; std::cout << std::endl; }
+  const std::vector<int>& getInlierIdx() const { return _vInliersPnP; }
+  void cvtInlier() {
+    _vInliersPnP.clear();
+    for (int r = 0; r < (int)_inliers.size(); r++) if (1 == _inliers[r]) _vInliersPnP.push_back(r);
+  }
+  // sine of the angle between predicted and observed bearing (reference :204-210)
+  Tp getError(int index) const {
+    Point3 Xc = _R_cw * getPointGlob(index) + _t_w;
+    Xc.normalize();
+    return Xc.cross(getBearingVector(index)).norm();
+  }
+  void setMaxVotes(int votes) { _max_votes = votes; }
+  int getMaxVotes() { return _max_votes; }
+  bool isInlier23(int index) const { return _inliers[index] == 1; }
+  Tp weight23(int index) const { return _weights.empty() ? Tp(1.0) : _weights[index]; }
+  void sortIdx() { _idx = sortIndexes<Tp>(_weights); }
+  void getSortedIdx(std::vector<int>& select_) const {
+    for (size_t i = 0; i < select_.size(); ++i) { const int j = select_[i]; if (j < (int)_idx.size()) select_[i] = _idx[j]; }
+  }
+
+  // ---- additive accessors for the device backend
+  const Tp* bearingData() const { return _bearingVectors.p; }
+  const Tp* pointsGlobData() const { return _points_g.p; }
+  std::vector<short>& inlierMask23() { return _inliers; }
+  const std::vector<short>& inlierMask23() const { return _inliers; }
+  const std::vector<Tp>& weights23() const { return _weights; }
+
+ protected:
+  void init() { _inliers.assign((size_t)_bearingVectors.cols(), (short)1); _max_votes = 0; }
+  template <class M> void setWeights23(const M& weights) {
+    _weights.resize(weights.rows());
+    for (int i = 0; i < (int)weights.rows(); i++) _weights[i] = weights(i, 0);
+    this->device().weight_changed_on_host(RPE_MOD_23);
+  }
+  rpe::ColumnView<Tp> _bearingVectors, _points_g;
+  std::vector<short> _inliers;
+  std::vector<Tp> _weights;
+  std::vector<int> _idx;
+  std::vector<int> _vInliersPnP;
+  int _max_votes;
+};
+
+#endif

@@ -1,0 +1,71 @@
+// pose/PoseAdapterBase.hpp -- drop-in for the reference's header of the same name
+// (/root/reference/pose/PoseAdapterBase.hpp:28-146): the abstract correspondence accessor + pose carrier.
+// Same class name, same virtual interface, same pose/focal accessors; Eigen/Sophus types are replaced by the
+// Eigen-free value types of rpe/types.hpp (same spellings inside the class: Vector3, Point3, SO3_T, SE3_T).
+// Additive: device() -- the adapter's correspondence arrays resident in HBM, used by the HIP-backed solvers.
+#ifndef RPE_POSE_ADAPTERBASE_HEADER
+#define RPE_POSE_ADAPTERBASE_HEADER
+
+#include <memory>
+#include <vector>
+#include "../rpe/types.hpp"
+#include "../rpe/device.hpp"
+
+template <typename Tp>
+class PoseAdapterBase {
+ public:
+  typedef rpe::Point3<Tp> Vector3;
+  typedef rpe::Point3<Tp> Point3;
+  typedef rpe::SO3<Tp> SO3_T;
+  typedef rpe::SE3<Tp> SE3_T;
+
+  PoseAdapterBase() : _fx(0), _fy(0), _cx(0), _cy(0) {}
+  explicit PoseAdapterBase(const SO3_T& R) : _R_cw(R), _fx(0), _fy(0), _cx(0), _cy(0) {}
+  PoseAdapterBase(const Vector3& t, const SO3_T& R) : _t_w(t), _R_cw(R), _fx(0), _fy(0), _cx(0), _cy(0) {}
+  virtual ~PoseAdapterBase() {}
+
+  // per-correspondence access (reference :81-101)
+  virtual Point3 getBearingVector(int index) const = 0;
+  virtual Tp getWeight(int index) const = 0;
+  virtual Point3 getPointGlob(int index) const = 0;
+  virtual int getNumberCorrespondences() const = 0;
+
+  // pose: Xc = R_cw * Xw + t_w (reference :109-130)
+  Vector3 gettw() const { return _t_w; }
+  void sett(const Vector3& t) { _t_w = t; }
+  SO3_T getRcw() const { return _R_cw; }
+  void setRcw(const SO3_T& R) { _R_cw = R; }
+  void setFocal(const Tp fx, const Tp fy) { _fx = fx; _fy = fy; }
+  Tp getFocal() const { return (_fx + _fy) / 2; }
+  SE3_T getTcw() { return SE3_T(_R_cw, _t_w); }
+
+  // ---- additive: HBM residency of this adapter's arrays
+  rpe::DeviceSet& device() const {
+    if (!_dev) _dev.reset(new rpe::DeviceSet());
+    return *_dev;
+  }
+  // call after changing the CONTENTS of a matrix the adapter references (the adapters hold references, reference
+  // :93-95 of AOOnlyPoseAdapter.hpp, and cache uploads by address)
+  void invalidateDevice() { _dev.reset(); }
+
+ protected:
+  Vector3 _t_w;
+  SO3_T _R_cw;
+  Tp _fx, _fy, _cx, _cy;
+  mutable std::shared_ptr<rpe::DeviceSet> _dev;
+};
+
+namespace rpe {
+// Non-owning view of a caller-owned 3 x N column-major matrix: anything with data() / rows() / cols()
+// (rpe::MatrixX<Tp>, Eigen::Matrix<Tp,Dynamic,Dynamic>, Eigen::Map<...>) binds to it.
+template <class Tp> struct ColumnView {
+  const Tp* p;
+  int n;
+  ColumnView() : p(nullptr), n(0) {}
+  template <class M> explicit ColumnView(const M& m) : p(m.data()), n((int)m.cols()) {}
+  Point3<Tp> col(int i) const { return Point3<Tp>(p + 3 * (size_t)i); }
+  int cols() const { return n; }
+};
+}  // namespace rpe
+
+#endif

@@ -1,0 +1,106 @@
+// pose/RansacEngine.hpp -- the one RANSAC/PROSAC driver behind every *_ransac / *_prosac of pose/*.hpp.
+//
+// The reference runs, per iteration: sample -> minimal solver(s) -> an O(N) vote loop over all correspondences ->
+// "if (votes > best) { keep pose + mask; Iter = RANSACUpdateNumIters(...) }" (e.g. AbsoluteOrientation.hpp:169-209).
+// The vote loops are the hot path.  Here hypotheses are generated on the host in batches, each batch is scored in
+// ONE pass over the HBM-resident arrays (rpe_score, kernel K4), and the batch results are then REPLAYED IN ORDER with
+// the reference's exact sequential semantics: strict '>' (ties keep the earlier hypothesis), Iter shrinks the moment
+// a better hypothesis is seen, and iterations at or beyond the new Iter are discarded.  The outcome (pose, votes,
+// Iter, mask) is therefore what the sequential loop would produce from the same hypothesis stream; only the sampler
+// may have been advanced further than the reference would have advanced rand().
+// The winner's inlier mask is written once at the end (rpe_inlier_mask, kernel K4b) instead of at every improvement.
+#ifndef RPE_RANSAC_ENGINE_HEADER
+#define RPE_RANSAC_ENGINE_HEADER
+
+#include <algorithm>
+#include <vector>
+#include "../rpe/types.hpp"
+#include "../rpe/device.hpp"
+
+template <typename T> int RANSACUpdateNumIters(T p, T ep, const int modelPoints, const int maxIters);
+
+namespace rpe {
+
+template <class Tp> struct VoteSpec {
+  int kind = RPE_VOTE_33;
+  Tp thre_3d = Tp(0);
+  Tp cos_thr = Tp(2);   // cos(atan(thre_2d / f))
+  Tp cos_nl = Tp(2);    // cos(nl_thre)
+  int modalities = 1;   // m in the outlier ratio (m N - votes) / (m N)
+  int model_points = 3; // K handed to RANSACUpdateNumIters
+};
+
+template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
+  const Quat<Tp>& q = s.so3().unit_quaternion();
+  q7[0] = q.w; q7[1] = q.x; q7[2] = q.y; q7[3] = q.z;
+  q7[4] = s.translation()[0]; q7[5] = s.translation()[1]; q7[6] = s.translation()[2];
+}
+
+// Adapter: any pose adapter (setMaxVotes/getMaxVotes/setRcw/sett/device()).
+// gen(out): advance the sampler by ONE reference iteration and append its 0..3 hypotheses, in the reference's order.
+// commit(mask): hand the winner's N x mask_cols short mask to the adapter (setInlier).
+template <class Tp, class Adapter, class Gen, class Commit>
+void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+  const int N = adapter.getNumberCorrespondences();
+  const Settings& cfg = Settings::get();
+  rpe_context* ctx = adapter.device().ctx();
+  adapter.setMaxVotes(-1);
+  bool have_best = false;
+  SE3<Tp> best;
+  int it = 0;
+  int batch = std::max(1, cfg.first_batch);
+  std::vector<SE3<Tp> > hyps;
+  std::vector<int> first;   // first[i] = index into hyps of iteration (it + i)'s first hypothesis
+  std::vector<double> q7;
+  std::vector<int> votes;
+  while (it < Iter) {
+    const int iters = std::min(batch, Iter - it);
+    hyps.clear(); first.assign(1, 0);
+    for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
+    if (!hyps.empty()) {
+      q7.resize(hyps.size() * 7);
+      for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
+      votes.resize(hyps.size());
+      check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+                      (double)spec.cos_nl, votes.data()), "rpe_score");
+    }
+    // sequential replay
+    for (int i = 0; i < iters && it + i < Iter; i++) {
+      for (int h = first[i]; h < first[i + 1]; h++) {
+        if (votes[h] > adapter.getMaxVotes()) {
+          adapter.setMaxVotes(votes[h]);
+          adapter.setRcw(hyps[h].so3());
+          adapter.sett(hyps[h].translation());
+          best = hyps[h]; have_best = true;
+          const int mN = spec.modalities * N;
+          // (Tp)(m N - votes) / N / m, evaluated like the reference (e.g. AbsoluteOrientation.hpp:429)
+          const Tp ep = spec.modalities == 1 ? (Tp)(N - votes[h]) / N : (Tp)(mN - votes[h]) / N / spec.modalities;
+          Iter = RANSACUpdateNumIters(confidence, ep, spec.model_points, Iter);
+        }
+      }
+    }
+    it += iters;
+    batch = std::min(batch * 2, std::max(1, cfg.max_batch));
+  }
+  if (have_best) {
+    double b7[7];
+    pose7<Tp>(best, b7);
+    int total = 0;
+    check(rpe_inlier_mask(ctx, spec.kind, cfg.score_mode, b7, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, &total),
+          "rpe_inlier_mask");
+    MatrixXs mask(N, mask_cols);
+    std::vector<short> col;
+    const bool has23 = spec.kind == RPE_VOTE_23 || spec.kind == RPE_VOTE_23_MATRIX || spec.kind == RPE_VOTE_33_23 ||
+                       spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33_23;
+    const bool has33 = spec.kind == RPE_VOTE_33 || spec.kind == RPE_VOTE_33_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
+    const bool hasnn = spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
+    if (has23 && mask_cols >= 1) { adapter.device().download_mask(RPE_MOD_23, col); for (int i = 0; i < N; i++) mask(i, 0) = col[i]; }
+    if (has33 && mask_cols >= 2) { adapter.device().download_mask(RPE_MOD_33, col); for (int i = 0; i < N; i++) mask(i, 1) = col[i]; }
+    if (hasnn && mask_cols >= 3) { adapter.device().download_mask(RPE_MOD_NN, col); for (int i = 0; i < N; i++) mask(i, 2) = col[i]; }
+    commit(mask);
+  }
+}
+
+}  // namespace rpe
+
+#endif

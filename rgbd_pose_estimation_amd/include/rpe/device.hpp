@@ -1,0 +1,92 @@
+// rpe/device.hpp -- how the header-only solvers of pose/*.hpp reach the GPU: a small RAII layer over the C ABI
+// (include/rgbd_pose_hip.h).  The host side stays C++; every device call goes through the extern "C" shim.
+// There is no CPU path behind these calls: a failing status throws rpe::DeviceError (no fallback, no silent retry).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <type_traits>
+#include "../../../include/rgbd_pose_hip.h"
+
+namespace rpe {
+
+struct DeviceError : std::runtime_error {
+  int code;
+  DeviceError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+inline void check(int rc, const char* where) {
+  if (rc != RPE_OK) throw DeviceError(rc, std::string(where) + ": " + rpe_last_error());
+}
+template <class Tp> struct DType;
+template <> struct DType<float> { enum { value = RPE_F32 }; };
+template <> struct DType<double> { enum { value = RPE_F64 }; };
+
+// process-wide defaults for the solver templates (the reference's free functions have no room for extra arguments)
+struct Settings {
+  int device = 0;
+  int score_mode = RPE_SCORE_FAST;     // RPE_SCORE_EXACT reproduces the CPU path's votes bit for bit
+  int first_batch = 64, max_batch = 2048;  // RANSAC hypotheses scored per launch (grows geometrically)
+  static Settings& get() { static Settings s; return s; }
+};
+
+// One adapter's correspondence arrays resident in HBM.  Uploaded once, reused by every solver run on that adapter
+// (TestMain.cpp runs seven solvers on one adapter, :186-221).
+class DeviceSet {
+ public:
+  DeviceSet() : _ctx(nullptr), _n(0), _dtype(-1) {
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
+    for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
+  }
+  ~DeviceSet() { if (_ctx) rpe_destroy(_ctx); }
+  DeviceSet(const DeviceSet&) = delete;
+  DeviceSet& operator=(const DeviceSet&) = delete;
+
+  rpe_context* ctx() {
+    if (!_ctx) check(rpe_create(&_ctx, Settings::get().device, nullptr), "rpe_create");
+    return _ctx;
+  }
+  // make sure array `slot` in HBM is the host array at `host` (3 x n of Tp)
+  template <class Tp> void ensure(int slot, const Tp* host, int64_t n) {
+    if (_n != n || _dtype != (int)DType<Tp>::value) {
+      check(rpe_set_problem(ctx(), n, DType<Tp>::value), "rpe_set_problem");
+      _n = n; _dtype = DType<Tp>::value;
+      for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
+      for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
+    }
+    if (_src[slot] != (const void*)host) {
+      check(rpe_upload(ctx(), slot, host), "rpe_upload");
+      _src[slot] = host;
+    }
+  }
+  void upload_mask(int mod, const std::vector<short>& m) {
+    if (_mask_fresh[mod]) return;
+    check(rpe_upload_mask(ctx(), mod, m.data()), "rpe_upload_mask");
+    _mask_fresh[mod] = true;
+  }
+  template <class Tp> void upload_weight(int mod, const std::vector<Tp>& w, Tp scale) {
+    if (_weight_fresh[mod]) return;
+    if (w.empty()) { check(rpe_upload_weight(ctx(), mod, nullptr), "rpe_upload_weight"); }
+    else {
+      std::vector<Tp> s(w.size());
+      for (size_t i = 0; i < w.size(); i++) s[i] = w[i] / scale;
+      check(rpe_upload_weight(ctx(), mod, s.data()), "rpe_upload_weight");
+    }
+    _weight_fresh[mod] = true;
+  }
+  void mask_changed_on_host(int mod) { _mask_fresh[mod] = false; }
+  void mask_written_on_device(int mod) { _mask_fresh[mod] = true; }
+  void weight_changed_on_host(int mod) { _weight_fresh[mod] = false; }
+  void download_mask(int mod, std::vector<short>& m) {
+    m.resize((size_t)_n);
+    check(rpe_download_mask(ctx(), mod, m.data()), "rpe_download_mask");
+  }
+ private:
+  rpe_context* _ctx;
+  int64_t _n;
+  int _dtype;
+  const void* _src[RPE_NUM_ARRAYS];
+  bool _mask_fresh[3], _weight_fresh[3];
+};
+
+}  // namespace rpe

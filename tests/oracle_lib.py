@@ -106,7 +106,9 @@ def ao_ransac(xw, xc, seed=1):
 
 
 def run(prob: Problem, method, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0, iters=0, confidence=0.99, seed=1, ls=LS_NONE,
-        adapter_kind_for_none=0, mask_in=None, pose_in=None, max_votes_in=1):
+        adapter_kind_for_none=None, mask_in=None, pose_in=None, max_votes_in=1):
+    if adapter_kind_for_none is None:  # the adapter the reference's demos would build for these arrays
+        adapter_kind_for_none = 2 if prob.nc is not None else (1 if prob.bv is not None else 0)
     R, t = np.zeros(9), np.zeros(3)
     if pose_in is not None:
         R[:] = np.asarray(pose_in[0], float).reshape(9)

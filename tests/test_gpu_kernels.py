@@ -21,6 +21,8 @@ def test_moments_match_numpy_and_closed_form(gpu_ctx_factory, oracle, n, f64):
     sc = util.scene33(10 + n, n, dt)
     ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P)
     m = ctx.p2p_moments(0)
+    assert m[17] == n
+    m = m[:17]
     xw, xc = sc.Q.astype(np.float64), sc.P.astype(np.float64)
     ref = np.concatenate([[n], xw.sum(0), xc.sum(0), (xc.T @ xw).reshape(9), [np.sum(xc * xc)]])
     scale = np.maximum(np.abs(ref), 1.0)
@@ -44,8 +46,10 @@ def test_moments_mask_weight_invalid(gpu_ctx_factory, n):
     ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=P)
     ctx.upload_mask(L.MOD_33, mask); ctx.upload_weight(L.MOD_33, w)
     m = ctx.p2p_moments(L.USE_MASK | L.USE_WEIGHT | L.SKIP_INVALID)
+    cnt, m = m[17], m[:17]
     ok = (mask == 1) & ~np.isnan(P).all(1)
     ww = w.astype(np.float64) * ok
+    assert cnt == ok.sum()
     xw, xc = sc.Q.astype(np.float64), np.nan_to_num(P.astype(np.float64))
     ref = np.concatenate([[ww.sum()], (ww[:, None] * xw).sum(0), (ww[:, None] * xc).sum(0), ((ww[:, None] * xc).T @ xw).reshape(9),
                           [np.sum(ww[:, None] * xc * xc)]])

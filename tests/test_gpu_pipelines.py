@@ -1,0 +1,152 @@
+"""-m gpu: the drop-in solver layer (pose/*.hpp through rpe_run / ao / ao_ransac) against the oracle's restatement
+of the same reference functions, same seeds (=> identical sample index streams), same thresholds."""
+import math
+
+import numpy as np
+import pytest
+
+from rgbd_pose_estimation_amd import _lib as L, api, simulator as S
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _orc_problem(oracle, sc, f64, **kw):
+    return oracle.Problem(f64, **kw)
+
+
+def _truth_inliers33(sc, thr):
+    return np.linalg.norm(sc.P.astype(np.float64) - (sc.Q.astype(np.float64) @ sc.R.T + sc.t), axis=1) < thr
+
+
+@pytest.mark.parametrize("n", [100, 1000, 32767, 307200])
+@pytest.mark.parametrize("method", ["ransac2", "prosac"])
+def test_shinji_ransac_noise_free_inliers_exact(oracle, n, method):
+    """Noise-free inliers + 20 % gross outliers: every all-inlier sample yields the exact pose, so the whole pipeline
+    (votes, Iter, mask, LS pose) must agree with the CPU path, integer outputs exactly."""
+    rng = np.random.default_rng(n)
+    R, t = S.random_pose(rng)
+    sc = S.simulate_3d_3d_correspondences(rng, R, t, n, 0.0, 0.2).astype(np.float32)
+    m = api.M_SHINJI_RANSAC2 if method == "ransac2" else api.M_SHINJI_PROSAC
+    mo = oracle.M_SHINJI_RANSAC2 if method == "ransac2" else oracle.M_SHINJI_PROSAC
+    kw = dict(thre_3d=0.05, iters=1000, confidence=0.99999, seed=11)
+    got = api.run(m, L.F32, xw=sc.Q, xc=sc.P, weights=sc.weights, ls=api.LS_SHINJI_INLIERS, score_mode=L.SCORE_EXACT, **kw)
+    ref = oracle.run(oracle.Problem(False, xw=sc.Q, xc=sc.P, weights=sc.weights), mo, ls=oracle.LS_SHINJI_INLIERS, **kw)
+    truth = _truth_inliers33(sc, 1e-3)
+    assert got["max_votes"] == ref["max_votes"] == int(truth.sum())
+    assert np.array_equal(got["masks"][1], ref["masks"][1]) and np.array_equal(got["masks"][1] == 1, truth)
+    assert got["iters"] == ref["iters"]
+    assert util.rot_err(got["R"], ref["R"]) < util.ROT_TOL_RAD and util.trans_rel_err(got["t"], ref["t"]) < util.TRANS_REL_TOL
+    assert util.rot_err(got["R"], sc.R) < 1e-5
+
+
+PIPELINES = [
+    # name, api method, oracle method, arrays, ls(api, oracle), thresholds
+    ("shinji_ransac", "M_SHINJI_RANSAC", ("xw", "xc", "bv"), "LS_SHINJI_INLIERS", dict(thre_3d=0.25)),
+    ("kneip_ransac", "M_KNEIP_RANSAC", ("xw", "bv"), "LS_NONE", dict(thre_2d=3.0)),
+    ("kneip_prosac", "M_KNEIP_PROSAC", ("xw", "bv"), "LS_NONE", dict(thre_2d=3.0)),
+    ("shinji_kneip_ransac", "M_SK_RANSAC", ("xw", "xc", "bv"), "LS_SHINJI_INLIERS", dict(thre_3d=0.25, thre_2d=3.0)),
+    ("shinji_kneip_prosac", "M_SK_PROSAC", ("xw", "xc", "bv"), "LS_SHINJI_INLIERS", dict(thre_3d=0.25, thre_2d=3.0)),
+    ("nl_kneip_ransac", "M_NL_KNEIP_RANSAC", ("xw", "xc", "bv", "nw", "nc"), "LS_NONE", dict(thre_2d=3.0, thre_nl=0.1)),
+    ("nl_shinji_ransac", "M_NL_SHINJI_RANSAC", ("xw", "xc", "bv", "nw", "nc"), "LS_NONE", dict(thre_3d=0.25, thre_nl=0.1)),
+    ("nl_shinji_kneip_ransac", "M_NL_SK_RANSAC", ("xw", "xc", "bv", "nw", "nc"), "LS_NL_BUGCOMPAT", dict(thre_3d=0.25, thre_2d=3.0, thre_nl=0.1)),
+]
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("n", [100, 2000])
+@pytest.mark.parametrize("pl", PIPELINES, ids=[p[0] for p in PIPELINES])
+def test_pipelines_agree_with_oracle(oracle, pl, n, f64):
+    """Noisy scenes: the host-side minimal solvers of product and oracle are separate implementations, so hypotheses
+    agree to rounding, not bit for bit; the pipelines must land on equally good consensus sets and the same pose
+    to well within the RANSAC noise (both within tolerance of the truth)."""
+    name, method, arrays, ls, thr = pl
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(500 + n, n, dt, n2d=1.0, n3d=0.05, nnl_deg=2.0, outliers=0.2, nan_frac=0.05)
+    data = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    sel = {k: data[k] for k in arrays}
+    kw = dict(iters=300, confidence=0.9999, seed=5, **thr)
+    got = api.run(getattr(api, method), L.F64 if f64 else L.F32, weights=sc.weights, ls=getattr(api, ls), score_mode=L.SCORE_EXACT, **sel, **kw)
+    ref = oracle.run(oracle.Problem(f64, weights=sc.weights, **sel), getattr(oracle, method), ls=getattr(oracle, ls), **kw)
+    assert got["max_votes"] > 0 and ref["max_votes"] > 0
+    assert abs(got["max_votes"] - ref["max_votes"]) <= max(3, 0.03 * ref["max_votes"])
+    e_got, e_ref = util.rot_err(got["R"], sc.R), util.rot_err(ref["R"], sc.R)
+    assert e_got < max(3 * e_ref, 0.02)
+    assert np.linalg.norm(got["t"] - sc.t) < max(3 * np.linalg.norm(ref["t"] - sc.t), 0.15)
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("bug", [True, False])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("n", [100, 5000, 200000])
+def test_nl_shinji_kneip_ls_matches_oracle(oracle, n, weighted, bug, f64):
+    """L1/L2 in isolation: same pose, masks and weights in -> same pose out (bug-compatible and fixed variants)."""
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(600 + n, n, dt, n2d=2.0, n3d=0.03, nnl_deg=2.0, outliers=0.1)
+    rng = np.random.default_rng(n)
+    R0, t0 = util.perturbed_pose(rng, sc.R, sc.t, ang=0.01, dt=0.03)
+    # inlier masks from the truth
+    m33 = _truth_inliers33(sc, 0.2)
+    pc = sc.Q.astype(np.float64) @ sc.R.T + sc.t
+    pc /= np.linalg.norm(pc, axis=1, keepdims=True)
+    m23 = np.einsum("ij,ij->i", pc, sc.U.astype(np.float64)) > math.cos(math.atan(8.0 / 585))
+    mnn = np.einsum("ij,ij->i", sc.N.astype(np.float64), sc.M.astype(np.float64) @ sc.R.T) > math.cos(0.1)
+    mask = np.stack([m23, m33, mnn]).astype(np.int16)
+    w = sc.weights if weighted else None
+    arrs = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    got = api.run(api.M_NONE, L.F64 if f64 else L.F32, weights=w, ls=api.LS_NL_BUGCOMPAT if bug else api.LS_NL_FIXED, mask_in=mask,
+                  pose_in=(R0, t0), **arrs)
+    ref = oracle.run(oracle.Problem(f64, weights=w, **arrs), oracle.M_NONE, ls=oracle.LS_NL_BUGCOMPAT if bug else oracle.LS_NL_FIXED,
+                     mask_in=mask, pose_in=(R0, t0))
+    tol_r, tol_t = (1e-9, 1e-9) if f64 else (util.ROT_TOL_RAD, util.TRANS_REL_TOL)
+    assert util.rot_err(got["R"], ref["R"]) < tol_r
+    assert util.trans_rel_err(got["t"], ref["t"]) < tol_t
+
+
+@pytest.mark.parametrize("n", [1000, 307200])
+def test_shinji_ls_variants_match_oracle(oracle, n):
+    sc = util.scene33(700 + n, n, np.float32)
+    mask = np.zeros((3, n), np.int16); mask[1] = _truth_inliers33(sc, 0.2)
+    for ls_a, ls_o in ((api.LS_SHINJI_INLIERS, oracle.LS_SHINJI_INLIERS), (api.LS_SHINJI_ALL, oracle.LS_SHINJI_ALL)):
+        got = api.run(api.M_NONE, L.F32, xw=sc.Q, xc=sc.P, ls=ls_a, mask_in=mask)
+        # the CPU reference for accuracy is the Tp=double instantiation on the same fp32-representable inputs
+        ref = oracle.run(oracle.Problem(True, xw=sc.Q, xc=sc.P), oracle.M_NONE, ls=ls_o, mask_in=mask)
+        assert util.rot_err(got["R"], ref["R"]) < util.ROT_TOL_RAD and util.trans_rel_err(got["t"], ref["t"]) < util.TRANS_REL_TOL
+
+
+def test_gn_adapter_level(oracle):
+    """GaussNewton.hpp through rpe_run: p2p / joint / p2plane / bearing refinements converge next to the oracle's fp64 GN."""
+    n = 20000
+    sc = util.scene_full(800, n, np.float32, n2d=1.0, n3d=0.02, outliers=0.0)
+    rng = np.random.default_rng(1)
+    R0, t0 = util.perturbed_pose(rng, sc.R, sc.t, ang=0.01, dt=0.02)
+    arrs = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    p0 = oracle.pose12(np.asarray(R0, np.float32), np.asarray(t0, np.float32))
+    for ls, terms in ((api.LS_GN_P2P, [dict(kind=oracle.GN_P2P, a=sc.Q, b=sc.P)]),
+                      (api.LS_GN_P2PLANE, [dict(kind=oracle.GN_P2PLANE, a=sc.Q, b=sc.P, c=sc.N)]),
+                      (api.LS_GN_JOINT, [dict(kind=oracle.GN_P2P, a=sc.Q, b=sc.P), dict(kind=oracle.GN_BEARING, a=sc.Q, b=sc.U)])):
+        got = api.run(api.M_NONE, L.F32, ls=ls, pose_in=(R0, t0), **arrs)
+        po, its, _, _ = oracle.gn_refine(terms, n, p0, max_iter=30, tol=1e-10)
+        assert got["iters"] > 0 and its > 0
+        assert util.rot_err(got["R"], po[:9].reshape(3, 3)) < util.ROT_TOL_RAD
+        assert util.trans_rel_err(got["t"], po[9:]) < util.TRANS_REL_TOL
+
+
+def test_ao_ransac_ffi(oracle):
+    """Library.cpp ao_ransac(): hard-coded Iter=1000, thre_3d=0.1, confidence=0.99999; result next to the oracle's."""
+    sc = util.scene33(900, 20000, np.float32, noise=0.02, outliers=0.2)
+    R, t = api.ao_ransac(sc.Q, sc.P)
+    Ro, to, it, votes = oracle.ao_ransac(sc.Q, sc.P, seed=1)
+    assert util.rot_err(R, sc.R) < 2e-3 and util.rot_err(Ro.astype(np.float64), sc.R) < 2e-3
+    assert util.rot_err(R, Ro.astype(np.float64)) < 2e-3
+
+
+def test_nan_columns_never_vote(oracle):
+    """isValid(): a camera point that is all-NaN takes part in no 3D-3D or N-N vote and in no 3D least squares."""
+    n = 4000
+    sc = util.scene_full(950, n, np.float32, outliers=0.0, nan_frac=0.5)
+    got = api.run(api.M_SK_RANSAC, L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, thre_3d=0.2, thre_2d=50.0, iters=100, confidence=0.999, seed=3,
+                  ls=api.LS_SHINJI_INLIERS, score_mode=L.SCORE_EXACT)
+    nan_rows = np.isnan(sc.P).all(1)
+    assert got["masks"][1][nan_rows].sum() == 0 and got["masks"][1][~nan_rows].sum() > 0.5 * (~nan_rows).sum()
+    assert util.rot_err(got["R"], sc.R) < 5e-3
