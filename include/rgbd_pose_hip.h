@@ -168,8 +168,15 @@ int rpe_inlier_mask(rpe_context* ctx, int kind, int mode, const double* pose7, d
  * recurrences.  Masks/weights of all three modalities are honoured (weights optional, scaled as the adapters do). */
 int rpe_nl_round(rpe_context* ctx, const double* c_opt3, const double* Cw3, const double* Cc3, const double* Rwc9, double* out44);
 
-/* ---- adapter-level pipelines, for hosts that cannot include the C++ headers (and for the parity tests):
- * runs the named solver of pose/ *.hpp on a freshly built adapter.  Same ids as oracle/oracle_capi.cpp. */
+/* ---- adapter-level pipelines, for hosts that cannot include the C++ headers (and for the parity tests): builds the
+ * adapter the reference's demos would build for the arrays given (AOOnly / PnP / AO / NormalAO), runs one solver of
+ * pose/ *.hpp on it, optionally a least-squares stage, and returns pose, votes, adapted Iter and the inlier masks.
+ * method: 0 shinji_ransac  1 shinji_ransac2  2 shinji_prosac  3 kneip_ransac  4 kneip_prosac  5 shinji_kneip_ransac
+ *         6 shinji_kneip_prosac  7 nl_kneip_ransac  8 nl_shinji_ransac  9 nl_shinji_kneip_ransac
+ *         10 none (pose R9/t3 and mask_in are INPUTS: least-squares stage only)
+ * ls:     0 none  1 shinji_ls / shinji_ls1 (inliers)  2 nl_shinji_kneip_ls (bug-compatible)  3 nl_shinji_kneip_ls (fixed)
+ *         4 shinji_ls2 (all)  5 gn_refine_p2p  6 gn_refine_joint  7 gn_refine_p2plane  8 gn_refine_bearing
+ * mask_in / mask_out: 3 x n shorts, row 0 = 2D-3D, 1 = 3D-3D, 2 = normal-normal.  seed: sampler stream. */
 typedef struct {
   int n;
   int dtype;              /* RPE_F32 / RPE_F64 */
@@ -184,6 +191,21 @@ typedef struct {
 } rpe_problem;
 int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
             uint64_t seed, int ls, int score_mode, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out);
+
+/* ---- host-side pieces of the solvers (no GPU needed): sampling, minimal solvers, small algebra.  They exist so that
+ * hosts in other languages do not have to re-implement them, and so that the host logic can be tested on a CPU box.
+ * 3 x K inputs are column-major doubles whose values are rounded to dtype before use. */
+void rpe_host_random_elements(int n, int m, uint64_t seed, int draws, int* out);                 /* Utility.hpp:124-156 */
+void rpe_host_prosac_samples(int dtype, int m, int n, uint64_t seed, int draws, int* out);       /* Utility.hpp:161-250 */
+int rpe_host_update_num_iters(int dtype, double p, double ep, int model_points, int max_iters);  /* P3P.hpp:296-318    */
+void rpe_host_sort_indexes(const double* w, int n, int* out);                                     /* Utility.hpp:107-118 */
+int rpe_host_kneip_main(int dtype, const double* xw4, const double* bv4, double* sols12);         /* P3P.hpp:63-232     */
+int rpe_host_kneip(int dtype, const double* xw4, const double* bv4, double* R9, double* t3);      /* P3P.hpp:250-294    */
+void rpe_host_nl_2p(int dtype, const double* v18, double* R9, double* t3);                        /* AbsoluteOrientationNormal.hpp:77-142 */
+void rpe_host_shinji(int dtype, const double* xw, const double* xc, int K, double* R9, double* t3); /* AbsoluteOrientation.hpp:47-99 */
+void rpe_host_se3_exp(const double* a6, double* R9, double* t3);                                  /* sophus/se3.hpp:321-342 */
+void rpe_host_svd3(const double* A9, double* U9, double* s3, double* V9);
+void rpe_host_calc_err(const double* Rgt9, const double* tgt3, const double* Rse9, const double* tse3, double* err2, double* pct2);
 
 #ifdef __cplusplus
 }

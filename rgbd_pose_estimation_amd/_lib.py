@@ -25,6 +25,8 @@ SYMBOLS = [
     "rpe_set_problem", "rpe_upload", "rpe_bind", "rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask",
     "rpe_p2p_moments", "rpe_pose_from_moments", "rpe_normal_eq", "rpe_normal_eq_device", "rpe_gn_solve", "rpe_gn_apply",
     "rpe_gn_step", "rpe_gn_refine", "rpe_timing_enable", "rpe_timing_collect", "rpe_score", "rpe_inlier_mask", "rpe_nl_round", "rpe_run",
+    "rpe_host_random_elements", "rpe_host_prosac_samples", "rpe_host_update_num_iters", "rpe_host_sort_indexes", "rpe_host_kneip_main",
+    "rpe_host_kneip", "rpe_host_nl_2p", "rpe_host_shinji", "rpe_host_se3_exp", "rpe_host_svd3", "rpe_host_calc_err",
 ]
 
 
@@ -103,6 +105,20 @@ def lib():
         if hasattr(L, "ao_ransac"):
             L.ao_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
             L.ao_ransac.restype = None
+        L.rpe_host_random_elements.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+        L.rpe_host_prosac_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+        L.rpe_host_update_num_iters.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.rpe_host_sort_indexes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rpe_host_kneip_main.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_host_kneip.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_host_nl_2p.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_host_shinji.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rpe_host_se3_exp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_host_svd3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_host_calc_err.argtypes = [C.c_void_p] * 6
+        for name in ("rpe_host_random_elements", "rpe_host_prosac_samples", "rpe_host_sort_indexes", "rpe_host_nl_2p", "rpe_host_shinji",
+                     "rpe_host_se3_exp", "rpe_host_svd3", "rpe_host_calc_err"):
+            getattr(L, name).restype = None
         L.py2c.argtypes = [C.c_void_p, C.c_int]
         L.py2c.restype = None
         _lib = L

@@ -150,6 +150,17 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
   return RPE_OK;
 }
 
+template <class Tp> rpe::MatrixX<Tp> mat_from(const double* p, int cols) {
+  rpe::MatrixX<Tp> m(3, cols);
+  for (int i = 0; i < 3 * cols; i++) m.data()[i] = (Tp)p[i];
+  return m;
+}
+template <class Tp> void pose_out(const rpe::SE3<Tp>& s, double* R9, double* t3) {
+  const rpe::Matrix3<Tp> R = s.so3().matrix();
+  for (int i = 0; i < 9; i++) R9[i] = (double)R.a[i];
+  for (int i = 0; i < 3; i++) t3[i] = (double)s.translation()[i];
+}
+
 void write_rowmajor(AOOnlyPoseAdapter<float>& adapter, float* R_cw_, float* t_) {
   const rpe::Matrix3<float> R = adapter.getRcw().matrix();  // row-major storage == the reference's Rp = R^T column-major dump (Library.cpp:35-39)
   for (int i = 0; i < 9; i++) R_cw_[i] = R.a[i];
@@ -194,6 +205,75 @@ void ao_ransac(float* x_w_, float* x_c_, int n_, float* R_cw_, float* t_) {
 
 void py2c(float* array, int N) {
   for (int i = 0; i < N; i++) std::cout << array[i] << std::endl;
+}
+
+// ---- host-side pieces of the solvers, callable without a GPU (CPU tests of the host logic; other-language hosts)
+void rpe_host_random_elements(int n, int m, uint64_t seed, int draws, int* out) {
+  rpe::Rand31 rnd(seed);
+  RandomElements<int> re(n);
+  std::vector<int> v;
+  for (int d = 0; d < draws; d++) { re.run(m, &v, rnd); for (int k = 0; k < m; k++) out[d * m + k] = v[k]; }
+}
+void rpe_host_prosac_samples(int dtype, int m, int n, uint64_t seed, int draws, int* out) {
+  rpe::Rand31 rnd(seed);
+  std::vector<int> v;
+  if (dtype == RPE_F64) { ProsacSampler<double> ps(m, n); for (int d = 0; d < draws; d++) { ps.sample(&v, rnd); for (int k = 0; k < m; k++) out[d * m + k] = v[k]; } }
+  else { ProsacSampler<float> ps(m, n); for (int d = 0; d < draws; d++) { ps.sample(&v, rnd); for (int k = 0; k < m; k++) out[d * m + k] = v[k]; } }
+}
+int rpe_host_update_num_iters(int dtype, double p, double ep, int model_points, int max_iters) {
+  return dtype == RPE_F64 ? RANSACUpdateNumIters<double>(p, ep, model_points, max_iters)
+                          : RANSACUpdateNumIters<float>((float)p, (float)ep, model_points, max_iters);
+}
+void rpe_host_sort_indexes(const double* w, int n, int* out) {
+  std::vector<double> v(w, w + n);
+  std::vector<int> idx = sortIndexes<double>(v);
+  for (int i = 0; i < n; i++) out[i] = idx[i];
+}
+// xw4, bv4: 3 x 4 column-major doubles (values are rounded to dtype).  sols12: up to 4 x (R9 | t3).  returns the count
+int rpe_host_kneip_main(int dtype, const double* xw4, const double* bv4, double* sols12) {
+  int cnt = 0;
+  if (dtype == RPE_F64) { std::vector<rpe::SE3<double> > v; kneip_main<double>(mat_from<double>(xw4, 4), mat_from<double>(bv4, 4), &v);
+    for (auto& s : v) { pose_out(s, sols12 + 12 * cnt, sols12 + 12 * cnt + 9); cnt++; } }
+  else { std::vector<rpe::SE3<float> > v; kneip_main<float>(mat_from<float>(xw4, 4), mat_from<float>(bv4, 4), &v);
+    for (auto& s : v) { pose_out(s, sols12 + 12 * cnt, sols12 + 12 * cnt + 9); cnt++; } }
+  return cnt;
+}
+int rpe_host_kneip(int dtype, const double* xw4, const double* bv4, double* R9, double* t3) {
+  if (dtype == RPE_F64) { rpe::SE3<double> s; if (!kneip<double>(mat_from<double>(xw4, 4), mat_from<double>(bv4, 4), &s)) return 0; pose_out(s, R9, t3); return 1; }
+  rpe::SE3<float> s; if (!kneip<float>(mat_from<float>(xw4, 4), mat_from<float>(bv4, 4), &s)) return 0; pose_out(s, R9, t3); return 1;
+}
+// v18: pt1_c nl1_c pt2_c pt1_w nl1_w pt2_w
+void rpe_host_nl_2p(int dtype, const double* v18, double* R9, double* t3) {
+  if (dtype == RPE_F64) { rpe::Point3<double> a[6]; for (int i = 0; i < 6; i++) a[i] = rpe::Point3<double>(v18 + 3 * i);
+    rpe::SE3<double> s; nl_2p<double>(a[0], a[1], a[2], a[3], a[4], a[5], &s); pose_out(s, R9, t3); }
+  else { rpe::Point3<float> a[6]; for (int i = 0; i < 6; i++) a[i] = rpe::Point3<float>((float)v18[3 * i], (float)v18[3 * i + 1], (float)v18[3 * i + 2]);
+    rpe::SE3<float> s; nl_2p<float>(a[0], a[1], a[2], a[3], a[4], a[5], &s); pose_out(s, R9, t3); }
+}
+// shinji() on K host columns (3 x K column-major doubles)
+void rpe_host_shinji(int dtype, const double* xw, const double* xc, int K, double* R9, double* t3) {
+  if (dtype == RPE_F64) pose_out(shinji<double>(mat_from<double>(xw, K), mat_from<double>(xc, K), K), R9, t3);
+  else pose_out(shinji<float>(mat_from<float>(xw, K), mat_from<float>(xc, K), K), R9, t3);
+}
+void rpe_host_se3_exp(const double* a6, double* R9, double* t3) { rpe::se3_exp(a6, R9, t3); }
+void rpe_host_svd3(const double* A9, double* U9, double* s3, double* V9) {
+  rpe::Mat3d A; for (int i = 0; i < 9; i++) A.a[i] = A9[i];
+  const rpe::Svd3 d = rpe::svd3(A);
+  for (int i = 0; i < 9; i++) { U9[i] = d.U.a[i]; V9[i] = d.V.a[i]; }
+  for (int i = 0; i < 3; i++) s3[i] = d.s[i];
+}
+// (t_e, r_e) of calc_err and calc_percentage_err (AbsoluteOrientation.hpp:11-43), double
+void rpe_host_calc_err(const double* Rgt9, const double* tgt3, const double* Rse9, const double* tse3, double* err2, double* pct2) {
+  rpe::Matrix3<double> A, B;
+  for (int i = 0; i < 9; i++) { A.a[i] = Rgt9[i]; B.a[i] = Rse9[i]; }
+  const rpe::SO3<double> Ra(A), Rb(B);
+  const rpe::Point3<double> ta(tgt3), tb(tse3);
+  const rpe::Point3<double> e = calc_err<double>(rpe::SE3<double>(Ra, ta), rpe::SE3<double>(Rb, tb));
+  err2[0] = e[0]; err2[1] = e[1];
+  rpe::MatrixX<double> none(3, 0);
+  AOOnlyPoseAdapter<double> ad(none, none);
+  ad.setRcw(Rb); ad.sett(tb);
+  const rpe::Point3<double> p = calc_percentage_err<double>(Ra, ta, &ad);
+  pct2[0] = p[0]; pct2[1] = p[1];
 }
 
 int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence, uint64_t seed,

@@ -1,0 +1,85 @@
+"""CPU, world_size 2, gloo: the multi-GPU driver (rgbd_pose_estimation_amd/distributed.py) shards correspondences by
+contiguous ranges, all-reduces the 32-double normal-equation record once per Gauss-Newton iteration and the int32 vote
+counters once per scoring batch, and every rank ends with the same pose.  The per-shard evaluator injected here is the
+oracle (test infrastructure) -- the product's own evaluator is the HIP kernel, which needs a GPU; the host solve and the
+SE(3) update are the product's (librgbdpose_hip.so host code)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import util
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    import oracle_lib as O
+    from rgbd_pose_estimation_amd.distributed import ShardedGaussNewton, ShardedScorer, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = util.scene33(42, n, np.float32, outliers=0.0)
+        lo, hi = shard_range(n, rank, world)
+        xw, xc = sc.Q[lo:hi], sc.P[lo:hi]
+
+        def local_ne(pose12):
+            rec = np.zeros(32)
+            rec[:29] = O.gn_normal_eq(O.GN_P2P, xw, xc, pose=pose12)
+            return torch.from_numpy(rec)
+
+        gn = ShardedGaussNewton(local_ne)
+        p0 = O.pose12(np.eye(3), np.zeros(3))
+        p, its, step = gn.refine(p0, max_iter=30, tol=1e-10)
+        prob = O.Problem(False, xw=xw, xc=xc)
+        hyps = np.array([O.pose7_from_Rt(*util.perturbed_pose(np.random.default_rng(h), sc.R, sc.t, 0.002 * h, 0.01 * h), False) for h in range(8)])
+        scorer = ShardedScorer(lambda q7: torch.from_numpy(O.votes(prob, O.V_33, q7, thre_3d=0.15).astype(np.int32)))
+        votes = scorer.score(hyps)
+        q.put((rank, p, its, votes, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 20000])
+def test_sharded_gn_and_scoring_equal_single_process(oracle, n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # shards tile [0, n) exactly
+    assert res[0][4][0] == 0 and res[0][4][1] == res[1][4][0] and res[1][4][1] == n
+    # every rank holds the same pose (bitwise: the all-reduced record is identical on all ranks)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    # and it is the single-process answer
+    sc = util.scene33(42, n, np.float32, outliers=0.0)
+    po, its, _, _ = oracle.gn_refine([dict(kind=oracle.GN_P2P, a=sc.Q, b=sc.P)], n, oracle.pose12(np.eye(3), np.zeros(3)), 30, 1e-10)
+    assert util.rot_err(res[0][1][:9].reshape(3, 3), po[:9].reshape(3, 3)) < 1e-10
+    assert util.trans_rel_err(res[0][1][9:], po[9:]) < 1e-10
+    Rk, tk, _ = oracle.shinji_f32in_f64(sc.Q, sc.P)
+    assert util.rot_err(res[0][1][:9].reshape(3, 3), Rk) < 1e-9
+    hyps = np.array([oracle.pose7_from_Rt(*util.perturbed_pose(np.random.default_rng(h), sc.R, sc.t, 0.002 * h, 0.01 * h), False) for h in range(8)])
+    full = oracle.votes(oracle.Problem(False, xw=sc.Q, xc=sc.P), oracle.V_33, hyps, thre_3d=0.15)
+    assert np.array_equal(res[0][3], full) and np.array_equal(res[1][3], full)
+
+
+def test_shard_range_tiles():
+    from rgbd_pose_estimation_amd.distributed import shard_range
+    for n in (0, 1, 7, 307200, 10_000_000):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
