@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-chunks", action="store_true")
     ap.add_argument("--time-every", type=int, default=8, help="record a HIP event pair around every k-th K1 launch of the timed region")
     args = ap.parse_args()
 
@@ -101,12 +102,17 @@ def main():
             sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
+    # Load librgbdpose_hip.so (and let it register its gfx950 code objects) BEFORE torch initialises HIP: measured on
+    # MI355X / ROCm 7.x, a library whose fat binary is registered after hipInit() pays 2-3x the launch latency per
+    # kernel (62 us vs 20 us per step here).  torch's bundled libamdhip64 is the one runtime of the process (_lib.py).
+    from rgbd_pose_estimation_amd import _lib as L, api
+    L.lib()
+    n_dev = L.device_count()
     import torch
     import torch.distributed as dist
-    from rgbd_pose_estimation_amd import _lib as L, api
     from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton
 
-    if not torch.cuda.is_available() or L.device_count() < 1:
+    if n_dev < 1 or not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1 or force_dist:
@@ -139,15 +145,25 @@ def main():
                 return p
             return gn.step(p)[0]
 
+        # untimed pre-warm, independent of --warmup: the first ~25 ms of launches after torch has initialised HIP contain a
+        # one-off ~35 ms stall (measured; runtime lazy initialisation), which must not land in a short timed region
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.25:
+            pose = one_step(pose)
+        pose = pose12(R0, t0)
         for _ in range(args.warmup):
             pose = one_step(pose)
-        ctx.timing_enable(args.steps, args.time_every)   # HIP events around every time_every-th kernel launch
+        if args.time_every > 0:
+            ctx.timing_enable(args.steps // args.time_every + 1, args.time_every)   # HIP events around every time_every-th K1 launch
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        for _ in range(args.steps):
+        chunk_t = []
+        for k in range(args.steps):
             pose = one_step(pose)
+            if args.debug_chunks and (k + 1) % 250 == 0:
+                chunk_t.append(time.perf_counter())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -203,6 +219,9 @@ def main():
         else:
             out["pose_error_vs_truth"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), sc.R), "trans_abs_m": float(np.linalg.norm(pose[9:] - sc.t))}
             out["cpu_baseline"] = None
+        if args.debug_chunks:
+            ts = [t_start] + chunk_t
+            out["chunk_us_per_step"] = [round((b - a) / 250 * 1e6, 1) for a, b in zip(ts[:-1], ts[1:])]
         print(json.dumps(out), flush=True)
 
     ctx.close()

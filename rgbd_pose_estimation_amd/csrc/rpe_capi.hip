@@ -45,7 +45,9 @@ struct rpe_context {
   size_t mask_cap[3] = {0, 0, 0};
   void* weight[3] = {nullptr, nullptr, nullptr};
   size_t weight_cap[3] = {0, 0, 0};
-  int max_blocks = 1024;
+  int max_blocks = 512;          // reduction kernels: cap on workgroups (one partial record each)
+  int score_blocks = 2048;       // scoring / mask kernels (256-thread workgroups)
+  int block = 0;                 // reduction workgroup size override (RPE_BLOCK), 0 = default
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
   double* d_out = nullptr;       // 64 doubles
   double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
@@ -97,13 +99,13 @@ int need_arrays(rpe_context* c, std::initializer_list<int> slots) {
 
 rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
-  rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks;
+  rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
   rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
   return rt;
 }
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   rpe::ReduceTarget rt;
-  rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks;
+  rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
   rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
   return rt;
 }
@@ -162,13 +164,15 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   c->device = device;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
   else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return fail(RPE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
-  if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->max_blocks = v; }
+  if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 4096) c->max_blocks = v; }
+  if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
+  if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)c->max_blocks * rpe::kNlLd * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)4096 * rpe::kNlLd * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
-  if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 64); }
-  if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 64);
+  if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 9 * 128); }
+  if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * 128);
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
@@ -471,7 +475,7 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
     const int hb = std::min(rpe::kMaxScoreH, H - h0);
     stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->max_blocks, c->stream));
+    HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, (size_t)hb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
@@ -495,7 +499,7 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   stage_poses(c->dtype, exact, pose7, 1, c->h_poses);
   HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, (exact ? 8 : 12) * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, c->d_poses, thr, c->d_votes, c->max_blocks, c->stream));
+  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, c->d_poses, thr, c->d_votes, c->score_blocks, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (votes_out) *votes_out = c->h_votes[0];

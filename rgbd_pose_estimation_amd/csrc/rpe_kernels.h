@@ -22,8 +22,9 @@ struct DeviceArrays {
 // Where a reduction kernel leaves its result (both stages run inside one launch, see reduce_and_finish).
 struct ReduceTarget {
   double* d_partials;          // max_blocks * kNlLd doubles of scratch
-  unsigned int* d_ticket;      // arrival counter, zero between launches
-  int max_blocks;
+  unsigned int* d_ticket;      // 9 arrival counters 128 B apart (8 shards + top), zero between launches
+  int max_blocks;              // cap on workgroups (= partial records)
+  int block;                   // workgroup size 256 / 512 / 1024, 0 = default
   double* d_out;               // record in HBM (for a collective), or null
   double* h_out;               // record in pinned host memory + sequence word at [LD], or null
   unsigned long long seq;      // sequence value published after the record

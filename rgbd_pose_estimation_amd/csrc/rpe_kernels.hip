@@ -113,16 +113,16 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
 
 struct Finish {
   double* partials;            // gridDim.x * LD doubles
-  unsigned int* ticket;        // zero before the launch; the last workgroup rearms it
+  unsigned int* ticket;        // 9 counters, 32 uints apart, zero before the launch; rearmed by the last arrivers
   double* out_dev;             // LD doubles in HBM, or null
   double* out_host;            // LD doubles + 1 sequence word in pinned host memory, or null
   unsigned long long seq;      // value published after the record
 };
 
-template <int NACC, int LD, int MODE>
+template <int NACC, int LD, int MODE, int BLK>
 __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Finish& fin) {
-  constexpr int NW = kBlock / 64;
-  constexpr int RG = kBlock / LD;
+  constexpr int NW = BLK / 64;
+  constexpr int RG = BLK / LD;
   __shared__ double red[NW][NACC];
   __shared__ double part[RG][LD];
   __shared__ double tot[LD];
@@ -149,8 +149,21 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned int prev = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = prev == (unsigned int)(G - 1);
+      // two-level arrival count: 8 shard counters (one 128-B line each) + a top counter.  A single counter costs
+      // ~12 ns per arrival at the memory side (MI355X_MICROARCH.md "fanin"), i.e. 3+ us for a few hundred workgroups.
+      const int shard = blockIdx.x & 7;
+      const unsigned int in_shard = (unsigned int)((G - shard + 7) >> 3), shards = (unsigned int)(G < 8 ? G : 8);
+      int last = 0;
+      unsigned int* sc = fin.ticket + 32 * shard;
+      if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+        __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rearm for the next launch
+        unsigned int* top = fin.ticket + 32 * 8;
+        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
+          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = 1;
+        }
+      }
+      s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -158,7 +171,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     const int j = threadIdx.x % LD, rg = threadIdx.x / LD;
     double s = 0.0;
     if (j < NACC) {
-      constexpr int U = 16;
+      constexpr int U = 8;
       for (int r0 = rg; r0 < G; r0 += RG * U) {
         double v[U];
 #pragma unroll
@@ -178,7 +191,6 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
       for (int k = 0; k < RG; k++) t += part[k][threadIdx.x];
       tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
     }
-    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rearm
   } else {
     if (threadIdx.x < LD) {
       double t = 0.0;
@@ -301,8 +313,8 @@ __device__ __forceinline__ void bearing_point(const PoseK<double>& T, C x, C y, 
   s[28] += w;
 }
 
-template <class T, int KIND>
-__global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
+template <class T, int KIND, int BLK>
+__global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                                                            const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                                                            PoseK<double> pose, Finish fin) {
   constexpr int P = Pk<T>::P;
@@ -311,8 +323,8 @@ __global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
   const int64_t groups = (n + P - 1) / P;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  for (int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x; g < groups; g += stride) {
     T vw[3 * P], vb[3 * P], vc[3 * P];
     load_group<T>(xw, g, n, vw);
     load_group<T>(b, g, n, vb);
@@ -351,23 +363,23 @@ __global__ __launch_bounds__(kBlock) void normal_eq_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < NACC; k++) acc[k] += (double)s[k];
   }
-  reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0>(acc, fin);
+  reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
 }
 
 // ================================================================================================
 // K1' : closed-form moments (both passes of shinji() in one): w | w Xw | w Xc | w Xc Xw^T | w |Xc|^2 | count
 // fp32 x fp32 products are exact in fp64, so only the fp64 summation rounds.
 // ================================================================================================
-template <class T>
-__global__ __launch_bounds__(kBlock) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const short* __restrict__ mask,
+template <class T, int BLK>
+__global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const short* __restrict__ mask,
                                                          const T* __restrict__ weight, int64_t n, int skip_invalid, Finish fin) {
   constexpr int P = Pk<T>::P;
   double acc[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) acc[k] = 0.0;
   const int64_t groups = (n + P - 1) / P;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  for (int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x; g < groups; g += stride) {
     T vw[3 * P], vc[3 * P];
     load_group<T>(xw, g, n, vw);
     load_group<T>(xc, g, n, vc);
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const T* __restrict__ x
       acc[16] = fma(wcx, cx, fma(wcy, cy, fma(wcz, cz, acc[16])));
     }
   }
-  reduce_and_finish<18, kNeLd, 0>(acc, fin);
+  reduce_and_finish<18, kNeLd, 0, BLK>(acc, fin);
 }
 
 // ================================================================================================
@@ -616,8 +628,8 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
 // ================================================================================================
 struct NlParams { double c_opt[3], Cw[3], Cc[3], Rwc[9]; };
 
-template <class T>
-__global__ __launch_bounds__(kBlock) void nl_round_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+template <class T, int BLK>
+__global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
                                                           const T* __restrict__ nw, const T* __restrict__ nc,
                                                           const short* __restrict__ k23, const short* __restrict__ k33,
                                                           const short* __restrict__ knn, const T* __restrict__ w23,
@@ -628,8 +640,8 @@ __global__ __launch_bounds__(kBlock) void nl_round_kernel(const T* __restrict__ 
 #pragma unroll
   for (int k = 0; k < 44; k++) acc[k] = 0.0;
   const int64_t groups = (n + P - 1) / P;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  for (int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x; g < groups; g += stride) {
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
     short a23[P], a33[P], ann[P];
     load_group<T>(xw, g, n, vw);
@@ -687,15 +699,26 @@ __global__ __launch_bounds__(kBlock) void nl_round_kernel(const T* __restrict__ 
       }
     }
   }
-  reduce_and_finish<44, kNlLd, 0>(acc, fin);
+  reduce_and_finish<44, kNlLd, 0, BLK>(acc, fin);
 }
 
 // ================================================================================================
 // launchers
 // ================================================================================================
-static inline int grid_for(int64_t n, int P, int max_blocks) {
+static inline int grid_for(int64_t n, int P, int max_blocks, int block = kBlock) {
   int64_t groups = (n + P - 1) / P;
-  int64_t g = (groups + kBlock - 1) / kBlock;
+  int64_t g = (groups + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+// Reduction kernels: one partial record per workgroup, so fewer workgroups = a shorter tail.  Give every thread two
+// groups when that still leaves >= 128 workgroups (measured on MI355X: 307 200 correspondences run 7 % faster with 128
+// workgroups of 512 threads than with 150; from 10 M correspondences up the cap of 2 workgroups per CU wins).
+static inline int reduce_grid(int64_t n, int P, int max_blocks, int block) {
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t one = (groups + block - 1) / block, two = (groups + 2 * (int64_t)block - 1) / (2 * (int64_t)block);
+  int64_t g = two < 128 ? (one < 128 ? one : 128) : two;
   if (g < 1) g = 1;
   if (g > max_blocks) g = max_blocks;
   return (int)g;
@@ -706,29 +729,50 @@ template <class T> static PoseK<T> make_pose(const double* p12) {
   for (int i = 0; i < 3; i++) k.t[i] = (T)p12[9 + i];
   return k;
 }
-
 static Finish make_finish(const ReduceTarget& rt) {
   Finish f;
   f.partials = rt.d_partials; f.ticket = rt.d_ticket; f.out_dev = rt.d_out; f.out_host = rt.h_out; f.seq = rt.seq;
   return f;
 }
+// Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)
+// costs latency proportional to the number of workgroups, the body wants every CU busy: 512-thread workgroups, at
+// most 2 per CU (512 records), is the measured sweet spot on MI355X from 307 200 correspondences up; rt.block /
+// rt.max_blocks (RPE_BLOCK / RPE_MAX_BLOCKS) override it for experiments.
+static inline int pick_block(const ReduceTarget& rt, bool allow_1024) {
+  int b = rt.block > 0 ? rt.block : 512;
+  if (b >= 1024 && allow_1024) return 1024;
+  if (b >= 512) return 512;
+  return 256;
+}
 
+template <class T, int KIND, int BLK>
+static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const ReduceTarget& rt, hipStream_t s) {
+  const T* xw = (const T*)A.a[0];
+  const T* b = (const T*)(KIND == KIND_BEARING ? A.a[2] : A.a[1]);
+  const T* c = (const T*)A.a[4];
+  const int mod = KIND == KIND_BEARING ? 0 : 1;
+  const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
+  const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
+  hipLaunchKernelGGL((normal_eq_kernel<T, KIND, BLK>), dim3(G), dim3(BLK), 0, s, xw, b, c, mask, weight, A.n, pose, make_finish(rt));
+}
 template <class T>
 static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                               hipEvent_t ev0, hipEvent_t ev1) {
-  const T* xw = (const T*)A.a[0];
-  const T* b = (const T*)(kind == KIND_BEARING ? A.a[2] : A.a[1]);
-  const T* c = (const T*)A.a[4];
-  const int mod = kind == KIND_BEARING ? 0 : 1;
-  const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
-  const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
-  const int G = grid_for(A.n, Pk<T>::P, rt.max_blocks);
-  PoseK<double> pose = make_pose<double>(pose12);
-  const Finish fin = make_finish(rt);
+  const PoseK<double> pose = make_pose<double>(pose12);
+  const int blk = pick_block(rt, kind == KIND_P2P);
   if (ev0) (void)hipEventRecord(ev0, s);
-  if (kind == KIND_P2P) hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2P>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, fin);
-  else if (kind == KIND_P2PLANE) hipLaunchKernelGGL((normal_eq_kernel<T, KIND_P2PLANE>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, fin);
-  else hipLaunchKernelGGL((normal_eq_kernel<T, KIND_BEARING>), dim3(G), dim3(kBlock), 0, s, xw, b, c, mask, weight, A.n, pose, fin);
+  if (kind == KIND_P2P) {
+    if (blk == 1024) normal_eq_launch<T, KIND_P2P, 1024>(A, flags, pose, rt, s);
+    else if (blk == 512) normal_eq_launch<T, KIND_P2P, 512>(A, flags, pose, rt, s);
+    else normal_eq_launch<T, KIND_P2P, 256>(A, flags, pose, rt, s);
+  } else if (kind == KIND_P2PLANE) {
+    if (blk == 512) normal_eq_launch<T, KIND_P2PLANE, 512>(A, flags, pose, rt, s);
+    else normal_eq_launch<T, KIND_P2PLANE, 256>(A, flags, pose, rt, s);
+  } else {
+    if (blk == 512) normal_eq_launch<T, KIND_BEARING, 512>(A, flags, pose, rt, s);
+    else normal_eq_launch<T, KIND_BEARING, 256>(A, flags, pose, rt, s);
+  }
   if (ev1) (void)hipEventRecord(ev1, s);
   return hipGetLastError();
 }
@@ -737,13 +781,20 @@ hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const do
   return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s, ev0, ev1);
 }
 
-template <class T>
-static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
+template <class T, int BLK>
+static void moments_launch(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
   const short* mask = (flags & F_USE_MASK) ? A.mask[1] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[1] : nullptr;
-  const int G = grid_for(A.n, Pk<T>::P, rt.max_blocks);
-  hipLaunchKernelGGL((moments_kernel<T>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], mask, weight, A.n,
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
+  hipLaunchKernelGGL((moments_kernel<T, BLK>), dim3(G), dim3(BLK), 0, s, (const T*)A.a[0], (const T*)A.a[1], mask, weight, A.n,
                      (flags & F_SKIP_INVALID) ? 1 : 0, make_finish(rt));
+}
+template <class T>
+static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
+  const int blk = pick_block(rt, true);
+  if (blk == 1024) moments_launch<T, 1024>(A, flags, rt, s);
+  else if (blk == 512) moments_launch<T, 512>(A, flags, rt, s);
+  else moments_launch<T, 256>(A, flags, rt, s);
   return hipGetLastError();
 }
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
@@ -805,15 +856,20 @@ hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d
   return hipGetLastError();
 }
 
+template <class T, int BLK>
+static void nl_round_launch(const DeviceArrays& A, const NlParams& prm, const ReduceTarget& rt, hipStream_t s) {
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
+  hipLaunchKernelGGL((nl_round_kernel<T, BLK>), dim3(G), dim3(BLK), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], (const T*)A.a[3],
+                     (const T*)A.a[4], (const short*)A.mask[0], (const short*)A.mask[1], (const short*)A.mask[2], (const T*)A.weight[0],
+                     (const T*)A.weight[1], (const T*)A.weight[2], A.n, prm, make_finish(rt));
+}
 template <class T>
 static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s) {
   NlParams prm;
   for (int i = 0; i < 3; i++) { prm.c_opt[i] = params24[i]; prm.Cw[i] = params24[3 + i]; prm.Cc[i] = params24[6 + i]; }
   for (int i = 0; i < 9; i++) prm.Rwc[i] = params24[9 + i];
-  const int G = grid_for(A.n, Pk<T>::P, rt.max_blocks);
-  hipLaunchKernelGGL((nl_round_kernel<T>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], (const T*)A.a[3],
-                     (const T*)A.a[4], (const short*)A.mask[0], (const short*)A.mask[1], (const short*)A.mask[2], (const T*)A.weight[0],
-                     (const T*)A.weight[1], (const T*)A.weight[2], A.n, prm, make_finish(rt));
+  if (pick_block(rt, false) == 512) nl_round_launch<T, 512>(A, prm, rt, s);
+  else nl_round_launch<T, 256>(A, prm, rt, s);
   return hipGetLastError();
 }
 hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s) {
