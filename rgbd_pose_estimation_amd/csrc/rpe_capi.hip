@@ -45,7 +45,7 @@ struct rpe_context {
   size_t mask_cap[3] = {0, 0, 0};
   void* weight[3] = {nullptr, nullptr, nullptr};
   size_t weight_cap[3] = {0, 0, 0};
-  int max_blocks = 512;          // reduction kernels: cap on workgroups (one partial record each)
+  int max_blocks = 256;          // reduction kernels: cap on workgroups = one per CU (multiples of 256 only: 320 or 384 lose 20-30 %)
   int score_blocks = 2048;       // scoring / mask kernels (256-thread workgroups)
   int block = 0;                 // reduction workgroup size override (RPE_BLOCK), 0 = default
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
