@@ -55,5 +55,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXAMPLES = ["simple_main", "test_main"]
+
+
+def build_examples(verbose: bool = False) -> list[str]:
+    """The reference's two demo drivers rebuilt on the drop-in headers: plain g++, linking only the C ABI."""
+    root = os.path.dirname(PKG)
+    outs = []
+    for ex in EXAMPLES:
+        src, out = os.path.join(root, "examples", ex + ".cpp"), os.path.join(root, "examples", ex)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(PKG, "include", "pose"), "-I", os.path.join(PKG, "include"),
+               src, "-L", LIBDIR, "-lrgbdpose_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../rgbd_pose_estimation_amd/lib", "-o", out]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--examples" in sys.argv:
+        print(build_examples(verbose=True))

@@ -1,0 +1,33 @@
+"""-m gpu: the reference's two demo drivers rebuilt on the drop-in C++ headers run end to end on the GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(name, *args):
+    exe = os.path.join(ROOT, "examples", name)
+    if not os.path.exists(exe):
+        from rgbd_pose_estimation_amd import build
+        build.build_examples()
+    env = dict(os.environ, RPE_QUIET="1")
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_simple_main_like_reference_demo():
+    r = _run("simple_main", "7")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "%test_3d_3d_2d()" in r.stdout and "sk prosac t_s =[" in r.stdout and "sk ransac r_l =[" in r.stdout
+    assert len(re.findall(r"%summary \w+: .* -> ok", r.stdout)) == 3
+
+
+@pytest.mark.parametrize("args", [(), ("noise_model=Kinect", "noise_2d=2", "test_n=10"), ("total=2000", "test_n=5", "noise_2d=3")])
+def test_test_main_all_solvers(args):
+    r = _run("test_main", *args)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = dict((m.group(1), (float(m.group(2)), float(m.group(3)))) for m in re.finditer(r"^(\w+)\s+([\d.eE+-]+)\s+([\d.eE+-]+)$", r.stdout, re.M))
+    assert set(rows) == {"k", "s", "sk", "nk", "ns", "nsk", "opt", "dw", "gn"}
