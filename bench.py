@@ -110,7 +110,7 @@ def main():
     n_dev = L.device_count()
     import torch
     import torch.distributed as dist
-    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton
+    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_native_comm
 
     if n_dev < 1 or not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
@@ -138,10 +138,16 @@ def main():
         shard.kind, shard.flags = L.RES_P2P, L.USE_MASK
         gn = ShardedGaussNewton(shard.normal_eq)
         pose = pose12(R0, t0)
+        # N > 1: the all-reduce runs inside the library on its own RCCL communicator (no Python-side collective per step);
+        # RPE_BENCH_TORCH_ALLREDUCE=1 forces the torch.distributed fallback path instead
+        native = dist_path and os.environ.get("RPE_BENCH_TORCH_ALLREDUCE") != "1" and init_native_comm(ctx)
 
         def one_step(p):
-            if world == 1 and not force_dist:
-                ctx.gn_step(L.RES_P2P, p, L.USE_MASK)   # in place: kernel + D2H + solve + exp-map
+            if not dist_path:
+                ctx.gn_step(L.RES_P2P, p, L.USE_MASK)   # in place: kernel + publish + solve + exp-map
+                return p
+            if native:
+                ctx.gn_step_dist(L.RES_P2P, p, L.USE_MASK)   # in place: kernel + RCCL all-reduce + publish + solve + exp-map
                 return p
             return gn.step(p)[0]
 
@@ -194,7 +200,8 @@ def main():
             "config": {"workload": f"configs[1]: 640x480 dense depth, {n} 3D-3D correspondences per GPU, point-to-point absolute "
                                    "orientation, Gauss-Newton step (K1 normal equations + host SE3 exp-map update) over the RANSAC inlier mask",
                        "corr_per_gpu": n, "global_corr": n * world, "inliers_rank0": int(inl), "accumulate": "fp64",
-                       "collective": "all-reduce(sum) of 32 fp64 per step over RCCL" if world > 1 else "none"},
+                       "collective": ("all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
+                                     if dist_path else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
@@ -222,11 +229,19 @@ def main():
         if args.debug_chunks:
             ts = [t_start] + chunk_t
             out["chunk_us_per_step"] = [round((b - a) / 250 * 1e6, 1) for a, b in zip(ts[:-1], ts[1:])]
-        print(json.dumps(out), flush=True)
-
+    # tear everything down first: RCCL prints its version banner on stdout around communicator life-cycle events, and
+    # the JSON line must be the LAST line rank 0 prints
     ctx.close()
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:  # RCCL's banner sits in the C stdio buffer until exit: push it out before the JSON line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

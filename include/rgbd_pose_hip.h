@@ -123,6 +123,16 @@ int rpe_gn_apply(const double* delta6, double* pose12);
 /* One Gauss-Newton step on one GPU (kernel -> D2H of the 32-double record -> solve -> exp-map update of pose12).
  * ne32_out / step_norm may be NULL. */
 int rpe_gn_step(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
+/* ---- multi-GPU: one process per GPU, correspondences sharded by contiguous index ranges, pose replicated.
+ * rank 0 obtains a 128-byte id (rpe_comm_unique_id) and hands it to every rank by any means (MPI, torch.distributed,
+ * a file); each rank then calls rpe_comm_init on its context (RCCL communicator on that context's device; librccl is
+ * resolved at run time).  rpe_gn_step_dist = rpe_gn_step with ONE in-place all-reduce(sum) of the 32-double record over
+ * RCCL/xGMI between the kernel and the host solve; every rank ends the step with the same pose.  With a communicator set,
+ * rpe_score all-reduces the H int32 vote counters the same way. */
+int rpe_comm_unique_id(void* id128);
+int rpe_comm_init(rpe_context* ctx, int world, int rank, const void* id128);
+int rpe_comm_destroy(rpe_context* ctx);
+int rpe_gn_step_dist(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
 /* Whole refinement loop on one GPU: up to 3 residual kinds summed with scales; stops when |delta| < tol.
  * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */
 int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,

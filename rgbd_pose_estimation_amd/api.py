@@ -135,6 +135,19 @@ class Context:
         L.check(L.lib().rpe_gn_step(self._h, kind, flags, _p(pose12_inout), None, C.byref(step)))
         return step.value
 
+    def gn_step_dist(self, kind: int, pose12_inout: np.ndarray, flags: int = 0) -> float:
+        """One sharded GN step in place (kernel -> RCCL all-reduce -> host solve); needs comm_init."""
+        step = C.c_double(0)
+        L.check(L.lib().rpe_gn_step_dist(self._h, kind, flags, _p(pose12_inout), None, C.byref(step)))
+        return step.value
+
+    def comm_init(self, world: int, rank: int, id128: bytes):
+        buf = (C.c_char * 128).from_buffer_copy(id128)
+        L.check(L.lib().rpe_comm_init(self._h, world, rank, buf))
+
+    def comm_destroy(self):
+        L.check(L.lib().rpe_comm_destroy(self._h))
+
     def timing_enable(self, max_records: int, stride: int = 1):
         L.check(L.lib().rpe_timing_enable(self._h, max_records, stride))
 
@@ -169,6 +182,12 @@ class Context:
         out = np.zeros(44)
         L.check(L.lib().rpe_nl_round(self._h, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out)))
         return out
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_char * 128)()
+    L.check(L.lib().rpe_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def pose_from_moments(m17):

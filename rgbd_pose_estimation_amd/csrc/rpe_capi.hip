@@ -5,6 +5,9 @@
 #include "rpe_kernels.h"
 #include "../include/rpe/linalg.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the RCCL entry points are resolved with dlopen/dlsym (no DT_NEEDED on librccl)
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +28,36 @@ int fail(int code, const char* fmt, ...) {
 
 size_t elem_size(int dtype) { return dtype == RPE_F64 ? 8 : 4; }
 
+}  // namespace
+
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  if (!r.h) {
+    // same soname as the copy PyTorch-ROCm bundles: if torch is in the process its librccl is reused
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    if (r.h) {
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+      r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+    }
+  }
+  return r;
+}
+#define NCCL_TRY(expr)                                                                                                  \
+  do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return fail(RPE_ERR_HIP, "%s: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r_) : "rccl error"); } while (0)
 }  // namespace
 
 namespace rpe {
@@ -60,6 +93,9 @@ struct rpe_context {
   // optional HIP-event timing of the stage-1 normal-equation kernel (bench.py roofline leg)
   std::vector<hipEvent_t> ev0, ev1;
   size_t ev_used = 0;
+  ncclComm_t comm = nullptr;      // this rank's communicator for the per-iteration all-reduce (rpe_comm_init)
+  int comm_world = 1;
+  unsigned long long* h_flag2 = nullptr;  // pinned sequence word of the vote publish
   bool timing = false;
   int timing_stride = 1;
   unsigned long long timing_calls = 0;
@@ -196,6 +232,7 @@ void rpe_destroy(rpe_context* c) {
   if (c->h_poses) (void)hipHostFree(c->h_poses);
   if (c->d_votes) (void)hipFree(c->d_votes);
   if (c->h_votes) (void)hipHostFree(c->h_votes);
+  if (c->comm && rccl().ok) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -427,6 +464,54 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   return RPE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- RCCL (multi-GPU)
+
+int rpe_comm_unique_id(void* id128) {
+  if (!id128) return fail(RPE_ERR_ARG, "null id");
+  if (!rccl().ok) return fail(RPE_ERR_STATE, "librccl.so.1 could not be loaded: %s", dlerror());
+  ncclUniqueId id;
+  NCCL_TRY(rccl().GetUniqueId(&id));
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, 128);
+  return RPE_OK;
+}
+
+int rpe_comm_init(rpe_context* c, int world, int rank, const void* id128) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(RPE_ERR_ARG, "rpe_comm_init: bad argument");
+  if (!rccl().ok) return fail(RPE_ERR_STATE, "librccl.so.1 could not be loaded");
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  NCCL_TRY(rccl().CommInitRank(&c->comm, world, id, rank));
+  c->comm_world = world;
+  return RPE_OK;
+}
+
+int rpe_comm_destroy(rpe_context* c) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (c->comm) { (void)hipStreamSynchronize(c->stream); NCCL_TRY(rccl().CommDestroy(c->comm)); c->comm = nullptr; c->comm_world = 1; }
+  return RPE_OK;
+}
+
+// Sharded Gauss-Newton step: local normal equations -> in-place all-reduce(sum) of the 32-double record over RCCL on the
+// context's stream -> publish to pinned host memory -> (every rank, identically) solve + exp-map update.
+int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double* ne32_out, double* step_norm) {
+  if (!c || !c->comm) return fail(RPE_ERR_STATE, "rpe_comm_init was not called");
+  int rc = normal_eq_launch(c, kind, flags, pose12, c->d_out);
+  if (rc) return rc;
+  NCCL_TRY(rccl().AllReduce(c->d_out, c->d_out, 32, ncclFloat64, ncclSum, c->comm, c->stream));
+  const unsigned long long seq = ++c->seq;
+  HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq, c->stream));
+  if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  double ne[32], d[6];
+  for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
+  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
+  rpe::se3_left_update(d, pose12);
+  if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
+  if (step_norm) *step_norm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+  return RPE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- K4
 static int vote_arrays(rpe_context* c, int kind) {
   switch (kind) {
@@ -476,6 +561,7 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
     stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
+    if (c->comm) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream));  // sharded correspondences
     HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, (size_t)hb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));

@@ -42,4 +42,8 @@ hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d
 // params24 = c_opt(3) Cw(3) Cc(3) Rwc(9) pad; record = 64 doubles
 hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s);
 
+// copy `count` reduced values from HBM to pinned host memory and then store `seq` to *h_flag (the host spins on it)
+hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
+hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
+
 }  // namespace rpe

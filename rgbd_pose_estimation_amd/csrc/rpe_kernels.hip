@@ -801,6 +801,24 @@ __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw,
   reduce_and_finish<44, kNlLd, 0, BLK>(acc, fin);
 }
 
+// ---- after a collective: copy the reduced record from HBM to the pinned host slot and raise the sequence word
+template <class E>
+__global__ void publish_kernel(const E* __restrict__ src, int count, E* __restrict__ h_dst, unsigned long long* __restrict__ h_flag,
+                               unsigned long long seq) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) __hip_atomic_store(h_dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL((publish_kernel<double>), dim3(1), dim3(64), 0, s, d_src, count, h_dst, h_flag, seq);
+  return hipGetLastError();
+}
+hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL((publish_kernel<int>), dim3(1), dim3(256), 0, s, d_src, count, h_dst, h_flag, seq);
+  return hipGetLastError();
+}
+
 // ================================================================================================
 // launchers
 // ================================================================================================

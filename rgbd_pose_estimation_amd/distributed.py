@@ -74,6 +74,24 @@ class ShardedScorer:
         return v.detach().to("cpu").numpy()
 
 
+def init_native_comm(ctx: "api.Context", group=None) -> bool:
+    """Give `ctx` its own RCCL communicator (one per rank, same device as the context): rank 0 draws the 128-byte id,
+    torch.distributed only ferries it to the other ranks.  After this, Context.gn_step_dist() runs the whole sharded step
+    -- kernel, in-place all-reduce of the 32-double record on the context's stream, publish, host solve -- inside
+    librgbdpose_hip.so, without a Python-side collective.  Returns False (and leaves ctx untouched) if RCCL cannot be set up."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    try:
+        box = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ctx.comm_init(world, rank, box[0])
+        return True
+    except Exception as e:  # noqa: BLE001 -- the torch.distributed path below stays available
+        print(f"[rgbd_pose_estimation_amd] native RCCL communicator unavailable ({e}); using torch.distributed all-reduce", flush=True)
+        return False
+
+
 class HipShard:
     """This rank's shard resident in HBM + the device-side record buffer the collective reduces in place."""
 
