@@ -583,11 +583,11 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   const int exact = mode == RPE_SCORE_EXACT;
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
-  stage_poses(c->dtype, exact, pose7, 1, c->h_poses);
-  HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, (exact ? 8 : 12) * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, c->d_poses, thr, c->d_votes, c->score_blocks, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  double staged[12];
+  stage_poses(RPE_F64, exact, pose7, 1, staged);  // layout only; the launcher rounds to the array dtype
+  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, staged, thr, host_target(c), c->stream));
+  if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  c->h_votes[0] = (int)c->h_out[0];
   if (votes_out) *votes_out = c->h_votes[0];
   return RPE_OK;
 }

@@ -37,7 +37,8 @@ hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& 
 // thr: {thre_3d (fast: squared), cos_thr, cos_nl} as doubles holding values of the array dtype.
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s);
-hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d_pose, const double* thr3, int* d_votes, int max_blocks,
+// pose12: fast = R row-major (9) t (3); exact = qw qx qy qz tx ty tz (rest ignored).  The vote total is record[0] of rt.
+hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
                        hipStream_t s);
 // params24 = c_opt(3) Cw(3) Cc(3) Rwc(9) pad; record = 64 doubles
 hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s);

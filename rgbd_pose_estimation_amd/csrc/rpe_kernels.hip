@@ -678,17 +678,31 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
   }
 }
 
+// P flags of one group as ONE store (8 bytes for fp32 / P = 4, 4 bytes for fp64 / P = 2): a thread owns P consecutive
+// correspondences, so its shorts are contiguous; 2-byte scattered stores cost an order of magnitude more per byte.
+__device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[4]) {
+  uint2 u;
+  u.x = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+  u.y = (unsigned int)v[2] | ((unsigned int)v[3] << 16);
+  *reinterpret_cast<uint2*>(m + 4 * g) = u;
+}
+__device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[2]) {
+  *reinterpret_cast<unsigned int*>(m + 2 * g) = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+}
+
+template <class T> struct PoseArg { T v[12]; };  // one hypothesis by value (kernel argument): no H2D copy for a single pose
+
 template <class T, int KIND, bool EXACT>
 __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
                                                       const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
-                                                      const T* __restrict__ pose, T thr33, T cthr, T cnl, short* __restrict__ m23,
-                                                      short* __restrict__ m33, short* __restrict__ mnn, int* __restrict__ votes) {
+                                                      PoseArg<T> pose, T thr33, T cthr, T cnl, short* __restrict__ m23,
+                                                      short* __restrict__ m33, short* __restrict__ mnn, Finish fin) {
   constexpr int P = Pk<T>::P;
   typedef VoteMods<KIND> MD;
   Hyp<T, EXACT> hyp;
-  hyp.load(pose, KIND == VOTE_23_MATRIX);
+  hyp.load(pose.v, KIND == VOTE_23_MATRIX);
   int cnt = 0;
-  const int64_t groups = (n + P - 1) / P;
+  const int64_t groups = (n + P - 1) / P, full = n / P;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
@@ -696,29 +710,36 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
     if (MD::need_xc) load_group<T>(xc, g, n, vc);
     if (MD::m23) load_group<T>(bv, g, n, vb);
     if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+    bool f23[P], f33[P], fnn[P];
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      const int64_t idx = g * P + i;
-      if (idx >= n) continue;
-      const bool valid = !MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]);
+      const bool present = (g * P + i) < n;
+      const bool valid = present & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
       const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-      if (MD::mnn) {
-        const bool v = valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
-        mnn[idx] = v ? 1 : 0; cnt += v;
-      }
-      if (MD::m33) {
-        const bool v = valid & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
-        m33[idx] = v ? 1 : 0; cnt += v;
-      }
-      if (MD::m23) {
-        const bool v = hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
-        m23[idx] = v ? 1 : 0; cnt += v;
+      fnn[i] = MD::mnn ? (valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl)) : false;
+      f33[i] = MD::m33 ? (valid & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33)) : false;
+      f23[i] = MD::m23 ? (present & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX)) : false;
+      cnt += (int)fnn[i] + (int)f33[i] + (int)f23[i];
+    }
+    if (g < full) {
+      if (MD::mnn) store_mask_full(mnn, g, fnn);
+      if (MD::m33) store_mask_full(m33, g, f33);
+      if (MD::m23) store_mask_full(m23, g, f23);
+    } else {
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        const int64_t idx = g * P + i;
+        if (idx < n) {
+          if (MD::mnn) mnn[idx] = fnn[i];
+          if (MD::m33) m33[idx] = f33[i];
+          if (MD::m23) m23[idx] = f23[i];
+        }
       }
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  if ((threadIdx.x & 63) == 0 && cnt != 0) atomicAdd(votes, cnt);
+  // the vote total rides the same in-launch reduction + pinned-host publish as the normal equations (exact: integers < 2^53)
+  double acc[1] = {(double)cnt};
+  reduce_and_finish<1, kNeLd, 0, kBlock>(acc, fin);
 }
 
 // ================================================================================================
@@ -729,11 +750,11 @@ struct NlParams { double c_opt[3], Cw[3], Cc[3], Rwc[9]; };
 
 template <class T, int BLK>
 __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
-                                                          const T* __restrict__ nw, const T* __restrict__ nc,
-                                                          const short* __restrict__ k23, const short* __restrict__ k33,
-                                                          const short* __restrict__ knn, const T* __restrict__ w23,
-                                                          const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n, NlParams prm,
-                                                          Finish fin) {
+                                                       const T* __restrict__ nw, const T* __restrict__ nc,
+                                                       const short* __restrict__ k23, const short* __restrict__ k33,
+                                                       const short* __restrict__ knn, const T* __restrict__ w23,
+                                                       const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n, NlParams prm,
+                                                       Finish fin) {
   constexpr int P = Pk<T>::P;
   double acc[44];
 #pragma unroll
@@ -743,58 +764,64 @@ __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw,
   for (int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x; g < groups; g += stride) {
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
     short a23[P], a33[P], ann[P];
+    T u23[P], u33[P], unn[P];
     load_group<T>(xw, g, n, vw);
-    load_scalars<T, short>(k23, g, n, a23, (short)0);
-    load_scalars<T, short>(k33, g, n, a33, (short)0);
-    if (knn) load_scalars<T, short>(knn, g, n, ann, (short)0);
-    else {
-#pragma unroll
-      for (int i = 0; i < P; i++) ann[i] = 0;
-    }
+    load_mask_group(k23, g, n, a23);
+    load_mask_group(k33, g, n, a33);
+    if (knn) load_mask_group(knn, g, n, ann);
+    if (w23) load_weight_group(w23, g, n, u23);
+    if (w33) load_weight_group(w33, g, n, u33);
+    if (wnn) load_weight_group(wnn, g, n, unn);
     if (bv) load_group<T>(bv, g, n, vb);
     if (xc) load_group<T>(xc, g, n, vc);
     if (nw) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      const int64_t idx = g * P + i;
       const double x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-      if (bv && a23[i] == 1) {
-        const double w = w23 ? (double)w23[idx] : 1.0;
+      {  // 2D-3D inliers: M23 and the find_opt_cc sums.  Predicated: w = 0 switches the term off, no divergent branch.
+        const bool on = bv != nullptr && a23[i] == 1;
+        const double w = on ? (w23 ? (double)u23[i] : 1.0) : 0.0;
         double ax = x - prm.c_opt[0], ay = y - prm.c_opt[1], az = z - prm.c_opt[2];
-        const double inv = 1.0 / sqrt(ax * ax + ay * ay + az * az);
-        ax *= inv; ay *= inv; az *= inv;
-        const double bx = vb[3 * i], by = vb[3 * i + 1], bz = vb[3 * i + 2];
+        const double n2 = ax * ax + ay * ay + az * az;
+        const double inv = 1.0 / sqrt(n2);
+        ax = on ? ax * inv : 0.0; ay = on ? ay * inv : 0.0; az = on ? az * inv : 0.0;  // selects: NaN * 0 must not reach the sums
+        const double bx = on ? (double)vb[3 * i] : 0.0, by = on ? (double)vb[3 * i + 1] : 0.0, bz = on ? (double)vb[3 * i + 2] : 0.0;
         acc[0] = fma(w * bx, ax, acc[0]); acc[1] = fma(w * bx, ay, acc[1]); acc[2] = fma(w * bx, az, acc[2]);
         acc[3] = fma(w * by, ax, acc[3]); acc[4] = fma(w * by, ay, acc[4]); acc[5] = fma(w * by, az, acc[5]);
         acc[6] = fma(w * bz, ax, acc[6]); acc[7] = fma(w * bz, ay, acc[7]); acc[8] = fma(w * bz, az, acc[8]);
-        acc[9] += w; acc[10] += 1.0;
+        acc[9] += w; acc[10] += on ? 1.0 : 0.0;
         // find_opt_cc: v = Rwc * bv ; A = I - v v^T ; AA += A ; bb += A * Xw
         const double vx = prm.Rwc[0] * bx + prm.Rwc[1] * by + prm.Rwc[2] * bz;
         const double vy = prm.Rwc[3] * bx + prm.Rwc[4] * by + prm.Rwc[5] * bz;
         const double vz = prm.Rwc[6] * bx + prm.Rwc[7] * by + prm.Rwc[8] * bz;
-        const double Axx = 1 - vx * vx, Axy = -vx * vy, Axz = -vx * vz, Ayy = 1 - vy * vy, Ayz = -vy * vz, Azz = 1 - vz * vz;
+        const double o = on ? 1.0 : 0.0;
+        const double xo = on ? x : 0.0, yo = on ? y : 0.0, zo = on ? z : 0.0;
+        const double Axx = o - vx * vx, Axy = -vx * vy, Axz = -vx * vz, Ayy = o - vy * vy, Ayz = -vy * vz, Azz = o - vz * vz;
         acc[32] += Axx; acc[33] += Axy; acc[34] += Axz; acc[35] += Ayy; acc[36] += Ayz; acc[37] += Azz;
-        acc[38] += Axx * x + Axy * y + Axz * z;
-        acc[39] += Axy * x + Ayy * y + Ayz * z;
-        acc[40] += Axz * x + Ayz * y + Azz * z;
+        acc[38] += Axx * xo + Axy * yo + Axz * zo;
+        acc[39] += Axy * xo + Ayy * yo + Ayz * zo;
+        acc[40] += Axz * xo + Ayz * yo + Azz * zo;
       }
-      if (xc && a33[i] == 1) {
-        const double v = w33 ? (double)w33[idx] : 1.0;
-        const double ax = x - prm.Cw[0], ay = y - prm.Cw[1], az = z - prm.Cw[2];
-        const double cx = vc[3 * i] - prm.Cc[0], cy = vc[3 * i + 1] - prm.Cc[1], cz = vc[3 * i + 2] - prm.Cc[2];
+      {  // 3D-3D inliers: centred covariance and sigma
+        const bool on = xc != nullptr && a33[i] == 1;
+        const double v = on ? (w33 ? (double)u33[i] : 1.0) : 0.0;
+        const double ax = on ? x - prm.Cw[0] : 0.0, ay = on ? y - prm.Cw[1] : 0.0, az = on ? z - prm.Cw[2] : 0.0;
+        const double cx = on ? (double)vc[3 * i] - prm.Cc[0] : 0.0, cy = on ? (double)vc[3 * i + 1] - prm.Cc[1] : 0.0,
+                     cz = on ? (double)vc[3 * i + 2] - prm.Cc[2] : 0.0;
         acc[20] += v * (cx * cx + cy * cy + cz * cz);
         acc[11] = fma(v * cx, ax, acc[11]); acc[12] = fma(v * cx, ay, acc[12]); acc[13] = fma(v * cx, az, acc[13]);
         acc[14] = fma(v * cy, ax, acc[14]); acc[15] = fma(v * cy, ay, acc[15]); acc[16] = fma(v * cy, az, acc[16]);
         acc[17] = fma(v * cz, ax, acc[17]); acc[18] = fma(v * cz, ay, acc[18]); acc[19] = fma(v * cz, az, acc[19]);
       }
-      if (nw && ann[i] == 1) {
-        const double l = wnn ? (double)wnn[idx] : 1.0;
-        const double ax = vnw[3 * i], ay = vnw[3 * i + 1], az = vnw[3 * i + 2];
-        const double cx = vnc[3 * i], cy = vnc[3 * i + 1], cz = vnc[3 * i + 2];
+      {  // normal-normal inliers
+        const bool on = nw != nullptr && knn != nullptr && ann[i] == 1;
+        const double l = on ? (wnn ? (double)unn[i] : 1.0) : 0.0;
+        const double ax = on ? (double)vnw[3 * i] : 0.0, ay = on ? (double)vnw[3 * i + 1] : 0.0, az = on ? (double)vnw[3 * i + 2] : 0.0;
+        const double cx = on ? (double)vnc[3 * i] : 0.0, cy = on ? (double)vnc[3 * i + 1] : 0.0, cz = on ? (double)vnc[3 * i + 2] : 0.0;
         acc[21] = fma(l * cx, ax, acc[21]); acc[22] = fma(l * cx, ay, acc[22]); acc[23] = fma(l * cx, az, acc[23]);
         acc[24] = fma(l * cy, ax, acc[24]); acc[25] = fma(l * cy, ay, acc[25]); acc[26] = fma(l * cy, az, acc[26]);
         acc[27] = fma(l * cz, ax, acc[27]); acc[28] = fma(l * cz, ay, acc[28]); acc[29] = fma(l * cz, az, acc[29]);
-        acc[30] += l; acc[31] += 1.0;
+        acc[30] += l; acc[31] += on ? 1.0 : 0.0;
       }
     }
   }
@@ -943,10 +970,12 @@ static void score_launch(const DeviceArrays& A, const void* d_poses, int H, cons
                      (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, hchunk, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
 }
 template <class T, int KIND, bool EXACT>
-static void mask_launch(const DeviceArrays& A, const void* d_pose, const double* thr, int* d_votes, int G, hipStream_t s) {
+static void mask_launch(const DeviceArrays& A, const double* pose12, const double* thr, const ReduceTarget& rt, int G, hipStream_t s) {
+  PoseArg<T> pa;
+  for (int i = 0; i < 12; i++) pa.v[i] = (T)pose12[i];
   hipLaunchKernelGGL((mask_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
-                     (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_pose, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2],
-                     d_votes);
+                     (const T*)A.a[3], (const T*)A.a[4], A.n, pa, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2],
+                     make_finish(rt));
 }
 #define RPE_KIND_SWITCH(FN, T, EX, ...)                                    \
   switch (kind) {                                                          \
@@ -976,18 +1005,17 @@ hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* 
   }
   return hipGetLastError();
 }
-hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const void* d_pose, const double* thr3, int* d_votes, int max_blocks,
+hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
                        hipStream_t s) {
-  hipError_t e = hipMemsetAsync(d_votes, 0, sizeof(int), s);
-  if (e != hipSuccess) return e;
+  const int cap = rt.max_blocks < 1024 ? 1024 : rt.max_blocks;  // streaming + stores: 4 workgroups of 256 per CU
   if (A.dtype) {
-    const int G = grid_for(A.n, 2, max_blocks);
-    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, d_pose, thr3, d_votes, G, s) }
-    else { RPE_KIND_SWITCH(mask_launch, double, false, A, d_pose, thr3, d_votes, G, s) }
+    const int G = grid_for(A.n, 2, cap);
+    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, pose12, thr3, rt, G, s) }
+    else { RPE_KIND_SWITCH(mask_launch, double, false, A, pose12, thr3, rt, G, s) }
   } else {
-    const int G = grid_for(A.n, 4, max_blocks);
-    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, d_pose, thr3, d_votes, G, s) }
-    else { RPE_KIND_SWITCH(mask_launch, float, false, A, d_pose, thr3, d_votes, G, s) }
+    const int G = grid_for(A.n, 4, cap);
+    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, pose12, thr3, rt, G, s) }
+    else { RPE_KIND_SWITCH(mask_launch, float, false, A, pose12, thr3, rt, G, s) }
   }
   return hipGetLastError();
 }
