@@ -71,12 +71,17 @@ struct rpe_context {
   bool own_stream = false;
   int64_t n = 0;
   int dtype = RPE_F32;
+  // ACTIVE pointers of the current problem (null = not uploaded / bound) ...
   void* arr[RPE_NUM_ARRAYS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool own[RPE_NUM_ARRAYS] = {false, false, false, false, false};
-  size_t cap[RPE_NUM_ARRAYS] = {0, 0, 0, 0, 0};
   short* mask[3] = {nullptr, nullptr, nullptr};
-  size_t mask_cap[3] = {0, 0, 0};
   void* weight[3] = {nullptr, nullptr, nullptr};
+  // ... and the storage this context owns; it survives rpe_set_problem so that a pooled context (rpe/device.hpp) serving
+  // one frame after another does not pay hipMalloc/hipFree per call
+  void* store[RPE_NUM_ARRAYS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[RPE_NUM_ARRAYS] = {0, 0, 0, 0, 0};
+  short* mask_store[3] = {nullptr, nullptr, nullptr};
+  size_t mask_cap[3] = {0, 0, 0};
+  void* weight_store[3] = {nullptr, nullptr, nullptr};
   size_t weight_cap[3] = {0, 0, 0};
   int max_blocks = 256;          // reduction kernels: cap on workgroups = one per CU (multiples of 256 only: 320 or 384 lose 20-30 %)
   int score_blocks = 2048;       // scoring / mask kernels (256-thread workgroups)
@@ -112,11 +117,14 @@ struct rpe_context {
 namespace {
 
 int ensure_mask(rpe_context* c, int mod, bool fill_ones) {
+  if (c->mask[mod]) return RPE_OK;
   const size_t need = (size_t)c->n * sizeof(short);
-  if (c->mask[mod] && c->mask_cap[mod] >= need) return RPE_OK;
-  if (c->mask[mod]) { HIP_TRY(hipFree(c->mask[mod])); c->mask[mod] = nullptr; }
-  HIP_TRY(hipMalloc((void**)&c->mask[mod], need ? need : 2));
-  c->mask_cap[mod] = need;
+  if (!c->mask_store[mod] || c->mask_cap[mod] < need) {
+    if (c->mask_store[mod]) { HIP_TRY(hipFree(c->mask_store[mod])); c->mask_store[mod] = nullptr; c->mask_cap[mod] = 0; }
+    HIP_TRY(hipMalloc((void**)&c->mask_store[mod], need ? need : 2));
+    c->mask_cap[mod] = need;
+  }
+  c->mask[mod] = c->mask_store[mod];
   if (fill_ones && c->n) {  // adapters start with all-ones masks (e.g. AOPoseAdapter.hpp:103-106)
     std::vector<short> ones((size_t)c->n, 1);
     HIP_TRY(hipMemcpyAsync(c->mask[mod], ones.data(), need, hipMemcpyHostToDevice, c->stream));
@@ -222,8 +230,8 @@ void rpe_destroy(rpe_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int i = 0; i < RPE_NUM_ARRAYS; i++) if (c->own[i] && c->arr[i]) (void)hipFree(c->arr[i]);
-  for (int i = 0; i < 3; i++) { if (c->mask[i]) (void)hipFree(c->mask[i]); if (c->weight[i]) (void)hipFree(c->weight[i]); }
+  for (int i = 0; i < RPE_NUM_ARRAYS; i++) if (c->store[i]) (void)hipFree(c->store[i]);
+  for (int i = 0; i < 3; i++) { if (c->mask_store[i]) (void)hipFree(c->mask_store[i]); if (c->weight_store[i]) (void)hipFree(c->weight_store[i]); }
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -249,18 +257,10 @@ int rpe_set_problem(rpe_context* c, int64_t n, int dtype) {
   if (!c) return fail(RPE_ERR_ARG, "null context");
   if (n < 0 || (dtype != RPE_F32 && dtype != RPE_F64)) return fail(RPE_ERR_ARG, "bad n (%lld) or dtype (%d)", (long long)n, dtype);
   HIP_TRY(hipSetDevice(c->device));
-  if (n != c->n || dtype != c->dtype) {
-    // a new problem invalidates every array, mask and weight of the old one
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < RPE_NUM_ARRAYS; i++) {
-      if (c->own[i] && c->arr[i]) (void)hipFree(c->arr[i]);
-      c->arr[i] = nullptr; c->cap[i] = 0; c->own[i] = false;
-    }
-    for (int i = 0; i < 3; i++) {
-      if (c->mask[i]) { (void)hipFree(c->mask[i]); c->mask[i] = nullptr; c->mask_cap[i] = 0; }
-      if (c->weight[i]) { (void)hipFree(c->weight[i]); c->weight[i] = nullptr; c->weight_cap[i] = 0; }
-    }
-  }
+  // a new problem (also one of the same size: new frame) invalidates every array, mask and weight; storage is kept
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < RPE_NUM_ARRAYS; i++) c->arr[i] = nullptr;
+  for (int i = 0; i < 3; i++) { c->mask[i] = nullptr; c->weight[i] = nullptr; }
   c->n = n; c->dtype = dtype;
   return RPE_OK;
 }
@@ -270,12 +270,12 @@ int rpe_upload(rpe_context* c, int slot, const void* host) {
   if (c->n <= 0) return fail(RPE_ERR_STATE, "rpe_set_problem first");
   HIP_TRY(hipSetDevice(c->device));
   const size_t bytes = (size_t)c->n * 3 * elem_size(c->dtype);
-  if (!c->own[slot] || c->cap[slot] < bytes) {
-    if (c->own[slot] && c->arr[slot]) HIP_TRY(hipFree(c->arr[slot]));
-    c->arr[slot] = nullptr; c->own[slot] = false;
-    HIP_TRY(hipMalloc(&c->arr[slot], bytes));
-    c->own[slot] = true; c->cap[slot] = bytes;
+  if (!c->store[slot] || c->cap[slot] < bytes) {
+    if (c->store[slot]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->store[slot])); c->store[slot] = nullptr; c->cap[slot] = 0; }
+    HIP_TRY(hipMalloc(&c->store[slot], bytes));
+    c->cap[slot] = bytes;
   }
+  c->arr[slot] = c->store[slot];
   HIP_TRY(hipMemcpyAsync(c->arr[slot], host, bytes, hipMemcpyHostToDevice, c->stream));
   return RPE_OK;
 }
@@ -283,15 +283,14 @@ int rpe_upload(rpe_context* c, int slot, const void* host) {
 int rpe_bind(rpe_context* c, int slot, const void* device_ptr) {
   if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS) return fail(RPE_ERR_ARG, "rpe_bind: bad argument");
   if (device_ptr && ((uintptr_t)device_ptr & 15u)) return fail(RPE_ERR_ALIGN, "device pointer %p is not 16-byte aligned", device_ptr);
-  if (c->own[slot] && c->arr[slot]) { HIP_TRY(hipFree(c->arr[slot])); }
-  c->arr[slot] = const_cast<void*>(device_ptr); c->own[slot] = false; c->cap[slot] = 0;
+  c->arr[slot] = const_cast<void*>(device_ptr);  // not owned; the context's own storage for this slot stays allocated but idle
   return RPE_OK;
 }
 
 int rpe_upload_mask(rpe_context* c, int mod, const short* host_mask) {
   if (!c || mod < 0 || mod > 2) return fail(RPE_ERR_ARG, "rpe_upload_mask: bad argument");
   HIP_TRY(hipSetDevice(c->device));
-  if (!host_mask) { if (c->mask[mod]) { HIP_TRY(hipFree(c->mask[mod])); c->mask[mod] = nullptr; c->mask_cap[mod] = 0; } return RPE_OK; }
+  if (!host_mask) { c->mask[mod] = nullptr; return RPE_OK; }
   int rc = ensure_mask(c, mod, false);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c->mask[mod], host_mask, (size_t)c->n * sizeof(short), hipMemcpyHostToDevice, c->stream));
@@ -302,14 +301,14 @@ int rpe_upload_mask(rpe_context* c, int mod, const short* host_mask) {
 int rpe_upload_weight(rpe_context* c, int mod, const void* host_weight) {
   if (!c || mod < 0 || mod > 2) return fail(RPE_ERR_ARG, "rpe_upload_weight: bad argument");
   HIP_TRY(hipSetDevice(c->device));
-  if (!host_weight) { if (c->weight[mod]) { HIP_TRY(hipFree(c->weight[mod])); c->weight[mod] = nullptr; c->weight_cap[mod] = 0; } return RPE_OK; }
+  if (!host_weight) { c->weight[mod] = nullptr; return RPE_OK; }
   const size_t need = (size_t)c->n * elem_size(c->dtype);
-  if (!c->weight[mod] || c->weight_cap[mod] < need) {
-    if (c->weight[mod]) HIP_TRY(hipFree(c->weight[mod]));
-    c->weight[mod] = nullptr;
-    HIP_TRY(hipMalloc(&c->weight[mod], need ? need : 8));
+  if (!c->weight_store[mod] || c->weight_cap[mod] < need) {
+    if (c->weight_store[mod]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->weight_store[mod])); c->weight_store[mod] = nullptr; }
+    HIP_TRY(hipMalloc(&c->weight_store[mod], need ? need : 8));
     c->weight_cap[mod] = need;
   }
+  c->weight[mod] = c->weight_store[mod];
   HIP_TRY(hipMemcpyAsync(c->weight[mod], host_weight, need, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RPE_OK;

@@ -46,24 +46,32 @@ std::vector<int> sortIndexes(const std::vector<T>& v) {
   return order;
 }
 
-// m distinct indices out of n by a partial Fisher-Yates pass from the top (reference :124-156):
-// the index table is re-initialised on every draw, position j swaps with rand() % (j + 1), j = n-1 ... n-m.
+// m distinct indices out of n by a partial Fisher-Yates pass from the top (reference :124-156): position j swaps with
+// rand() % (j + 1), j = n-1 ... n-m, on an index table that is RE-INITIALISED on every draw.  The reference rewrites
+// all n entries per draw (:141-143) -- O(N) host work per RANSAC iteration, as much as the vote loop this backend moved to
+// the GPU.  Because the table always starts as the identity, only the <= 2m entries a draw touches can differ from it:
+// they are kept in a tiny side list, every other position p still holds p.  Same index stream, O(m^2) per draw.
 template <class T>
 class RandomElements {
  public:
-  explicit RandomElements(int n) : _table((size_t)n), _n(n) {}
+  explicit RandomElements(int n) : _n(n) {}
   void run(int m, std::vector<T>* p_v_idx_) { run(m, p_v_idx_, rpe::global_rng()); }
   void run(int m, std::vector<T>* out, rpe::Rand31& rnd) {
     out->clear();
-    std::iota(_table.begin(), _table.end(), T(0));
+    _pos.clear(); _val.clear();
     for (int top = _n - 1; top > _n - m - 1; top--) {
       const int pick = rnd() % (top + 1);
-      std::swap(_table[pick], _table[top]);
-      out->push_back(_table[top]);
+      const T vp = get(pick), vt = get(top);
+      set(pick, vt);
+      set(top, vp);
+      out->push_back(vp);
     }
   }
  private:
-  std::vector<T> _table;
+  T get(int p) const { for (size_t i = 0; i < _pos.size(); i++) if (_pos[i] == p) return _val[i]; return T(p); }
+  void set(int p, T v) { for (size_t i = 0; i < _pos.size(); i++) if (_pos[i] == p) { _val[i] = v; return; } _pos.push_back(p); _val.push_back(v); }
+  std::vector<int> _pos;
+  std::vector<T> _val;
   int _n;
 };
 

@@ -3,7 +3,9 @@
 // There is no CPU path behind these calls: a failing status throws rpe::DeviceError (no fallback, no silent retry).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <stdexcept>
+#include <utility>
 #include <string>
 #include <vector>
 #include <type_traits>
@@ -32,23 +34,49 @@ struct Settings {
 
 // One adapter's correspondence arrays resident in HBM.  Uploaded once, reused by every solver run on that adapter
 // (TestMain.cpp runs seven solvers on one adapter, :186-221).
+class ContextPool {
+ public:
+  // idle contexts are deliberately NOT destroyed at process exit: by then the HIP runtime may already be unloading
+  ~ContextPool() {}
+  rpe_context* acquire(int device) {
+    std::lock_guard<std::mutex> g(_m);
+    for (size_t i = 0; i < _idle.size(); i++)
+      if (_idle[i].first == device) { rpe_context* c = _idle[i].second; _idle.erase(_idle.begin() + i); return c; }
+    return nullptr;
+  }
+  void release(rpe_context* c, int device) {
+    std::lock_guard<std::mutex> g(_m);
+    if (_idle.size() < 4) _idle.emplace_back(device, c); else rpe_destroy(c);
+  }
+ private:
+  std::mutex _m;
+  std::vector<std::pair<int, rpe_context*> > _idle;
+};
+inline ContextPool& pool() { static ContextPool p; return p; }
+
 class DeviceSet {
  public:
-  DeviceSet() : _ctx(nullptr), _n(0), _dtype(-1) {
+  DeviceSet() : _ctx(nullptr), _device(0), _n(0), _dtype(-1) {
     for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
     for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
   }
-  ~DeviceSet() { if (_ctx) rpe_destroy(_ctx); }
+  ~DeviceSet() { if (_ctx) pool().release(_ctx, _device); }
   DeviceSet(const DeviceSet&) = delete;
   DeviceSet& operator=(const DeviceSet&) = delete;
 
+  // Contexts (stream + workspace + array storage, ~1 ms to create) are recycled through a small process-wide pool: a
+  // caller that builds one adapter per frame, as Library.cpp:ao() does, pays for context creation once, not per call.
   rpe_context* ctx() {
-    if (!_ctx) check(rpe_create(&_ctx, Settings::get().device, nullptr), "rpe_create");
+    if (!_ctx) {
+      _device = Settings::get().device;
+      _ctx = pool().acquire(_device);
+      if (!_ctx) check(rpe_create(&_ctx, _device, nullptr), "rpe_create");
+    }
     return _ctx;
   }
   // make sure array `slot` in HBM is the host array at `host` (3 x n of Tp)
   template <class Tp> void ensure(int slot, const Tp* host, int64_t n) {
-    if (_n != n || _dtype != (int)DType<Tp>::value) {
+    if (_n != n || _dtype != (int)DType<Tp>::value) {  // first use of this set (a recycled context still holds its last frame)
       check(rpe_set_problem(ctx(), n, DType<Tp>::value), "rpe_set_problem");
       _n = n; _dtype = DType<Tp>::value;
       for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
@@ -83,6 +111,7 @@ class DeviceSet {
   }
  private:
   rpe_context* _ctx;
+  int _device;
   int64_t _n;
   int _dtype;
   const void* _src[RPE_NUM_ARRAYS];
