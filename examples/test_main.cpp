@@ -4,7 +4,7 @@
 // 0.05 m / 2 deg, 300 iterations, thre_2d 8, thre_3d 0.2, normal_thre 0.1, Gaussian); override with key=value arguments
 // (total= outlier= noise_2d= noise_3d= noise_normal= iteration= thre_2d= thre_3d= normal_thre= test_n= noise_model= seed=).
 // The OpenCV EPnP / iterative competitor column and the MATLAB boxplot emitter are out of scope; a table of medians is
-// printed instead, plus a 'gn' column (GaussNewton.hpp joint refinement, new).
+// printed instead, plus 'gn' (3D-3D + 2D-3D Gauss-Newton) and 'gnf' (all three modalities fused, Huber) columns (GaussNewton.hpp, new).
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -38,8 +38,8 @@ int main(int argc, char** argv) {
   try {
     const rpe::Point3<double> t = generate_random_translation_uniform<double>(5.0);
     const rpe::SO3<double> R = generate_random_rotation<double>(M_PI / 2, false);
-    const char* names[9] = {"k", "s", "sk", "nk", "ns", "nsk", "opt", "dw", "gn"};
-    std::vector<double> te[9], re[9];
+    const char* names[10] = {"k", "s", "sk", "nk", "ns", "nsk", "opt", "dw", "gn", "gnf"};
+    std::vector<double> te[10], re[10];
     for (int jj = 0; jj < test_n; jj++) {
       MatrixXd Q, P, U, M, N, all_weights(total, 3);
       if (noise_model == "Kinect") {
@@ -71,11 +71,14 @@ int main(int argc, char** argv) {
       nl_shinji_kneip_ls<double>(adapter); record(7);
       adapter.setRcw(R_nsk); adapter.sett(t_nsk);
       gn_refine_joint<double>(adapter); record(8);
+      adapter.setRcw(R_nsk); adapter.sett(t_nsk);
+      rpe::JointOptions jo; jo.robust = RPE_ROBUST_HUBER; jo.k_33 = 0.1; jo.k_23 = 0.02; jo.k_nn = 0.06;
+      gn_refine_full<double>(adapter, jo); record(9);   // all three modalities, one fused pass per iteration
     }
     std::printf("%%total = %d  outlier = %g  noise_2d = %g  noise_3d = %g  noise_normal(rad) = %g  iteration = %d  test_n = %d  model = %s\n", total,
                 orr, n2d, n3d, nnl, iteration, test_n, noise_model.c_str());
     std::printf("%%method  median t_e%%  median r_e%%\n");
-    for (int k = 0; k < 9; k++) std::printf("%-6s %10.4f %10.4f\n", names[k], median(te[k]), median(re[k]));
+    for (int k = 0; k < 10; k++) std::printf("%-6s %10.4f %10.4f\n", names[k], median(te[k]), median(re[k]));
     // smoke criterion: the joint solvers and their refinements land within a few percent on the default scene
     const bool ok = median(te[5]) < 5 && median(re[5]) < 2 && median(te[6]) < 5 && median(re[6]) < 2 && median(te[8]) < 5 && median(re[8]) < 2;
     return ok ? 0 : 1;

@@ -110,7 +110,9 @@ int rpe_pose_from_moments(const double* m18, double* R9, double* t3);
 enum {
   RPE_RES_P2P = 0,      /* r = R*Xw + t - Xc                         (3)  arrays XW, XC      24 B/corr fp32 */
   RPE_RES_P2PLANE = 1,  /* r = Nc . (R*Xw + t - Xc)                  (1)  arrays XW, XC, NC  36 B/corr      */
-  RPE_RES_BEARING = 2   /* r = normalize(R*Xw + t) x bv  (P3P.hpp:482-485) (3)  arrays XW, BV  24 B/corr      */
+  RPE_RES_BEARING = 2,  /* r = normalize(R*Xw + t) x bv  (P3P.hpp:482-485) (3)  arrays XW, BV  24 B/corr      */
+  RPE_RES_NORMAL = 3    /* r = R*Nw - Nc   (alignment scored at AbsoluteOrientationNormal.hpp:248) (3)  arrays NW, NC  24 B/corr;
+                           rotation only.  Served by the joint kernel (rpe_normal_eq_joint); mask / weight of modality NN */
 };
 int rpe_normal_eq(rpe_context* ctx, int kind, int flags, const double* pose12, double* out32);
 /* Same, result left in HBM at d_out32 (32 doubles, must not be NULL) for a caller-side collective (RCCL
@@ -120,6 +122,17 @@ int rpe_normal_eq_device(rpe_context* ctx, int kind, int flags, const double* po
 int rpe_gn_solve(const double* ne32, double* delta6);
 /* Host: pose <- exp(delta) * pose  (Sophus SE3::exp, sophus/se3.hpp:321-342). */
 int rpe_gn_apply(const double* delta6, double* pose12);
+/* ---- fused joint normal equations: up to four residual kinds (at most one of P2P / P2PLANE) in ONE pass over the arrays,
+ * each term with its modality's inlier mask (RPE_USE_MASK) and weights (RPE_USE_WEIGHT), a scale, and an optional robust
+ * IRLS weight on the residual-block norm s: Huber min(1, k/s) or Cauchy 1/(1 + (s/k)^2).  out32 as rpe_normal_eq, with
+ * cost = sum scale*w*r^2 and the last entry = number-weighted count over all terms.  This is the single-kernel form of the
+ * joint 2D-3D + 3D-3D + N-N objective the reference's nl_shinji_kneip_ls alternates over (:484-510). */
+enum { RPE_ROBUST_NONE = 0, RPE_ROBUST_HUBER = 1, RPE_ROBUST_CAUCHY = 2 };
+typedef struct { int kind; double scale; int robust; double robust_k; } rpe_term;
+int rpe_normal_eq_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, const double* pose12, double* out32);
+int rpe_gn_refine_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
+                        int* iters_out, double* last_step, double* final_cost);
+
 /* One Gauss-Newton step on one GPU (kernel -> D2H of the 32-double record -> solve -> exp-map update of pose12).
  * ne32_out / step_norm may be NULL. */
 int rpe_gn_step(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);

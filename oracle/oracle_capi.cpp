@@ -348,6 +348,13 @@ void orc_gn_normal_eq(int in_f64, int kind, const void* a, const void* b, const 
   else gn_normal_eq<float>(kind, (const float*)a, (const float*)b, (const float*)c, mask, (const float*)weight, n, pose12, &ne);
   ne.pack(out29);
 }
+void orc_gn_normal_eq_robust(int in_f64, int kind, const void* a, const void* b, const void* c, const short* mask, const void* weight, long n,
+                             const double* pose12, int robust, double robust_k, double* out29) {
+  NormalEq ne;
+  if (in_f64) gn_normal_eq<double>(kind, (const double*)a, (const double*)b, (const double*)c, mask, (const double*)weight, n, pose12, &ne, robust, robust_k);
+  else gn_normal_eq<float>(kind, (const float*)a, (const float*)b, (const float*)c, mask, (const float*)weight, n, pose12, &ne, robust, robust_k);
+  ne.pack(out29);
+}
 int orc_gn_solve(const double* packed29, double* delta6) {
   double H[6][6] = {{0}}, g[6]; int k = 0;
   for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) H[a][b] = packed29[k++];
@@ -357,11 +364,12 @@ int orc_gn_solve(const double* packed29, double* delta6) {
 void orc_gn_apply(const double* delta6, double* pose12) { gn_apply(delta6, pose12); }
 // up to 3 terms; per term: kind, a, b, c, mask, weight, scale
 int orc_gn_refine(int in_f64, int nterms, const int* kinds, const void** as, const void** bs, const void** cs, const short** masks,
-                  const void** weights, const double* scales, long n, double* pose12, int max_iter, double tol, double* last_step,
-                  double* final_cost) {
+                  const void** weights, const double* scales, const int* robusts, const double* robust_ks, long n, double* pose12, int max_iter,
+                  double tol, double* last_step, double* final_cost) {
   GnTerm t[4];
   for (int k = 0; k < nterms && k < 4; k++) { t[k].kind = kinds[k]; t[k].a = as[k]; t[k].b = bs[k]; t[k].c = cs ? cs[k] : nullptr;
-    t[k].mask = masks ? masks[k] : nullptr; t[k].weight = weights ? weights[k] : nullptr; t[k].scale = scales ? scales[k] : 1.0; }
+    t[k].mask = masks ? masks[k] : nullptr; t[k].weight = weights ? weights[k] : nullptr; t[k].scale = scales ? scales[k] : 1.0;
+    t[k].robust = robusts ? robusts[k] : 0; t[k].robust_k = robust_ks ? robust_ks[k] : 1.0; }
   return in_f64 ? gn_refine<double>(t, nterms, n, pose12, max_iter, tol, last_step, final_cost)
                 : gn_refine<float>(t, nterms, n, pose12, max_iter, tol, last_step, final_cost);
 }

@@ -8,6 +8,8 @@
 //   point-to-plane   no reference counterpart (F2): PARITY UNPINNED, pinned by this fp64 GN + numpy
 //   bearing (sine)   residual definition |normalize(R Xw + t) x bv|  pose/P3P.hpp:482-485,
 //                    pose/PnPPoseAdapter.hpp:204-210 ; the refinement itself is new (F3)
+//   normal-normal    r = R Nw - Nc: the alignment the reference scores with Nc.(R Nw) (AbsoluteOrientationNormal.hpp:248)
+//                    and fits through MNN in nl_shinji_kneip_ls (:498-503); as a GN term it is new
 // Conventions: Xc = R Xw + t ; left perturbation T <- exp(delta) T, delta = (upsilon, omega) in the
 // Sophus order (sophus/se3.hpp:314-316) ; p = R Xw + t ; dp/ddelta = [ I | -[p]x ].
 // Output layout (29 doubles): H upper triangle row-major (21) | g = J^T r (6) | sum w r^2 | sum w.
@@ -16,7 +18,14 @@
 
 namespace orc {
 
-enum GnKind { GN_P2P = 0, GN_P2PLANE = 1, GN_BEARING = 2 };
+enum GnKind { GN_P2P = 0, GN_P2PLANE = 1, GN_BEARING = 2, GN_NORMAL = 3 };
+enum GnRobust { ROBUST_NONE = 0, ROBUST_HUBER = 1, ROBUST_CAUCHY = 2 };
+// IRLS weight of a residual block of norm s: Huber min(1, k/s), Cauchy 1/(1 + (s/k)^2)
+inline double robust_weight(int robust, double k, double s) {
+  if (robust == ROBUST_HUBER) return s <= k ? 1.0 : k / s;
+  if (robust == ROBUST_CAUCHY) return 1.0 / (1.0 + (s / k) * (s / k));
+  return 1.0;
+}
 
 struct NormalEq {
   double H[6][6];
@@ -43,7 +52,7 @@ struct NormalEq {
 // NaN-invalid columns of b (all three NaN, the reference's isValid) are skipped.
 template <class Tin>
 void gn_normal_eq(int kind, const Tin* a, const Tin* b, const Tin* c, const short* mask, const Tin* weight, long n,
-                  const double pose[12], NormalEq* ne) {
+                  const double pose[12], NormalEq* ne, int robust = ROBUST_NONE, double robust_k = 1.0) {
   const double* R = pose; const double* t = pose + 9;
   for (long i = 0; i < n; i++) {
     if (mask && mask[i] != 1) continue;
@@ -56,17 +65,27 @@ void gn_normal_eq(int kind, const Tin* a, const Tin* b, const Tin* c, const shor
     const double Jp[3][6] = {{1, 0, 0, 0, p[2], -p[1]}, {0, 1, 0, -p[2], 0, p[0]}, {0, 0, 1, p[1], -p[0], 0}};
     if (kind == GN_P2P) {
       double r[3] = {p[0] - bx, p[1] - by, p[2] - bz};
+      w *= robust_weight(robust, robust_k, std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]));
       for (int k = 0; k < 3; k++) ne->add_row(Jp[k], r[k], w);
     } else if (kind == GN_P2PLANE) {
       double nx = c[3 * i], ny = c[3 * i + 1], nz = c[3 * i + 2];
       double r = nx * (p[0] - bx) + ny * (p[1] - by) + nz * (p[2] - bz);
+      w *= robust_weight(robust, robust_k, std::fabs(r));
       double J[6];
       for (int k = 0; k < 6; k++) J[k] = nx * Jp[0][k] + ny * Jp[1][k] + nz * Jp[2][k];
       ne->add_row(J, r, w);
+    } else if (kind == GN_NORMAL) {
+      // a = Nw, b = Nc ; q = R Nw ; r = q - Nc ; dq/ddelta = [0 | -[q]x]
+      double q[3] = {R[0] * x + R[1] * y + R[2] * z, R[3] * x + R[4] * y + R[5] * z, R[6] * x + R[7] * y + R[8] * z};
+      double r[3] = {q[0] - bx, q[1] - by, q[2] - bz};
+      w *= robust_weight(robust, robust_k, std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]));
+      const double Jq[3][6] = {{0, 0, 0, 0, q[2], -q[1]}, {0, 0, 0, -q[2], 0, q[0]}, {0, 0, 0, q[1], -q[0], 0}};
+      for (int k = 0; k < 3; k++) ne->add_row(Jq[k], r[k], w);
     } else {
       double len = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
       double ph[3] = {p[0] / len, p[1] / len, p[2] / len};
       double r[3] = {ph[1] * bz - ph[2] * by, ph[2] * bx - ph[0] * bz, ph[0] * by - ph[1] * bx};  // ph x bv
+      w *= robust_weight(robust, robust_k, std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]));
       // A = -[bv]x (I - ph ph^T) / len   (3x3), J = A Jp
       double P[3][3], A[3][3];
       for (int u = 0; u < 3; u++) for (int v = 0; v < 3; v++) P[u][v] = ((u == v ? 1.0 : 0.0) - ph[u] * ph[v]) / len;
@@ -114,7 +133,7 @@ inline void gn_apply(const double delta[6], double pose[12]) {  // T <- exp(delt
 }
 
 // terms: up to 3 residual blocks summed into one normal equation (joint 3D-3D + 2D-3D refinement etc.)
-struct GnTerm { int kind; const void* a; const void* b; const void* c; const short* mask; const void* weight; double scale; };
+struct GnTerm { int kind; const void* a; const void* b; const void* c; const short* mask; const void* weight; double scale; int robust; double robust_k; };
 
 template <class Tin>
 int gn_refine(const GnTerm* terms, int nterms, long n, double pose[12], int max_iter, double tol, double* last_step, double* final_cost) {
@@ -125,7 +144,7 @@ int gn_refine(const GnTerm* terms, int nterms, long n, double pose[12], int max_
     for (int k = 0; k < nterms; k++) {
       NormalEq ne;
       gn_normal_eq<Tin>(terms[k].kind, (const Tin*)terms[k].a, (const Tin*)terms[k].b, (const Tin*)terms[k].c, terms[k].mask,
-                        (const Tin*)terms[k].weight, n, pose, &ne);
+                        (const Tin*)terms[k].weight, n, pose, &ne, terms[k].robust, terms[k].robust_k);
       double s = terms[k].scale;
       for (int a = 0; a < 6; a++) { tot.g[a] += s * ne.g[a]; for (int b = a; b < 6; b++) tot.H[a][b] += s * ne.H[a][b]; }
       tot.cost += s * ne.cost; tot.wsum += ne.wsum;

@@ -14,7 +14,8 @@ F32, F64 = 0, 1
 XW, XC, BV, NW, NC = 0, 1, 2, 3, 4
 MOD_23, MOD_33, MOD_NN = 0, 1, 2
 USE_MASK, USE_WEIGHT, SKIP_INVALID = 1, 2, 4
-RES_P2P, RES_P2PLANE, RES_BEARING = 0, 1, 2
+RES_P2P, RES_P2PLANE, RES_BEARING, RES_NORMAL = 0, 1, 2, 3
+ROBUST_NONE, ROBUST_HUBER, ROBUST_CAUCHY = 0, 1, 2
 VOTE_33, VOTE_23, VOTE_33_23, VOTE_NN_23, VOTE_NN_33, VOTE_NN_33_23, VOTE_23_MATRIX = 0, 1, 2, 3, 4, 5, 6
 SCORE_FAST, SCORE_EXACT = 0, 1
 
@@ -24,7 +25,7 @@ SYMBOLS = [
     "rpe_abi_version", "rpe_last_error", "rpe_device_count", "rpe_create", "rpe_destroy", "rpe_synchronize",
     "rpe_set_problem", "rpe_upload", "rpe_bind", "rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask",
     "rpe_p2p_moments", "rpe_pose_from_moments", "rpe_normal_eq", "rpe_normal_eq_device", "rpe_gn_solve", "rpe_gn_apply",
-    "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_gn_step_dist", "rpe_gn_refine", "rpe_timing_enable", "rpe_timing_collect", "rpe_score", "rpe_inlier_mask", "rpe_nl_round", "rpe_run",
+    "rpe_normal_eq_joint", "rpe_gn_refine_joint", "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_gn_step_dist", "rpe_gn_refine", "rpe_timing_enable", "rpe_timing_collect", "rpe_score", "rpe_inlier_mask", "rpe_nl_round", "rpe_run",
     "rpe_host_random_elements", "rpe_host_prosac_samples", "rpe_host_update_num_iters", "rpe_host_sort_indexes", "rpe_host_kneip_main",
     "rpe_host_kneip", "rpe_host_nl_2p", "rpe_host_shinji", "rpe_host_se3_exp", "rpe_host_svd3", "rpe_host_calc_err",
 ]
@@ -33,6 +34,10 @@ SYMBOLS = [
 class RpeProblem(C.Structure):
     _fields_ = [("n", C.c_int), ("dtype", C.c_int), ("bv", C.c_void_p), ("xc", C.c_void_p), ("nc", C.c_void_p), ("xw", C.c_void_p),
                 ("nw", C.c_void_p), ("weights", C.c_void_p), ("wcols", C.c_int), ("fx", C.c_double), ("fy", C.c_double)]
+
+
+class RpeTerm(C.Structure):
+    _fields_ = [("kind", C.c_int), ("scale", C.c_double), ("robust", C.c_int), ("robust_k", C.c_double)]
 
 
 class RpeError(RuntimeError):
@@ -91,6 +96,8 @@ def lib():
         L.rpe_gn_apply.argtypes = [C.c_void_p, C.c_void_p]
         L.rpe_gn_refine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_normal_eq_joint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rpe_gn_refine_joint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_gn_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_comm_unique_id.argtypes = [C.c_void_p]
         L.rpe_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]

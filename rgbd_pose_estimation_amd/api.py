@@ -129,6 +129,31 @@ class Context:
         L.check(L.lib().rpe_normal_eq_device(self._h, kind, flags, _p(p), C.c_void_p(d_out_ptr)))
         return p
 
+    @staticmethod
+    def _terms(terms):
+        """terms: list of (kind, scale[, robust, robust_k]) tuples or dicts."""
+        arr = (L.RpeTerm * len(terms))()
+        for i, t in enumerate(terms):
+            if isinstance(t, dict):
+                t = (t["kind"], t.get("scale", 1.0), t.get("robust", 0), t.get("robust_k", 1.0))
+            t = tuple(t) + (1.0, 0, 1.0)[len(t) - 1:]
+            arr[i].kind, arr[i].scale, arr[i].robust, arr[i].robust_k = int(t[0]), float(t[1]), int(t[2]), float(t[3])
+        return arr
+
+    def normal_eq_joint(self, terms, pose, flags: int = 0) -> np.ndarray:
+        arr = self._terms(terms)
+        p = np.array(pose, np.float64).reshape(12).copy()
+        out = np.zeros(32)
+        L.check(L.lib().rpe_normal_eq_joint(self._h, len(arr), arr, flags, _p(p), _p(out)))
+        return out
+
+    def gn_refine_joint(self, terms, pose, flags: int = 0, max_iter: int = 20, tol: float = 1e-9):
+        arr = self._terms(terms)
+        p = np.array(pose, np.float64).reshape(12).copy()
+        it, step, cost = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.check(L.lib().rpe_gn_refine_joint(self._h, len(arr), arr, flags, _p(p), max_iter, tol, C.byref(it), C.byref(step), C.byref(cost)))
+        return p, it.value, step.value, cost.value
+
     def gn_step(self, kind: int, pose12_inout: np.ndarray, flags: int = 0) -> float:
         """One GN step in place on a float64[12] array; returns |delta|."""
         step = C.c_double(0)

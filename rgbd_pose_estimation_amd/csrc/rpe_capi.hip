@@ -173,12 +173,13 @@ int kind_arrays(rpe_context* c, int kind) {
     case RPE_RES_P2P: return need_arrays(c, {RPE_XW, RPE_XC});
     case RPE_RES_P2PLANE: return need_arrays(c, {RPE_XW, RPE_XC, RPE_NC});
     case RPE_RES_BEARING: return need_arrays(c, {RPE_XW, RPE_BV});
+    case RPE_RES_NORMAL: return need_arrays(c, {RPE_XW, RPE_NW, RPE_NC});
   }
   return fail(RPE_ERR_ARG, "unknown residual kind %d", kind);
 }
 
 int check_flags(rpe_context* c, int kind, int flags) {
-  const int mod = kind == RPE_RES_BEARING ? RPE_MOD_23 : RPE_MOD_33;
+  const int mod = kind == RPE_RES_BEARING ? RPE_MOD_23 : (kind == RPE_RES_NORMAL ? RPE_MOD_NN : RPE_MOD_33);
   if ((flags & RPE_USE_MASK) && !c->mask[mod]) return fail(RPE_ERR_STATE, "RPE_USE_MASK but no mask for modality %d", mod);
   if ((flags & RPE_USE_WEIGHT) && !c->weight[mod]) return fail(RPE_ERR_STATE, "RPE_USE_WEIGHT but no weight for modality %d", mod);
   return RPE_OK;
@@ -350,7 +351,13 @@ int rpe_pose_from_moments(const double* m, double* R9, double* t3) {
 }
 
 // ---------------------------------------------------------------------------------------------- K1/K2/K3
+static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12);
 static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
+  if (kind == RPE_RES_NORMAL && !d_out32) {
+    const rpe_term t = {RPE_RES_NORMAL, 1.0, RPE_ROBUST_NONE, 1.0};
+    return joint_launch_checked(c, 1, &t, flags, pose12);
+  }
+  if (kind == RPE_RES_NORMAL) return fail(RPE_ERR_ARG, "RPE_RES_NORMAL is served by rpe_normal_eq / rpe_normal_eq_joint (host record)");
   int rc = kind_arrays(c, kind);
   if (rc) return rc;
   if (!pose12) return fail(RPE_ERR_ARG, "null argument");
@@ -419,6 +426,58 @@ int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, dou
   return RPE_OK;
 }
 
+static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12) {
+  if (!c || !terms || nterms < 1 || nterms > 4 || !pose12) return fail(RPE_ERR_ARG, "rpe_normal_eq_joint: bad argument");
+  int bits = 0, robust[4] = {0, 0, 0, 0};
+  double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1};
+  for (int t = 0; t < nterms; t++) {
+    const int k = terms[t].kind;
+    if (k < 0 || k > 3) return fail(RPE_ERR_ARG, "unknown residual kind %d", k);
+    if (bits & (1 << k)) return fail(RPE_ERR_ARG, "residual kind %d listed twice", k);
+    int rc = kind_arrays(c, k);
+    if (rc) return rc;
+    if ((rc = check_flags(c, k, flags))) return rc;
+    if (terms[t].robust < 0 || terms[t].robust > 2 || (terms[t].robust && !(terms[t].robust_k > 0))) return fail(RPE_ERR_ARG, "bad robust setting");
+    bits |= 1 << k; scale[k] = terms[t].scale; robust[k] = terms[t].robust; rk[k] = terms[t].robust_k > 0 ? terms[t].robust_k : 1.0;
+  }
+  if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, host_target(c), c->stream));
+  return RPE_OK;
+}
+
+int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, double* out32) {
+  if (!out32) return fail(RPE_ERR_ARG, "null out32");
+  int rc = joint_launch_checked(c, nterms, terms, flags, pose12);
+  if (rc) return rc;
+  if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
+  return RPE_OK;
+}
+
+int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol, int* iters_out,
+                        double* last_step, double* final_cost) {
+  int it = 0;
+  double step = 0, cost = 0;
+  for (; it < max_iter; it++) {
+    double ne[32], d[6];
+    int rc = rpe_normal_eq_joint(c, nterms, terms, flags, pose12, ne);
+    if (rc) return rc;
+    cost = ne[27];
+    if (!rpe::solve_normal_eq6(ne, d)) {
+      if (iters_out) *iters_out = it;
+      return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, ne[28]);
+    }
+    rpe::se3_left_update(d, pose12);
+    step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    if (step < tol) { it++; break; }
+  }
+  if (iters_out) *iters_out = it;
+  if (last_step) *last_step = step;
+  if (final_cost) *final_cost = cost;
+  return RPE_OK;
+}
+
 int rpe_gn_solve(const double* ne32, double* delta6) {
   if (!ne32 || !delta6) return fail(RPE_ERR_ARG, "null argument");
   if (!rpe::solve_normal_eq6(ne32, delta6)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite");
@@ -433,25 +492,23 @@ int rpe_gn_apply(const double* delta6, double* pose12) {
 
 int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter, double tol,
                   int* iters_out, double* last_step, double* final_cost) {
-  if (!c || nterms < 1 || nterms > 3 || !kinds || !pose12) return fail(RPE_ERR_ARG, "rpe_gn_refine: bad argument");
+  if (!c || nterms < 1 || nterms > 4 || !kinds || !pose12) return fail(RPE_ERR_ARG, "rpe_gn_refine: bad argument");
+  if (nterms > 1 || kinds[0] == RPE_RES_NORMAL) {  // several residual kinds: ONE fused pass per iteration
+    rpe_term terms[4];
+    for (int t = 0; t < nterms; t++) { terms[t].kind = kinds[t]; terms[t].scale = scales ? scales[t] : 1.0; terms[t].robust = 0; terms[t].robust_k = 1.0; }
+    return rpe_gn_refine_joint(c, nterms, terms, flags, pose12, max_iter, tol, iters_out, last_step, final_cost);
+  }
   int it = 0;
   double step = 0, cost = 0;
+  const double sc = scales ? scales[0] : 1.0;
   for (; it < max_iter; it++) {
-    double tot[32];
-    for (int k = 0; k < 32; k++) tot[k] = 0.0;
-    for (int t = 0; t < nterms; t++) {
-      double ne[32];
-      int rc = rpe_normal_eq(c, kinds[t], flags, pose12, ne);
-      if (rc) return rc;
-      const double s = scales ? scales[t] : 1.0;
-      for (int k = 0; k < 28; k++) tot[k] += s * ne[k];
-      tot[28] += ne[28];
-    }
-    cost = tot[27];
-    double d[6];
-    if (!rpe::solve_normal_eq6(tot, d)) {
+    double ne[32], d[6];
+    int rc = rpe_normal_eq(c, kinds[0], flags, pose12, ne);
+    if (rc) return rc;
+    cost = sc * ne[27];
+    if (!rpe::solve_normal_eq6(ne, d)) {
       if (iters_out) *iters_out = it;
-      return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, tot[28]);
+      return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, ne[28]);
     }
     rpe::se3_left_update(d, pose12);
     step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);

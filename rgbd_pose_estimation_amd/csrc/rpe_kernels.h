@@ -33,6 +33,9 @@ struct ReduceTarget {
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s);
+// fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
+hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,
+                                  const double* robust_k4, const ReduceTarget& rt, hipStream_t s);
 // d_poses: H x 12 (fast: R row-major, t) or H x 8 (exact: qw qx qy qz tx ty tz pad) values of the array dtype.
 // thr: {thre_3d (fast: squared), cos_thr, cos_nl} as doubles holding values of the array dtype.
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,

@@ -5,7 +5,10 @@
 //   gn_refine_p2p      r = R Xw + t - Xc               same objective as shinji() (AbsoluteOrientation.hpp:47-99)   K1
 //   gn_refine_p2plane  r = Nc . (R Xw + t - Xc)        point-to-plane, no reference counterpart                     K2
 //   gn_refine_bearing  r = normalize(R Xw + t) x bv    the residual of lsq_pnp / getError (P3P.hpp:482-485)         K3
-//   gn_refine_joint    scale_33 * p2p + scale_23 * bearing over both inlier sets of an AOPoseAdapter
+//   gn_refine_joint    scale_33 * p2p + scale_23 * bearing over both inlier sets of an AOPoseAdapter      K1+K3 fused
+//   gn_refine_full     3D-3D (point-to-point or point-to-plane) + 2D-3D + normal-normal terms of a NormalAOPoseAdapter in
+//                      ONE fused pass per iteration, optional robust (Huber / Cauchy) weights and the adapter's weights:
+//                      the Gauss-Newton counterpart of nl_shinji_kneip_ls (AbsoluteOrientationNormal.hpp:447-552)
 // All use the adapter's inlier masks (what RANSAC left there) unless use_inliers = false.  Return = iterations run.
 #ifndef RPE_GAUSS_NEWTON_HEADER
 #define RPE_GAUSS_NEWTON_HEADER
@@ -13,6 +16,7 @@
 #include "AOOnlyPoseAdapter.hpp"
 #include "AOPoseAdapter.hpp"
 #include "NormalAOPoseAdapter.hpp"
+#include "AbsoluteOrientationNormal.hpp"
 
 namespace rpe {
 template <typename Tp, class Adapter>
@@ -73,6 +77,41 @@ int gn_refine_joint(AOPoseAdapter<Tp>& adapter, double scale_33 = 1.0, double sc
   const int kinds[2] = {RPE_RES_P2P, RPE_RES_BEARING};
   const double scales[2] = {scale_33, scale_23};
   return rpe::gn_run<Tp>(adapter, 2, kinds, scales, use_inliers, max_iter, tol);
+}
+
+namespace rpe {
+struct JointOptions {
+  double scale_33 = 1.0, scale_23 = 1.0, scale_nn = 1.0;
+  bool point_to_plane = false;        // 3D-3D term: r = Nc . (p - Xc) instead of p - Xc
+  int robust = RPE_ROBUST_NONE;       // applied to every term with the k below
+  double k_33 = 0.1, k_23 = 0.01, k_nn = 0.1;
+  bool use_inliers = true, use_weights = false;
+  int max_iter = 20;
+  double tol = 1e-9;
+};
+}  // namespace rpe
+
+template <typename Tp>
+int gn_refine_full(NormalAOPoseAdapter<Tp>& adapter, const rpe::JointOptions& o = rpe::JointOptions()) {
+  rpe::ensure_all_arrays<Tp>(adapter);
+  if (o.use_inliers || o.use_weights) rpe::sync_masks_and_weights<Tp>(adapter);
+  rpe_term terms[3] = {{o.point_to_plane ? RPE_RES_P2PLANE : RPE_RES_P2P, o.scale_33, o.robust, o.k_33},
+                       {RPE_RES_BEARING, o.scale_23, o.robust, o.k_23},
+                       {RPE_RES_NORMAL, o.scale_nn, o.robust, o.k_nn}};
+  double pose[12];
+  const rpe::Matrix3<Tp> R = adapter.getRcw().matrix();
+  for (int i = 0; i < 9; i++) pose[i] = R.a[i];
+  for (int i = 0; i < 3; i++) pose[9 + i] = adapter.gettw()[i];
+  int iters = 0;
+  double step = 0, cost = 0;
+  const int flags = (o.use_inliers ? RPE_USE_MASK : 0) | ((o.use_weights && !adapter.weights33().empty()) ? RPE_USE_WEIGHT : 0);
+  rpe::check(rpe_gn_refine_joint(adapter.device().ctx(), 3, terms, flags, pose, o.max_iter, o.tol, &iters, &step, &cost), "rpe_gn_refine_joint");
+  rpe::Matrix3<Tp> Rt;
+  for (int i = 0; i < 9; i++) Rt.a[i] = (Tp)pose[i];
+  const rpe::Quat<Tp> q = rpe::quat_from_R<Tp>(Rt.a);
+  adapter.setRcw(rpe::SO3<Tp>::fromQuaternion(q.w, q.x, q.y, q.z));
+  adapter.sett(rpe::Point3<Tp>((Tp)pose[9], (Tp)pose[10], (Tp)pose[11]));
+  return iters;
 }
 
 #endif

@@ -17,7 +17,8 @@ M_SHINJI_RANSAC, M_SHINJI_RANSAC2, M_SHINJI_PROSAC, M_KNEIP_RANSAC, M_KNEIP_PROS
 M_SK_RANSAC, M_SK_PROSAC, M_NL_KNEIP_RANSAC, M_NL_SHINJI_RANSAC, M_NL_SK_RANSAC, M_NONE = 5, 6, 7, 8, 9, 10
 LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL = 0, 1, 2, 3, 4
 V_33, V_23, V_33_23, V_NN_23, V_NN_33, V_NN_33_23, V_23_MATRIX = 0, 1, 2, 3, 4, 5, 6
-GN_P2P, GN_P2PLANE, GN_BEARING = 0, 1, 2
+GN_P2P, GN_P2PLANE, GN_BEARING, GN_NORMAL = 0, 1, 2, 3
+ROBUST_NONE, ROBUST_HUBER, ROBUST_CAUCHY = 0, 1, 2
 
 
 class OrcProblem(C.Structure):
@@ -288,13 +289,14 @@ def pose7_from_Rt(R, t, is_f64):
     return np.concatenate([q, np.asarray(t, dt).astype(np.float64)])
 
 
-def gn_normal_eq(kind, a, b, c=None, mask=None, weight=None, pose=None, in_f64=False):
+def gn_normal_eq(kind, a, b, c=None, mask=None, weight=None, pose=None, in_f64=False, robust=0, robust_k=1.0):
     dt = _dt(in_f64)
     a, b, c, weight = _arr(a, dt), _arr(b, dt), _arr(c, dt), _arr(weight, dt)
     mask = None if mask is None else np.ascontiguousarray(mask, np.int16)
     p = np.ascontiguousarray(pose, np.float64)
     out = np.zeros(29)
-    lib().orc_gn_normal_eq(int(in_f64), kind, _p(a), _p(b), _p(c), _p(mask), _p(weight), C.c_long(len(a)), _p(p), _p(out))
+    lib().orc_gn_normal_eq_robust(int(in_f64), kind, _p(a), _p(b), _p(c), _p(mask), _p(weight), C.c_long(len(a)), _p(p), robust,
+                                  C.c_double(robust_k), _p(out))
     return out
 
 
@@ -331,8 +333,10 @@ def gn_refine(terms, n, pose, max_iter=20, tol=1e-9, in_f64=False):
     masks = vp("mask", lambda v: np.ascontiguousarray(v, np.int16))
     ws = vp("weight", lambda v: _arr(v, dt))
     scales = (C.c_double * k)(*[float(tm.get("scale", 1.0)) for tm in terms])
+    robusts = (C.c_int * k)(*[int(tm.get("robust", 0)) for tm in terms])
+    rks = (C.c_double * k)(*[float(tm.get("robust_k", 1.0)) for tm in terms])
     p = np.array(pose, np.float64).copy()
     step, cost = C.c_double(0), C.c_double(0)
-    its = lib().orc_gn_refine(int(in_f64), k, kinds, as_, bs, cs, masks, ws, scales, C.c_long(n), _p(p), max_iter, C.c_double(tol),
-                              C.byref(step), C.byref(cost))
+    its = lib().orc_gn_refine(int(in_f64), k, kinds, as_, bs, cs, masks, ws, scales, robusts, rks, C.c_long(n), _p(p), max_iter,
+                              C.c_double(tol), C.byref(step), C.byref(cost))
     return p, its, step.value, cost.value

@@ -30,4 +30,4 @@ def test_test_main_all_solvers(args):
     r = _run("test_main", *args)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rows = dict((m.group(1), (float(m.group(2)), float(m.group(3)))) for m in re.finditer(r"^(\w+)\s+([\d.eE+-]+)\s+([\d.eE+-]+)$", r.stdout, re.M))
-    assert set(rows) == {"k", "s", "sk", "nk", "ns", "nsk", "opt", "dw", "gn"}
+    assert set(rows) == {"k", "s", "sk", "nk", "ns", "nsk", "opt", "dw", "gn", "gnf"}
