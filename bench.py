@@ -223,6 +223,20 @@ def main():
             except Exception as e:
                 out["pose_error_vs_cpu"] = {"error": repr(e)}
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(sc, args.cpu_seconds)
+            # extra (not the headline: the north star keeps the exp-map on the host): the same iterations with the 6x6 solve and
+            # the SE(3) update done by the kernel's last workgroup, one launch per iteration, one host wait at the end
+            try:
+                K = 500
+                p0d = pose12(R0, t0)
+                ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0d, L.USE_MASK, 50, 0.0)
+                t0d = time.perf_counter()
+                pd, itd, _, _ = ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0d, L.USE_MASK, K, 0.0)
+                dtd = time.perf_counter() - t0d
+                out["device_resident_loop"] = {"value": n * K / dtd, "unit": "correspondence-residuals/s", "us_per_iteration": dtd / K * 1e6,
+                                               "iterations": itd, "rot_rad_vs_host_loop": rot_err(pd[:9].reshape(3, 3), pose[:9].reshape(3, 3)),
+                                               "note": "rpe_gn_refine_device: solve + exp-map on the GPU; reported beside, not instead of, the host-update headline"}
+            except Exception as e:
+                out["device_resident_loop"] = {"error": repr(e)}
         else:
             out["pose_error_vs_truth"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), sc.R), "trans_abs_m": float(np.linalg.norm(pose[9:] - sc.t))}
             out["cpu_baseline"] = None

@@ -133,6 +133,12 @@ int rpe_normal_eq_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int
 int rpe_gn_refine_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
                         int* iters_out, double* last_step, double* final_cost);
 
+/* Device-resident variant of rpe_gn_refine_joint: pose and loop state stay in HBM, every iteration is one kernel launch whose
+ * last workgroup solves the 6x6 system (LDL^T) and applies the SE(3) exp-map update on the GPU; the host enqueues max_iter
+ * launches and waits once.  Launches after convergence return immediately.  Same arithmetic as the host loop. */
+int rpe_gn_refine_device(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
+                         int* iters_out, double* last_step, double* final_cost);
+
 /* One Gauss-Newton step on one GPU (kernel -> D2H of the 32-double record -> solve -> exp-map update of pose12).
  * ne32_out / step_norm may be NULL. */
 int rpe_gn_step(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);

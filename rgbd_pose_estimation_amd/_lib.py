@@ -25,7 +25,7 @@ SYMBOLS = [
     "rpe_abi_version", "rpe_last_error", "rpe_device_count", "rpe_create", "rpe_destroy", "rpe_synchronize",
     "rpe_set_problem", "rpe_upload", "rpe_bind", "rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask",
     "rpe_p2p_moments", "rpe_pose_from_moments", "rpe_normal_eq", "rpe_normal_eq_device", "rpe_gn_solve", "rpe_gn_apply",
-    "rpe_normal_eq_joint", "rpe_gn_refine_joint", "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_gn_step_dist", "rpe_gn_refine", "rpe_timing_enable", "rpe_timing_collect", "rpe_score", "rpe_inlier_mask", "rpe_nl_round", "rpe_run",
+    "rpe_normal_eq_joint", "rpe_gn_refine_joint", "rpe_gn_refine_device", "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_gn_step_dist", "rpe_gn_refine", "rpe_timing_enable", "rpe_timing_collect", "rpe_score", "rpe_inlier_mask", "rpe_nl_round", "rpe_run",
     "rpe_host_random_elements", "rpe_host_prosac_samples", "rpe_host_update_num_iters", "rpe_host_sort_indexes", "rpe_host_kneip_main",
     "rpe_host_kneip", "rpe_host_nl_2p", "rpe_host_shinji", "rpe_host_se3_exp", "rpe_host_svd3", "rpe_host_calc_err",
 ]
@@ -98,6 +98,7 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_normal_eq_joint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rpe_gn_refine_joint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_gn_refine_device.argtypes = L.rpe_gn_refine_joint.argtypes
         L.rpe_gn_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_comm_unique_id.argtypes = [C.c_void_p]
         L.rpe_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]

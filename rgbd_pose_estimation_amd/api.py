@@ -154,6 +154,14 @@ class Context:
         L.check(L.lib().rpe_gn_refine_joint(self._h, len(arr), arr, flags, _p(p), max_iter, tol, C.byref(it), C.byref(step), C.byref(cost)))
         return p, it.value, step.value, cost.value
 
+    def gn_refine_device(self, terms, pose, flags: int = 0, max_iter: int = 20, tol: float = 1e-9):
+        """Device-resident loop: one launch per iteration, solve + exp-map on the GPU, one host wait at the end."""
+        arr = self._terms(terms)
+        p = np.array(pose, np.float64).reshape(12).copy()
+        it, step, cost = C.c_int(0), C.c_double(0), C.c_double(0)
+        L.check(L.lib().rpe_gn_refine_device(self._h, len(arr), arr, flags, _p(p), max_iter, tol, C.byref(it), C.byref(step), C.byref(cost)))
+        return p, it.value, step.value, cost.value
+
     def gn_step(self, kind: int, pose12_inout: np.ndarray, flags: int = 0) -> float:
         """One GN step in place on a float64[12] array; returns |delta|."""
         step = C.c_double(0)

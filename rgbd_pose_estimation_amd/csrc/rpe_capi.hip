@@ -91,6 +91,8 @@ struct rpe_context {
   double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
   unsigned int* d_ticket = nullptr;
   unsigned long long seq = 0;
+  double* d_gn_pose = nullptr;          // device-resident Gauss-Newton: pose (12 doubles) ...
+  rpe::GnState* d_gn_state = nullptr;   // ... and loop state, both in HBM
   void* d_poses = nullptr;       // kMaxScoreH * 12 doubles
   void* h_poses = nullptr;       // pinned staging
   int* d_votes = nullptr;        // kMaxScoreH ints
@@ -218,6 +220,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 9 * 128); }
   if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * 128);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_pose, 16 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_state, sizeof(rpe::GnState));
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
@@ -236,6 +240,8 @@ void rpe_destroy(rpe_context* c) {
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_ticket) (void)hipFree(c->d_ticket);
+  if (c->d_gn_pose) (void)hipFree(c->d_gn_pose);
+  if (c->d_gn_state) (void)hipFree(c->d_gn_state);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->h_poses) (void)hipHostFree(c->h_poses);
@@ -475,6 +481,45 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
   if (iters_out) *iters_out = it;
   if (last_step) *last_step = step;
   if (final_cost) *final_cost = cost;
+  return RPE_OK;
+}
+
+// Device-resident Gauss-Newton: the pose and the loop state live in HBM; every iteration is ONE launch whose last workgroup
+// solves the 6x6 system and applies the exp-map update; the host only enqueues the launches and waits for the final record.
+int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol, int* iters_out,
+                         double* last_step, double* final_cost) {
+  if (!c || !terms || nterms < 1 || nterms > 4 || !pose12 || max_iter < 1) return fail(RPE_ERR_ARG, "rpe_gn_refine_device: bad argument");
+  int bits = 0, robust[4] = {0, 0, 0, 0};
+  double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1};
+  for (int t = 0; t < nterms; t++) {
+    const int k = terms[t].kind;
+    if (k < 0 || k > 3 || (bits & (1 << k))) return fail(RPE_ERR_ARG, "bad residual kind list");
+    int rc = kind_arrays(c, k);
+    if (rc) return rc;
+    if ((rc = check_flags(c, k, flags))) return rc;
+    bits |= 1 << k; scale[k] = terms[t].scale; robust[k] = terms[t].robust; rk[k] = terms[t].robust_k > 0 ? terms[t].robust_k : 1.0;
+  }
+  if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
+  HIP_TRY(hipSetDevice(c->device));
+  rpe::GnState st;
+  st.tol = tol; st.step = 0; st.cost = 0; st.max_iters = max_iter; st.iters = 0; st.done = 0; st.status = 0;
+  HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+  rpe::ReduceTarget rt = host_target(c);   // ONE sequence value for the whole batch: only the finishing launch publishes
+  rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
+  // a single plain kind other than N-N uses the dedicated kernel (structured sums for p2p), several kinds the fused one
+  const bool single = nterms == 1 && terms[0].kind != RPE_RES_NORMAL && terms[0].robust == 0 && terms[0].scale == 1.0;
+  for (int it = 0; it < max_iter; it++) {
+    if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose12, rt, c->stream));
+    else HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, rt, c->stream));
+  }
+  int rc = wait_host(c, rpe::kNeLd);
+  if (rc) return rc;
+  for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
+  if (last_step) *last_step = c->h_out[12];
+  if (final_cost) *final_cost = c->h_out[13];
+  if (iters_out) *iters_out = (int)c->h_out[14];
+  if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
   return RPE_OK;
 }
 

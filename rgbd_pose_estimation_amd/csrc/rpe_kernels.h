@@ -19,6 +19,16 @@ struct DeviceArrays {
   int dtype;
 };
 
+// State of a device-resident Gauss-Newton loop (lives in HBM next to the pose; one launch per iteration, no host round trip).
+struct GnState {
+  double tol;        // stop when |delta| < tol
+  double step, cost; // of the last iteration
+  int max_iters;     // stop after this many iterations
+  int iters;         // iterations done
+  int done;          // 1: converged / failed / max_iters reached -> later launches of the same batch return at once
+  int status;        // 0 ok, 1 normal equations not positive definite
+};
+
 // Where a reduction kernel leaves its result (both stages run inside one launch, see reduce_and_finish).
 struct ReduceTarget {
   double* d_partials;          // max_blocks * kNlLd doubles of scratch
@@ -28,6 +38,8 @@ struct ReduceTarget {
   double* d_out;               // record in HBM (for a collective), or null
   double* h_out;               // record in pinned host memory + sequence word at [LD], or null
   unsigned long long seq;      // sequence value published after the record
+  double* gn_pose = nullptr;   // device-resident GN: 12 doubles in HBM, read at kernel start, updated by the last workgroup
+  GnState* gn = nullptr;       // its state (null = ordinary launch: pose from the kernel argument, record published)
 };
 // ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,

@@ -131,7 +131,107 @@ struct Finish {
   double* out_dev;             // LD doubles in HBM, or null
   double* out_host;            // LD doubles + 1 sequence word in pinned host memory, or null
   unsigned long long seq;      // value published after the record
+  double* gn_pose;             // device-resident Gauss-Newton: pose in HBM (null = pose comes as a kernel argument)
+  GnState* gn;                 // and its state
 };
+
+// ---- device-resident Gauss-Newton: solve H d = -g (LDL^T) and T <- exp(d) T by ONE lane of the last workgroup.
+// Fully unrolled so that every matrix entry is a register (a rolled version over LDS arrays took ~10 us per call: one
+// lane, ~500 dependent LDS round trips); the streaming body's occupancy is unaffected as long as the kernel stays within
+// 256 VGPRs (one 512-thread workgroup per CU = 2 waves per SIMD).  Arithmetic mirrors rpe/linalg.hpp operation for operation.
+__device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* LDS */, double* __restrict__ pose /* LDS, 12, in/out */,
+                                             double* step_out) {
+  double A[6][6], Lm[6][6], D[6], y[6], d[6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = i; j < 6; j++) { A[i][j] = rec[k]; A[j][i] = rec[k]; k++; }
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = A[j][j];
+#pragma unroll
+    for (int m = 0; m < j; m++) dj -= Lm[j][m] * Lm[j][m] * D[m];
+    ok = ok && (dj > 0) && (dj < 1e300);
+    D[j] = dj;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double sacc = A[i][j];
+#pragma unroll
+      for (int m = 0; m < j; m++) sacc -= Lm[i][m] * Lm[j][m] * D[m];
+      Lm[i][j] = sacc / dj;
+    }
+  }
+  if (!ok) return false;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double sacc = -rec[21 + i];
+#pragma unroll
+    for (int m = 0; m < i; m++) sacc -= Lm[i][m] * y[m];
+    y[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] /= D[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double sacc = y[i];
+#pragma unroll
+    for (int m = i + 1; m < 6; m++) sacc -= Lm[m][i] * d[m];
+    d[i] = sacc;
+  }
+  double n2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { ok = ok && (d[i] == d[i]) && (d[i] < 1e300 && d[i] > -1e300); n2 += d[i] * d[i]; }
+  if (!ok) return false;
+  *step_out = sqrt(n2);
+  // exp(d): rotation from the quaternion (cos(th/2), sin(th/2) w / th), V = I + c1 W + c2 W^2  (sophus/se3.hpp:321-342)
+  const double wx = d[3], wy = d[4], wz = d[5];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+  double imag, real;
+  if (th < 1e-10) { imag = 0.5 - th2 / 48.0 + th2 * th2 / 3840.0; real = 1.0 - th2 / 8.0 + th2 * th2 / 384.0; }
+  else { imag = sin(0.5 * th) / th; real = cos(0.5 * th); }
+  double Rd[9], V[9];
+  {
+    const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    Rd[0] = 1 - (tyy + tzz); Rd[1] = txy - twz; Rd[2] = txz + twy;
+    Rd[3] = txy + twz; Rd[4] = 1 - (txx + tzz); Rd[5] = tyz - twx;
+    Rd[6] = txz - twy; Rd[7] = tyz + twx; Rd[8] = 1 - (txx + tyy);
+  }
+  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  if (th < 1e-10) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) V[k] = Rd[k];
+  } else {
+    const double c1 = (1.0 - cos(th)) / th2, c2 = (th - sin(th)) / (th2 * th);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) {
+        const double w2 = W[3 * i] * W[jj] + W[3 * i + 1] * W[3 + jj] + W[3 * i + 2] * W[6 + jj];
+        V[3 * i + jj] = (i == jj ? 1.0 : 0.0) + c1 * W[3 * i + jj] + c2 * w2;
+      }
+    }
+  }
+  double P0[12], Pn[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) P0[k] = pose[k];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double td = V[3 * i] * d[0] + V[3 * i + 1] * d[1] + V[3 * i + 2] * d[2];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) Pn[3 * i + jj] = Rd[3 * i] * P0[jj] + Rd[3 * i + 1] * P0[3 + jj] + Rd[3 * i + 2] * P0[6 + jj];
+    Pn[9 + i] = Rd[3 * i] * P0[9] + Rd[3 * i + 1] * P0[10] + Rd[3 * i + 2] * P0[11] + td;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) pose[k] = Pn[k];
+  return true;
+}
 
 template <int NACC, int LD, int MODE, int BLK>
 __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Finish& fin) {
@@ -236,9 +336,39 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
         default: val = 0.0;
       }
     }
-    if (fin.out_dev) fin.out_dev[threadIdx.x] = val;
-    // pinned, coherent host memory: system-scope stores go straight out over PCIe (posted, ordered)
-    if (fin.out_host) __hip_atomic_store(fin.out_host + threadIdx.x, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (fin.gn == nullptr) {
+      if (fin.out_dev) fin.out_dev[threadIdx.x] = val;
+      // pinned, coherent host memory: system-scope stores go straight out over PCIe (posted, ordered)
+      if (fin.out_host) __hip_atomic_store(fin.out_host + threadIdx.x, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (fin.gn != nullptr) {
+    // device-resident Gauss-Newton: this workgroup solves the 6x6 system, updates the pose in HBM and decides whether
+    // the loop is finished; only a finished loop is published to the host (pose 12 | step | cost | iters | status)
+    __shared__ double gn_rec[LD];
+    __shared__ double gn_pose_s[12];
+    if (threadIdx.x < LD) gn_rec[threadIdx.x] = val;
+    if (threadIdx.x < 12) gn_pose_s[threadIdx.x] = fin.gn_pose[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      GnState* st = fin.gn;
+      double step = 0.0;
+      const bool ok = gn_solve_update(gn_rec, gn_pose_s, &step);
+      const int iters = st->iters + 1;
+      const int done = (!ok) || step < st->tol || iters >= st->max_iters;
+      st->iters = iters; st->step = step; st->cost = gn_rec[27]; st->status = ok ? 0 : 1; st->done = done;
+      if (ok) { for (int k = 0; k < 12; k++) fin.gn_pose[k] = gn_pose_s[k]; }
+      if (done && fin.out_host) {
+        for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, gn_pose_s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 12, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 13, gn_rec[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 14, (double)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
   }
   if (fin.out_host) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -371,6 +501,13 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   constexpr int P = Pk<T>::P;
   constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
   typedef typename Pk<T>::V V;
+  if (fin.gn != nullptr) {  // device-resident Gauss-Newton: finished loops cost an empty launch; the pose lives in HBM
+    if (fin.gn->done) return;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose.R[k] = fin.gn_pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
+  }
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
@@ -557,6 +694,13 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(const T* __restric
   constexpr int P = Pk<T>::P;
   constexpr bool HAS33 = (TERMS & (TERM_P2P | TERM_P2PLANE)) != 0;
   constexpr bool NEED_NC = (TERMS & (TERM_P2PLANE | TERM_NORMAL)) != 0;
+  if (fin.gn != nullptr) {
+    if (fin.gn->done) return;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose.R[k] = fin.gn_pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
+  }
   double acc[29];
 #pragma unroll
   for (int k = 0; k < 29; k++) acc[k] = 0.0;
@@ -1027,6 +1171,7 @@ template <class T> static PoseK<T> make_pose(const double* p12) {
 static Finish make_finish(const ReduceTarget& rt) {
   Finish f;
   f.partials = rt.d_partials; f.ticket = rt.d_ticket; f.out_dev = rt.d_out; f.out_host = rt.h_out; f.seq = rt.seq;
+  f.gn_pose = rt.gn_pose; f.gn = rt.gn;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

@@ -11,6 +11,13 @@
 #include <limits>
 #include <algorithm>
 
+// the small solves below also run on the GPU (device-resident Gauss-Newton loop, last workgroup of the kernel)
+#if defined(__HIPCC__)
+#define RPE_HD __host__ __device__
+#else
+#define RPE_HD
+#endif
+
 namespace rpe {
 
 struct Vec3d {
@@ -157,7 +164,7 @@ template <class T> Quat<T> quat_from_R(const T* R /*row-major*/) {
   }
   return q;
 }
-template <class T> void quat_to_R(const Quat<T>& q, T* R /*row-major*/) {
+template <class T> RPE_HD void quat_to_R(const Quat<T>& q, T* R /*row-major*/) {
   const T tx = T(2) * q.x, ty = T(2) * q.y, tz = T(2) * q.z;
   const T twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
   const T tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
@@ -177,39 +184,39 @@ template <class T> Quat<T> quat_mul(const Quat<T>& a, const Quat<T>& b) {
 }
 
 // ---- SE(3) exponential, tangent (upsilon, omega), as Sophus (se3.hpp:321-342 / so3.hpp:322-355)
-inline void se3_exp(const double a[6], double R[9], double t[3]) {
+RPE_HD inline void se3_exp(const double a[6], double R[9], double t[3]) {
   const double wx = a[3], wy = a[4], wz = a[5];
-  const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
   double imag, real;
   if (th < 1e-10) { imag = 0.5 - th2 / 48.0 + th2 * th2 / 3840.0; real = 1.0 - th2 / 8.0 + th2 * th2 / 384.0; }
-  else { imag = std::sin(0.5 * th) / th; real = std::cos(0.5 * th); }
+  else { imag = sin(0.5 * th) / th; real = cos(0.5 * th); }
   Quat<double> q{real, imag * wx, imag * wy, imag * wz};
   quat_to_R(q, R);
   const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
   double W2[9];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
   double V[9];
-  if (th < 1e-10) { std::memcpy(V, R, sizeof(V)); }
+  if (th < 1e-10) { for (int k = 0; k < 9; k++) V[k] = R[k]; }
   else {
-    const double c1 = (1.0 - std::cos(th)) / th2, c2 = (th - std::sin(th)) / (th2 * th);
+    const double c1 = (1.0 - cos(th)) / th2, c2 = (th - sin(th)) / (th2 * th);
     for (int k = 0; k < 9; k++) V[k] = (k % 4 == 0 ? 1.0 : 0.0) + c1 * W[k] + c2 * W2[k];
   }
   for (int i = 0; i < 3; i++) t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
 }
 // pose12 (R row-major | t) <- exp(delta) * pose12
-inline void se3_left_update(const double delta[6], double pose[12]) {
+RPE_HD inline void se3_left_update(const double delta[6], double pose[12]) {
   double Rd[9], td[3], Rn[9], tn[3];
   se3_exp(delta, Rd, td);
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) Rn[3 * i + j] = Rd[3 * i] * pose[j] + Rd[3 * i + 1] * pose[3 + j] + Rd[3 * i + 2] * pose[6 + j];
     tn[i] = Rd[3 * i] * pose[9] + Rd[3 * i + 1] * pose[10] + Rd[3 * i + 2] * pose[11] + td[i];
   }
-  std::memcpy(pose, Rn, sizeof(Rn));
-  std::memcpy(pose + 9, tn, sizeof(tn));
+  for (int k = 0; k < 9; k++) pose[k] = Rn[k];
+  for (int k = 0; k < 3; k++) pose[9 + k] = tn[k];
 }
 
 // Solve the 6x6 SPD system H d = -g given the packed record (H upper triangle row-major 21 | g 6).  false if not SPD.
-inline bool solve_normal_eq6(const double* ne, double d[6]) {
+RPE_HD inline bool solve_normal_eq6(const double* ne, double d[6]) {
   double A[6][6];
   int k = 0;
   for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) { A[i][j] = ne[k]; A[j][i] = ne[k]; k++; }
@@ -219,7 +226,7 @@ inline bool solve_normal_eq6(const double* ne, double d[6]) {
   for (int j = 0; j < 6; j++) {
     double dj = A[j][j];
     for (int m = 0; m < j; m++) dj -= L[j][m] * L[j][m] * D[m];
-    if (!(dj > 0) || !std::isfinite(dj)) return false;
+    if (!(dj > 0) || !(dj < 1e300)) return false;
     D[j] = dj;
     L[j][j] = 1.0;
     for (int i = j + 1; i < 6; i++) {
@@ -232,7 +239,7 @@ inline bool solve_normal_eq6(const double* ne, double d[6]) {
   for (int i = 0; i < 6; i++) { double s = -g[i]; for (int m = 0; m < i; m++) s -= L[i][m] * y[m]; y[i] = s; }
   for (int i = 0; i < 6; i++) y[i] /= D[i];
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int m = i + 1; m < 6; m++) s -= L[m][i] * d[m]; d[i] = s; }
-  for (int i = 0; i < 6; i++) if (!std::isfinite(d[i])) return false;
+  for (int i = 0; i < 6; i++) if (!(d[i] == d[i]) || !(d[i] < 1e300 && d[i] > -1e300)) return false;
   return true;
 }
 

@@ -94,3 +94,37 @@ def test_joint_rejects_bad_term_sets(gpu_ctx_factory):
         with pytest.raises(L.RpeError) as e:
             ctx.normal_eq_joint(bad, p)
         assert e.value.code == L.RPE_ERR_ARG
+
+
+@pytest.mark.parametrize("terms", [[(L.RES_P2P, 1.0)], [(L.RES_P2PLANE, 1.0)], [(L.RES_P2P, 1.0), (L.RES_BEARING, 2.0)],
+                                   [(L.RES_P2P, 1.0, L.ROBUST_HUBER, 0.1), (L.RES_BEARING, 1.0, L.ROBUST_HUBER, 0.02), (L.RES_NORMAL, 0.5, L.ROBUST_CAUCHY, 0.1)]])
+def test_device_resident_loop_equals_host_loop(gpu_ctx_factory, terms):
+    """The loop with the solve + exp-map on the GPU follows the host loop iteration for iteration."""
+    n = 307200
+    sc = util.scene_full(600, n, np.float32, n2d=2.0, n3d=0.03, outliers=0.1)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    ctx.inlier_mask(L.VOTE_NN_33_23, api.pose7_from_Rt(sc.R, sc.t), 0.15, math.cos(math.atan(8 / 585)), math.cos(0.1))
+    p0 = api.pose12(*util.perturbed_pose(np.random.default_rng(2), sc.R, sc.t, 0.02, 0.05))
+    ph, ith, steph, costh = ctx.gn_refine_joint(terms, p0, flags=L.USE_MASK, max_iter=25, tol=1e-8)
+    pd, itd, stepd, costd = ctx.gn_refine_device(terms, p0, flags=L.USE_MASK, max_iter=25, tol=1e-8)
+    assert itd == ith and 0 < itd < 25
+    assert util.rot_err(pd[:9].reshape(3, 3), ph[:9].reshape(3, 3)) < 1e-9 and np.linalg.norm(pd[9:] - ph[9:]) < 1e-9  # device sin/cos vs libm
+    assert abs(costd - costh) <= 1e-9 * abs(costh)
+    # max_iter cap and a second call on the same context (state is re-armed)
+    p1, it1, _, _ = ctx.gn_refine_device(terms, p0, flags=L.USE_MASK, max_iter=2, tol=0.0)
+    h1, _, _, _ = ctx.gn_refine_joint(terms, p0, flags=L.USE_MASK, max_iter=2, tol=0.0)
+    assert it1 == 2 and np.allclose(p1, h1, atol=1e-10)
+
+
+def test_device_resident_loop_reports_degenerate(gpu_ctx_factory):
+    ctx = gpu_ctx_factory()
+    ctx.set_problem(8, L.F32)
+    ctx.upload(L.XW, np.zeros((8, 3), np.float32)); ctx.upload(L.XC, np.zeros((8, 3), np.float32))
+    with pytest.raises(L.RpeError) as e:
+        ctx.gn_refine_device([(L.RES_P2P, 1.0)], api.pose12(np.eye(3), np.zeros(3)))
+    assert e.value.code == L.RPE_ERR_DEGENERATE
+    # and the context stays usable
+    sc = util.scene33(1, 1000)
+    ctx.load(L.F32, xw=sc.Q, xc=sc.P)
+    p, it, _, _ = ctx.gn_refine_device([(L.RES_P2P, 1.0)], api.pose12(sc.R, sc.t), max_iter=10, tol=1e-8)
+    assert it > 0
