@@ -83,6 +83,9 @@ enum { RPE_MOD_23 = 0, RPE_MOD_33 = 1, RPE_MOD_NN = 2 };
 int rpe_set_problem(rpe_context* ctx, int64_t n, int dtype);
 /* Copy a host array (3 x n, dtype of the problem) into HBM.  Asynchronous on the context stream. */
 int rpe_upload(rpe_context* ctx, int slot, const void* host);
+/* Copy array `slot` back to the host (3 x n of the problem's dtype); synchronises.  For arrays produced on the device
+ * (rpe_associate) and for tests. */
+int rpe_download(rpe_context* ctx, int slot, void* host);
 /* Use a buffer that already lives in HBM (must be 16-byte aligned, 3*n elements); no copy, not owned. */
 int rpe_bind(rpe_context* ctx, int slot, const void* device_ptr);
 /* n shorts (0/1) / n weights for one modality; host pointers, NULL clears. */
@@ -220,6 +223,44 @@ typedef struct {
 } rpe_problem;
 int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
             uint64_t seed, int ls, int score_mode, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 3 -- front end (additive): the step BEFORE the hot path.  A depth frame becomes
+ * the adapters' arrays directly in HBM: points_c / normal_c / bearingVectors of the frame, points_g / normal_g of the
+ * model it is registered against.  Camera model = the reference simulator's pinhole (u - cx = fx * X / Z,
+ * pose/Simulator.hpp:150-162; defaults f = 585, 640 x 480, principal point at the centre).  All fp32.
+ * The reference has no counterpart of this stage; its contract is the numpy statement the parity tests hold.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { double fx, fy, cx, cy; int width, height; } rpe_camera;
+enum { RPE_DEPTH_U16 = 0, RPE_DEPTH_F32 = 1 };
+/* F1: upload one depth image (host, row-major, width*height values; metres = value * depth_scale) and build the frame's
+ * maps: vertex map (NaN where depth is 0 / NaN / outside (dmin, dmax)), unit bearing vectors (every pixel), normal map
+ * (central differences, towards the camera; NaN on the border, next to invalid depth, or where a neighbour's depth
+ * differs by more than max_jump metres). */
+int rpe_frame_set_depth(rpe_context* ctx, const void* depth, int depth_type, const rpe_camera* cam, double depth_scale, double dmin,
+                        double dmax, double max_jump);
+enum { RPE_MAP_VERTEX = 0, RPE_MAP_NORMAL = 1, RPE_MAP_BEARING = 2, RPE_MAP_MODEL_VERTEX = 3, RPE_MAP_MODEL_NORMAL = 4 };
+/* copy one map (3 x width*height floats) to the host */
+int rpe_frame_download(rpe_context* ctx, int which, float* out);
+/* F2: the model := this frame's maps moved to the world frame under pose12 (Xw = R^T (Xc - t)); the model view's pose
+ * and camera := pose12 and the frame's camera.  Device to device. */
+int rpe_model_from_frame(rpe_context* ctx, const double* pose12);
+/* ... or a model rendered elsewhere: world-frame vertex / normal maps (host, 3 x width*height floats, NaN = empty)
+ * as seen from the view `pose12` (world -> model camera) with intrinsics `cam`. */
+int rpe_model_upload(rpe_context* ctx, const float* vertex_w, const float* normal_w, const rpe_camera* cam, const double* pose12);
+/* F3: projective data association of the frame against the model under the pose guess pose12 (frame: Xc = R Xw + t).
+ * Each frame vertex is moved to the world, projected into the model view (nearest pixel), and paired with the model
+ * vertex there if it lies within dist_thr metres and (use_normals) the normals agree to cos_thr.  Declares the problem
+ * (n = width*height, RPE_F32) and fills XW, XC, BV, NW, NC in place, index = frame pixel; pixels without a partner get a
+ * NaN column in XC / BV / NC (the reference's isValid convention, AOPoseAdapter.hpp:147-152) which every kernel skips.
+ * matched (may be NULL: no host synchronisation) = number of pairs. */
+int rpe_associate(rpe_context* ctx, const double* pose12, double dist_thr, double cos_thr, int use_normals, int64_t* matched);
+/* ICP: max_iter rounds of { rpe_associate under the current pose ; one Gauss-Newton step of residual `kind`
+ * (RPE_RES_P2PLANE uses the FRAME's normals, RPE_RES_P2P none) }.  device_resident = 1 keeps pose, solve and exp-map on
+ * the GPU (two launches per round, one host wait at the end), 0 solves on the host each round. */
+typedef struct { int kind; int max_iter; double tol; double dist_thr; double cos_thr; int use_normals; int device_resident; } rpe_icp_options;
+int rpe_icp(rpe_context* ctx, const rpe_icp_options* opt, double* pose12, int* iters_out, double* last_step, double* final_cost,
+            int64_t* matched);
 
 /* ---- host-side pieces of the solvers (no GPU needed): sampling, minimal solvers, small algebra.  They exist so that
  * hosts in other languages do not have to re-implement them, and so that the host logic can be tested on a CPU box.

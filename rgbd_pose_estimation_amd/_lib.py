@@ -18,14 +18,17 @@ RES_P2P, RES_P2PLANE, RES_BEARING, RES_NORMAL = 0, 1, 2, 3
 ROBUST_NONE, ROBUST_HUBER, ROBUST_CAUCHY = 0, 1, 2
 VOTE_33, VOTE_23, VOTE_33_23, VOTE_NN_23, VOTE_NN_33, VOTE_NN_33_23, VOTE_23_MATRIX = 0, 1, 2, 3, 4, 5, 6
 SCORE_FAST, SCORE_EXACT = 0, 1
+DEPTH_U16, DEPTH_F32 = 0, 1
+MAP_VERTEX, MAP_NORMAL, MAP_BEARING, MAP_MODEL_VERTEX, MAP_MODEL_NORMAL = 0, 1, 2, 3, 4
 
 # every symbol include/rgbd_pose_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "ao", "ao_ransac", "py2c",
     "rpe_abi_version", "rpe_last_error", "rpe_device_count", "rpe_create", "rpe_destroy", "rpe_synchronize",
-    "rpe_set_problem", "rpe_upload", "rpe_bind", "rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask",
+    "rpe_set_problem", "rpe_upload", "rpe_download", "rpe_bind", "rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask",
     "rpe_p2p_moments", "rpe_pose_from_moments", "rpe_normal_eq", "rpe_normal_eq_device", "rpe_gn_solve", "rpe_gn_apply",
     "rpe_normal_eq_joint", "rpe_gn_refine_joint", "rpe_gn_refine_device", "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_gn_step_dist", "rpe_gn_refine", "rpe_timing_enable", "rpe_timing_collect", "rpe_score", "rpe_inlier_mask", "rpe_nl_round", "rpe_run",
+    "rpe_frame_set_depth", "rpe_frame_download", "rpe_model_from_frame", "rpe_model_upload", "rpe_associate", "rpe_icp",
     "rpe_host_random_elements", "rpe_host_prosac_samples", "rpe_host_update_num_iters", "rpe_host_sort_indexes", "rpe_host_kneip_main",
     "rpe_host_kneip", "rpe_host_nl_2p", "rpe_host_shinji", "rpe_host_se3_exp", "rpe_host_svd3", "rpe_host_calc_err",
 ]
@@ -38,6 +41,15 @@ class RpeProblem(C.Structure):
 
 class RpeTerm(C.Structure):
     _fields_ = [("kind", C.c_int), ("scale", C.c_double), ("robust", C.c_int), ("robust_k", C.c_double)]
+
+
+class RpeCamera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("width", C.c_int), ("height", C.c_int)]
+
+
+class RpeIcpOptions(C.Structure):
+    _fields_ = [("kind", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double), ("dist_thr", C.c_double), ("cos_thr", C.c_double),
+                ("use_normals", C.c_int), ("device_resident", C.c_int)]
 
 
 class RpeError(RuntimeError):
@@ -83,7 +95,7 @@ def lib():
         L.rpe_destroy.argtypes = [C.c_void_p]
         L.rpe_destroy.restype = None
         L.rpe_set_problem.argtypes = [C.c_void_p, C.c_int64, C.c_int]
-        for name in ("rpe_upload", "rpe_bind"):
+        for name in ("rpe_upload", "rpe_download", "rpe_bind"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         for name in ("rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -109,6 +121,12 @@ def lib():
         L.rpe_score.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.rpe_inlier_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.rpe_nl_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_frame_set_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(RpeCamera), C.c_double, C.c_double, C.c_double, C.c_double]
+        L.rpe_frame_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rpe_model_from_frame.argtypes = [C.c_void_p, C.c_void_p]
+        L.rpe_model_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RpeCamera), C.c_void_p]
+        L.rpe_associate.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.rpe_icp.argtypes = [C.c_void_p, C.POINTER(RpeIcpOptions), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if hasattr(L, "rpe_run"):
             L.rpe_run.argtypes = [C.c_int, C.POINTER(RpeProblem), C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_uint64,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -84,6 +84,11 @@ class Context:
         L.check(L.lib().rpe_upload(self._h, slot, _p(a)))
         L.check(L.lib().rpe_synchronize(self._h))
 
+    def download(self, slot: int) -> np.ndarray:
+        out = np.empty((self.n, 3), _np_dtype(self.dtype))
+        L.check(L.lib().rpe_download(self._h, slot, _p(out)))
+        return out
+
     def bind(self, slot: int, device_ptr: int):
         L.check(L.lib().rpe_bind(self._h, slot, C.c_void_p(device_ptr)))
 
@@ -173,6 +178,73 @@ class Context:
         step = C.c_double(0)
         L.check(L.lib().rpe_gn_step_dist(self._h, kind, flags, _p(pose12_inout), None, C.byref(step)))
         return step.value
+
+    # ---- front end (Part 3 of the C ABI): depth frame -> maps -> projective association -> ICP
+    @staticmethod
+    def _camera(cam) -> "L.RpeCamera":
+        """cam: (fx, fy, cx, cy, width, height); defaults of the reference simulator: (585, 585, 320, 240, 640, 480)."""
+        fx, fy, cx, cy, w, h = cam
+        return L.RpeCamera(float(fx), float(fy), float(cx), float(cy), int(w), int(h))
+
+    def frame_set_depth(self, depth: np.ndarray, cam=(585.0, 585.0, 320.0, 240.0, 640, 480), depth_scale: float | None = None,
+                        dmin: float = 0.0, dmax: float = 1e30, max_jump: float = 0.1):
+        """depth: (height, width) uint16 (default scale 0.001: millimetres) or float32 (default scale 1: metres)."""
+        k = self._camera(cam)
+        d = np.ascontiguousarray(depth)
+        if d.shape != (k.height, k.width):
+            raise ValueError(f"depth shape {d.shape} does not match the camera ({k.height}, {k.width})")
+        if d.dtype == np.uint16:
+            kind, scale = L.DEPTH_U16, 0.001 if depth_scale is None else depth_scale
+        elif d.dtype == np.float32:
+            kind, scale = L.DEPTH_F32, 1.0 if depth_scale is None else depth_scale
+        else:
+            raise TypeError("depth must be uint16 or float32")
+        L.check(L.lib().rpe_frame_set_depth(self._h, _p(d), kind, C.byref(k), scale, dmin, dmax, max_jump))
+        self._pixels = k.width * k.height
+        return self
+
+    def frame_download(self, which: int) -> np.ndarray:
+        """One map as (pixels, 3) float32; pixels of the model's view for the MAP_MODEL_* maps."""
+        n = self._model_pixels if which >= L.MAP_MODEL_VERTEX else self._pixels
+        out = np.empty((n, 3), np.float32)
+        L.check(L.lib().rpe_frame_download(self._h, which, _p(out)))
+        return out
+
+    def model_from_frame(self, pose12):
+        p = np.array(pose12, np.float64).reshape(12)
+        L.check(L.lib().rpe_model_from_frame(self._h, _p(p)))
+        self._model_pixels = self._pixels
+        return self
+
+    def model_upload(self, vertex_w: np.ndarray, normal_w: np.ndarray, cam, pose12):
+        k = self._camera(cam)
+        v = np.ascontiguousarray(vertex_w, np.float32).reshape(-1, 3)
+        nw = np.ascontiguousarray(normal_w, np.float32).reshape(-1, 3)
+        if len(v) != k.width * k.height or len(nw) != len(v):
+            raise ValueError("model maps must hold width*height xyz triples")
+        p = np.array(pose12, np.float64).reshape(12)
+        L.check(L.lib().rpe_model_upload(self._h, _p(v), _p(nw), C.byref(k), _p(p)))
+        self._model_pixels = len(v)
+        return self
+
+    def associate(self, pose12, dist_thr: float = 0.1, cos_thr: float = 0.9, use_normals: bool = True, count: bool = True):
+        """Fill XW XC BV NW NC of this context from the frame and the model; returns the number of pairs (or None)."""
+        p = np.array(pose12, np.float64).reshape(12)
+        m = C.c_int64(0)
+        L.check(L.lib().rpe_associate(self._h, _p(p), dist_thr, cos_thr, int(use_normals), C.byref(m) if count else None))
+        self.n, self.dtype = self._pixels, L.F32
+        return m.value if count else None
+
+    def icp(self, pose12, kind: int = L.RES_P2PLANE, max_iter: int = 10, tol: float = 1e-6, dist_thr: float = 0.1, cos_thr: float = 0.9,
+            use_normals: bool = True, device_resident: bool = False):
+        """Projective-association ICP; returns (pose12, iterations, last |delta|, cost, pairs of the last round)."""
+        p = np.array(pose12, np.float64).reshape(12).copy()
+        o = L.RpeIcpOptions(kind, max_iter, tol, dist_thr, cos_thr, int(use_normals), int(device_resident))
+        it, step, cost, m = C.c_int(0), C.c_double(0), C.c_double(0), C.c_int64(0)
+        L.check(L.lib().rpe_icp(self._h, C.byref(o), _p(p), C.byref(it), C.byref(step), C.byref(cost), C.byref(m)))
+        self.n, self.dtype = self._pixels, L.F32
+        return p, it.value, step.value, cost.value, m.value
+
 
     def comm_init(self, world: int, rank: int, id128: bytes):
         buf = (C.c_char * 128).from_buffer_copy(id128)

@@ -106,6 +106,18 @@ struct rpe_context {
   bool timing = false;
   int timing_stride = 1;
   unsigned long long timing_calls = 0;
+  // front end (Part 3): the current depth frame's maps and the model it is registered against, all in HBM
+  struct Frontend {
+    rpe::Camera cam{}, mcam{};
+    bool have_frame = false, have_model = false;
+    void* d_depth = nullptr; size_t depth_cap = 0;
+    float* fmap[3] = {nullptr, nullptr, nullptr};   // vertex, normal, bearing (camera frame)
+    size_t fcap = 0;
+    float* mmap[2] = {nullptr, nullptr};            // model vertex, normal (world frame)
+    size_t mcap = 0;
+    double mpose[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    int* d_count = nullptr;
+  } fe;
 
   rpe::DeviceArrays arrays() const {
     rpe::DeviceArrays A;
@@ -247,6 +259,10 @@ void rpe_destroy(rpe_context* c) {
   if (c->h_poses) (void)hipHostFree(c->h_poses);
   if (c->d_votes) (void)hipFree(c->d_votes);
   if (c->h_votes) (void)hipHostFree(c->h_votes);
+  if (c->fe.d_depth) (void)hipFree(c->fe.d_depth);
+  for (float* m : c->fe.fmap) if (m) (void)hipFree(m);
+  for (float* m : c->fe.mmap) if (m) (void)hipFree(m);
+  if (c->fe.d_count) (void)hipFree(c->fe.d_count);
   if (c->comm && rccl().ok) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
@@ -284,6 +300,15 @@ int rpe_upload(rpe_context* c, int slot, const void* host) {
   }
   c->arr[slot] = c->store[slot];
   HIP_TRY(hipMemcpyAsync(c->arr[slot], host, bytes, hipMemcpyHostToDevice, c->stream));
+  return RPE_OK;
+}
+
+int rpe_download(rpe_context* c, int slot, void* host) {
+  if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS || !host) return fail(RPE_ERR_ARG, "rpe_download: bad argument");
+  if (!c->arr[slot]) return fail(RPE_ERR_STATE, "array slot %d was never uploaded, bound or produced", slot);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(host, c->arr[slot], (size_t)c->n * 3 * elem_size(c->dtype), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return RPE_OK;
 }
 
@@ -710,6 +735,202 @@ int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const 
   HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, host_target(c), c->stream));
   if ((rc = wait_host(c, rpe::kNlLd))) return rc;
   for (int i = 0; i < 44; i++) out44[i] = c->h_out[i];
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Part 3: front end
+namespace {
+int camera_of(const rpe_camera* cam, rpe::Camera* out) {
+  if (!cam || cam->width < 1 || cam->height < 1 || !(cam->fx > 0) || !(cam->fy > 0) || (int64_t)cam->width * cam->height > (int64_t)1 << 28)
+    return fail(RPE_ERR_ARG, "bad camera (need width, height >= 1 and fx, fy > 0)");
+  out->fx = (float)cam->fx; out->fy = (float)cam->fy; out->cx = (float)cam->cx; out->cy = (float)cam->cy;
+  out->width = cam->width; out->height = cam->height;
+  return RPE_OK;
+}
+rpe::PoseF pose_f(const double* p12) {
+  rpe::PoseF T;
+  for (int i = 0; i < 9; i++) T.R[i] = (float)p12[i];
+  for (int i = 0; i < 3; i++) T.t[i] = (float)p12[9 + i];
+  return T;
+}
+// (re)allocate `count` float maps of n pixels each
+int ensure_maps(rpe_context* c, float** maps, int count, size_t* cap, int64_t n) {
+  const size_t bytes = (size_t)n * 3 * sizeof(float);
+  if (maps[0] && *cap >= bytes) return RPE_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < count; i++) { if (maps[i]) { HIP_TRY(hipFree(maps[i])); maps[i] = nullptr; } }
+  *cap = 0;
+  for (int i = 0; i < count; i++) HIP_TRY(hipMalloc((void**)&maps[i], bytes));
+  *cap = bytes;
+  return RPE_OK;
+}
+// the solver slots the association writes: the context's own storage, n = pixels, fp32
+int claim_slots(rpe_context* c, int64_t n) {
+  const size_t bytes = (size_t)n * 3 * sizeof(float);
+  for (int s = 0; s < RPE_NUM_ARRAYS; s++) {
+    if (!c->store[s] || c->cap[s] < bytes) {
+      if (c->store[s]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->store[s])); c->store[s] = nullptr; c->cap[s] = 0; }
+      HIP_TRY(hipMalloc(&c->store[s], bytes));
+      c->cap[s] = bytes;
+    }
+  }
+  if (c->n != n || c->dtype != RPE_F32) {  // a different problem was loaded before: its masks / weights do not apply
+    for (int i = 0; i < 3; i++) { c->mask[i] = nullptr; c->weight[i] = nullptr; }
+  }
+  c->n = n; c->dtype = RPE_F32;
+  for (int s = 0; s < RPE_NUM_ARRAYS; s++) c->arr[s] = c->store[s];
+  return RPE_OK;
+}
+int associate_launch(rpe_context* c, const double* pose12, double dist_thr, double cos_thr, int use_normals, bool pose_on_device, bool count) {
+  auto& F = c->fe;
+  const int64_t n = (int64_t)F.cam.width * F.cam.height;
+  const float d = (float)dist_thr;
+  if (count) HIP_TRY(hipMemsetAsync(F.d_count, 0, sizeof(int), c->stream));
+  HIP_TRY(rpe::launch_associate(F.fmap[0], F.fmap[1], F.fmap[2], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(pose12), pose_f(F.mpose), d * d,
+                                (float)cos_thr, use_normals, pose_on_device ? c->d_gn_pose : nullptr,
+                                pose_on_device ? &c->d_gn_state->done : nullptr, (float*)c->arr[RPE_XW], (float*)c->arr[RPE_XC],
+                                (float*)c->arr[RPE_BV], (float*)c->arr[RPE_NW], (float*)c->arr[RPE_NC], count ? F.d_count : nullptr, c->stream));
+  return RPE_OK;
+}
+int associate_ready(rpe_context* c) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (!c->fe.have_frame) return fail(RPE_ERR_STATE, "no frame: call rpe_frame_set_depth first");
+  if (!c->fe.have_model) return fail(RPE_ERR_STATE, "no model: call rpe_model_from_frame or rpe_model_upload first");
+  return RPE_OK;
+}
+}  // namespace
+
+int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const rpe_camera* cam, double depth_scale, double dmin, double dmax,
+                        double max_jump) {
+  if (!c || !depth || (depth_type != RPE_DEPTH_U16 && depth_type != RPE_DEPTH_F32)) return fail(RPE_ERR_ARG, "rpe_frame_set_depth: bad argument");
+  rpe::Camera k;
+  int rc = camera_of(cam, &k);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  auto& F = c->fe;
+  const int64_t n = (int64_t)k.width * k.height;
+  const size_t bytes = (size_t)n * (depth_type == RPE_DEPTH_U16 ? 2 : 4);
+  if (!F.d_depth || F.depth_cap < bytes) {
+    if (F.d_depth) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(F.d_depth)); F.d_depth = nullptr; F.depth_cap = 0; }
+    HIP_TRY(hipMalloc(&F.d_depth, bytes));
+    F.depth_cap = bytes;
+  }
+  if (!F.d_count) HIP_TRY(hipMalloc((void**)&F.d_count, 64));
+  if ((rc = ensure_maps(c, F.fmap, 3, &F.fcap, n))) return rc;
+  F.have_frame = false;
+  HIP_TRY(hipMemcpyAsync(F.d_depth, depth, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(rpe::launch_frame_maps(F.d_depth, depth_type, k, (float)depth_scale, (float)dmin, (float)dmax, (float)max_jump, F.fmap[0], F.fmap[1],
+                                 F.fmap[2], c->stream));
+  F.cam = k; F.have_frame = true;
+  return RPE_OK;
+}
+
+int rpe_frame_download(rpe_context* c, int which, float* out) {
+  if (!c || !out || which < 0 || which > RPE_MAP_MODEL_NORMAL) return fail(RPE_ERR_ARG, "rpe_frame_download: bad argument");
+  auto& F = c->fe;
+  const bool model = which >= RPE_MAP_MODEL_VERTEX;
+  if (model ? !F.have_model : !F.have_frame) return fail(RPE_ERR_STATE, model ? "no model" : "no frame");
+  const rpe::Camera& k = model ? F.mcam : F.cam;
+  const float* src = model ? F.mmap[which - RPE_MAP_MODEL_VERTEX] : F.fmap[which];
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(out, src, (size_t)k.width * k.height * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RPE_OK;
+}
+
+int rpe_model_from_frame(rpe_context* c, const double* pose12) {
+  if (!c || !pose12) return fail(RPE_ERR_ARG, "rpe_model_from_frame: bad argument");
+  auto& F = c->fe;
+  if (!F.have_frame) return fail(RPE_ERR_STATE, "no frame: call rpe_frame_set_depth first");
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t n = (int64_t)F.cam.width * F.cam.height;
+  int rc = ensure_maps(c, F.mmap, 2, &F.mcap, n);
+  if (rc) return rc;
+  HIP_TRY(rpe::launch_to_world(F.fmap[0], F.fmap[1], n, pose_f(pose12), F.mmap[0], F.mmap[1], c->stream));
+  F.mcam = F.cam;
+  std::memcpy(F.mpose, pose12, sizeof(F.mpose));
+  F.have_model = true;
+  return RPE_OK;
+}
+
+int rpe_model_upload(rpe_context* c, const float* vertex_w, const float* normal_w, const rpe_camera* cam, const double* pose12) {
+  if (!c || !vertex_w || !normal_w || !pose12) return fail(RPE_ERR_ARG, "rpe_model_upload: bad argument");
+  rpe::Camera k;
+  int rc = camera_of(cam, &k);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  auto& F = c->fe;
+  const int64_t n = (int64_t)k.width * k.height;
+  if ((rc = ensure_maps(c, F.mmap, 2, &F.mcap, n))) return rc;
+  HIP_TRY(hipMemcpyAsync(F.mmap[0], vertex_w, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(F.mmap[1], normal_w, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the caller may free its buffers on return
+  F.mcam = k;
+  std::memcpy(F.mpose, pose12, sizeof(F.mpose));
+  F.have_model = true;
+  return RPE_OK;
+}
+
+int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double cos_thr, int use_normals, int64_t* matched) {
+  int rc = associate_ready(c);
+  if (rc) return rc;
+  if (!pose12 || !(dist_thr >= 0)) return fail(RPE_ERR_ARG, "rpe_associate: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
+  if ((rc = associate_launch(c, pose12, dist_thr, cos_thr, use_normals, false, matched != nullptr))) return rc;
+  if (matched) {
+    HIP_TRY(hipMemcpyAsync(c->h_votes, c->fe.d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *matched = c->h_votes[0];
+  }
+  return RPE_OK;
+}
+
+int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters_out, double* last_step, double* final_cost, int64_t* matched) {
+  int rc = associate_ready(c);
+  if (rc) return rc;
+  if (!o || !pose12 || o->max_iter < 1 || (o->kind != RPE_RES_P2P && o->kind != RPE_RES_P2PLANE) || !(o->dist_thr >= 0))
+    return fail(RPE_ERR_ARG, "rpe_icp: bad options (kind must be RPE_RES_P2P or RPE_RES_P2PLANE, max_iter >= 1)");
+  if (o->kind == RPE_RES_P2PLANE && !o->use_normals)
+    return fail(RPE_ERR_ARG, "rpe_icp: point-to-plane needs use_normals = 1 (pairs without a frame normal would poison the sums)");
+  HIP_TRY(hipSetDevice(c->device));
+  if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
+  int it = 0;
+  double step = 0, cost = 0, pairs = 0;
+  if (o->device_resident) {
+    rpe::GnState st;
+    st.tol = o->tol; st.step = 0; st.cost = 0; st.max_iters = o->max_iter; st.iters = 0; st.done = 0; st.status = 0;
+    HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    rpe::ReduceTarget rt = host_target(c);
+    rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
+    for (int k = 0; k < o->max_iter; k++) {
+      if ((rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, true, false))) return rc;
+      HIP_TRY(rpe::launch_normal_eq(c->arrays(), o->kind, 0, pose12, rt, c->stream));
+    }
+    if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+    for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
+    step = c->h_out[12]; cost = c->h_out[13]; it = (int)c->h_out[14]; pairs = c->h_out[16];
+    if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
+  } else {
+    for (; it < o->max_iter; it++) {
+      if ((rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, false, false))) return rc;
+      double ne[32], d[6];
+      if ((rc = rpe_normal_eq(c, o->kind, 0, pose12, ne))) return rc;
+      cost = ne[27]; pairs = ne[28];
+      if (!rpe::solve_normal_eq6(ne, d)) {
+        if (iters_out) *iters_out = it;
+        return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d (%g pairs)", it, pairs);
+      }
+      rpe::se3_left_update(d, pose12);
+      step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+      if (step < o->tol) { it++; break; }
+    }
+  }
+  if (iters_out) *iters_out = it;
+  if (last_step) *last_step = step;
+  if (final_cost) *final_cost = cost;
+  if (matched) *matched = (int64_t)pairs;   // pairs of the last round (the record's weight sum)
   return RPE_OK;
 }
 

@@ -62,4 +62,18 @@ hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const 
 hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 
+// ---- front end (rpe_frontend.hip): depth frame -> maps -> projective association; fp32 throughout
+struct Camera { float fx, fy, cx, cy; int width, height; };
+struct PoseF { float R[9]; float t[3]; };   // Xc = R Xw + t, R row-major
+// depth_type 0 = uint16 (metres = value * scale), 1 = float32 (metres = value * scale); maps are 3 x (width*height) floats
+hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax, float max_jump,
+                             float* vmap, float* nmap, float* bmap, hipStream_t s);
+hipError_t launch_to_world(const float* vmap, const float* nmap, int64_t n, const PoseF& T, float* vw, float* nw, hipStream_t s);
+// d_count (may be null): incremented by the number of associated pixels.  pose_dev (may be null): T read from HBM (12 doubles).
+// done (may be null): device flag; when set the launch does nothing.
+hipError_t launch_associate(const float* vmap, const float* nmap, const float* bmap, int64_t n, const float* mv, const float* mn,
+                            const Camera& mcam, const PoseF& T, const PoseF& M, float dist_sq, float cos_thr, int use_normals,
+                            const double* pose_dev, const int* done, float* xw, float* xc, float* bv, float* nw, float* nc, int* d_count,
+                            hipStream_t s);
+
 }  // namespace rpe

@@ -344,7 +344,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
   }
   if (fin.gn != nullptr) {
     // device-resident Gauss-Newton: this workgroup solves the 6x6 system, updates the pose in HBM and decides whether
-    // the loop is finished; only a finished loop is published to the host (pose 12 | step | cost | iters | status)
+    // the loop is finished; only a finished loop is published to the host (pose 12 | step | cost | iters | status | weight sum)
     __shared__ double gn_rec[LD];
     __shared__ double gn_pose_s[12];
     if (threadIdx.x < LD) gn_rec[threadIdx.x] = val;
@@ -364,6 +364,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
         __hip_atomic_store(fin.out_host + 13, gn_rec[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 14, (double)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 16, gn_rec[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // weight sum of the last round
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }

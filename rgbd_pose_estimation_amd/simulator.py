@@ -224,3 +224,58 @@ def dense_depth_scene(seed: int, number: int = 307200, noise_3d: float = 0.05, o
     rng = np.random.default_rng(seed)
     R, t = random_pose(rng)
     return simulate_3d_3d_correspondences(rng, R, t, number, noise_3d, outlier_ratio).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Depth frames for the front end (rpe_frame_set_depth / rpe_associate / rpe_icp).  The reference simulator only draws
+# sparse points inside the frustum of its 640 x 480, f = 585 camera (Simulator.hpp:157-173); a dense frame of the same
+# camera is rendered here by casting one ray per pixel into a small analytic scene (a room with spheres in it), so that
+# every pixel has an exact depth and the scene constrains all six degrees of freedom.
+# ---------------------------------------------------------------------------------------------------------------------
+DEFAULT_CAMERA = (585.0, 585.0, 320.0, 240.0, 640, 480)
+
+
+def default_room():
+    """(box_min, box_max, spheres[k, 4] = centre xyz + radius): the camera sits inside the box."""
+    spheres = np.array([[-0.9, 0.3, 2.6, 0.55], [0.8, -0.4, 3.4, 0.7], [0.1, 0.9, 2.0, 0.35], [1.6, 0.8, 4.2, 0.5], [-1.7, -0.7, 3.9, 0.6]])
+    return np.array([-2.5, -1.6, -1.0]), np.array([2.7, 1.5, 5.0]), spheres
+
+
+def render_depth(R, t, cam=DEFAULT_CAMERA, room=None, noise_sigma: float = 0.0, rng=None, as_u16: bool = False):
+    """Depth image (height, width) of the room seen by the camera Xc = R Xw + t: float32 metres, or uint16 millimetres.
+    noise_sigma: Gaussian depth noise in metres (rng required)."""
+    fx, fy, cx, cy, w, h = cam
+    lo, hi, spheres = room if room is not None else default_room()
+    R = np.asarray(R, np.float64)
+    t = np.asarray(t, np.float64)
+    C0 = -R.T @ t                                    # camera centre in the world
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    d_cam = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1).reshape(-1, 3)
+    d = d_cam @ R                                    # world direction of each pixel's ray (rows: R^T d_cam); z_cam = lambda
+    lam = np.full(len(d), np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for ax in range(3):                          # the six walls, seen from inside
+            for bound in (lo[ax], hi[ax]):
+                l = (bound - C0[ax]) / d[:, ax]
+                p = C0 + l[:, None] * d
+                ok = l > 1e-9
+                for o in range(3):
+                    if o != ax:
+                        ok &= (p[:, o] >= lo[o] - 1e-9) & (p[:, o] <= hi[o] + 1e-9)
+                lam = np.where(ok & (l < lam), l, lam)
+        for sx, sy, sz, r in spheres:
+            oc = C0 - np.array([sx, sy, sz])
+            a = np.sum(d * d, 1)
+            b = 2.0 * d @ oc
+            c = oc @ oc - r * r
+            disc = b * b - 4 * a * c
+            l = (-b - np.sqrt(np.where(disc > 0, disc, np.nan))) / (2 * a)
+            ok = (disc > 0) & (l > 1e-9)
+            lam = np.where(ok & (l < lam), l, lam)
+    z = np.where(np.isfinite(lam), lam, 0.0)
+    if noise_sigma > 0:
+        z = np.where(z > 0, z + noise_sigma * rng.standard_normal(z.shape), 0.0)
+    z = z.reshape(h, w)
+    if as_u16:
+        return np.clip(np.rint(z * 1000.0), 0, 65535).astype(np.uint16)
+    return z.astype(np.float32)
