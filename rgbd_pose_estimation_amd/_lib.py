@@ -49,7 +49,7 @@ class RpeCamera(C.Structure):
 
 class RpeIcpOptions(C.Structure):
     _fields_ = [("kind", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double), ("dist_thr", C.c_double), ("cos_thr", C.c_double),
-                ("use_normals", C.c_int), ("device_resident", C.c_int)]
+                ("use_normals", C.c_int), ("device_resident", C.c_int), ("fused", C.c_int)]
 
 
 class RpeError(RuntimeError):

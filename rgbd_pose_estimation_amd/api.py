@@ -236,10 +236,10 @@ class Context:
         return m.value if count else None
 
     def icp(self, pose12, kind: int = L.RES_P2PLANE, max_iter: int = 10, tol: float = 1e-6, dist_thr: float = 0.1, cos_thr: float = 0.9,
-            use_normals: bool = True, device_resident: bool = False):
+            use_normals: bool = True, device_resident: bool = False, fused: bool = False):
         """Projective-association ICP; returns (pose12, iterations, last |delta|, cost, pairs of the last round)."""
         p = np.array(pose12, np.float64).reshape(12).copy()
-        o = L.RpeIcpOptions(kind, max_iter, tol, dist_thr, cos_thr, int(use_normals), int(device_resident))
+        o = L.RpeIcpOptions(kind, max_iter, tol, dist_thr, cos_thr, int(use_normals), int(device_resident), int(fused))
         it, step, cost, m = C.c_int(0), C.c_double(0), C.c_double(0), C.c_int64(0)
         L.check(L.lib().rpe_icp(self._h, C.byref(o), _p(p), C.byref(it), C.byref(step), C.byref(cost), C.byref(m)))
         self.n, self.dtype = self._pixels, L.F32

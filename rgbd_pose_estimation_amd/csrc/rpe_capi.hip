@@ -897,6 +897,21 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
   if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
   int it = 0;
   double step = 0, cost = 0, pairs = 0;
+  auto& F = c->fe;
+  const int64_t n = (int64_t)F.cam.width * F.cam.height;
+  const float dgate = (float)o->dist_thr;
+  // one round's kernels, enqueued on the context's stream
+  auto round = [&](const double* pose, const rpe::ReduceTarget& rt, bool pose_on_device) -> int {
+    if (o->fused) {
+      HIP_TRY(rpe::launch_icp_fused(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr,
+                                    o->use_normals, o->kind, pose, rt, c->stream));
+      return RPE_OK;
+    }
+    int r = associate_launch(c, pose, o->dist_thr, o->cos_thr, o->use_normals, pose_on_device, false);
+    if (r) return r;
+    HIP_TRY(rpe::launch_normal_eq(c->arrays(), o->kind, 0, pose, rt, c->stream));
+    return RPE_OK;
+  };
   if (o->device_resident) {
     rpe::GnState st;
     st.tol = o->tol; st.step = 0; st.cost = 0; st.max_iters = o->max_iter; st.iters = 0; st.done = 0; st.status = 0;
@@ -904,19 +919,17 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     rpe::ReduceTarget rt = host_target(c);
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
-    for (int k = 0; k < o->max_iter; k++) {
-      if ((rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, true, false))) return rc;
-      HIP_TRY(rpe::launch_normal_eq(c->arrays(), o->kind, 0, pose12, rt, c->stream));
-    }
+    for (int k = 0; k < o->max_iter; k++) if ((rc = round(pose12, rt, true))) return rc;
     if ((rc = wait_host(c, rpe::kNeLd))) return rc;
     for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
     step = c->h_out[12]; cost = c->h_out[13]; it = (int)c->h_out[14]; pairs = c->h_out[16];
     if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
   } else {
     for (; it < o->max_iter; it++) {
-      if ((rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, false, false))) return rc;
+      if ((rc = round(pose12, host_target(c), false))) return rc;
+      if ((rc = wait_host(c, rpe::kNeLd))) return rc;
       double ne[32], d[6];
-      if ((rc = rpe_normal_eq(c, o->kind, 0, pose12, ne))) return rc;
+      for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
       cost = ne[27]; pairs = ne[28];
       if (!rpe::solve_normal_eq6(ne, d)) {
         if (iters_out) *iters_out = it;
@@ -927,6 +940,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       if (step < o->tol) { it++; break; }
     }
   }
+  if (o->fused && (rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, false, false))) return rc;  // leave the pairs in the slots
   if (iters_out) *iters_out = it;
   if (last_step) *last_step = step;
   if (final_cost) *final_cost = cost;

@@ -14,7 +14,7 @@
 // evaluated in fp32 in the written order with FMA contraction off, and the numpy statement performs the same IEEE operations.
 // All three kernels are image-parallel and HBM/L2 streaming: one thread owns 4 consecutive pixels so that every
 // xyz-interleaved map is read and written as three 16-byte accesses per lane, like the solver kernels read them.
-#include "rpe_kernels.h"
+#include "rpe_assoc.h"
 
 namespace rpe {
 
@@ -110,19 +110,6 @@ __global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restric
   store4(bmap, g, n, B);
 }
 
-// Xw = R^T (Xc - t), rows of R^T = columns of R
-__device__ __forceinline__ void to_world(const PoseF& T, float x, float y, float z, float& ox, float& oy, float& oz) {
-  const float dx = x - T.t[0], dy = y - T.t[1], dz = z - T.t[2];
-  ox = T.R[0] * dx + T.R[3] * dy + T.R[6] * dz;
-  oy = T.R[1] * dx + T.R[4] * dy + T.R[7] * dz;
-  oz = T.R[2] * dx + T.R[5] * dy + T.R[8] * dz;
-}
-__device__ __forceinline__ void rot_to_world(const PoseF& T, float x, float y, float z, float& ox, float& oy, float& oz) {
-  ox = T.R[0] * x + T.R[3] * y + T.R[6] * z;
-  oy = T.R[1] * x + T.R[4] * y + T.R[7] * z;
-  oz = T.R[2] * x + T.R[5] * y + T.R[8] * z;
-}
-
 // ---------------------------------------------------------------------------------------------- F2
 __global__ __launch_bounds__(kFeBlock) void to_world_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n, PoseF T,
                                                             float* __restrict__ vw, float* __restrict__ nw) {
@@ -147,8 +134,7 @@ __global__ __launch_bounds__(kFeBlock) void to_world_kernel(const float* __restr
 // done != null: the launch returns at once when *done is set (GnState::done of that loop).
 __global__ __launch_bounds__(kFeBlock) void associate_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap,
                                                              const float* __restrict__ bmap, int64_t n, const float* __restrict__ mv,
-                                                             const float* __restrict__ mn, Camera mcam, PoseF T, PoseF M, float dist_sq,
-                                                             float cos_thr, int use_normals, const double* __restrict__ pose_dev,
+                                                             const float* __restrict__ mn, PoseF T, AssocParams P, const double* __restrict__ pose_dev,
                                                              const int* __restrict__ done, float* __restrict__ xw, float* __restrict__ xc, float* __restrict__ bv,
                                                              float* __restrict__ nw, float* __restrict__ nc, int* __restrict__ count) {
   const int64_t g = (int64_t)blockIdx.x * kFeBlock + threadIdx.x;
@@ -168,32 +154,12 @@ __global__ __launch_bounds__(kFeBlock) void associate_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float x = V[3 * k], y = V[3 * k + 1], z = V[3 * k + 2];
-      bool ok = !(x != x || y != y || z != z);
-      float wx, wy, wz;
-      to_world(T, x, y, z, wx, wy, wz);
-      const float px = M.R[0] * wx + M.R[1] * wy + M.R[2] * wz + M.t[0];
-      const float py = M.R[3] * wx + M.R[4] * wy + M.R[5] * wz + M.t[1];
-      const float pz = M.R[6] * wx + M.R[7] * wy + M.R[8] * wz + M.t[2];
-      ok = ok && pz > 0.0f;
-      const float uf = floorf(mcam.fx * (px / pz) + mcam.cx + 0.5f), vf = floorf(mcam.fy * (py / pz) + mcam.cy + 0.5f);
-      ok = ok && uf >= 0.0f && uf <= (float)(mcam.width - 1) && vf >= 0.0f && vf <= (float)(mcam.height - 1);
-      float mx = 0.f, my = 0.f, mz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-      if (ok) {
-        const int64_t j = (int64_t)(int)vf * mcam.width + (int)uf;
-        mx = mv[3 * j]; my = mv[3 * j + 1]; mz = mv[3 * j + 2];
-        gx = mn[3 * j]; gy = mn[3 * j + 1]; gz = mn[3 * j + 2];
-        const float ex = mx - wx, ey = my - wy, ez = mz - wz;
-        ok = (ex * ex + ey * ey + ez * ez) <= dist_sq;  // false for a NaN model vertex
-        if (use_normals) {
-          float qx, qy, qz;
-          rot_to_world(T, N[3 * k], N[3 * k + 1], N[3 * k + 2], qx, qy, qz);
-          ok = ok && (qx * gx + qy * gy + qz * gz) >= cos_thr;  // false if either normal is NaN
-        }
-      }
+      float mx, my, mz, gx, gy, gz;
+      const bool ok = associate_pixel(T, P, mv, mn, x, y, z, N[3 * k], N[3 * k + 1], N[3 * k + 2], mx, my, mz, gx, gy, gz);
       matched += ok ? 1 : 0;
       const float nan = qnan();
-      OW[3 * k] = ok ? mx : 0.f; OW[3 * k + 1] = ok ? my : 0.f; OW[3 * k + 2] = ok ? mz : 0.f;
-      ONW[3 * k] = ok ? gx : 0.f; ONW[3 * k + 1] = ok ? gy : 0.f; ONW[3 * k + 2] = ok ? gz : 0.f;
+      OW[3 * k] = mx; OW[3 * k + 1] = my; OW[3 * k + 2] = mz;
+      ONW[3 * k] = gx; ONW[3 * k + 1] = gy; ONW[3 * k + 2] = gz;
       OC[3 * k] = ok ? x : nan; OC[3 * k + 1] = ok ? y : nan; OC[3 * k + 2] = ok ? z : nan;
       ONC[3 * k] = ok ? N[3 * k] : nan; ONC[3 * k + 1] = ok ? N[3 * k + 1] : nan; ONC[3 * k + 2] = ok ? N[3 * k + 2] : nan;
       OB[3 * k] = ok ? B[3 * k] : nan; OB[3 * k + 1] = ok ? B[3 * k + 1] : nan; OB[3 * k + 2] = ok ? B[3 * k + 2] : nan;
@@ -238,8 +204,10 @@ hipError_t launch_associate(const float* vmap, const float* nmap, const float* b
                             const double* pose_dev, const int* done, float* xw, float* xc, float* bv, float* nw, float* nc, int* d_count,
                             hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(associate_kernel, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, vmap, nmap, bmap, n, mv, mn, mcam, T, M, dist_sq, cos_thr,
-                     use_normals, pose_dev, done, xw, xc, bv, nw, nc, d_count);
+  AssocParams P;
+  P.mcam = mcam; P.M = M; P.dist_sq = dist_sq; P.cos_thr = cos_thr; P.use_normals = use_normals;
+  hipLaunchKernelGGL(associate_kernel, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, vmap, nmap, bmap, n, mv, mn, T, P, pose_dev, done, xw, xc, bv,
+                     nw, nc, d_count);
   return hipGetLastError();
 }
 

@@ -75,5 +75,9 @@ hipError_t launch_associate(const float* vmap, const float* nmap, const float* b
                             const Camera& mcam, const PoseF& T, const PoseF& M, float dist_sq, float cos_thr, int use_normals,
                             const double* pose_dev, const int* done, float* xw, float* xc, float* bv, float* nw, float* nc, int* d_count,
                             hipStream_t s);
+// one ICP round in one kernel: association + normal equations of kind 0 (p2p) / 1 (p2plane, frame normals); record as launch_normal_eq
+hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam,
+                            const PoseF& M, float dist_sq, float cos_thr, int use_normals, int kind, const double* pose12, const ReduceTarget& rt,
+                            hipStream_t s);
 
 }  // namespace rpe

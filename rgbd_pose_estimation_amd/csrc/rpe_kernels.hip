@@ -11,6 +11,7 @@
 // (4) grids of at most a few workgroups per CU with a grid-stride loop, so a launch covers all 8 XCDs and a
 // workgroup re-reads the same slice every Gauss-Newton iteration (slice stays in its XCD's L2 when it fits).
 #include "rpe_kernels.h"
+#include "rpe_assoc.h"
 
 namespace rpe {
 
@@ -562,6 +563,73 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     if (MASK) load_scalars<T, short>(mask, full, n, m, (short)0);
     if (WEIGHT) load_scalars<T, T>(weight, full, n, wv, T(0));
     normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, (int)(n - full * P), acc);
+  }
+  reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
+}
+
+// ================================================================================================
+// F3 + K1/K2 fused: one ICP round in ONE pass.  Each frame vertex is paired with the model by projective association
+// (rpe_assoc.h, the same function the stand-alone association kernel runs) and its residual is accumulated at once: the
+// pairs never exist in HBM (48 B/pixel read -- frame vertex + normal streamed, model vertex + normal gathered -- against
+// 120 B/pixel for the association pass plus 36 B/pixel for the normal-equation pass).  The pairing function
+// and the per-pixel arithmetic are those of the two-kernel path; only the summation order differs (1e-13 relative).
+// ================================================================================================
+template <int KIND, int BLK>
+__global__ __launch_bounds__(BLK) void icp_fused_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n,
+                                                        const float* __restrict__ mv, const float* __restrict__ mn, AssocParams P,
+                                                        PoseK<double> pose, Finish fin) {
+  constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
+  if (fin.gn != nullptr) {
+    if (fin.gn->done) return;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose.R[k] = fin.gn_pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
+  }
+  PoseF T;
+#pragma unroll
+  for (int k = 0; k < 9; k++) T.R[k] = (float)pose.R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) T.t[k] = (float)pose.t[k];
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+  const short m_none[4] = {1, 1, 1, 1};
+  const float w_none[4] = {1.f, 1.f, 1.f, 1.f};
+  const float nan = __int_as_float(0x7fc00000);
+  const int64_t full = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  const float4* __restrict__ v4 = reinterpret_cast<const float4*>(vmap);
+  const float4* __restrict__ n4 = reinterpret_cast<const float4*>(nmap);
+  for (int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x; g < full; g += stride) {
+    float V[12], N[12], vw[12], vb[12], vc[12];
+    unpack3(v4[3 * g], v4[3 * g + 1], v4[3 * g + 2], V);
+    unpack3(n4[3 * g], n4[3 * g + 1], n4[3 * g + 2], N);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float gx, gy, gz;
+      const bool ok = associate_pixel(T, P, mv, mn, V[3 * i], V[3 * i + 1], V[3 * i + 2], N[3 * i], N[3 * i + 1], N[3 * i + 2], vw[3 * i],
+                                      vw[3 * i + 1], vw[3 * i + 2], gx, gy, gz);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { vb[3 * i + k] = ok ? V[3 * i + k] : nan; vc[3 * i + k] = ok ? N[3 * i + k] : nan; }
+    }
+    normal_eq_group<float, KIND, false, false, NACC>(pose, vw, vb, vc, m_none, w_none, 4, acc);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && full * 4 < n) {  // leftover pixels
+    float vw[12], vb[12], vc[12];
+    const int left = (int)(n - full * 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float x = nan, y = nan, z = nan, nx = nan, ny = nan, nz = nan, gx, gy, gz;
+      if (i < left) {
+        const int64_t q = 3 * (full * 4 + i);
+        x = vmap[q]; y = vmap[q + 1]; z = vmap[q + 2]; nx = nmap[q]; ny = nmap[q + 1]; nz = nmap[q + 2];
+      }
+      const bool ok = associate_pixel(T, P, mv, mn, x, y, z, nx, ny, nz, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], gx, gy, gz);
+      vb[3 * i] = ok ? x : nan; vb[3 * i + 1] = ok ? y : nan; vb[3 * i + 2] = ok ? z : nan;
+      vc[3 * i] = ok ? nx : nan; vc[3 * i + 1] = ok ? ny : nan; vc[3 * i + 2] = ok ? nz : nan;
+    }
+    normal_eq_group<float, KIND, false, false, NACC>(pose, vw, vb, vc, m_none, w_none, left, acc);
   }
   reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
 }
@@ -1224,6 +1292,33 @@ static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const 
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev0, hipEvent_t ev1) {
   return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s, ev0, ev1);
+}
+
+hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam,
+                            const PoseF& M, float dist_sq, float cos_thr, int use_normals, int kind, const double* pose12, const ReduceTarget& rt,
+                            hipStream_t s) {
+  AssocParams P;
+  P.mcam = mcam; P.M = M; P.dist_sq = dist_sq; P.cos_thr = cos_thr; P.use_normals = use_normals;
+  const PoseK<double> pose = make_pose<double>(pose12);
+  const Finish fin = make_finish(rt);
+  // geometry: the body (dependent gathers + fp64 accumulation) is heavier than a streaming pass, so every thread gets ONE pixel
+  // group and the grid covers the image (150 workgroups of 512 at 640 x 480: 17.4 us per round against 20.6 us with the 128
+  // workgroups a streaming reduction of this size uses; measured, scripts/icp_sweep.sh); RPE_ICP_BLOCK / RPE_ICP_GRID override
+  static const int env_blk = getenv("RPE_ICP_BLOCK") ? atoi(getenv("RPE_ICP_BLOCK")) : 0;
+  static const int env_grid = getenv("RPE_ICP_GRID") ? atoi(getenv("RPE_ICP_GRID")) : 0;
+  const int blk = env_blk == 256 || env_blk == 512 ? env_blk : pick_block(rt, false);
+  const int64_t groups = (n + 3) / 4;
+  int G = env_grid > 0 ? env_grid : rt.max_blocks;
+  if ((int64_t)G > (groups + blk - 1) / blk) G = (int)((groups + blk - 1) / blk);
+  if (G < 1) G = 1;
+  if (blk == 512) {
+    if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 512>), dim3(G), dim3(512), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
+    else hipLaunchKernelGGL((icp_fused_kernel<KIND_P2PLANE, 512>), dim3(G), dim3(512), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
+  } else {
+    if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
+    else hipLaunchKernelGGL((icp_fused_kernel<KIND_P2PLANE, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
+  }
+  return hipGetLastError();
 }
 
 template <class T, int TERMS>

@@ -56,11 +56,11 @@ inline ContextPool& pool() { static ContextPool p; return p; }
 
 class DeviceSet {
  public:
-  DeviceSet() : _ctx(nullptr), _device(0), _n(0), _dtype(-1) {
+  DeviceSet() : _ctx(nullptr), _device(0), _n(0), _dtype(-1), _borrowed(false) {
     for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
     for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
   }
-  ~DeviceSet() { if (_ctx) pool().release(_ctx, _device); }
+  ~DeviceSet() { if (_ctx && !_borrowed) pool().release(_ctx, _device); }
   DeviceSet(const DeviceSet&) = delete;
   DeviceSet& operator=(const DeviceSet&) = delete;
 
@@ -73,6 +73,15 @@ class DeviceSet {
       if (!_ctx) check(rpe_create(&_ctx, _device, nullptr), "rpe_create");
     }
     return _ctx;
+  }
+  // Use a context whose arrays were PRODUCED on the device (the depth front end, pose/DepthFrontEnd.hpp): host[slot] is the
+  // address of the host copy of each array (what the adapter was constructed over), so ensure() finds them resident and
+  // uploads nothing.  The context stays owned by the caller and must outlive this set.
+  void adopt(rpe_context* ctx, int device, int64_t n, int dtype, const void* const host[RPE_NUM_ARRAYS]) {
+    if (_ctx && !_borrowed) pool().release(_ctx, _device);
+    _ctx = ctx; _device = device; _n = n; _dtype = dtype; _borrowed = true;
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = host[i];
+    for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
   }
   // make sure array `slot` in HBM is the host array at `host` (3 x n of Tp)
   template <class Tp> void ensure(int slot, const Tp* host, int64_t n) {
@@ -116,6 +125,7 @@ class DeviceSet {
   int _dtype;
   const void* _src[RPE_NUM_ARRAYS];
   bool _mask_fresh[3], _weight_fresh[3];
+  bool _borrowed;
 };
 
 }  // namespace rpe

@@ -31,3 +31,13 @@ def test_test_main_all_solvers(args):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rows = dict((m.group(1), (float(m.group(2)), float(m.group(3)))) for m in re.finditer(r"^(\w+)\s+([\d.eE+-]+)\s+([\d.eE+-]+)$", r.stdout, re.M))
     assert set(rows) == {"k", "s", "sk", "nk", "ns", "nsk", "opt", "dw", "gn", "gnf"}
+
+
+@pytest.mark.parametrize("scale", ["1", "0.3"])
+def test_icp_main_dense_frame_registration(scale):
+    """Front end + ICP + the reference's RANSAC on device-born pairs, from C++ (pose/DepthFrontEnd.hpp)."""
+    r = _run("icp_main", scale)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "%summary icp_main -> ok" in r.stdout
+    m = re.search(r"^icp\s+iterations (\d+)\s+pairs (\d+)\s+rot_err ([\d.eE+-]+) rad\s+trans_err ([\d.eE+-]+) m", r.stdout, re.M)
+    assert m and int(m.group(2)) > 200000 and float(m.group(3)) < 1e-3 and float(m.group(4)) < 3e-3

@@ -189,3 +189,23 @@ def test_frontend_errors(gpu_ctx_factory):
     with pytest.raises(L.RpeError) as e:
         ctx.icp(I, L.RES_P2PLANE, 3)
     assert e.value.code == L.RPE_ERR_DEGENERATE
+
+
+@pytest.mark.parametrize("cam", [SMALL_CAM, FULL_CAM, (100.0, 90.0, 18.3, 11.1, 37, 23)])
+@pytest.mark.parametrize("kind", [L.RES_P2PLANE, L.RES_P2P])
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_fused_icp_matches_the_two_kernel_icp(gpu_ctx_factory, cam, kind, device_resident):
+    """One kernel per round (pair + accumulate) against association kernel + normal-equation kernel: same pairing function and
+    per-pixel arithmetic, different summation order => poses agree to rounding (1e-9), pair counts exactly unless a pose that
+    differs in the last digits flips a pixel at a gate."""
+    ctx = gpu_ctx_factory()
+    (V, N, B, MV, MN), pA, pB = load_pair(ctx, cam, noise=0.002)
+    start = pA if cam[4] >= 160 else pB      # the 37 x 23 toy camera only supports a refinement from the true pose
+    iters = 8
+    two = ctx.icp(start, kind, iters, 0.0, 0.15, 0.8, device_resident=device_resident, fused=False)
+    one = ctx.icp(start, kind, iters, 0.0, 0.15, 0.8, device_resident=device_resident, fused=True)
+    assert rot_err(one[0][:9].reshape(3, 3), two[0][:9].reshape(3, 3)) < 1e-9 and np.linalg.norm(one[0][9:] - two[0][9:]) < 1e-9
+    assert one[1] == two[1] and abs(one[4] - two[4]) <= 2 and abs(one[3] - two[3]) <= 1e-6 * abs(two[3])
+    # the slots hold the pairs under the returned pose
+    XW, XC, BV, NW, NC, cnt = FO.associate(V, N, B, MV, MN, cam, one[0], pA, 0.15, 0.8, True)
+    assert same(ctx.download(L.XC), XC) and same(ctx.download(L.XW), XW) and same(ctx.download(L.NC), NC)
