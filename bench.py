@@ -242,6 +242,34 @@ def main():
                 pass
             except Exception as e:
                 out["device_resident_loop"] = {"error": repr(e)}
+            # extra: the step BEFORE the path -- two rendered 640x480 depth frames of the reference camera,
+            # dense projective ICP with association and normal equations fused in one kernel per round, pose kept on the GPU
+            try:
+                if args.no_extras:
+                    raise StopIteration
+                from rgbd_pose_estimation_amd import simulator as S
+                Ra, ta = S._rot_zyx(0.05, -0.1, 0.02), np.array([0.1, -0.05, 0.2])
+                dR = S._rot_zyx(0.02, -0.015, 0.01)
+                Rb, tb = dR @ Ra, dR @ ta + np.array([0.03, -0.02, 0.025])
+                fctx = api.Context(local_rank)
+                fctx.frame_set_depth(S.render_depth(Ra, ta, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
+                fctx.model_from_frame(pose12(Ra, ta))
+                fctx.frame_set_depth(S.render_depth(Rb, tb, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
+                K, reps = 20, 25
+                fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
+                t0i = time.perf_counter()
+                for _ in range(reps):
+                    pi, iti, _, _, pairs = fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
+                dti = (time.perf_counter() - t0i) / reps
+                out["icp_frame_loop"] = {"value": pairs * K / dti, "unit": "pixel-residuals/s", "us_per_round": dti / K * 1e6, "rounds": K,
+                                         "pairs": pairs, "pixels": 307200, "rot_err_rad_vs_truth": rot_err(pi[:9].reshape(3, 3), Rb),
+                                         "trans_err_m_vs_truth": float(np.linalg.norm(pi[9:] - tb)),
+                                         "note": "rpe_icp fused + device-resident: projective association + point-to-plane normal equations in one kernel per round"}
+                fctx.close()
+            except StopIteration:
+                pass
+            except Exception as e:
+                out["icp_frame_loop"] = {"error": repr(e)}
         else:
             out["pose_error_vs_truth"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), sc.R), "trans_abs_m": float(np.linalg.norm(pose[9:] - sc.t))}
             out["cpu_baseline"] = None
