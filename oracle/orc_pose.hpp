@@ -54,10 +54,12 @@ template <class T> class PoseAdapterBase {
   T _fx, _fy, _cx, _cy;
 };
 
-template <class T> std::vector<int> sortIndexes(const std::vector<T>& v) {  // pose/Utility.hpp:107-118 (descending)
+// pose/Utility.hpp:107-118 (descending).  The reference's comparator (v[a] > v[b]) leaves the order of EQUAL weights to
+// std::sort, i.e. unspecified; ties go to the lower index here so that the order is unique and comparable across builds.
+template <class T> std::vector<int> sortIndexes(const std::vector<T>& v) {
   std::vector<int> idx(v.size());
   std::iota(idx.begin(), idx.end(), 0);
-  std::sort(idx.begin(), idx.end(), [&v](int a, int b) { return v[a] > v[b]; });
+  std::sort(idx.begin(), idx.end(), [&v](int a, int b) { return v[a] > v[b] || (v[a] == v[b] && a < b); });
   return idx;
 }
 

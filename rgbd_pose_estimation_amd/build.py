@@ -55,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-EXAMPLES = ["simple_main", "test_main", "icp_main"]
+EXAMPLES = ["simple_main", "test_main", "icp_main", "engine_profile"]
 
 
 def build_examples(verbose: bool = False) -> list[str]:

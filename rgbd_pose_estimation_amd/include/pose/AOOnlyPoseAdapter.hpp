@@ -49,6 +49,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   // N x 2 mask: column 1 is the 3D-3D inlier flag; an N x 1 mask is ignored (reference :185-198)
   virtual void setInlier(const rpe::MatrixXs& inliers) {
     if (inliers.cols() != 1) {
+      _vInliersAO.flush(_inliers_3d);
       for (int i = 0; i < inliers.rows(); i++) _inliers_3d[i] = inliers(i, 1);
       this->device().mask_changed_on_host(RPE_MOD_33);
     }
@@ -62,20 +63,17 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
     }
   }
   virtual void printInlier() const { for (short v : _inliers_3d) std::cout << v << " "; std::cout << std::endl; }
-  const std::vector<int>& getInlierIdx() const { return _vInliersAO; }
-  void cvtInlier() {
-    _vInliersAO.clear();
-    for (int r = 0; r < (int)_inliers_3d.size(); r++) if (1 == _inliers_3d[r]) _vInliersAO.push_back(r);
-  }
-  void sortIdx() { _idx = sortIndexes<Tp>(_weights_3d); }
-  void getSortedIdx(std::vector<int>& select_) const {
-    for (size_t i = 0; i < select_.size(); ++i) { const int j = select_[i]; if (j < (int)_idx.size()) select_[i] = _idx[j]; }
-  }
+  const std::vector<int>& getInlierIdx() const { return _vInliersAO.get(_inliers_3d); }
+  void cvtInlier() { _vInliersAO.request(); }  // built on first read (rpe::InlierIndex)
+  void forgetInlierIdx() { _vInliersAO.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
+  // top_k >= 0: only the first top_k positions of the order are needed now (the rest is sorted on demand)
+  void sortIdx(int top_k = -1) { _idx = sortIndexes<Tp>(_weights_3d, top_k); }
+  void getSortedIdx(std::vector<int>& select_) const { mapSortedIdx<Tp>(_weights_3d, _idx, select_); }
 
   // ---- additive accessors for the device backend
   const Tp* pointsCurrData() const { return _points_c.p; }
   const Tp* pointsGlobData() const { return _points_g.p; }
-  std::vector<short>& inlierMask33() { return _inliers_3d; }
+  std::vector<short>& inlierMask33() { _vInliersAO.flush(_inliers_3d); return _inliers_3d; }
   const std::vector<short>& inlierMask33() const { return _inliers_3d; }
   const std::vector<Tp>& weights33() const { return _weights_3d; }
   Tp weightScale33() const { return Tp(1); }
@@ -85,8 +83,8 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   rpe::ColumnView<Tp> _points_c, _points_g;
   std::vector<short> _inliers_3d;
   std::vector<Tp> _weights_3d;
-  std::vector<int> _idx;
-  std::vector<int> _vInliersAO;
+  mutable std::vector<int> _idx;
+  rpe::InlierIndex _vInliersAO;
   int _max_votes;
 };
 

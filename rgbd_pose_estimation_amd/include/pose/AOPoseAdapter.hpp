@@ -36,6 +36,7 @@ class AOPoseAdapter : public PnPPoseAdapter<Tp> {
   virtual void setInlier(const rpe::MatrixXs& inliers) {  // reference :171-184
     PnPPoseAdapter<Tp>::setInlier(inliers);
     if (inliers.cols() != 1) {
+      _vInliersAO.flush(_inliers_3d);
       for (int i = 0; i < inliers.rows(); i++) _inliers_3d[i] = inliers(i, 1);
       this->device().mask_changed_on_host(RPE_MOD_33);
     }
@@ -49,15 +50,13 @@ class AOPoseAdapter : public PnPPoseAdapter<Tp> {
     for (short v : _inliers_3d) std::cout << v << " ";
     std::cout << std::endl;
   }
-  const std::vector<int>& getInlierIdx() const { return _vInliersAO; }
-  void cvtInlier() {
-    _vInliersAO.clear();
-    for (int r = 0; r < (int)_inliers_3d.size(); r++) if (1 == _inliers_3d[r]) _vInliersAO.push_back(r);
-  }
+  const std::vector<int>& getInlierIdx() const { return _vInliersAO.get(_inliers_3d); }
+  void cvtInlier() { _vInliersAO.request(); }  // built on first read (rpe::InlierIndex)
+  void forgetInlierIdx() { _vInliersAO.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
 
   // ---- additive accessors for the device backend
   const Tp* pointsCurrData() const { return _points_c.p; }
-  std::vector<short>& inlierMask33() { return _inliers_3d; }
+  std::vector<short>& inlierMask33() { _vInliersAO.flush(_inliers_3d); return _inliers_3d; }
   const std::vector<short>& inlierMask33() const { return _inliers_3d; }
   const std::vector<Tp>& weights33() const { return _weights_3d; }
   Tp weightScale33() const { return (Tp)std::numeric_limits<short>::max(); }
@@ -72,7 +71,7 @@ class AOPoseAdapter : public PnPPoseAdapter<Tp> {
   rpe::ColumnView<Tp> _points_c;
   std::vector<short> _inliers_3d;
   std::vector<Tp> _weights_3d;
-  std::vector<int> _vInliersAO;
+  rpe::InlierIndex _vInliersAO;
 };
 
 #endif

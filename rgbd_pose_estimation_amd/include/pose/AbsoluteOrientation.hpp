@@ -82,7 +82,7 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
-  if (prosac) adapter.sortIdx();
+  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K)); if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
   ProsacSampler<Tp> ps(K, N);
   VoteSpec<Tp> spec;
   spec.kind = RPE_VOTE_33; spec.thre_3d = dist_thre_3d_; spec.modalities = 1; spec.model_points = K;
@@ -99,7 +99,7 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
     }
     out.push_back(shinji<Tp>(Xw, Xc, K));
   };
-  auto commit = [&](const MatrixXs& m) { adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_33); };
+  auto commit = [&](const MatrixXs& m) { adapter.forgetInlierIdx(); adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_33); };
   ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   adapter.cvtInlier();
 }
@@ -149,7 +149,7 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
-  if (prosac) adapter.sortIdx();
+  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K + 1)); if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
   ProsacSampler<Tp> ps(K + 1, N);
   VoteSpec<Tp> spec;
   spec.kind = RPE_VOTE_33_23; spec.thre_3d = dist_thre_3d_;
@@ -168,6 +168,7 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
     if (kneip<Tp>(X_w, bv, &sk)) out.push_back(sk);
   };
   auto commit = [&](const MatrixXs& m) {
+    { PnPPoseAdapter<Tp>* p23 = &adapter; p23->forgetInlierIdx(); adapter.forgetInlierIdx(); }  // both are requested again below
     adapter.setInlier(m);
     dev.mask_written_on_device(RPE_MOD_23); dev.mask_written_on_device(RPE_MOD_33);
   };

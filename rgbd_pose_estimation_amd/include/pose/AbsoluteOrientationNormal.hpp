@@ -140,6 +140,10 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
   };
   DeviceSet& dev = adapter.device();
   auto commit = [&](const MatrixXs& m) {
+    // the lists requested again after the engine (same levels as the cvtInlier calls below)
+    if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->forgetInlierIdx(); }
+    if (which != 0) { AOPoseAdapter<Tp>* p = &adapter; p->forgetInlierIdx(); }
+    adapter.forgetInlierIdx();
     adapter.setInlier(m);
     dev.mask_written_on_device(RPE_MOD_NN);
     if (which != 1) dev.mask_written_on_device(RPE_MOD_23);

@@ -41,6 +41,7 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
     if (inliers.cols() == 2) AOPoseAdapter<Tp>::setInlier(inliers);
     if (inliers.cols() == 3) {
       AOPoseAdapter<Tp>::setInlier(inliers);
+      _vInliersNN.flush(_inliers_nl);
       for (int i = 0; i < inliers.rows(); i++) _inliers_nl[i] = inliers(i, 2);
       this->device().mask_changed_on_host(RPE_MOD_NN);
     }
@@ -60,16 +61,14 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
     for (short v : _inliers_nl) std::cout << v << " ";
     std::cout << std::endl;
   }
-  const std::vector<int>& getInlierIdx() const { return _vInliersNN; }
-  void cvtInlier() {
-    _vInliersNN.clear();
-    for (int r = 0; r < (int)_inliers_nl.size(); r++) if (1 == _inliers_nl[r]) _vInliersNN.push_back(r);
-  }
+  const std::vector<int>& getInlierIdx() const { return _vInliersNN.get(_inliers_nl); }
+  void cvtInlier() { _vInliersNN.request(); }  // built on first read (rpe::InlierIndex)
+  void forgetInlierIdx() { _vInliersNN.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
 
   // ---- additive accessors for the device backend
   const Tp* normalCurrData() const { return _normal_c.p; }
   const Tp* normalGlobData() const { return _normal_g.p; }
-  std::vector<short>& inlierMaskNN() { return _inliers_nl; }
+  std::vector<short>& inlierMaskNN() { _vInliersNN.flush(_inliers_nl); return _inliers_nl; }
   const std::vector<short>& inlierMaskNN() const { return _inliers_nl; }
   const std::vector<Tp>& weightsNN() const { return _weights_nl; }
   Tp weightScaleNN() const { return (Tp)std::numeric_limits<short>::max(); }
@@ -79,7 +78,7 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
   rpe::ColumnView<Tp> _normal_c, _normal_g;
   std::vector<short> _inliers_nl;
   std::vector<Tp> _weights_nl;
-  std::vector<int> _vInliersNN;
+  rpe::InlierIndex _vInliersNN;
 };
 
 #endif

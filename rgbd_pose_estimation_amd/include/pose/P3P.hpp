@@ -164,7 +164,7 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
   const int N = adapter.getNumberCorrespondences();
   const int K = 4;
   RandomElements<int> re(N);
-  if (prosac) adapter.sortIdx();
+  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K)); if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
   ProsacSampler<Tp> ps(K, N);
   VoteSpec<Tp> spec;
   // kneip_ransac multiplies by so3().matrix() (:365) and kneip_prosac by so3() (:442): two arithmetic variants
@@ -187,7 +187,7 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
     }
     if (arg >= 0) out.push_back(sols[arg]);
   };
-  auto commit = [&](const MatrixXs& m) { adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_23); };
+  auto commit = [&](const MatrixXs& m) { adapter.forgetInlierIdx(); adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_23); };
   ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/1);
   adapter.cvtInlier();
 }

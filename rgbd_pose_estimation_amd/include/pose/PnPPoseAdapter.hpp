@@ -33,16 +33,15 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
 
   // column 0 of the mask (reference :196-202 memcpy's rows()*2 bytes = column 0 of a column-major short matrix)
   virtual void setInlier(const rpe::MatrixXs& inliers) {
+    _vInliersPnP.flush(_inliers);
     for (int i = 0; i < inliers.rows(); i++) _inliers[i] = inliers(i, 0);
     this->device().mask_changed_on_host(RPE_MOD_23);
   }
   template <class M> void setWeights(const M& weights) { setWeights23(weights); }
   virtual void printInlier() const { for (short v : _inliers) std::cout << v << " "; std::cout << std::endl; }
-  const std::vector<int>& getInlierIdx() const { return _vInliersPnP; }
-  void cvtInlier() {
-    _vInliersPnP.clear();
-    for (int r = 0; r < (int)_inliers.size(); r++) if (1 == _inliers[r]) _vInliersPnP.push_back(r);
-  }
+  const std::vector<int>& getInlierIdx() const { return _vInliersPnP.get(_inliers); }
+  void cvtInlier() { _vInliersPnP.request(); }  // built on first read (rpe::InlierIndex)
+  void forgetInlierIdx() { _vInliersPnP.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
   // sine of the angle between predicted and observed bearing (reference :204-210)
   Tp getError(int index) const {
     Point3 Xc = _R_cw * getPointGlob(index) + _t_w;
@@ -53,15 +52,14 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   int getMaxVotes() { return _max_votes; }
   bool isInlier23(int index) const { return _inliers[index] == 1; }
   Tp weight23(int index) const { return _weights.empty() ? Tp(1.0) : _weights[index]; }
-  void sortIdx() { _idx = sortIndexes<Tp>(_weights); }
-  void getSortedIdx(std::vector<int>& select_) const {
-    for (size_t i = 0; i < select_.size(); ++i) { const int j = select_[i]; if (j < (int)_idx.size()) select_[i] = _idx[j]; }
-  }
+  // top_k >= 0: only the first top_k positions of the order are needed now (the rest is sorted on demand)
+  void sortIdx(int top_k = -1) { _idx = sortIndexes<Tp>(_weights, top_k); }
+  void getSortedIdx(std::vector<int>& select_) const { mapSortedIdx<Tp>(_weights, _idx, select_); }
 
   // ---- additive accessors for the device backend
   const Tp* bearingData() const { return _bearingVectors.p; }
   const Tp* pointsGlobData() const { return _points_g.p; }
-  std::vector<short>& inlierMask23() { return _inliers; }
+  std::vector<short>& inlierMask23() { _vInliersPnP.flush(_inliers); return _inliers; }
   const std::vector<short>& inlierMask23() const { return _inliers; }
   const std::vector<Tp>& weights23() const { return _weights; }
 
@@ -75,8 +73,8 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   rpe::ColumnView<Tp> _bearingVectors, _points_g;
   std::vector<short> _inliers;
   std::vector<Tp> _weights;
-  std::vector<int> _idx;
-  std::vector<int> _vInliersPnP;
+  mutable std::vector<int> _idx;
+  rpe::InlierIndex _vInliersPnP;
   int _max_votes;
 };
 

@@ -66,6 +66,31 @@ template <class Tp> struct ColumnView {
   Point3<Tp> col(int i) const { return Point3<Tp>(p + 3 * (size_t)i); }
   int cols() const { return n; }
 };
+// rows of a 0/1 mask that are 1, in order (the adapters' cvtInlier, e.g. reference AOOnlyPoseAdapter.hpp:214-222).  Branch-free
+// compaction: the inlier pattern is unpredictable, a conditional push_back mispredicts on every outlier (4x slower at 307200 rows)
+inline void indices_of_ones(const std::vector<short>& mask, std::vector<int>& out) {
+  out.resize(mask.size() + 1);
+  int* o = out.data();
+  size_t k = 0;
+  for (size_t r = 0; r < mask.size(); r++) { o[k] = (int)r; k += (mask[r] == 1); }
+  out.resize(k);
+}
+// The index list behind cvtInlier() / getInlierIdx().  cvtInlier() only RECORDS the request; the list is built when it is
+// first read, or just before the mask it was requested for changes -- so a reader always sees the list of the mask as it was
+// when cvtInlier() ran (the reference's behaviour), and solvers that never read it (every pipeline here keeps its masks on
+// the device) do not pay 0.16 ms per modality at 307200 rows.
+class InlierIndex {
+ public:
+  void request() { _pending = true; }
+  // a solver that is about to replace the mask AND request the list again may drop an unread request: between those two steps
+  // nothing can read the list, so the skipped snapshot is unobservable
+  void drop() { _pending = false; }
+  void flush(const std::vector<short>& mask) const { if (_pending) { indices_of_ones(mask, _idx); _pending = false; } }
+  const std::vector<int>& get(const std::vector<short>& mask) const { flush(mask); return _idx; }
+ private:
+  mutable std::vector<int> _idx;
+  mutable bool _pending = false;
+};
 }  // namespace rpe
 
 #endif

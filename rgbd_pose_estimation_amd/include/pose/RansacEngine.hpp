@@ -30,6 +30,11 @@ template <class Tp> struct VoteSpec {
   int model_points = 3; // K handed to RANSACUpdateNumIters
 };
 
+// how many leading positions of the PROSAC order a run of at most `iters` iterations can read: the sampler's n starts at K and
+// grows by at most one per draw, position n itself is read, and the engine never draws more than the current iteration bound
+// (a batch is clipped to Iter - it, and Iter only shrinks)
+inline int prosac_prefix(int iters, int K) { return iters + K + 2; }
+
 template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
   const Quat<Tp>& q = s.so3().unit_quaternion();
   q7[0] = q.w; q7[1] = q.x; q7[2] = q.y; q7[3] = q.z;
@@ -42,7 +47,10 @@ template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
 template <class Tp, class Adapter, class Gen, class Commit>
 void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
   const int N = adapter.getNumberCorrespondences();
-  const Settings& cfg = Settings::get();
+  Settings& cfg = Settings::get();
+  const bool prof = cfg.profile;
+  double tp = prof ? now_us() : 0;
+  auto lap = [&](double& acc) { if (prof) { const double t = now_us(); acc += t - tp; tp = t; } };
   rpe_context* ctx = adapter.device().ctx();
   adapter.setMaxVotes(-1);
   bool have_best = false;
@@ -56,7 +64,10 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
   while (it < Iter) {
     const int iters = std::min(batch, Iter - it);
     hyps.clear(); first.assign(1, 0);
+    if (prof) tp = now_us();
     for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
+    lap(cfg.prof.generate);
+    if (prof) { cfg.prof.hypotheses += (int)hyps.size(); cfg.prof.batches++; }
     if (!hyps.empty()) {
       q7.resize(hyps.size() * 7);
       for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
@@ -64,6 +75,7 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
       check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
                       (double)spec.cos_nl, votes.data()), "rpe_score");
     }
+    lap(cfg.prof.score);
     // sequential replay
     for (int i = 0; i < iters && it + i < Iter; i++) {
       for (int h = first[i]; h < first[i + 1]; h++) {
@@ -79,25 +91,30 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
         }
       }
     }
+    lap(cfg.prof.replay);
     it += iters;
     batch = std::min(batch * 2, std::max(1, cfg.max_batch));
   }
   if (have_best) {
+    if (prof) tp = now_us();
     double b7[7];
     pose7<Tp>(best, b7);
     int total = 0;
     check(rpe_inlier_mask(ctx, spec.kind, cfg.score_mode, b7, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, &total),
           "rpe_inlier_mask");
-    MatrixXs mask(N, mask_cols);
-    std::vector<short> col;
+    // reused across runs: a fresh 1-2 MB matrix per run costs more in page faults than the mask kernel and its download together
+    static thread_local MatrixXs mask;
+    mask.resize(N, mask_cols);  // zero-filled: columns of modalities this solver does not vote on stay 0, as in the reference
     const bool has23 = spec.kind == RPE_VOTE_23 || spec.kind == RPE_VOTE_23_MATRIX || spec.kind == RPE_VOTE_33_23 ||
                        spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33_23;
     const bool has33 = spec.kind == RPE_VOTE_33 || spec.kind == RPE_VOTE_33_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
     const bool hasnn = spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
-    if (has23 && mask_cols >= 1) { adapter.device().download_mask(RPE_MOD_23, col); for (int i = 0; i < N; i++) mask(i, 0) = col[i]; }
-    if (has33 && mask_cols >= 2) { adapter.device().download_mask(RPE_MOD_33, col); for (int i = 0; i < N; i++) mask(i, 1) = col[i]; }
-    if (hasnn && mask_cols >= 3) { adapter.device().download_mask(RPE_MOD_NN, col); for (int i = 0; i < N; i++) mask(i, 2) = col[i]; }
+    // column-major N x cols: each modality's column is contiguous, the device mask lands in it directly
+    if (has23 && mask_cols >= 1) adapter.device().download_mask(RPE_MOD_23, mask.data());
+    if (has33 && mask_cols >= 2) adapter.device().download_mask(RPE_MOD_33, mask.data() + (size_t)N);
+    if (hasnn && mask_cols >= 3) adapter.device().download_mask(RPE_MOD_NN, mask.data() + 2 * (size_t)N);
     commit(mask);
+    lap(cfg.prof.mask);
   }
 }
 

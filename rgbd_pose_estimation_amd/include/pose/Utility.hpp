@@ -12,7 +12,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <numeric>
+#include <utility>
 #include <vector>
 
 namespace rpe {
@@ -37,13 +39,72 @@ inline Rand31& global_rng() { static Rand31 g(1); return g; }
 inline void seed(uint64_t s) { global_rng().reseed(s); }
 }  // namespace rpe
 
-// indices that sort v in DESCENDING order (reference :107-118)
+// indices that sort v in DESCENDING order (reference :107-118).  The reference's comparator leaves the order of equal
+// weights to std::sort; here ties go to the lower index, which makes the order unique -- so the first top_k entries can be
+// produced alone (std::partial_sort, O(N log top_k)) and are exactly the prefix of the full order.  PROSAC reads position
+// j of this order only for j <= m + (number of draws so far) (ProsacSampler below: n grows by at most one per draw), so a
+// run bounded by Iter iterations needs a prefix of about Iter entries, not all N: 20 ms -> 0.4 ms at N = 307200.
+namespace rpe {
+// (weight, index) as one integer whose ASCENDING order is "weight descending, then index ascending"; float only
+inline uint64_t prosac_key(float w, int index) {
+  w += 0.0f;  // -0 -> +0, so that equal weights compare equal as integers too
+  uint32_t u;
+  std::memcpy(&u, &w, 4);
+  u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;   // order-preserving map of IEEE floats to unsigned
+  return ((uint64_t)(~u) << 32) | (uint32_t)index;
+}
+template <class T> inline void sort_candidates(std::vector<std::pair<T, int> >& cand, int top_k, std::vector<int>& order) {
+  std::sort(cand.begin(), cand.end(), [](const std::pair<T, int>& a, const std::pair<T, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+  order.resize((size_t)top_k);
+  for (int i = 0; i < top_k; i++) order[i] = cand[i].second;
+}
+inline void sort_candidates(std::vector<std::pair<float, int> >& cand, int top_k, std::vector<int>& order) {
+  std::vector<uint64_t> keys(cand.size());
+  for (size_t i = 0; i < cand.size(); i++) keys[i] = prosac_key(cand[i].first, cand[i].second);
+  // plain integer compares; select the prefix first (linear), then order only the prefix
+  if ((size_t)top_k < keys.size()) { std::nth_element(keys.begin(), keys.begin() + top_k, keys.end()); keys.resize((size_t)top_k); }
+  std::sort(keys.begin(), keys.end());
+  order.resize((size_t)top_k);
+  for (int i = 0; i < top_k; i++) order[i] = (int)(uint32_t)keys[i];
+}
+}  // namespace rpe
+
 template <typename T>
-std::vector<int> sortIndexes(const std::vector<T>& v) {
-  std::vector<int> order(v.size());
+std::vector<int> sortIndexes(const std::vector<T>& v, int top_k = -1) {
+  const size_t N = v.size();
+  auto before = [&v](int a, int b) { return v[a] > v[b] || (v[a] == v[b] && a < b); };
+  std::vector<int> order;
+  if (top_k >= 0 && (size_t)top_k < N && N >= 65536 && (size_t)top_k * 16 < N) {
+    // a short prefix of a long array: a strided subsample gives a cut value that keeps about 2 top_k candidates; every element
+    // at or above the cut is collected in one sequential scan.  If at least top_k were found, the true prefix is among them
+    // (anything below the cut ranks after all of them), so sorting the candidates alone is exact; otherwise fall through.
+    const size_t S = 1024, stride = N / S;
+    std::vector<T> sample(S);
+    for (size_t i = 0; i < S; i++) sample[i] = v[i * stride];
+    std::sort(sample.begin(), sample.end(), [](T a, T b) { return a > b; });
+    const size_t rank = std::min(S - 1, (size_t)(2.0 * top_k * S / N) + 12);
+    const T cut = sample[rank];
+    std::vector<std::pair<T, int> > cand;
+    cand.reserve((size_t)top_k * 3);
+    const T* p = v.data();
+    for (size_t i = 0; i < N; i++) if (p[i] >= cut) cand.emplace_back(p[i], (int)i);
+    if (cand.size() >= (size_t)top_k) { rpe::sort_candidates(cand, top_k, order); return order; }
+  }
+  order.resize(N);
   std::iota(order.begin(), order.end(), 0);
-  std::sort(order.begin(), order.end(), [&v](int a, int b) { return v[a] > v[b]; });
+  if (top_k < 0 || (size_t)top_k >= N) { std::sort(order.begin(), order.end(), before); return order; }
+  std::partial_sort(order.begin(), order.begin() + top_k, order.end(), before);
+  order.resize((size_t)top_k);
   return order;
+}
+// positions -> correspondence indices through a (possibly partial) order; a position beyond the prefix extends it to the full order
+template <typename T>
+void mapSortedIdx(const std::vector<T>& weights, std::vector<int>& order, std::vector<int>& select_) {
+  for (size_t i = 0; i < select_.size(); ++i) {
+    const int j = select_[i];
+    if (j >= (int)order.size() && order.size() < weights.size()) order = sortIndexes<T>(weights);
+    if (j < (int)order.size()) select_[i] = order[j];
+  }
 }
 
 // m distinct indices out of n by a partial Fisher-Yates pass from the top (reference :124-156): position j swaps with

@@ -2,6 +2,7 @@
 // (include/rgbd_pose_hip.h).  The host side stays C++; every device call goes through the extern "C" shim.
 // There is no CPU path behind these calls: a failing status throws rpe::DeviceError (no fallback, no silent retry).
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <mutex>
 #include <stdexcept>
@@ -25,12 +26,18 @@ template <> struct DType<float> { enum { value = RPE_F32 }; };
 template <> struct DType<double> { enum { value = RPE_F64 }; };
 
 // process-wide defaults for the solver templates (the reference's free functions have no room for extra arguments)
+// where a RANSAC / PROSAC run spent its wall time (microseconds), accumulated while Settings::profile is set
+struct EngineProfile { double generate = 0, score = 0, replay = 0, mask = 0, upload = 0, sort = 0; int hypotheses = 0, batches = 0; };
 struct Settings {
   int device = 0;
+  bool profile = false;
+  EngineProfile prof;
   int score_mode = RPE_SCORE_FAST;     // RPE_SCORE_EXACT reproduces the CPU path's votes bit for bit
   int first_batch = 64, max_batch = 2048;  // RANSAC hypotheses scored per launch (grows geometrically)
   static Settings& get() { static Settings s; return s; }
 };
+
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // One adapter's correspondence arrays resident in HBM.  Uploaded once, reused by every solver run on that adapter
 // (TestMain.cpp runs seven solvers on one adapter, :186-221).
@@ -92,8 +99,10 @@ class DeviceSet {
       for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
     }
     if (_src[slot] != (const void*)host) {
+      const double t0 = Settings::get().profile ? now_us() : 0;
       check(rpe_upload(ctx(), slot, host), "rpe_upload");
       _src[slot] = host;
+      if (Settings::get().profile) { check(rpe_synchronize(ctx()), "rpe_synchronize"); Settings::get().prof.upload += now_us() - t0; }
     }
   }
   void upload_mask(int mod, const std::vector<short>& m) {
@@ -114,6 +123,7 @@ class DeviceSet {
   void mask_changed_on_host(int mod) { _mask_fresh[mod] = false; }
   void mask_written_on_device(int mod) { _mask_fresh[mod] = true; }
   void weight_changed_on_host(int mod) { _weight_fresh[mod] = false; }
+  void download_mask(int mod, short* dst) { check(rpe_download_mask(ctx(), mod, dst), "rpe_download_mask"); }
   void download_mask(int mod, std::vector<short>& m) {
     m.resize((size_t)_n);
     check(rpe_download_mask(ctx(), mod, m.data()), "rpe_download_mask");

@@ -1,0 +1,112 @@
+// Host-side logic of the drop-in headers that needs no GPU (compiled and run by tests/test_host_cpp.py):
+// partial PROSAC order == prefix of the full order (ties included), lazy extension, cvtInlier snapshot semantics,
+// sparse RandomElements == the reference's re-initialised Fisher-Yates table.
+#include <cstdio>
+#include <cstdlib>
+#include "AOOnlyPoseAdapter.hpp"
+#include "NormalAOPoseAdapter.hpp"
+#include "Utility.hpp"
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+int main() {
+  // ---- sortIndexes: partial prefix, ties to the lower index
+  rpe::Rand31 rnd(3);
+  std::vector<float> w(5000);
+  for (float& x : w) x = (float)(rnd() % 97) / 7.0f;   // many ties
+  const std::vector<int> full = sortIndexes<float>(w);
+  for (size_t i = 1; i < full.size(); i++) CHECK(w[full[i - 1]] > w[full[i]] || (w[full[i - 1]] == w[full[i]] && full[i - 1] < full[i]));
+  for (int k : {0, 1, 7, 300, 4999, 5000, 9000}) {
+    const std::vector<int> part = sortIndexes<float>(w, k);
+    CHECK(part.size() == (size_t)std::min(k, 5000));
+    for (size_t i = 0; i < part.size(); i++) CHECK(part[i] == full[i]);
+  }
+  {
+    std::vector<int> order = sortIndexes<float>(w, 10), sel = {0, 9, 3};
+    mapSortedIdx<float>(w, order, sel);
+    CHECK(order.size() == 10 && sel[0] == full[0] && sel[1] == full[9] && sel[2] == full[3]);
+    sel = {2, 10, 4321};                         // beyond the prefix: extended to the full order, still exact
+    mapSortedIdx<float>(w, order, sel);
+    CHECK(order.size() == 5000 && sel[0] == full[2] && sel[1] == full[10] && sel[2] == full[4321]);
+  }
+  {  // long array, short prefix: the subsampled-cut path, with heavy ties and with all-equal weights (cut keeps everything)
+    std::vector<float> big(200000);
+    for (float& x : big) x = (float)(rnd() % 1000);
+    const std::vector<int> fb = sortIndexes<float>(big);
+    for (int k : {1, 100, 3053, 12000}) {
+      const std::vector<int> pb = sortIndexes<float>(big, k);
+      CHECK(pb.size() == (size_t)k);
+      for (size_t i = 0; i < pb.size(); i++) CHECK(pb[i] == fb[i]);
+    }
+    std::vector<double> flat(100000, 1.0);
+    const std::vector<int> pf = sortIndexes<double>(flat, 50);
+    for (int i = 0; i < 50; i++) CHECK(pf[i] == i);
+    flat[77777] = 2.0;
+    CHECK(sortIndexes<double>(flat, 3) == (std::vector<int>{77777, 0, 1}));
+  }
+  // ---- adapters: sortIdx(top_k) + getSortedIdx, cvtInlier / getInlierIdx
+  const int N = 1000;
+  rpe::MatrixX<float> P(3, N), Q(3, N), Wt(N, 3);
+  for (int i = 0; i < N; i++) { Wt(i, 0) = (float)(rnd() % 50); Wt(i, 1) = (float)(rnd() % 1000); Wt(i, 2) = 1.f; }
+  AOOnlyPoseAdapter<float> a(P, Q);
+  a.setWeights(Wt);
+  std::vector<float> w1(N);
+  for (int i = 0; i < N; i++) w1[i] = Wt(i, 1);
+  const std::vector<int> f1 = sortIndexes<float>(w1);
+  a.sortIdx(20);
+  std::vector<int> sel = {0, 19, 5};
+  a.getSortedIdx(sel);
+  CHECK(sel[0] == f1[0] && sel[1] == f1[19] && sel[2] == f1[5]);
+  sel = {999, 20};
+  a.getSortedIdx(sel);
+  CHECK(sel[0] == f1[999] && sel[1] == f1[20]);
+  // cvtInlier lists the mask AS IT WAS when it was called, even though the list is built lazily
+  rpe::MatrixXs m(N, 2);
+  for (int i = 0; i < N; i++) m(i, 1) = (short)(i % 3 == 0);
+  a.setInlier(m);
+  a.cvtInlier();
+  for (int i = 0; i < N; i++) m(i, 1) = (short)(i % 5 == 0);
+  a.setInlier(m);                                 // mask changes AFTER cvtInlier and BEFORE the first read
+  const std::vector<int>& idx = a.getInlierIdx();
+  CHECK(idx.size() == 334);
+  for (size_t i = 0; i < idx.size(); i++) CHECK(idx[i] == (int)(3 * i));
+  a.cvtInlier();
+  CHECK(a.getInlierIdx().size() == 200 && a.getInlierIdx()[1] == 5);
+  a.cvtInlier();
+  a.inlierMask33()[0] = 0;                        // the backend's write access also snapshots first
+  CHECK(a.getInlierIdx().size() == 200 && a.getInlierIdx()[0] == 0);
+  // what a solver does: drop the unread request, replace the mask, request again -> the reader sees the new mask's list
+  a.cvtInlier();
+  a.forgetInlierIdx();
+  for (int i = 0; i < N; i++) m(i, 1) = (short)(i % 100 == 0);
+  a.setInlier(m);
+  a.cvtInlier();
+  CHECK(a.getInlierIdx().size() == 10 && a.getInlierIdx()[9] == 900);
+  // every level of the NormalAO hierarchy keeps its own list (name hiding, reference AbsoluteOrientation.hpp:433-435)
+  rpe::MatrixX<float> U(3, N), Nc(3, N), Nw(3, N);
+  NormalAOPoseAdapter<float> na(U, P, Nc, Q, Nw);
+  rpe::MatrixXs m3(N, 3);
+  for (int i = 0; i < N; i++) { m3(i, 0) = (short)(i % 2 == 0); m3(i, 1) = (short)(i % 4 == 0); m3(i, 2) = (short)(i % 10 == 0); }
+  na.setInlier(m3);
+  PnPPoseAdapter<float>* p23 = &na; AOPoseAdapter<float>* p33 = &na;
+  p23->cvtInlier(); p33->cvtInlier(); na.cvtInlier();
+  CHECK(p23->getInlierIdx().size() == 500 && p33->getInlierIdx().size() == 250 && na.getInlierIdx().size() == 100);
+  CHECK(p23->getInlierIdx()[3] == 6 && p33->getInlierIdx()[3] == 12 && na.getInlierIdx()[3] == 30);
+  // ---- RandomElements: same stream as the reference's table that is rebuilt as the identity on every draw (Utility.hpp:124-156)
+  {
+    const int n = 50;
+    rpe::Rand31 r1(11), r2(11);
+    RandomElements<int> re(n);
+    for (int draw = 0; draw < 200; draw++) {
+      const int mm = 1 + draw % 6;
+      std::vector<int> got, table(n), want;
+      re.run(mm, &got, r1);
+      for (int i = 0; i < n; i++) table[i] = i;
+      for (int top = n - 1; top > n - mm - 1; top--) { const int pick = r2() % (top + 1); std::swap(table[pick], table[top]); want.push_back(table[top]); }
+      CHECK(got == want);
+    }
+  }
+  std::printf(fails ? "host_logic: %d FAILURES\n" : "host_logic: ok\n", fails);
+  return fails ? 1 : 0;
+}
