@@ -73,10 +73,14 @@ def cpu_baseline(sc, seconds: float):
         pose = np.concatenate([np.eye(3).reshape(9), np.zeros(3)])
         out = np.zeros(29)
         g = lib.orc_time_gn_p2p(p(xw), p(xc), C.c_long(n), 20, p(pose), p(out)) / 20
+        # all-core variant of the same pass: the reference itself is single-threaded, so this is beside, not instead
+        threads = max(1, min(64, (os.cpu_count() or 1)))
+        lib.orc_time_gn_p2p_threads.restype = C.c_double
+        ga = lib.orc_time_gn_p2p_threads(p(xw), p(xc), C.c_long(n), 200, p(pose), p(out), threads) / 200
         return {"value": n * reps / spent, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port",
                 "sample": f"{reps} calls of the oracle's shinji_ls2<float> (AOOnlyPoseAdapter virtual getters, gather + centroid + covariance "
                           f"passes + 3x3 SVD = Library.cpp ao()) on the same {n}-correspondence scene, g++ -O2, 1 thread, {spent:.1f} s",
-                "gn_pass_fp64_value": n / g, "host_cpus": os.cpu_count()}
+                "gn_pass_fp64_value": n / g, "gn_pass_fp64_all_cores": {"value": n / ga, "threads": threads}, "host_cpus": os.cpu_count()}
     except Exception as e:  # the baseline is a reported number, never a dependency of the GPU path
         return {"value": None, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e!r}"}
 

@@ -5,6 +5,7 @@
 #include "orc_gn.hpp"
 #include <cstdio>
 #include <chrono>
+#include <thread>
 
 using namespace orc;
 
@@ -386,6 +387,25 @@ double orc_time_gn_p2p(const float* x_w, const float* x_c, long n, int reps, con
   auto t0 = std::chrono::steady_clock::now();
   for (int r = 0; r < reps; r++) { NormalEq ne; gn_normal_eq<float>(GN_P2P, x_w, x_c, nullptr, nullptr, nullptr, n, pose12, &ne); ne.pack(out29); }
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+// the same pass spread over `threads` host threads (contiguous shards, per-thread sums added at the end): the all-core CPU figure
+// SURVEY.md 8(d) asks for beside the single-thread one.  Every thread runs its shard `reps` times; the wall time of the whole is returned.
+double orc_time_gn_p2p_threads(const float* x_w, const float* x_c, long n, int reps, const double* pose12, double* out29, int threads) {
+  if (threads < 1) threads = 1;
+  std::vector<NormalEq> part((size_t)threads);
+  std::vector<std::thread> pool;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < threads; k++)
+    pool.emplace_back([&, k]() {
+      const long lo = n * k / threads, hi = n * (k + 1) / threads;
+      for (int r = 0; r < reps; r++) { NormalEq ne; gn_normal_eq<float>(GN_P2P, x_w + 3 * lo, x_c + 3 * lo, nullptr, nullptr, nullptr, hi - lo, pose12, &ne); part[(size_t)k] = ne; }
+    });
+  for (std::thread& th : pool) th.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  NormalEq tot;
+  for (const NormalEq& ne : part) { for (int a = 0; a < 6; a++) { tot.g[a] += ne.g[a]; for (int b = a; b < 6; b++) tot.H[a][b] += ne.H[a][b]; } tot.cost += ne.cost; tot.wsum += ne.wsum; }
+  tot.pack(out29);
+  return dt;
 }
 // vote loop of shinji_ransac2 (V2) for H hypotheses, float
 double orc_time_votes33(const float* x_w, const float* x_c, int n, const double* poses7, int H, float thre_3d, int* votes) {

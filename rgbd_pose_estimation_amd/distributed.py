@@ -82,14 +82,29 @@ def init_native_comm(ctx: "api.Context", group=None) -> bool:
     if not (dist.is_available() and dist.is_initialized()):
         return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ok = 1
     try:
         box = [api.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)
-        ctx.comm_init(world, rank, box[0])
-        return True
-    except Exception as e:  # noqa: BLE001 -- the torch.distributed path below stays available
-        print(f"[rgbd_pose_estimation_amd] native RCCL communicator unavailable ({e}); using torch.distributed all-reduce", flush=True)
+    except Exception as e:  # noqa: BLE001
+        box, ok = [None], 0
+        print(f"[rgbd_pose_estimation_amd] rank {rank}: no RCCL unique id ({e})", flush=True)
+    dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        return False          # rank 0 could not draw an id: every rank sees None and takes the torch.distributed path
+    try:
+        if ok:
+            ctx.comm_init(world, rank, box[0])
+    except Exception as e:  # noqa: BLE001 -- the torch.distributed path stays available
+        ok = 0
+        print(f"[rgbd_pose_estimation_amd] rank {rank}: native RCCL communicator unavailable ({e})", flush=True)
+    # all ranks must take the same path: one rank on the library's communicator and another on torch's would dead-lock
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if ok:
+            ctx.comm_destroy()
         return False
+    return True
 
 
 class HipShard:
