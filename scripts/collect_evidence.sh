@@ -16,5 +16,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- 
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > /dev/null 2>&1
 timeout 600 python3 $root/scripts/roofline_runs.py > $out/roofline_runs.jsonl 2>&1
 timeout 300 python3 $root/scripts/gn_modes.py > $out/gn_modes.txt 2>&1
-timeout 600 python3 $root/scripts/pipeline_times.py > $out/pipeline_times.jsonl 2>&1
+timeout 600 python3 $root/tests/perf/pipeline_times.py > $out/pipeline_times.jsonl 2>&1
+timeout 300 python3 $root/scripts/frontend_times.py > $out/frontend_times.jsonl 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_frontend -- python3 $root/scripts/frontend_times.py > /dev/null 2>&1
+RPE_QUIET=1 timeout 300 $root/examples/engine_profile > $out/engine_profile.txt 2>&1
 ls -R $out | head -60

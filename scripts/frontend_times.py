@@ -2,10 +2,17 @@
 (host-update and device-resident), for DESIGN.md / profiles.  Run under rocprofv3 --kernel-trace --stats for kernel times."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from rgbd_pose_estimation_amd import _lib as L, api, simulator as S
-from frontend_util import two_views, pose12
+from rgbd_pose_estimation_amd.api import pose12
+
+def two_views(cam, noise, as_u16):
+    rng = np.random.default_rng(0)
+    RA, tA = S._rot_zyx(0.05, -0.1, 0.02), np.array([0.1, -0.05, 0.2])
+    dR = S._rot_zyx(0.02, -0.015, 0.01)
+    RB, tB = dR @ RA, dR @ tA + np.array([0.03, -0.02, 0.025])
+    return ((RA, tA, S.render_depth(RA, tA, cam, noise_sigma=noise, rng=rng, as_u16=as_u16)),
+            (RB, tB, S.render_depth(RB, tB, cam, noise_sigma=noise, rng=rng, as_u16=as_u16)))
 
 cam = S.DEFAULT_CAMERA
 n = cam[4] * cam[5]

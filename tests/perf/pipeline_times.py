@@ -1,8 +1,9 @@
-"""End-to-end wall time of the reference-shaped pipelines on the GPU backend vs the CPU oracle (development aid; numbers quoted
-in DESIGN.md).  Includes H2D upload of the arrays (the adapter-level entry points take host matrices, like the reference)."""
+"""End-to-end wall time of the reference-shaped pipelines on the GPU backend vs the CPU oracle (numbers quoted in DESIGN.md;
+lives under tests/ because it times the oracle, which only tests/, smoke() and bench.py's cpu_baseline may touch).  Includes H2D upload of the arrays (the adapter-level entry points take host matrices, like the reference)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["RPE_QUIET"] = "1"
 import numpy as np
 from rgbd_pose_estimation_amd import _lib as L, api, simulator as S
