@@ -181,6 +181,7 @@ def main():
         elapsed = time.perf_counter() - t_start
         cnt, k_total_ms, k_min_ms = ctx.timing_collect()
         ctx.timing_enable(0, 1)
+        ev_avg_ms, ev_min_ms = ctx.timing_calibrate(200)   # what an empty event pair reads: the marker latency inside every interval
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -211,7 +212,9 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
                          "avg_launch_us": k_avg_s * 1e6, "min_launch_us": k_min_ms * 1e3, "launches_timed": cnt,
-                         "note": "HIP events on the kernel's own stream around every stage-1 launch of the timed region; 7.99 MB working set is "
+                         "empty_event_pair_us": ev_avg_ms * 1e3, "avg_launch_us_net_of_event_pair": (k_avg_s * 1e3 - ev_avg_ms) * 1e3,
+                         "note": "HIP events on the kernel's own stream around every stage-1 launch of the timed region (achieved uses the raw interval; an "
+                                 "empty pair measured the same way reads empty_event_pair_us, the net figure is what rocprofv3's dispatch timestamps show); 7.99 MB working set is "
                                  "L2/Infinity-Cache resident after the first step, so this is not an HBM-streaming figure (see DESIGN.md)"},
         }
         # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)

@@ -155,6 +155,16 @@ int rpe_comm_unique_id(void* id128);
 int rpe_comm_init(rpe_context* ctx, int world, int rank, const void* id128);
 int rpe_comm_destroy(rpe_context* ctx);
 int rpe_gn_step_dist(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
+/* Peer-to-peer variant of the collective for ONE node (<= 8 ranks): instead of RCCL, the normal-equation kernel's last
+ * workgroup writes the 32-double record straight into a mailbox of every peer over xGMI (HIP IPC mappings, flag-in-data
+ * words), waits for the peers' records in its own mailbox, adds them in rank order and publishes the sum -- the whole sharded
+ * step is ONE kernel launch, and every rank gets bitwise the same record.  Each rank calls rpe_p2p_export (64-byte IPC handle),
+ * all handles are gathered by any means (world x 64 bytes, rank order), each rank calls rpe_p2p_init; rpe_gn_step_dist then
+ * uses this path (it takes precedence over an RCCL communicator).  A rank that waits more than ~0.25 s for a peer fails the
+ * step with RPE_ERR_HIP instead of hanging.  Callers barrier before rpe_p2p_destroy. */
+int rpe_p2p_export(rpe_context* ctx, void* handle64);
+int rpe_p2p_init(rpe_context* ctx, int world, int rank, const void* handles);
+int rpe_p2p_destroy(rpe_context* ctx);
 /* Whole refinement loop on one GPU: up to 3 residual kinds summed with scales; stops when |delta| < tol.
  * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */
 int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
@@ -165,6 +175,10 @@ int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* 
  * returns the number of pairs and their total / minimum elapsed milliseconds, and rearms.  enable(0, 1) = off. */
 int rpe_timing_enable(rpe_context* ctx, int max_records, int stride);
 int rpe_timing_collect(rpe_context* ctx, int* count, double* total_ms, double* min_ms);
+/* Elapsed time an EMPTY event pair reports on this context's stream (average and minimum over `pairs` pairs): what the pair
+ * itself adds to every interval rpe_timing_collect returns (about 2 us on MI355X), so that event-based kernel times can be
+ * compared with rocprofv3's dispatch timestamps. */
+int rpe_timing_calibrate(rpe_context* ctx, int pairs, double* avg_ms, double* min_ms);
 
 /* ---- K4 batched hypothesis scoring: the vote loops V1..V8.
  * kind selects the modality set exactly as the reference's loops combine them. */

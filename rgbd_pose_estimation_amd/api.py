@@ -250,11 +250,31 @@ class Context:
         buf = (C.c_char * 128).from_buffer_copy(id128)
         L.check(L.lib().rpe_comm_init(self._h, world, rank, buf))
 
+    def p2p_export(self) -> bytes:
+        """64-byte HIP IPC handle of this context's mailbox (peer-to-peer all-reduce over xGMI)."""
+        buf = (C.c_char * 64)()
+        L.check(L.lib().rpe_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_init(self, world: int, rank: int, handles: bytes):
+        assert len(handles) == 64 * world
+        buf = (C.c_char * len(handles)).from_buffer_copy(handles)
+        L.check(L.lib().rpe_p2p_init(self._h, world, rank, buf))
+
+    def p2p_destroy(self):
+        L.check(L.lib().rpe_p2p_destroy(self._h))
+
     def comm_destroy(self):
         L.check(L.lib().rpe_comm_destroy(self._h))
 
     def timing_enable(self, max_records: int, stride: int = 1):
         L.check(L.lib().rpe_timing_enable(self._h, max_records, stride))
+
+    def timing_calibrate(self, pairs: int = 200):
+        """(average, minimum) milliseconds an empty HIP event pair reports on this context's stream."""
+        a, m = C.c_double(0), C.c_double(0)
+        L.check(L.lib().rpe_timing_calibrate(self._h, pairs, C.byref(a), C.byref(m)))
+        return a.value, m.value
 
     def timing_collect(self):
         cnt, tot, mn = C.c_int(0), C.c_double(0), C.c_double(0)

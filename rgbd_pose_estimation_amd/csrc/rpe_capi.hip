@@ -106,6 +106,13 @@ struct rpe_context {
   bool timing = false;
   int timing_stride = 1;
   unsigned long long timing_calls = 0;
+  // peer-to-peer all-reduce over xGMI (rpe_p2p_*): own mailbox (fine-grained HBM, IPC-exported), the peers' mailboxes as
+  // mapped here, the descriptor the kernels read, and the collective step counter (identical on every rank)
+  unsigned long long* p2p_box = nullptr;
+  void* p2p_peer[rpe::kP2PMaxWorld] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  rpe::P2PDesc* d_p2p = nullptr;
+  int p2p_world = 0, p2p_rank = 0;
+  unsigned long long p2p_step = 0;
   void* h_stage = nullptr;        // pinned staging for device -> host copies into caller (pageable) memory
   size_t h_stage_cap = 0;
   // front end (Part 3): the current depth frame's maps and the model it is registered against, all in HBM
@@ -282,6 +289,7 @@ void rpe_destroy(rpe_context* c) {
   if (c->h_poses) (void)hipHostFree(c->h_poses);
   if (c->d_votes) (void)hipFree(c->d_votes);
   if (c->h_votes) (void)hipHostFree(c->h_votes);
+  (void)rpe_p2p_destroy(c);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->fe.d_depth) (void)hipFree(c->fe.d_depth);
   for (float* m : c->fe.fmap) if (m) (void)hipFree(m);
@@ -454,6 +462,27 @@ int rpe_timing_collect(rpe_context* c, int* count, double* total_ms, double* min
   if (total_ms) *total_ms = tot;
   if (min_ms) *min_ms = c->ev_used ? mn : 0.0;
   c->ev_used = 0;
+  return RPE_OK;
+}
+
+int rpe_timing_calibrate(rpe_context* c, int pairs, double* avg_ms, double* min_ms) {
+  if (!c || pairs < 1 || pairs > 4096) return fail(RPE_ERR_ARG, "rpe_timing_calibrate: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  double tot = 0, mn = 1e30;
+  for (int i = 0; i < pairs; i++) {  // one pair at a time, stream idle in between: the way the timed launches see their pair
+    HIP_TRY(hipEventRecord(a, c->stream));
+    HIP_TRY(hipEventRecord(b, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    tot += ms; if (ms < mn) mn = ms;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  if (avg_ms) *avg_ms = tot / pairs;
+  if (min_ms) *min_ms = mn;
   return RPE_OK;
 }
 
@@ -640,18 +669,92 @@ int rpe_comm_destroy(rpe_context* c) {
   return RPE_OK;
 }
 
+// ---- peer-to-peer exchange over xGMI (one process per GPU, one node, <= 8 ranks)
+int rpe_p2p_export(rpe_context* c, void* handle64) {
+  if (!c || !handle64) return fail(RPE_ERR_ARG, "rpe_p2p_export: bad argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->p2p_box) {
+    void* p = nullptr;
+    // fine-grained (uncached across the fabric) device memory, as collective libraries use for their flag buffers
+    hipError_t e = hipExtMallocWithFlags(&p, rpe::kP2PMailboxBytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&p, rpe::kP2PMailboxBytes)); }
+    c->p2p_box = (unsigned long long*)p;
+  }
+  HIP_TRY(hipMemset(c->p2p_box, 0, rpe::kP2PMailboxBytes));
+  HIP_TRY(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, c->p2p_box));
+  std::memcpy(handle64, &h, 64);
+  return RPE_OK;
+}
+
+int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
+  if (!c || !handles || world < 1 || world > rpe::kP2PMaxWorld || rank < 0 || rank >= world) return fail(RPE_ERR_ARG, "rpe_p2p_init: bad argument (1 <= world <= 8)");
+  if (!c->p2p_box) return fail(RPE_ERR_STATE, "rpe_p2p_export first");
+  HIP_TRY(hipSetDevice(c->device));
+  rpe::P2PDesc d;
+  d.world = world; d.rank = rank;
+  for (int r = 0; r < rpe::kP2PMaxWorld; r++) d.peer[r] = nullptr;
+  for (int r = 0; r < world; r++) {
+    if (r == rank) { d.peer[r] = c->p2p_box; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, (const char*)handles + 64 * (size_t)r, 64);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (int k = 0; k < r; k++) if (c->p2p_peer[k]) { (void)hipIpcCloseMemHandle(c->p2p_peer[k]); c->p2p_peer[k] = nullptr; }
+      return fail(RPE_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+    }
+    c->p2p_peer[r] = p;
+    d.peer[r] = (unsigned long long*)p;
+  }
+  if (!c->d_p2p) HIP_TRY(hipMalloc((void**)&c->d_p2p, sizeof(rpe::P2PDesc)));
+  HIP_TRY(hipMemcpy(c->d_p2p, &d, sizeof(d), hipMemcpyHostToDevice));
+  c->p2p_world = world; c->p2p_rank = rank; c->p2p_step = 0;
+  return RPE_OK;
+}
+
+int rpe_p2p_destroy(rpe_context* c) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (!c->p2p_box && !c->d_p2p) return RPE_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int r = 0; r < rpe::kP2PMaxWorld; r++) if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]); c->p2p_peer[r] = nullptr; }
+  if (c->d_p2p) { (void)hipFree(c->d_p2p); c->d_p2p = nullptr; }
+  if (c->p2p_box) { (void)hipFree(c->p2p_box); c->p2p_box = nullptr; }
+  c->p2p_world = 0; c->p2p_step = 0;
+  return RPE_OK;
+}
+
 // Sharded Gauss-Newton step: local normal equations -> in-place all-reduce(sum) of the 32-double record over RCCL on the
 // context's stream -> publish to pinned host memory -> (every rank, identically) solve + exp-map update.
 int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double* ne32_out, double* step_norm) {
-  if (!c || !c->comm) return fail(RPE_ERR_STATE, "rpe_comm_init was not called");
-  int rc = normal_eq_launch(c, kind, flags, pose12, c->d_out);
-  if (rc) return rc;
-  NCCL_TRY(rccl().AllReduce(c->d_out, c->d_out, 32, ncclFloat64, ncclSum, c->comm, c->stream));
-  const unsigned long long seq = ++c->seq;
-  HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq, c->stream));
+  if (!c || (!c->comm && c->p2p_world < 1)) return fail(RPE_ERR_STATE, "neither rpe_p2p_init nor rpe_comm_init was called");
+  int rc;
+  if (c->p2p_world >= 1) {
+    // ONE launch: the kernel's last workgroup exchanges the record with the peers over xGMI, sums in rank order, publishes
+    if (kind == RPE_RES_NORMAL) return fail(RPE_ERR_ARG, "RPE_RES_NORMAL is not served by the sharded step");
+    if ((rc = kind_arrays(c, kind))) return rc;
+    if (!pose12) return fail(RPE_ERR_ARG, "null argument");
+    if ((rc = check_flags(c, kind, flags))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+    rpe::ReduceTarget rt = host_target(c);
+    rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++;
+    HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
+  } else {
+    if ((rc = normal_eq_launch(c, kind, flags, pose12, c->d_out))) return rc;
+    NCCL_TRY(rccl().AllReduce(c->d_out, c->d_out, 32, ncclFloat64, ncclSum, c->comm, c->stream));
+    const unsigned long long seq = ++c->seq;
+    HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq, c->stream));
+  }
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   double ne[32], d[6];
   for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
+  if (c->p2p_world >= 1 && ne[31] != 0.0) return fail(RPE_ERR_HIP, "peer-to-peer exchange timed out at step %llu (a peer did not deliver its record)", c->p2p_step - 1);
   if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
   rpe::se3_left_update(d, pose12);
   if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));

@@ -29,6 +29,18 @@ struct GnState {
   int status;        // 0 ok, 1 normal equations not positive definite
 };
 
+// Peer-to-peer all-reduce of the 32-double record over xGMI, inside the reduction kernel (one process per GPU, <= 8 ranks).
+// Every rank owns a mailbox in fine-grained HBM that all peers map through HIP IPC:
+//   mailbox[parity 2][source rank kP2PMaxWorld][64 words], word = { lo 32 bits: one half of a double, hi 32 bits: step tag }.
+// The tag travels WITH the data in one 8-byte store (the "LL" flag-in-data protocol), so no ordering between stores is assumed.
+constexpr int kP2PMaxWorld = 8;
+constexpr int kP2PWords = 64;                                  // 32 doubles = 64 halves
+constexpr size_t kP2PMailboxBytes = (size_t)2 * kP2PMaxWorld * kP2PWords * 8;
+struct P2PDesc {
+  int world, rank;
+  unsigned long long* peer[kP2PMaxWorld];   // every rank's mailbox as mapped in THIS process; peer[rank] is the own one
+};
+
 // Where a reduction kernel leaves its result (both stages run inside one launch, see reduce_and_finish).
 struct ReduceTarget {
   double* d_partials;          // max_blocks * kNlLd doubles of scratch
@@ -40,6 +52,8 @@ struct ReduceTarget {
   unsigned long long seq;      // sequence value published after the record
   double* gn_pose = nullptr;   // device-resident GN: 12 doubles in HBM, read at kernel start, updated by the last workgroup
   GnState* gn = nullptr;       // its state (null = ordinary launch: pose from the kernel argument, record published)
+  const P2PDesc* p2p = nullptr;   // multi-GPU: exchange + sum the record with the peers before publishing (h_out path only)
+  unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
 };
 // ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,

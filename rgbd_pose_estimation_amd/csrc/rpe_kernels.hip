@@ -134,7 +134,46 @@ struct Finish {
   unsigned long long seq;      // value published after the record
   double* gn_pose;             // device-resident Gauss-Newton: pose in HBM (null = pose comes as a kernel argument)
   GnState* gn;                 // and its state
+  const P2PDesc* p2p;          // multi-GPU peer-to-peer all-reduce of the record (null = single GPU / collective done elsewhere)
+  unsigned long long p2p_step;
 };
+
+// ---- all-reduce(sum) of the 32-double record across <= 8 GPUs, by the first wave of the LAST workgroup, without leaving the
+// kernel: lane l owns half l of the record (two 32-bit halves per double); it stores {half, tag} as ONE 8-byte word into slot
+// [parity][my rank][l] of every rank's mailbox (remote stores travel over xGMI), then polls slot [parity][r][l] of its OWN
+// mailbox for every r until the tag shows up, and adds the records in rank order -- the same order on every rank, so all
+// ranks publish bitwise the same sums.  Parity alternates per step: a fast peer's next record cannot overwrite one that is
+// still being read.  Bounded wait (~0.25 s of the 100 MHz clock): on a timeout *failed is set and the caller publishes an
+// error marker instead of hanging the GPU.  `val`: lanes 0..31 hold the local record.  Returns the global record in lanes 0..31.
+__device__ __forceinline__ double p2p_allreduce32(double val, const Finish& fin, int* failed) {
+  const P2PDesc& D = *fin.p2p;
+  const int lane = threadIdx.x & 63;
+  const unsigned int tag = (unsigned int)(fin.p2p_step % 0xFFFFFFFFull) + 1u;   // never 0 (= an empty mailbox)
+  const size_t parity = (size_t)(fin.p2p_step & 1ull);
+  const double mine = __shfl(val, lane >> 1, 64);
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+  const unsigned int half = (lane & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+  const unsigned long long word = ((unsigned long long)tag << 32) | half;
+  const size_t slot = (parity * kP2PMaxWorld + (size_t)D.rank) * kP2PWords + lane;
+  for (int r = 0; r < D.world; r++) __hip_atomic_store(D.peer[r] + slot, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long* box = D.peer[D.rank] + parity * kP2PMaxWorld * kP2PWords;
+  const unsigned long long t0 = wall_clock64();
+  double sum = 0.0;
+  int bad = 0;
+  for (int r = 0; r < D.world; r++) {
+    unsigned long long w;
+    for (;;) {
+      w = __hip_atomic_load(box + (size_t)r * kP2PWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned int)(w >> 32) == tag) break;
+      if (wall_clock64() - t0 > 25000000ull) { bad = 1; break; }
+    }
+    if (__any(bad)) { bad = 1; break; }
+    const unsigned int lo = __shfl((unsigned int)w, (lane << 1) & 63, 64), hi = __shfl((unsigned int)w, ((lane << 1) + 1) & 63, 64);
+    sum += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));   // meaningful in lanes 0..31
+  }
+  *failed = bad;
+  return sum;
+}
 
 // ---- device-resident Gauss-Newton: solve H d = -g (LDL^T) and T <- exp(d) T by ONE lane of the last workgroup.
 // Fully unrolled so that every matrix entry is a register (a rolled version over LDS arrays took ~10 us per call: one
@@ -337,6 +376,13 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
         default: val = 0.0;
       }
     }
+  }
+  if (LD == 32 && fin.p2p != nullptr && threadIdx.x < 64) {   // wave 0 (uniform branch): all 64 lanes take part in the exchange
+    int failed = 0;
+    val = p2p_allreduce32(val, fin, &failed);
+    if (failed && threadIdx.x == 31) val = 1e300;   // error marker in the last (padding) entry of the record: the host checks it
+  }
+  if (threadIdx.x < LD) {
     if (fin.gn == nullptr) {
       if (fin.out_dev) fin.out_dev[threadIdx.x] = val;
       // pinned, coherent host memory: system-scope stores go straight out over PCIe (posted, ordered)
@@ -1241,6 +1287,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   Finish f;
   f.partials = rt.d_partials; f.ticket = rt.d_ticket; f.out_dev = rt.d_out; f.out_host = rt.h_out; f.seq = rt.seq;
   f.gn_pose = rt.gn_pose; f.gn = rt.gn;
+  f.p2p = rt.p2p; f.p2p_step = rt.p2p_step;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

@@ -107,6 +107,40 @@ def init_native_comm(ctx: "api.Context", group=None) -> bool:
     return True
 
 
+def init_p2p(ctx: "api.Context", group=None) -> bool:
+    """Peer-to-peer all-reduce over xGMI for ONE node (<= 8 ranks): every rank exports the HIP IPC handle of its mailbox,
+    torch.distributed gathers the handles, every rank maps its peers' mailboxes.  After this Context.gn_step_dist() is ONE
+    kernel launch per step (the kernel's last workgroup exchanges and sums the records).  All ranks return the same answer;
+    False leaves the context untouched (use init_native_comm / the torch.distributed path instead)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world > 8:
+        return False
+    ok, handle = 1, None
+    try:
+        handle = ctx.p2p_export()
+    except Exception as e:  # noqa: BLE001
+        ok = 0
+        print(f"[rgbd_pose_estimation_amd] rank {rank}: no IPC handle for the peer-to-peer mailbox ({e})", flush=True)
+    handles = [None] * world
+    dist.all_gather_object(handles, handle, group=group)
+    if any(h is None for h in handles):
+        ok = 0
+    if ok:
+        try:
+            ctx.p2p_init(world, rank, b"".join(handles))
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[rgbd_pose_estimation_amd] rank {rank}: peers' mailboxes cannot be mapped ({e})", flush=True)
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        ctx.p2p_destroy()
+        return False
+    return True
+
+
 class HipShard:
     """This rank's shard resident in HBM + the device-side record buffer the collective reduces in place."""
 

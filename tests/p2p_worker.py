@@ -1,0 +1,67 @@
+"""Worker of tests/test_gpu_p2p.py: one rank of a sharded Gauss-Newton run whose per-step all-reduce is the peer-to-peer
+exchange inside the kernel (rpe_p2p_*).  All ranks share cuda:0 here (one-GPU box): the IPC mapping, the flag-in-data mailbox
+protocol, the rank-ordered sum and the time-out path are the real ones; only the wire (xGMI) is missing."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from rgbd_pose_estimation_amd import _lib as L, api  # noqa: E402
+from rgbd_pose_estimation_amd.distributed import init_p2p, shard_range  # noqa: E402
+from util import scene33  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    mode = sys.argv[1]
+    n, steps = int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scene33(11, n, np.float32, noise=0.02, outliers=0.0)
+    lo, hi = shard_range(n, rank, world)
+    ctx = api.Context(0)
+    ctx.load(L.F32, xw=sc.Q[lo:hi], xc=sc.P[lo:hi])
+    out = {"rank": rank, "p2p": bool(init_p2p(ctx))}
+    pose = api.pose12(np.eye(3), np.zeros(3))
+    try:
+        if out["p2p"]:
+            if mode == "straggler" and rank == world - 1:
+                import time
+                ctx.gn_step_dist(L.RES_P2P, pose)      # step 0 together ...
+                dist.barrier()
+                time.sleep(1.0)                        # ... then this rank goes missing for longer than the time-out
+                out["slept"] = True
+            else:
+                for k in range(steps):
+                    ctx.gn_step_dist(L.RES_P2P, pose)
+                    if mode == "straggler" and k == 0:
+                        dist.barrier()
+            out["pose"] = pose.tolist()
+    except L.RpeError as e:
+        out["error"] = str(e)
+        out["code"] = e.code
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        ref = None
+        if mode == "steps":
+            full = api.Context(0)
+            full.load(L.F32, xw=sc.Q, xc=sc.P)
+            ref = api.pose12(np.eye(3), np.zeros(3))
+            for _ in range(steps):
+                full.gn_step(L.RES_P2P, ref)
+            ref = ref.tolist()
+            full.close()
+        print("RESULT " + json.dumps({"ranks": gathered, "reference": ref}), flush=True)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

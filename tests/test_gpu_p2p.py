@@ -1,0 +1,57 @@
+"""-m gpu: the peer-to-peer all-reduce inside the normal-equation kernel (rpe_p2p_export / rpe_p2p_init / rpe_gn_step_dist),
+exercised with 2, 3 and 8 ranks that share the one GPU of the test box (tests/p2p_worker.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(world, mode, n, steps, timeout=240):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPE_QUIET="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), mode, str(n), str(steps)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("p2p workers timed out")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")]
+    assert line, outs[0][-2000:]
+    return json.loads(line[0][7:])
+
+
+@pytest.mark.parametrize("world,n", [(2, 20000), (3, 100003), (8, 307200)])
+def test_p2p_sharded_steps_match_the_single_gpu_run(world, n):
+    res = run_world(world, "steps", n, 6)
+    ranks = res["ranks"]
+    assert all(r["p2p"] for r in ranks), ranks
+    assert all("error" not in r for r in ranks), ranks
+    poses = [np.array(r["pose"]) for r in ranks]
+    for p in poses[1:]:
+        assert np.array_equal(p, poses[0])            # rank-ordered sums: bitwise the same record on every rank
+    ref = np.array(res["reference"])
+    assert np.abs(poses[0] - ref).max() < 1e-9         # shards add up to the whole (different summation order only)
+
+
+def test_p2p_missing_peer_times_out_instead_of_hanging():
+    res = run_world(2, "straggler", 20000, 3)
+    r0, r1 = res["ranks"]
+    assert r0["p2p"] and r1["p2p"]
+    assert r1.get("slept") and "error" not in r1
+    assert r0.get("code") == -2 and "timed out" in r0["error"]     # RPE_ERR_HIP after ~0.25 s, no hang
