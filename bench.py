@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line.  Nothing here reads /root/reference.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import math
 import os
@@ -115,15 +116,21 @@ def main():
     n_dev = L.device_count()
     import torch
     import torch.distributed as dist
-    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_native_comm
+    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_native_comm, init_p2p
 
     if n_dev < 1 or not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("RPE_BENCH_BACKEND", "nccl")
+    cdev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"   # where tensors handed to torch.distributed live
     if world > 1 or force_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # plumbing backend: "nccl" (= RCCL) in production; "gloo" lets the tests run two ranks on ONE GPU (RCCL refuses that)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n = args.n_per_gpu
     sc = make_shard(rank, n)
@@ -143,9 +150,40 @@ def main():
         shard.kind, shard.flags = L.RES_P2P, L.USE_MASK
         gn = ShardedGaussNewton(shard.normal_eq)
         pose = pose12(R0, t0)
-        # N > 1: the all-reduce runs inside the library on its own RCCL communicator (no Python-side collective per step);
-        # RPE_BENCH_TORCH_ALLREDUCE=1 forces the torch.distributed fallback path instead
-        native = dist_path and os.environ.get("RPE_BENCH_TORCH_ALLREDUCE") != "1" and init_native_comm(ctx)
+        # N > 1, in order of preference (every rank takes the same branch; RPE_BENCH_COLLECTIVE=p2p|rccl|torch forces one):
+        #   p2p   the kernel's last workgroup exchanges the 32-double record with its peers over xGMI (HIP IPC mailboxes) and sums
+        #         in rank order: the sharded step is ONE launch, no collective library on the critical path
+        #   rccl  kernel -> in-place ncclAllReduce on the library's own communicator -> publish kernel
+        #   torch kernel -> torch.distributed.all_reduce -> .cpu()   (fallback)
+        want = os.environ.get("RPE_BENCH_COLLECTIVE", "torch" if os.environ.get("RPE_BENCH_TORCH_ALLREDUCE") == "1" else "auto")
+        p2p = native = False
+        if dist_path and want in ("auto", "p2p"):
+            p2p = init_p2p(ctx)
+            if p2p:   # trust, but verify once against the collective library before timing anything
+                chk = pose12(R0, t0)
+                rec = np.zeros(32)
+                try:
+                    L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
+                    delivered = 1
+                except L.RpeError as e:   # e.g. a peer's record never arrived (bounded wait inside the kernel)
+                    delivered = 0
+                    print(f"[bench] rank {rank}: peer-to-peer step failed: {e}", file=sys.stderr, flush=True)
+                ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
+                dist.all_reduce(ref)
+                ref = ref.cpu().numpy()
+                good = int(delivered and np.all(np.abs(rec[:29] - ref[:29]) <= 1e-9 * (1.0 + np.abs(ref[:29]))))
+                flag = torch.tensor([good], dtype=torch.int32, device=cdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if rank == 0:
+                        print("[bench] peer-to-peer record differs from the all-reduced one: falling back to RCCL", file=sys.stderr, flush=True)
+                    ctx.p2p_destroy()
+                    p2p = False
+        if dist_path and not p2p and want in ("auto", "rccl", "p2p"):
+            native = init_native_comm(ctx)
+        native = native or p2p
+        collective = "none" if not dist_path else ("peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
+                                                   "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
 
         def one_step(p):
             if not dist_path:
@@ -158,9 +196,13 @@ def main():
 
         # untimed pre-warm, independent of --warmup: the first ~25 ms of launches after torch has initialised HIP contain a
         # one-off ~35 ms stall (measured; runtime lazy initialisation), which must not land in a short timed region
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.25:
-            pose = one_step(pose)
+        if dist_path:
+            for _ in range(int(os.environ.get("RPE_BENCH_PREWARM_STEPS", "6000"))):   # a FIXED count: every rank must issue the same number of collective steps
+                pose = one_step(pose)
+        else:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < 0.25:
+                pose = one_step(pose)
         pose = pose12(R0, t0)
         for _ in range(args.warmup):
             pose = one_step(pose)
@@ -184,7 +226,7 @@ def main():
         ev_avg_ms, ev_min_ms = ctx.timing_calibrate(200)   # what an empty event pair reads: the marker latency inside every interval
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -206,8 +248,7 @@ def main():
             "config": {"workload": f"configs[1]: 640x480 dense depth, {n} 3D-3D correspondences per GPU, point-to-point absolute "
                                    "orientation, Gauss-Newton step (K1 normal equations + host SE3 exp-map update) over the RANSAC inlier mask",
                        "corr_per_gpu": n, "global_corr": n * world, "inliers_rank0": int(inl), "accumulate": "fp64",
-                       "collective": ("all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
-                                     if dist_path else "none"},
+                       "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
@@ -285,6 +326,8 @@ def main():
             out["chunk_us_per_step"] = [round((b - a) / 250 * 1e6, 1) for a, b in zip(ts[:-1], ts[1:])]
     # tear everything down first: RCCL prints its version banner on stdout around communicator life-cycle events, and
     # the JSON line must be the LAST line rank 0 prints
+    if world > 1:
+        dist.barrier()   # no rank may unmap its mailbox / destroy its communicator while a peer can still reach it
     ctx.close()
     if world > 1 or force_dist:
         dist.destroy_process_group()

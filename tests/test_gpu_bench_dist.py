@@ -1,0 +1,41 @@
+"""-m gpu: bench.py's N > 1 code path (launcher env, fixed collective-step counts, peer-to-peer record verification, JSON contract)
+with two ranks sharing the one GPU of the test box (gloo carries the plumbing there because RCCL refuses two ranks on one device;
+the RCCL path itself is exercised with one rank by RPE_BENCH_FORCE_DIST=1).  The driver's real multi-GPU run uses one GPU per rank."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_gpu():
+    collective = "p2p"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        # both ranks on cuda:0: LOCAL_RANK = 0 for both (bench.py reads the device from LOCAL_RANK)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_COLLECTIVE=collective, RPE_BENCH_PREWARM_STEPS="300", RPE_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "30",
+                                       "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=280))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("bench ranks timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-800:] + e[-1500:] for o, e in outs)
+    line = outs[0][0].strip().splitlines()[-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 1e9
+    assert j["config"]["global_corr"] == 2 * j["config"]["corr_per_gpu"]
+    assert "peer-to-peer" in j["config"]["collective"]
+    assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2
+    assert outs[1][0].strip() == "" or not outs[1][0].strip().startswith("{")   # only rank 0 prints the JSON line
