@@ -584,7 +584,12 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
   // a single plain kind other than N-N uses the dedicated kernel (structured sums for p2p), several kinds the fused one
   const bool single = nterms == 1 && terms[0].kind != RPE_RES_NORMAL && terms[0].robust == 0 && terms[0].scale == 1.0;
+  // sharded (rpe_p2p_init): every launch's last workgroup first exchanges the record with the peers, then solves -- identical
+  // records on every rank give identical poses and identical stop decisions, so the loop stays one launch per iteration at any
+  // number of GPUs.  Launches after convergence skip the exchange on every rank alike; the step counter advances per launch.
+  const bool sharded = c->p2p_world >= 1;
   for (int it = 0; it < max_iter; it++) {
+    if (sharded) { rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++; }
     if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose12, rt, c->stream));
     else HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, rt, c->stream));
   }
@@ -594,6 +599,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   if (last_step) *last_step = c->h_out[12];
   if (final_cost) *final_cost = c->h_out[13];
   if (iters_out) *iters_out = (int)c->h_out[14];
+  if (c->h_out[15] == 2.0) return fail(RPE_ERR_HIP, "peer-to-peer exchange timed out at iteration %d (a peer did not deliver its record)", (int)c->h_out[14] - 1);
   if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
   return RPE_OK;
 }

@@ -400,17 +400,18 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     if (threadIdx.x == 0) {
       GnState* st = fin.gn;
       double step = 0.0;
-      const bool ok = gn_solve_update(gn_rec, gn_pose_s, &step);
+      const bool delivered = !(LD == 32 && fin.p2p != nullptr && gn_rec[LD - 1] != 0.0);   // sharded loop: did every peer's record arrive?
+      const bool ok = delivered && gn_solve_update(gn_rec, gn_pose_s, &step);
       const int iters = st->iters + 1;
       const int done = (!ok) || step < st->tol || iters >= st->max_iters;
-      st->iters = iters; st->step = step; st->cost = gn_rec[27]; st->status = ok ? 0 : 1; st->done = done;
+      st->iters = iters; st->step = step; st->cost = gn_rec[27]; st->status = ok ? 0 : (delivered ? 1 : 2); st->done = done;
       if (ok) { for (int k = 0; k < 12; k++) fin.gn_pose[k] = gn_pose_s[k]; }
       if (done && fin.out_host) {
         for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, gn_pose_s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 12, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 13, gn_rec[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 14, (double)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (delivered ? 1.0 : 2.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 16, gn_rec[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // weight sum of the last round
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

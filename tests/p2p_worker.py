@@ -36,6 +36,9 @@ def main():
                 dist.barrier()
                 time.sleep(1.0)                        # ... then this rank goes missing for longer than the time-out
                 out["slept"] = True
+            elif mode == "device":
+                pose, its, step, cost = ctx.gn_refine_device([(L.RES_P2P, 1.0)], pose, 0, steps, 1e-10)
+                out["iters"] = its
             else:
                 for k in range(steps):
                     ctx.gn_step_dist(L.RES_P2P, pose)
@@ -49,13 +52,17 @@ def main():
     dist.all_gather_object(gathered, out)
     if rank == 0:
         ref = None
-        if mode == "steps":
+        if mode in ("steps", "device"):
             full = api.Context(0)
             full.load(L.F32, xw=sc.Q, xc=sc.P)
             ref = api.pose12(np.eye(3), np.zeros(3))
-            for _ in range(steps):
-                full.gn_step(L.RES_P2P, ref)
-            ref = ref.tolist()
+            if mode == "steps":
+                for _ in range(steps):
+                    full.gn_step(L.RES_P2P, ref)
+            else:
+                ref, its, _, _ = full.gn_refine_device([(L.RES_P2P, 1.0)], ref, 0, steps, 1e-10)
+                gathered[0]["ref_iters"] = its
+            ref = np.asarray(ref).tolist()
             full.close()
         print("RESULT " + json.dumps({"ranks": gathered, "reference": ref}), flush=True)
     dist.barrier()

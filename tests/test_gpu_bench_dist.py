@@ -22,7 +22,7 @@ def test_bench_two_ranks_one_gpu():
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_COLLECTIVE=collective, RPE_BENCH_PREWARM_STEPS="300", RPE_BENCH_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "30",
-                                       "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                       "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
         try:
@@ -38,4 +38,5 @@ def test_bench_two_ranks_one_gpu():
     assert j["config"]["global_corr"] == 2 * j["config"]["corr_per_gpu"]
     assert "peer-to-peer" in j["config"]["collective"]
     assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2
+    assert j["device_resident_loop"]["iterations"] == 500 and j["device_resident_loop"]["rot_rad_vs_host_loop"] < 1e-9
     assert outs[1][0].strip() == "" or not outs[1][0].strip().startswith("{")   # only rank 0 prints the JSON line

@@ -49,6 +49,19 @@ def test_p2p_sharded_steps_match_the_single_gpu_run(world, n):
     assert np.abs(poses[0] - ref).max() < 1e-9         # shards add up to the whole (different summation order only)
 
 
+@pytest.mark.parametrize("world,n", [(2, 20000), (8, 307200)])
+def test_p2p_sharded_device_resident_loop(world, n):
+    """One launch per iteration on every rank: exchange + sum + solve + exp-map in the kernel's last workgroup."""
+    res = run_world(world, "device", n, 30)
+    ranks = res["ranks"]
+    assert all(r["p2p"] and "error" not in r for r in ranks), ranks
+    poses = [np.array(r["pose"]) for r in ranks]
+    for p, r in zip(poses, ranks):
+        assert np.array_equal(p, poses[0]) and r["iters"] == ranks[0]["iters"]   # identical records -> identical decisions
+    assert ranks[0]["iters"] == ranks[0]["ref_iters"] < 30
+    assert np.abs(poses[0] - np.array(res["reference"])).max() < 1e-9
+
+
 def test_p2p_missing_peer_times_out_instead_of_hanging():
     res = run_world(2, "straggler", 20000, 3)
     r0, r1 = res["ranks"]
