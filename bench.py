@@ -254,6 +254,15 @@ def main():
         k_avg_s = (k_total_ms / max(cnt, 1)) * 1e-3
         achieved = BYTES_PER_CORR * n / k_avg_s / 1e9 if k_avg_s > 0 else None
         traffic = None
+        rocprof_avg_us = None
+        try:   # the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), for side-by-side reading
+            import csv
+            with open(os.path.join(ROOT, "profiles", "r01_bench_rocprofv3_kernel_stats.csv")) as fh:
+                for row in csv.DictReader(fh):
+                    if "normal_eq_kernel<float, 0" in row["Name"]:
+                        rocprof_avg_us = float(row["AverageNs"]) * 1e-3
+        except Exception:
+            rocprof_avg_us = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -272,9 +281,10 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
                          "avg_launch_us": k_avg_s * 1e6, "min_launch_us": k_min_ms * 1e3, "launches_timed": cnt,
-                         "empty_event_pair_us": ev_avg_ms * 1e3, "avg_launch_us_net_of_event_pair": (k_avg_s * 1e3 - ev_avg_ms) * 1e3,
-                         "note": "HIP events on the kernel's own stream around every stage-1 launch of the timed region (achieved uses the raw interval; an "
-                                 "empty pair measured the same way reads empty_event_pair_us, the net figure is what rocprofv3's dispatch timestamps show); 7.99 MB working set is "
+                         "empty_event_pair_us": ev_avg_ms * 1e3, "rocprofv3_avg_launch_us": rocprof_avg_us,
+                         "note": "HIP events on the kernel's own stream around every stage-1 launch of the timed region; achieved uses that raw interval, which "
+                                 "contains the markers' own latency (an EMPTY pair on the idle stream reads empty_event_pair_us); rocprofv3_avg_launch_us is the "
+                                 "dispatch-timestamp average of the same command from the committed profiles/ summary; 7.99 MB working set is "
                                  "L2/Infinity-Cache resident after the first step, so this is not an HBM-streaming figure (see DESIGN.md)"},
         }
         # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)
