@@ -55,6 +55,7 @@ class Context:
         self.n = 0
         self.dtype = L.F32
         self._keep = {}
+        self._pixels = self._model_pixels = 0   # front end: pixels of the current frame / of the model view
 
     def close(self):
         if self._h:

@@ -23,7 +23,11 @@ struct PinholeCamera {
   double fx = 585., fy = 585., cx = 320., cy = 240.;   // Simulator.hpp:160-162, SimpleMain.cpp:42
   int width = 640, height = 480;
 };
-struct DepthRange { double scale = 0.001, dmin = 0.3, dmax = 8.0, max_jump = 0.1; };   // uint16 millimetres by default
+struct DepthRange {   // metres = raw value * scale; vertices outside (dmin, dmax) are invalid; normals are dropped across jumps > max_jump
+  double scale, dmin, dmax, max_jump;
+  static DepthRange millimetres() { return DepthRange{0.001, 0.3, 8.0, 0.1}; }   // the usual uint16 sensor frame
+  static DepthRange metres() { return DepthRange{1.0, 0.3, 8.0, 0.1}; }
+};
 struct IcpOptions {
   int kind = RPE_RES_P2PLANE;
   int max_iter = 10;
@@ -47,11 +51,8 @@ class DepthFrontEnd {
   DepthFrontEnd(const DepthFrontEnd&) = delete;
   DepthFrontEnd& operator=(const DepthFrontEnd&) = delete;
 
-  void setDepth(const unsigned short* depth, const PinholeCamera& cam, const DepthRange& r = DepthRange()) { set(depth, RPE_DEPTH_U16, cam, r); }
-  void setDepth(const float* depth_m, const PinholeCamera& cam, DepthRange r = DepthRange()) {
-    if (r.scale == 0.001) r.scale = 1.0;  // float frames are metres unless the caller says otherwise
-    set(depth_m, RPE_DEPTH_F32, cam, r);
-  }
+  void setDepth(const unsigned short* depth, const PinholeCamera& cam, const DepthRange& r = DepthRange::millimetres()) { set(depth, RPE_DEPTH_U16, cam, r); }
+  void setDepth(const float* depth, const PinholeCamera& cam, const DepthRange& r = DepthRange::metres()) { set(depth, RPE_DEPTH_F32, cam, r); }
   // the current frame, seen from T_cw, becomes the model the next frames are registered against
   void setModelFromFrame(const Pose& T_cw) {
     double p[12]; pose12(T_cw, p);

@@ -168,7 +168,6 @@ def test_frontend_errors(gpu_ctx_factory):
     ctx = gpu_ctx_factory()
     I = pose12(np.eye(3), np.zeros(3))
     with pytest.raises(L.RpeError) as e:
-        ctx._pixels = 4
         ctx.associate(I)
     assert e.value.code == L.RPE_ERR_STATE
     d = np.full((120, 160), 2.0, np.float32)
