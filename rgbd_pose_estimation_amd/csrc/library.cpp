@@ -85,7 +85,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_P2P) Iter = gn_refine_p2p<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    masks_out(nullptr, &ad.inlierMask33(), nullptr);
+    if (mask_out) { const auto& cad = ad; masks_out(nullptr, &cad.inlierMask33(), nullptr); }   // host copies are fetched only when asked for
   } else if (pnp) {
     PnPPoseAdapter<Tp> ad(bv, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -99,7 +99,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_BEARING) Iter = gn_refine_bearing<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    masks_out(&ad.inlierMask23(), nullptr, nullptr);
+    if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), nullptr, nullptr); }
   } else if (ao) {
     AOPoseAdapter<Tp> ad(bv, xc, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -120,7 +120,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_BEARING) Iter = gn_refine_bearing<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    masks_out(&ad.inlierMask23(), &ad.inlierMask33(), nullptr);
+    if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), &cad.inlierMask33(), nullptr); }
   } else {
     NormalAOPoseAdapter<Tp> ad(bv, xc, nc, xw, nw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -144,7 +144,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_JOINT) Iter = gn_refine_joint<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    masks_out(&ad.inlierMask23(), &ad.inlierMask33(), &ad.inlierMaskNN());
+    if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), &cad.inlierMask33(), &cad.inlierMaskNN()); }
   }
   if (iter_io) *iter_io = Iter;
   return RPE_OK;

@@ -33,7 +33,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
       : PoseAdapterBase<Tp>(t, R), _points_c(points_c), _points_g(points_g) { init(); }
   virtual ~AOOnlyPoseAdapter() {}
 
-  bool isInlier33(int index) const { return _inliers_3d[index] == 1; }
+  bool isInlier33(int index) const { return mask33()[index] == 1; }
   Tp weight33(int index) const { return _weights_3d.empty() ? Tp(1.0) : _weights_3d[index]; }  // raw weight (reference :175-183)
   virtual Point3 getBearingVector(int) const { return Point3(); }
   virtual Point3 getPointCurr(int index) const { return _points_c.col(index); }
@@ -49,9 +49,19 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   // N x 2 mask: column 1 is the 3D-3D inlier flag; an N x 1 mask is ignored (reference :185-198)
   virtual void setInlier(const rpe::MatrixXs& inliers) {
     if (inliers.cols() != 1) {
-      _vInliersAO.flush(_inliers_3d);
-      for (int i = 0; i < inliers.rows(); i++) _inliers_3d[i] = inliers(i, 1);
-      this->device().mask_changed_on_host(RPE_MOD_33);
+      flushInlierIdx();
+      std::vector<short>& m = _inliers_3d.replace(this->device(), RPE_MOD_33);
+      for (int i = 0; i < inliers.rows(); i++) m[i] = inliers(i, 1);
+    }
+  }
+  // additive, for the GPU solvers: setInlier() of an N x cols matrix whose columns in `device_cols` (bit c = column c) are the
+  // masks a kernel just wrote on the device -- adopted without a download -- and whose other columns are zero, as the matrix the
+  // reference's solvers build would be (AbsoluteOrientation.hpp:134-143 allocates N x 2 and fills column 1 only)
+  virtual void setInlierFromDevice(int cols, unsigned device_cols) {
+    if (cols != 1) {
+      flushInlierIdx();
+      if (device_cols & 2u) _inliers_3d.device_is_newer(this->device(), RPE_MOD_33);
+      else { std::vector<short>& m = _inliers_3d.replace(this->device(), RPE_MOD_33); std::fill(m.begin(), m.end(), (short)0); }
     }
   }
   // N x 3 weights: column 1 (reference :200-212 tests rows() == 1)
@@ -62,8 +72,8 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
       this->device().weight_changed_on_host(RPE_MOD_33);
     }
   }
-  virtual void printInlier() const { for (short v : _inliers_3d) std::cout << v << " "; std::cout << std::endl; }
-  const std::vector<int>& getInlierIdx() const { return _vInliersAO.get(_inliers_3d); }
+  virtual void printInlier() const { for (short v : mask33()) std::cout << v << " "; std::cout << std::endl; }
+  const std::vector<int>& getInlierIdx() const { flushInlierIdx(); return _vInliersAO.get(mask33()); }
   void cvtInlier() { _vInliersAO.request(); }  // built on first read (rpe::InlierIndex)
   void forgetInlierIdx() { _vInliersAO.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
   // top_k >= 0: only the first top_k positions of the order are needed now (the rest is sorted on demand)
@@ -73,15 +83,18 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   // ---- additive accessors for the device backend
   const Tp* pointsCurrData() const { return _points_c.p; }
   const Tp* pointsGlobData() const { return _points_g.p; }
-  std::vector<short>& inlierMask33() { _vInliersAO.flush(_inliers_3d); return _inliers_3d; }
-  const std::vector<short>& inlierMask33() const { return _inliers_3d; }
+  std::vector<short>& inlierMask33() { flushInlierIdx(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }   // host copy, for modification
+  const std::vector<short>& inlierMask33() const { return mask33(); }                                                  // host copy, read only
+  void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }                                             // device copy current
   const std::vector<Tp>& weights33() const { return _weights_3d; }
   Tp weightScale33() const { return Tp(1); }
 
  protected:
   void init() { _inliers_3d.assign((size_t)_points_c.cols(), (short)1); _max_votes = 0; }
+  const std::vector<short>& mask33() const { return _inliers_3d.read(this->device(), RPE_MOD_33); }
+  void flushInlierIdx() const { if (_vInliersAO.pending()) _vInliersAO.flush(mask33()); }
   rpe::ColumnView<Tp> _points_c, _points_g;
-  std::vector<short> _inliers_3d;
+  rpe::HostMask _inliers_3d;
   std::vector<Tp> _weights_3d;
   mutable std::vector<int> _idx;
   rpe::InlierIndex _vInliersAO;

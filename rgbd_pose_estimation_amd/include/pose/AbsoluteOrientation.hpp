@@ -66,7 +66,7 @@ void pose_from_device_moments(Adapter& adapter, int flags) {
   DeviceSet& dev = adapter.device();
   dev.template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
   dev.template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
-  if (flags & RPE_USE_MASK) dev.upload_mask(RPE_MOD_33, adapter.inlierMask33());
+  if (flags & RPE_USE_MASK) adapter.pushMask33();
   double m[18], R[9], t[3];
   check(rpe_p2p_moments(dev.ctx(), flags, m), "rpe_p2p_moments");
   check(rpe_pose_from_moments(m, R, t), "rpe_pose_from_moments");
@@ -99,7 +99,7 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
     }
     out.push_back(shinji<Tp>(Xw, Xc, K));
   };
-  auto commit = [&](const MatrixXs& m) { adapter.forgetInlierIdx(); adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_33); };
+  auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
   ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   adapter.cvtInlier();
 }
@@ -167,10 +167,9 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
     SE3<Tp> sk;
     if (kneip<Tp>(X_w, bv, &sk)) out.push_back(sk);
   };
-  auto commit = [&](const MatrixXs& m) {
+  auto commit = [&](int cols, unsigned device_cols) {
     { PnPPoseAdapter<Tp>* p23 = &adapter; p23->forgetInlierIdx(); adapter.forgetInlierIdx(); }  // both are requested again below
-    adapter.setInlier(m);
-    dev.mask_written_on_device(RPE_MOD_23); dev.mask_written_on_device(RPE_MOD_33);
+    adapter.setInlierFromDevice(cols, device_cols);
   };
   ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   PnPPoseAdapter<Tp>* pAdapter = &adapter;

@@ -27,9 +27,9 @@ void ensure_all_arrays(NormalAOPoseAdapter<Tp>& adapter) {
 template <typename Tp>
 void sync_masks_and_weights(NormalAOPoseAdapter<Tp>& adapter) {
   DeviceSet& dev = adapter.device();
-  dev.upload_mask(RPE_MOD_23, adapter.inlierMask23());
-  dev.upload_mask(RPE_MOD_33, adapter.inlierMask33());
-  dev.upload_mask(RPE_MOD_NN, adapter.inlierMaskNN());
+  adapter.pushMask23();
+  adapter.pushMask33();
+  adapter.pushMaskNN();
   dev.template upload_weight<Tp>(RPE_MOD_23, adapter.weights23(), Tp(1));
   dev.template upload_weight<Tp>(RPE_MOD_33, adapter.weights33(), adapter.weightScale33());
   dev.template upload_weight<Tp>(RPE_MOD_NN, adapter.weightsNN(), adapter.weightScaleNN());
@@ -139,15 +139,12 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
     out.push_back(sn);
   };
   DeviceSet& dev = adapter.device();
-  auto commit = [&](const MatrixXs& m) {
+  auto commit = [&](int cols, unsigned device_cols) {
     // the lists requested again after the engine (same levels as the cvtInlier calls below)
     if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->forgetInlierIdx(); }
     if (which != 0) { AOPoseAdapter<Tp>* p = &adapter; p->forgetInlierIdx(); }
     adapter.forgetInlierIdx();
-    adapter.setInlier(m);
-    dev.mask_written_on_device(RPE_MOD_NN);
-    if (which != 1) dev.mask_written_on_device(RPE_MOD_23);
-    if (which != 0) dev.mask_written_on_device(RPE_MOD_33);
+    adapter.setInlierFromDevice(cols, device_cols);
   };
   ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/3);
   if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->cvtInlier(); }

@@ -43,7 +43,7 @@ int gn_refine_p2p(Adapter& adapter, int max_iter = 20, double tol = 1e-9, bool u
   const int N = adapter.getNumberCorrespondences();
   adapter.device().template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
   adapter.device().template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
-  if (use_inliers) adapter.device().upload_mask(RPE_MOD_33, adapter.inlierMask33());
+  if (use_inliers) adapter.pushMask33();
   const int kind = RPE_RES_P2P;
   return rpe::gn_run<Tp>(adapter, 1, &kind, nullptr, use_inliers, max_iter, tol);
 }
@@ -53,7 +53,7 @@ int gn_refine_p2plane(NormalAOPoseAdapter<Tp>& adapter, int max_iter = 20, doubl
   adapter.device().template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
   adapter.device().template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
   adapter.device().template ensure<Tp>(RPE_NC, adapter.normalCurrData(), N);
-  if (use_inliers) adapter.device().upload_mask(RPE_MOD_33, adapter.inlierMask33());
+  if (use_inliers) adapter.pushMask33();
   const int kind = RPE_RES_P2PLANE;
   return rpe::gn_run<Tp>(adapter, 1, &kind, nullptr, use_inliers, max_iter, tol);
 }
@@ -62,7 +62,7 @@ int gn_refine_bearing(PnPPoseAdapter<Tp>& adapter, int max_iter = 20, double tol
   const int N = adapter.getNumberCorrespondences();
   adapter.device().template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
   adapter.device().template ensure<Tp>(RPE_BV, adapter.bearingData(), N);
-  if (use_inliers) adapter.device().upload_mask(RPE_MOD_23, adapter.inlierMask23());
+  if (use_inliers) adapter.pushMask23();
   const int kind = RPE_RES_BEARING;
   return rpe::gn_run<Tp>(adapter, 1, &kind, nullptr, use_inliers, max_iter, tol);
 }
@@ -73,7 +73,7 @@ int gn_refine_joint(AOPoseAdapter<Tp>& adapter, double scale_33 = 1.0, double sc
   adapter.device().template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
   adapter.device().template ensure<Tp>(RPE_XC, adapter.pointsCurrData(), N);
   adapter.device().template ensure<Tp>(RPE_BV, adapter.bearingData(), N);
-  if (use_inliers) { adapter.device().upload_mask(RPE_MOD_33, adapter.inlierMask33()); adapter.device().upload_mask(RPE_MOD_23, adapter.inlierMask23()); }
+  if (use_inliers) { adapter.pushMask33(); adapter.pushMask23(); }
   const int kinds[2] = {RPE_RES_P2P, RPE_RES_BEARING};
   const double scales[2] = {scale_33, scale_23};
   return rpe::gn_run<Tp>(adapter, 2, kinds, scales, use_inliers, max_iter, tol);

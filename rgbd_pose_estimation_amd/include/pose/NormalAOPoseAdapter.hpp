@@ -32,7 +32,7 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
       : AOPoseAdapter<Tp>(bearingVectors, points_c, points_g, t, R), _normal_c(normal_c), _normal_g(normal_g) { initn(); }
   virtual ~NormalAOPoseAdapter() {}
 
-  bool isInlierNN(int index) const { return _inliers_nl[index] == 1; }
+  bool isInlierNN(int index) const { return maskNN()[index] == 1; }
   Tp weightNN(int index) const { return _weights_nl.empty() ? Tp(1.0) : Tp(_weights_nl[index]) / std::numeric_limits<short>::max(); }  // :153-161
   virtual Point3 getNormalCurr(int index) const { return _normal_c.col(index); }
   virtual Point3 getNormalGlob(int index) const { return _normal_g.col(index); }
@@ -41,9 +41,19 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
     if (inliers.cols() == 2) AOPoseAdapter<Tp>::setInlier(inliers);
     if (inliers.cols() == 3) {
       AOPoseAdapter<Tp>::setInlier(inliers);
-      _vInliersNN.flush(_inliers_nl);
-      for (int i = 0; i < inliers.rows(); i++) _inliers_nl[i] = inliers(i, 2);
-      this->device().mask_changed_on_host(RPE_MOD_NN);
+      flushInlierIdxNN();
+      std::vector<short>& m = _inliers_nl.replace(this->device(), RPE_MOD_NN);
+      for (int i = 0; i < inliers.rows(); i++) m[i] = inliers(i, 2);
+    }
+  }
+  virtual void setInlierFromDevice(int cols, unsigned device_cols) {   // additive, see AOOnlyPoseAdapter::setInlierFromDevice
+    if (cols == 1) PnPPoseAdapter<Tp>::setInlierFromDevice(cols, device_cols);
+    if (cols == 2) AOPoseAdapter<Tp>::setInlierFromDevice(cols, device_cols);
+    if (cols == 3) {
+      AOPoseAdapter<Tp>::setInlierFromDevice(cols, device_cols);
+      flushInlierIdxNN();
+      if (device_cols & 4u) _inliers_nl.device_is_newer(this->device(), RPE_MOD_NN);
+      else { std::vector<short>& m = _inliers_nl.replace(this->device(), RPE_MOD_NN); std::fill(m.begin(), m.end(), (short)0); }
     }
   }
   template <class M> void setWeights(const M& weights) {  // reference :197-212 dispatches on cols()
@@ -58,25 +68,28 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
   }
   virtual void printInlier() const {
     AOPoseAdapter<Tp>::printInlier();
-    for (short v : _inliers_nl) std::cout << v << " ";
+    for (short v : maskNN()) std::cout << v << " ";
     std::cout << std::endl;
   }
-  const std::vector<int>& getInlierIdx() const { return _vInliersNN.get(_inliers_nl); }
+  const std::vector<int>& getInlierIdx() const { flushInlierIdxNN(); return _vInliersNN.get(maskNN()); }
   void cvtInlier() { _vInliersNN.request(); }  // built on first read (rpe::InlierIndex)
   void forgetInlierIdx() { _vInliersNN.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
 
   // ---- additive accessors for the device backend
   const Tp* normalCurrData() const { return _normal_c.p; }
   const Tp* normalGlobData() const { return _normal_g.p; }
-  std::vector<short>& inlierMaskNN() { _vInliersNN.flush(_inliers_nl); return _inliers_nl; }
-  const std::vector<short>& inlierMaskNN() const { return _inliers_nl; }
+  std::vector<short>& inlierMaskNN() { flushInlierIdxNN(); return _inliers_nl.edit(this->device(), RPE_MOD_NN); }
+  const std::vector<short>& inlierMaskNN() const { return maskNN(); }
+  void pushMaskNN() const { _inliers_nl.push(this->device(), RPE_MOD_NN); }
   const std::vector<Tp>& weightsNN() const { return _weights_nl; }
   Tp weightScaleNN() const { return (Tp)std::numeric_limits<short>::max(); }
 
  protected:
   void initn() { _inliers_nl.assign((size_t)_bearingVectors.cols(), (short)1); }
+  const std::vector<short>& maskNN() const { return _inliers_nl.read(this->device(), RPE_MOD_NN); }
+  void flushInlierIdxNN() const { if (_vInliersNN.pending()) _vInliersNN.flush(maskNN()); }
   rpe::ColumnView<Tp> _normal_c, _normal_g;
-  std::vector<short> _inliers_nl;
+  rpe::HostMask _inliers_nl;
   std::vector<Tp> _weights_nl;
   rpe::InlierIndex _vInliersNN;
 };

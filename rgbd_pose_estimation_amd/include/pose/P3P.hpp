@@ -187,7 +187,7 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
     }
     if (arg >= 0) out.push_back(sols[arg]);
   };
-  auto commit = [&](const MatrixXs& m) { adapter.forgetInlierIdx(); adapter.setInlier(m); adapter.device().mask_written_on_device(RPE_MOD_23); };
+  auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
   ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/1);
   adapter.cvtInlier();
 }

@@ -33,13 +33,20 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
 
   // column 0 of the mask (reference :196-202 memcpy's rows()*2 bytes = column 0 of a column-major short matrix)
   virtual void setInlier(const rpe::MatrixXs& inliers) {
-    _vInliersPnP.flush(_inliers);
-    for (int i = 0; i < inliers.rows(); i++) _inliers[i] = inliers(i, 0);
-    this->device().mask_changed_on_host(RPE_MOD_23);
+    flushInlierIdx23();
+    std::vector<short>& m = _inliers.replace(this->device(), RPE_MOD_23);
+    for (int i = 0; i < inliers.rows(); i++) m[i] = inliers(i, 0);
+  }
+  // additive, for the GPU solvers (see AOOnlyPoseAdapter::setInlierFromDevice): column 0 from the device, or zero
+  virtual void setInlierFromDevice(int cols, unsigned device_cols) {
+    (void)cols;
+    flushInlierIdx23();
+    if (device_cols & 1u) _inliers.device_is_newer(this->device(), RPE_MOD_23);
+    else { std::vector<short>& m = _inliers.replace(this->device(), RPE_MOD_23); std::fill(m.begin(), m.end(), (short)0); }
   }
   template <class M> void setWeights(const M& weights) { setWeights23(weights); }
-  virtual void printInlier() const { for (short v : _inliers) std::cout << v << " "; std::cout << std::endl; }
-  const std::vector<int>& getInlierIdx() const { return _vInliersPnP.get(_inliers); }
+  virtual void printInlier() const { for (short v : mask23()) std::cout << v << " "; std::cout << std::endl; }
+  const std::vector<int>& getInlierIdx() const { flushInlierIdx23(); return _vInliersPnP.get(mask23()); }
   void cvtInlier() { _vInliersPnP.request(); }  // built on first read (rpe::InlierIndex)
   void forgetInlierIdx() { _vInliersPnP.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
   // sine of the angle between predicted and observed bearing (reference :204-210)
@@ -50,7 +57,7 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   }
   void setMaxVotes(int votes) { _max_votes = votes; }
   int getMaxVotes() { return _max_votes; }
-  bool isInlier23(int index) const { return _inliers[index] == 1; }
+  bool isInlier23(int index) const { return mask23()[index] == 1; }
   Tp weight23(int index) const { return _weights.empty() ? Tp(1.0) : _weights[index]; }
   // top_k >= 0: only the first top_k positions of the order are needed now (the rest is sorted on demand)
   void sortIdx(int top_k = -1) { _idx = sortIndexes<Tp>(_weights, top_k); }
@@ -59,19 +66,22 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   // ---- additive accessors for the device backend
   const Tp* bearingData() const { return _bearingVectors.p; }
   const Tp* pointsGlobData() const { return _points_g.p; }
-  std::vector<short>& inlierMask23() { _vInliersPnP.flush(_inliers); return _inliers; }
-  const std::vector<short>& inlierMask23() const { return _inliers; }
+  std::vector<short>& inlierMask23() { flushInlierIdx23(); return _inliers.edit(this->device(), RPE_MOD_23); }
+  const std::vector<short>& inlierMask23() const { return mask23(); }
+  void pushMask23() const { _inliers.push(this->device(), RPE_MOD_23); }
   const std::vector<Tp>& weights23() const { return _weights; }
 
  protected:
   void init() { _inliers.assign((size_t)_bearingVectors.cols(), (short)1); _max_votes = 0; }
+  const std::vector<short>& mask23() const { return _inliers.read(this->device(), RPE_MOD_23); }
+  void flushInlierIdx23() const { if (_vInliersPnP.pending()) _vInliersPnP.flush(mask23()); }
   template <class M> void setWeights23(const M& weights) {
     _weights.resize(weights.rows());
     for (int i = 0; i < (int)weights.rows(); i++) _weights[i] = weights(i, 0);
     this->device().weight_changed_on_host(RPE_MOD_23);
   }
   rpe::ColumnView<Tp> _bearingVectors, _points_g;
-  std::vector<short> _inliers;
+  rpe::HostMask _inliers;
   std::vector<Tp> _weights;
   mutable std::vector<int> _idx;
   rpe::InlierIndex _vInliersPnP;

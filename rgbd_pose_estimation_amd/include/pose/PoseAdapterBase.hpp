@@ -75,6 +75,29 @@ inline void indices_of_ones(const std::vector<short>& mask, std::vector<int>& ou
   for (size_t r = 0; r < mask.size(); r++) { o[k] = (int)r; k += (mask[r] == 1); }
   out.resize(k);
 }
+// One modality's inlier mask as the adapters keep it on the host (N shorts, 0/1) -- except that after a RANSAC run on the GPU
+// the TRUTH is the device copy (rpe_inlier_mask wrote it there), and most callers never look at the host copy: the least-squares
+// stages read the device masks.  So the host copy is fetched on first access instead of after every solver run (0.15 ms per
+// modality at 307200 rows, half of a whole RANSAC run).  read(): host access; edit(): host access that will modify;
+// replace(): the whole content is about to be overwritten; device_is_newer(): a kernel just wrote the device copy.
+class HostMask {
+ public:
+  void assign(size_t n, short v) { _v.assign(n, v); _stale = false; }
+  size_t size() const { return _v.size(); }
+  const std::vector<short>& read(DeviceSet& dev, int mod) const {
+    if (_stale) { dev.download_mask(mod, _v.data()); _stale = false; }
+    return _v;
+  }
+  std::vector<short>& edit(DeviceSet& dev, int mod) { read(dev, mod); dev.mask_changed_on_host(mod); return _v; }
+  std::vector<short>& replace(DeviceSet& dev, int mod) { _stale = false; dev.mask_changed_on_host(mod); return _v; }
+  void device_is_newer(DeviceSet& dev, int mod) { _stale = true; dev.mask_written_on_device(mod); }
+  // make the device copy current (no-op when it already is, in particular when it is the newer one)
+  void push(DeviceSet& dev, int mod) const { if (!dev.mask_fresh(mod)) dev.upload_mask(mod, _v); }
+ private:
+  mutable std::vector<short> _v;
+  mutable bool _stale = false;
+};
+
 // The index list behind cvtInlier() / getInlierIdx().  cvtInlier() only RECORDS the request; the list is built when it is
 // first read, or just before the mask it was requested for changes -- so a reader always sees the list of the mask as it was
 // when cvtInlier() ran (the reference's behaviour), and solvers that never read it (every pipeline here keeps its masks on
@@ -85,6 +108,7 @@ class InlierIndex {
   // a solver that is about to replace the mask AND request the list again may drop an unread request: between those two steps
   // nothing can read the list, so the skipped snapshot is unobservable
   void drop() { _pending = false; }
+  bool pending() const { return _pending; }
   void flush(const std::vector<short>& mask) const { if (_pending) { indices_of_ones(mask, _idx); _pending = false; } }
   const std::vector<int>& get(const std::vector<short>& mask) const { flush(mask); return _idx; }
  private:

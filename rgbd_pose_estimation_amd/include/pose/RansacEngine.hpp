@@ -8,7 +8,8 @@
 // a better hypothesis is seen, and iterations at or beyond the new Iter are discarded.  The outcome (pose, votes,
 // Iter, mask) is therefore what the sequential loop would produce from the same hypothesis stream; only the sampler
 // may have been advanced further than the reference would have advanced rand().
-// The winner's inlier mask is written once at the end (rpe_inlier_mask, kernel K4b) instead of at every improvement.
+// The winner's inlier mask is written once at the end (rpe_inlier_mask, kernel K4b) instead of at every improvement, and stays on
+// the device until somebody reads the adapter's host copy.
 #ifndef RPE_RANSAC_ENGINE_HEADER
 #define RPE_RANSAC_ENGINE_HEADER
 
@@ -43,7 +44,7 @@ template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
 
 // Adapter: any pose adapter (setMaxVotes/getMaxVotes/setRcw/sett/device()).
 // gen(out): advance the sampler by ONE reference iteration and append its 0..3 hypotheses, in the reference's order.
-// commit(mask): hand the winner's N x mask_cols short mask to the adapter (setInlier).
+// commit(cols, device_cols): the winner's masks are on the device; the adapter adopts them (setInlierFromDevice).
 template <class Tp, class Adapter, class Gen, class Commit>
 void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
   const int N = adapter.getNumberCorrespondences();
@@ -102,18 +103,15 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
     int total = 0;
     check(rpe_inlier_mask(ctx, spec.kind, cfg.score_mode, b7, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, &total),
           "rpe_inlier_mask");
-    // reused across runs: a fresh 1-2 MB matrix per run costs more in page faults than the mask kernel and its download together
-    static thread_local MatrixXs mask;
-    mask.resize(N, mask_cols);  // zero-filled: columns of modalities this solver does not vote on stay 0, as in the reference
     const bool has23 = spec.kind == RPE_VOTE_23 || spec.kind == RPE_VOTE_23_MATRIX || spec.kind == RPE_VOTE_33_23 ||
                        spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33_23;
     const bool has33 = spec.kind == RPE_VOTE_33 || spec.kind == RPE_VOTE_33_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
     const bool hasnn = spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
-    // column-major N x cols: each modality's column is contiguous, the device mask lands in it directly
-    if (has23 && mask_cols >= 1) adapter.device().download_mask(RPE_MOD_23, mask.data());
-    if (has33 && mask_cols >= 2) adapter.device().download_mask(RPE_MOD_33, mask.data() + (size_t)N);
-    if (hasnn && mask_cols >= 3) adapter.device().download_mask(RPE_MOD_NN, mask.data() + 2 * (size_t)N);
-    commit(mask);
+    // the device masks ARE the result: the adapter adopts them without a download (its host copy is fetched on first access,
+    // rpe::HostMask); columns of modalities this solver does not vote on become zero, as in the matrix the reference builds
+    const unsigned device_cols = (has23 && mask_cols >= 1 ? 1u : 0u) | (has33 && mask_cols >= 2 ? 2u : 0u) | (hasnn && mask_cols >= 3 ? 4u : 0u);
+    commit(mask_cols, device_cols);
+
     lap(cfg.prof.mask);
   }
 }

@@ -120,6 +120,7 @@ class DeviceSet {
     }
     _weight_fresh[mod] = true;
   }
+  bool mask_fresh(int mod) const { return _mask_fresh[mod]; }
   void mask_changed_on_host(int mod) { _mask_fresh[mod] = false; }
   void mask_written_on_device(int mod) { _mask_fresh[mod] = true; }
   void weight_changed_on_host(int mod) { _weight_fresh[mod] = false; }

@@ -83,6 +83,13 @@ int main() {
   a.setInlier(m);
   a.cvtInlier();
   CHECK(a.getInlierIdx().size() == 10 && a.getInlierIdx()[9] == 900);
+  // setInlierFromDevice with no device column = setInlier of an all-zero matrix (what the reference's solvers leave in the columns
+  // they do not vote on); cols == 1 leaves the 3-D mask alone, as setInlier does
+  a.setInlierFromDevice(1, 0u);
+  CHECK(a.isInlier33(0) && a.isInlier33(100));
+  a.setInlierFromDevice(2, 0u);
+  a.cvtInlier();
+  CHECK(!a.isInlier33(0) && !a.isInlier33(100) && a.getInlierIdx().empty());
   // every level of the NormalAO hierarchy keeps its own list (name hiding, reference AbsoluteOrientation.hpp:433-435)
   rpe::MatrixX<float> U(3, N), Nc(3, N), Nw(3, N);
   NormalAOPoseAdapter<float> na(U, P, Nc, Q, Nw);
