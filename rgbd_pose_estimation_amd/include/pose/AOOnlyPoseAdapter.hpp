@@ -86,6 +86,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   std::vector<short>& inlierMask33() { flushInlierIdx(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }   // host copy, for modification
   const std::vector<short>& inlierMask33() const { return mask33(); }                                                  // host copy, read only
   void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }                                             // device copy current
+  virtual void syncHostMasks() const { (void)mask33(); }
   const std::vector<Tp>& weights33() const { return _weights_3d; }
   Tp weightScale33() const { return Tp(1); }
 

@@ -67,6 +67,7 @@ class AOPoseAdapter : public PnPPoseAdapter<Tp> {
   std::vector<short>& inlierMask33() { flushInlierIdx33(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }
   const std::vector<short>& inlierMask33() const { return mask33(); }
   void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }
+  virtual void syncHostMasks() const { PnPPoseAdapter<Tp>::syncHostMasks(); (void)mask33(); }
   const std::vector<Tp>& weights33() const { return _weights_3d; }
   Tp weightScale33() const { return (Tp)std::numeric_limits<short>::max(); }
 

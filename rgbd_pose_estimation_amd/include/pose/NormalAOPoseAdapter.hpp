@@ -81,6 +81,7 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
   std::vector<short>& inlierMaskNN() { flushInlierIdxNN(); return _inliers_nl.edit(this->device(), RPE_MOD_NN); }
   const std::vector<short>& inlierMaskNN() const { return maskNN(); }
   void pushMaskNN() const { _inliers_nl.push(this->device(), RPE_MOD_NN); }
+  virtual void syncHostMasks() const { AOPoseAdapter<Tp>::syncHostMasks(); (void)maskNN(); }
   const std::vector<Tp>& weightsNN() const { return _weights_nl; }
   Tp weightScaleNN() const { return (Tp)std::numeric_limits<short>::max(); }
 

@@ -69,6 +69,7 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   std::vector<short>& inlierMask23() { flushInlierIdx23(); return _inliers.edit(this->device(), RPE_MOD_23); }
   const std::vector<short>& inlierMask23() const { return mask23(); }
   void pushMask23() const { _inliers.push(this->device(), RPE_MOD_23); }
+  virtual void syncHostMasks() const { (void)mask23(); }
   const std::vector<Tp>& weights23() const { return _weights; }
 
  protected:

@@ -46,7 +46,9 @@ class PoseAdapterBase {
   }
   // call after changing the CONTENTS of a matrix the adapter references (the adapters hold references, reference
   // :93-95 of AOOnlyPoseAdapter.hpp, and cache uploads by address)
-  void invalidateDevice() { _dev.reset(); }
+  void invalidateDevice() { syncHostMasks(); _dev.reset(); }
+  // bring every host-side inlier mask up to date (they may live on the device only, see rpe::HostMask)
+  virtual void syncHostMasks() const {}
 
  protected:
   Vector3 _t_w;
