@@ -103,6 +103,7 @@ struct rpe_context {
   ncclComm_t comm = nullptr;      // this rank's communicator for the per-iteration all-reduce (rpe_comm_init)
   int comm_world = 1;
   unsigned long long* h_flag2 = nullptr;  // pinned sequence word of the vote publish
+  unsigned long long vote_seq = 0;
   bool timing = false;
   int timing_stride = 1;
   unsigned long long timing_calls = 0;
@@ -212,6 +213,18 @@ int wait_host(rpe_context* c, int ld) {
   }
 }
 
+// same spin on an arbitrary pinned sequence word
+int wait_flag(rpe_context* c, unsigned long long* flag, unsigned long long want) {
+  for (unsigned long long spins = 0;; spins++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return RPE_OK;
+    if ((spins & 0xFFFFF) == 0xFFFFF) {
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+      if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu)", want);
+    }
+  }
+}
+
 int kind_arrays(rpe_context* c, int kind) {
   switch (kind) {
     case RPE_RES_P2P: return need_arrays(c, {RPE_XW, RPE_XC});
@@ -267,7 +280,10 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, (size_t)rpe::kMaxScoreH * sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMemset(c->d_votes, 0, (size_t)rpe::kMaxScoreH * sizeof(int));   // the scoring kernels accumulate into zeroed counters
+  // pinned + device-mapped: the vote read-out kernel stores straight into it; the sequence word sits behind the counters
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) { std::memset(c->h_votes, 0, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int)); c->h_flag2 = reinterpret_cast<unsigned long long*>(c->h_votes + rpe::kMaxScoreH); }
   if (e != hipSuccess) { rpe_destroy(c); return fail(RPE_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e)); }
   *out = c;
   return RPE_OK;
@@ -818,8 +834,11 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
     if (c->comm) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream));  // sharded correspondences
-    HIP_TRY(hipMemcpyAsync(c->h_votes, c->d_votes, (size_t)hb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counters into pinned host memory, raises
+    // a sequence word the host spins on, and clears the counters for the next launch
+    const unsigned long long seq = ++c->vote_seq;
+    HIP_TRY(rpe::launch_publish_votes(c->d_votes, hb, c->h_votes, c->h_flag2, seq, c->stream));
+    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
   }
   return RPE_OK;

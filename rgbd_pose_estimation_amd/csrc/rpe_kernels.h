@@ -64,6 +64,7 @@ hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, c
                                   const double* robust_k4, const ReduceTarget& rt, hipStream_t s);
 // d_poses: H x 12 (fast: R row-major, t) or H x 8 (exact: qw qx qy qz tx ty tz pad) values of the array dtype.
 // thr: {thre_3d (fast: squared), cos_thr, cos_nl} as doubles holding values of the array dtype.
+// d_votes[0..H) must be zero on entry (launch_publish_votes leaves them so)
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s);
 // pose12: fast = R row-major (9) t (3); exact = qw qx qy qz tx ty tz (rest ignored).  The vote total is record[0] of rt.
@@ -74,6 +75,8 @@ hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const 
 
 // copy `count` reduced values from HBM to pinned host memory and then store `seq` to *h_flag (the host spins on it)
 hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
+// publish the vote counters to pinned host memory, raise the sequence word, and zero the counters for the next launch_score
+hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 
 // ---- front end (rpe_frontend.hip): depth frame -> maps -> projective association; fp32 throughout

@@ -1256,6 +1256,22 @@ hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned 
   hipLaunchKernelGGL((publish_kernel<int>), dim3(1), dim3(256), 0, s, d_src, count, h_dst, h_flag, seq);
   return hipGetLastError();
 }
+// vote counters: publish to the host AND clear them for the next scoring launch (the counters are accumulated with atomics, so
+// they must start at zero; clearing here saves a memset per launch)
+__global__ void publish_votes_kernel(int* __restrict__ votes, int count, int* __restrict__ h_dst, unsigned long long* __restrict__ h_flag,
+                                     unsigned long long seq) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    __hip_atomic_store(h_dst + i, votes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    votes[i] = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(publish_votes_kernel, dim3(1), dim3(count > 256 ? 1024 : 256), 0, s, d_votes, count, h_dst, h_flag, seq);
+  return hipGetLastError();
+}
 
 // ================================================================================================
 // launchers
@@ -1463,8 +1479,7 @@ static void mask_launch(const DeviceArrays& A, const double* pose12, const doubl
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s) {
   if (H < 1 || H > kMaxScoreH) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(d_votes, 0, (size_t)H * sizeof(int), s);
-  if (e != hipSuccess) return e;
+  // d_votes must be zero on entry: allocated zeroed, and re-zeroed by launch_publish_votes after every read-out
   if (A.dtype) {
     const int G = grid_for(A.n, 2, max_blocks);
     if (exact) { RPE_KIND_SWITCH(score_launch, double, true, A, d_poses, H, thr3, d_votes, G, s) }
