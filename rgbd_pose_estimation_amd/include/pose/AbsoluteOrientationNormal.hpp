@@ -138,7 +138,6 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
     nl_2p<Tp>(Xc.col(0), Nc.col(0), Xc.col(1), Xw.col(0), Nw.col(0), Xw.col(1), &sn);
     out.push_back(sn);
   };
-  DeviceSet& dev = adapter.device();
   auto commit = [&](int cols, unsigned device_cols) {
     // the lists requested again after the engine (same levels as the cvtInlier calls below)
     if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->forgetInlierIdx(); }
