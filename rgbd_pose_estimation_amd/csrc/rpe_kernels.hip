@@ -1290,6 +1290,8 @@ static inline int reduce_grid(int64_t n, int P, int max_blocks, int block) {
   const int64_t groups = (n + P - 1) / P;
   const int64_t one = (groups + block - 1) / block, two = (groups + 2 * (int64_t)block - 1) / (2 * (int64_t)block);
   int64_t g = two < 128 ? (one < 128 ? one : 128) : two;
+  static const int force = getenv("RPE_REDUCE_GROUPS") ? atoi(getenv("RPE_REDUCE_GROUPS")) : 0;   // experiments: 1 / 2 groups per thread
+  if (force == 1) g = one; else if (force == 2) g = two;
   if (g < 1) g = 1;
   if (g > max_blocks) g = max_blocks;
   return (int)g;
