@@ -239,3 +239,57 @@ def test_errors_are_loud(gpu_ctx_factory):
     assert e.value.code == L.RPE_ERR_DEGENERATE
     with pytest.raises(L.RpeError):
         ctx.normal_eq(L.RES_P2P, api.pose12(np.eye(3), np.zeros(3)), flags=L.USE_MASK)
+
+
+def _nl_round_numpy(sc, m23, m33, mnn, w23, w33, wnn, c_opt, Cw, Cc, Rwc):
+    """fp64 statement of one round of nl_shinji_kneip_ls (AbsoluteOrientationNormal.hpp:484-505) + find_opt_cc (:24-39) over the
+    fp32/fp64 arrays as given: the 44-value record of rpe_nl_round."""
+    Q, P, U, M, N = (np.asarray(a, np.float64) for a in (sc.Q, sc.P, sc.U, sc.M, sc.N))
+    out = np.zeros(44)
+    on = m23 == 1
+    w = (w23 if w23 is not None else np.ones(len(Q)))[on].astype(np.float64)
+    d = Q[on] - c_opt
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out[0:9] = ((w[:, None] * U[on]).T @ d).reshape(9)
+    out[9], out[10] = w.sum(), on.sum()
+    v = U[on] @ np.asarray(Rwc, np.float64).reshape(3, 3).T
+    A = np.eye(3)[None] - v[:, :, None] * v[:, None, :]
+    AA = A.sum(0)
+    out[32:38] = [AA[0, 0], AA[0, 1], AA[0, 2], AA[1, 1], AA[1, 2], AA[2, 2]]
+    out[38:41] = np.einsum("nij,nj->i", A, Q[on])
+    on = m33 == 1
+    vv = (w33 if w33 is not None else np.ones(len(Q)))[on].astype(np.float64)
+    a, c = Q[on] - Cw, P[on] - Cc
+    out[11:20] = ((vv[:, None] * c).T @ a).reshape(9)
+    out[20] = (vv * (c * c).sum(1)).sum()
+    on = mnn == 1
+    l = (wnn if wnn is not None else np.ones(len(Q)))[on].astype(np.float64)
+    out[21:30] = ((l[:, None] * N[on]).T @ M[on]).reshape(9)
+    out[30], out[31] = l.sum(), on.sum()
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 4099, 307200])
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_nl_round_record_vs_numpy(gpu_ctx_factory, n, f64, weighted):
+    """K5 against an independent fp64 numpy statement of the same sums (the pipelines only see it through the final pose)."""
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(21 + n, n, dt, nan_frac=0.0)
+    rng = np.random.default_rng(n)
+    m23, m33, mnn = ((rng.random(n) < 0.8).astype(np.int16) for _ in range(3))
+    if n == 1:
+        m23[:] = m33[:] = mnn[:] = 1
+    w = [rng.random(n).astype(dt) + 0.1 for _ in range(3)] if weighted else [None, None, None]
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    for mod, m in ((L.MOD_23, m23), (L.MOD_33, m33), (L.MOD_NN, mnn)):
+        ctx.upload_mask(mod, m)
+    for mod, ww in ((L.MOD_23, w[0]), (L.MOD_33, w[1]), (L.MOD_NN, w[2])):
+        ctx.upload_weight(mod, ww)
+    c_opt = -sc.R.T @ sc.t + 0.05
+    Cw, Cc = np.asarray(sc.Q, np.float64).mean(0), np.asarray(sc.P, np.float64).mean(0)
+    got = ctx.nl_round(c_opt, Cw, Cc, sc.R.T)
+    ref = _nl_round_numpy(sc, m23, m33, mnn, w[0], w[1], w[2], c_opt, Cw, Cc, sc.R.T)
+    scale = np.abs(ref).max() + 1.0
+    assert np.array_equal(got[[10, 31]], ref[[10, 31]])                 # inlier counts: exact
+    assert np.abs(got - ref).max() <= 1e-11 * scale * max(1.0, np.sqrt(n))   # all arithmetic is fp64 over the same inputs
