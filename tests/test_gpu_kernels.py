@@ -292,4 +292,7 @@ def test_nl_round_record_vs_numpy(gpu_ctx_factory, n, f64, weighted):
     ref = _nl_round_numpy(sc, m23, m33, mnn, w[0], w[1], w[2], c_opt, Cw, Cc, sc.R.T)
     scale = np.abs(ref).max() + 1.0
     assert np.array_equal(got[[10, 31]], ref[[10, 31]])                 # inlier counts: exact
-    assert np.abs(got - ref).max() <= 1e-11 * scale * max(1.0, np.sqrt(n))   # all arithmetic is fp64 over the same inputs
+    # products in the array dtype (as the reference's Tp accumulators, and as K1-K3), sums in fp64: fp64 arrays agree to fp64
+    # rounding, fp32 arrays to the per-term fp32 rounding, which averages out over the sum (relative to the largest entry)
+    tol = 1e-11 * max(1.0, np.sqrt(n)) if f64 else 4e-7
+    assert np.abs(got - ref).max() <= tol * scale
