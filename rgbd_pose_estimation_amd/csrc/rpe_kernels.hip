@@ -482,11 +482,22 @@ __device__ __forceinline__ void p2plane_point(const PoseK<double>& T, C x, C y, 
   add_row(J, r, w, s);
   s[28] += w;
 }
+// 1 / sqrt(x) in fp64 without the ~45-instruction IEEE sqrt + divide sequences: the fp32 hardware estimate (v_rsq_f32, 1e-7)
+// refined by two Newton steps y <- y (3/2 - x/2 y^2), each squaring the error: ~1 ulp of fp64 in ~10 instructions.  x is a
+// squared point norm in metres^2 (fits fp32 comfortably).
+__device__ __forceinline__ double rsqrt64(double x) {
+  double y = (double)rsqrtf((float)x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
 template <class C>
 __device__ __forceinline__ void bearing_point(const PoseK<double>& T, C x, C y, C z, C bx, C by, C bz, C w, C (&s)[29]) {
   double pxd, pyd, pzd;
   transform<C>(T, x, y, z, pxd, pyd, pzd);
-  const double invd = 1.0 / sqrt(pxd * pxd + pyd * pyd + pzd * pzd);
+  const double invd = rsqrt64(pxd * pxd + pyd * pyd + pzd * pzd);
   const double hxd = pxd * invd, hyd = pyd * invd, hzd = pzd * invd;
   // sine residual p^ x bv: near the optimum p^ ~ bv, so this too is a cancelling difference -> fp64
   const C r[3] = {(C)(hyd * (double)bz - hzd * (double)by), (C)(hzd * (double)bx - hxd * (double)bz), (C)(hxd * (double)by - hyd * (double)bx)};
@@ -691,11 +702,15 @@ __global__ __launch_bounds__(BLK) void icp_fused_kernel(const float* __restrict_
 enum { TERM_P2P = 1, TERM_P2PLANE = 2, TERM_BEARING = 4, TERM_NORMAL = 8 };
 struct JointParams { double scale[4]; int robust[4]; double robust_k[4]; };  // indexed by residual kind 0..3
 
-template <class C> __device__ __forceinline__ C robust_weight(int robust, C k, C s) {
+// `robust` is a kernel argument (wave-uniform): the branch is a scalar one, and the common case -- no robust weight -- pays
+// neither the square root its argument needs nor the two divisions
+template <class C, class F> __device__ __forceinline__ C robust_weight(int robust, C k, F norm_of_residual) {
+  if (robust == 0) return C(1);
+  const C s = norm_of_residual();
   const C huber = s <= k ? C(1) : k / s;
   const C q = s / k;
   const C cauchy = C(1) / (C(1) + q * q);
-  return robust == 1 ? huber : (robust == 2 ? cauchy : C(1));
+  return robust == 1 ? huber : cauchy;
 }
 // point-to-point block written straight into the packed record (J = [I | -[p]x]: 35 flops instead of 3 generic rows)
 template <class C> __device__ __forceinline__ void p2p_packed(C px, C py, C pz, C rx, C ry, C rz, C w, C w_unscaled, C (&s)[29]) {
@@ -737,14 +752,14 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
       const T qx = on ? px : T(0), qy = on ? py : T(0), qz = on ? pz : T(0);
       if (TERMS & TERM_P2P) {
         const T w0 = on ? u33[i] : T(0);
-        const T w = w0 * robust_weight<T>(prm.robust[0], (T)prm.robust_k[0], sqrt(rx * rx + ry * ry + rz * rz));
+        const T w = w0 * robust_weight<T>(prm.robust[0], (T)prm.robust_k[0], [&]() { return sqrt(rx * rx + ry * ry + rz * rz); });
         p2p_packed<T>(qx, qy, qz, rx, ry, rz, (T)prm.scale[0] * w, w, s);
       }
       if (TERMS & TERM_P2PLANE) {
         const T nx = on ? vnc[3 * i] : T(0), ny = on ? vnc[3 * i + 1] : T(0), nz = on ? vnc[3 * i + 2] : T(0);
         const T r = nx * rx + ny * ry + nz * rz;
         const T w0 = on ? u33[i] : T(0);
-        const T w = w0 * robust_weight<T>(prm.robust[1], (T)prm.robust_k[1], fabs(r));
+        const T w = w0 * robust_weight<T>(prm.robust[1], (T)prm.robust_k[1], [&]() { return fabs(r); });
         const T J[6] = {nx, ny, nz, qy * nz - qz * ny, qz * nx - qx * nz, qx * ny - qy * nx};
         add_row(J, r, (T)prm.scale[1] * w, s);
         s[28] += w;
@@ -755,11 +770,11 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
       const bool on = present & (k23[i] == 1) & !all_nan(bx0, by0, bz0);
       const T bx = on ? bx0 : T(0), by = on ? by0 : T(0), bz = on ? bz0 : T(1);
       const double sx = on ? pxd : 0.0, sy = on ? pyd : 0.0, sz = on ? pzd : 1.0;  // keeps the normalisation finite when off
-      const double invd = 1.0 / sqrt(sx * sx + sy * sy + sz * sz);
+      const double invd = rsqrt64(sx * sx + sy * sy + sz * sz);
       const double hxd = sx * invd, hyd = sy * invd, hzd = sz * invd;
       const T r[3] = {(T)(hyd * (double)bz - hzd * (double)by), (T)(hzd * (double)bx - hxd * (double)bz), (T)(hxd * (double)by - hyd * (double)bx)};
       const T w0 = on ? u23[i] : T(0);
-      const T w = w0 * robust_weight<T>(prm.robust[2], (T)prm.robust_k[2], sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]));
+      const T w = w0 * robust_weight<T>(prm.robust[2], (T)prm.robust_k[2], [&]() { return sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]); });
       const T ws = (T)prm.scale[2] * w;
       const T qx = (T)sx, qy = (T)sy, qz = (T)sz, inv = (T)invd;
       const T h[3] = {(T)hxd, (T)hyd, (T)hzd};
@@ -785,7 +800,7 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
       const T qx = on ? (T)qxd : T(0), qy = on ? (T)qyd : T(0), qz = on ? (T)qzd : T(0);
       const T rx = on ? (T)(qxd - (double)cx0) : T(0), ry = on ? (T)(qyd - (double)cy0) : T(0), rz = on ? (T)(qzd - (double)cz0) : T(0);
       const T w0 = on ? unn[i] : T(0);
-      const T w = w0 * robust_weight<T>(prm.robust[3], (T)prm.robust_k[3], sqrt(rx * rx + ry * ry + rz * rz));
+      const T w = w0 * robust_weight<T>(prm.robust[3], (T)prm.robust_k[3], [&]() { return sqrt(rx * rx + ry * ry + rz * rz); });
       const T ws = (T)prm.scale[3] * w;
       // J = [0 | -[q]x] : only the rotation block:  H_ww += |q|^2 I - q q^T ,  g_w += q x r
       const T wx = ws * qx, wy = ws * qy, wz = ws * qz;
@@ -1506,9 +1521,20 @@ hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, con
   return hipGetLastError();
 }
 
+template <class T, int TERMS, int BLK>
+static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s);
 template <class T, int TERMS>
 static void joint_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s) {
-  constexpr int BLK = 512;
+  static const int env_blk = getenv("RPE_JOINT_BLOCK") ? atoi(getenv("RPE_JOINT_BLOCK")) : 0;
+  // register-heavy kernel (up to three residual kinds, 29 fp64 accumulators): frames of the 640x480 class run 20 % faster with
+  // 256-thread workgroups (one wave per SIMD, more workgroups in flight: 27.9 us vs 35.6 us at 307200), streaming sizes slightly
+  // faster with 512 (10 M: 205 us vs 217 us)
+  const int blk = env_blk == 256 || env_blk == 512 ? env_blk : (rt.block == 256 || rt.block == 512 ? rt.block : (A.n <= 2000000 ? 256 : 512));
+  if (blk == 256) joint_launch_b<T, TERMS, 256>(A, flags, pose, prm, rt, s);
+  else joint_launch_b<T, TERMS, 512>(A, flags, pose, prm, rt, s);
+}
+template <class T, int TERMS, int BLK>
+static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s) {
   const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
   hipLaunchKernelGGL((normal_eq_joint_kernel<T, TERMS, BLK>), dim3(G), dim3(BLK), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
