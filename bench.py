@@ -185,27 +185,34 @@ def main():
         collective = "none" if not dist_path else ("peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
                                                    "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
 
-        def one_step(p):
+        # The host side of the loop (launch, wait for the published record, 6x6 solve, SE(3) exp-map update) is C++ inside the
+        # library -- rpe_gn_refine / rpe_gn_steps_dist with tol = 0 run exactly k iterations -- so that the timed region contains
+        # no Python per step (a ctypes call per step costs 2-3 us of the ~18).  The torch fallback keeps its Python loop.
+        def run_steps(p, k):
+            if k <= 0:
+                return p
             if not dist_path:
-                ctx.gn_step(L.RES_P2P, p, L.USE_MASK)   # in place: kernel + publish + solve + exp-map
-                return p
+                q, its, _, _ = ctx.gn_refine([L.RES_P2P], p, None, L.USE_MASK, k, 0.0)   # k x (kernel + publish + solve + exp-map)
+                assert its == k
+                return q
             if native:
-                ctx.gn_step_dist(L.RES_P2P, p, L.USE_MASK)   # in place: kernel + RCCL all-reduce + publish + solve + exp-map
+                ctx.gn_steps_dist(L.RES_P2P, p, k, L.USE_MASK)   # k x (kernel [+ peer exchange | RCCL all-reduce + publish] + solve + exp-map)
                 return p
-            return gn.step(p)[0]
+            for _ in range(k):
+                p = gn.step(p)[0]
+            return p
 
         # untimed pre-warm, independent of --warmup: the first ~25 ms of launches after torch has initialised HIP contain a
-        # one-off ~35 ms stall (measured; runtime lazy initialisation), which must not land in a short timed region
+        # one-off ~35 ms stall (measured; runtime lazy initialisation), and the FIRST process on a freshly booted box runs its
+        # kernels ~25 % slower for about a second (measured: 16.4 us vs 12.7 us per launch; 1 s of pre-warm removes it) --
+        # neither may land in the timed region
         if dist_path:
-            for _ in range(int(os.environ.get("RPE_BENCH_PREWARM_STEPS", "6000"))):   # a FIXED count: every rank must issue the same number of collective steps
-                pose = one_step(pose)
+            pose = run_steps(pose, int(os.environ.get("RPE_BENCH_PREWARM_STEPS", "60000")))   # a FIXED count: every rank must issue the same number of collective steps
         else:
             t_pre = time.perf_counter()
-            while time.perf_counter() - t_pre < 0.25:
-                pose = one_step(pose)
-        pose = pose12(R0, t0)
-        for _ in range(args.warmup):
-            pose = one_step(pose)
+            while time.perf_counter() - t_pre < float(os.environ.get("RPE_BENCH_PREWARM_S", "1.5")):
+                pose = run_steps(pose, 500)
+        pose = run_steps(pose12(R0, t0), args.warmup)
         if args.time_every > 0:
             ctx.timing_enable(args.steps // args.time_every + 1, args.time_every)   # HIP events around every time_every-th K1 launch
         if world > 1:
@@ -213,10 +220,12 @@ def main():
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         chunk_t = []
-        for k in range(args.steps):
-            pose = one_step(pose)
-            if args.debug_chunks and (k + 1) % 250 == 0:
+        if args.debug_chunks:
+            for k in range(0, args.steps, 250):
+                pose = run_steps(pose, min(250, args.steps - k))
                 chunk_t.append(time.perf_counter())
+        else:
+            pose = run_steps(pose, args.steps)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -157,6 +157,8 @@ int rpe_comm_unique_id(void* id128);
 int rpe_comm_init(rpe_context* ctx, int world, int rank, const void* id128);
 int rpe_comm_destroy(rpe_context* ctx);
 int rpe_gn_step_dist(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
+/* `steps` such steps in one call (every rank passes the same count). */
+int rpe_gn_steps_dist(rpe_context* ctx, int kind, int flags, double* pose12, int steps, double* last_step_norm);
 /* Peer-to-peer variant of the collective for ONE node (<= 8 ranks): instead of RCCL, the normal-equation kernel's last
  * workgroup writes the 32-double record straight into a mailbox of every peer over xGMI (HIP IPC mappings, flag-in-data
  * words), waits for the peers' records in its own mailbox, adds them in rank order and publishes the sum -- the whole sharded

@@ -247,6 +247,12 @@ class Context:
         return p, it.value, step.value, cost.value, m.value
 
 
+    def gn_steps_dist(self, kind: int, pose12_inout: np.ndarray, steps: int, flags: int = 0) -> float:
+        """`steps` sharded GN steps in place, the loop inside the library; returns the last |delta|."""
+        step = C.c_double(0)
+        L.check(L.lib().rpe_gn_steps_dist(self._h, kind, flags, _p(pose12_inout), steps, C.byref(step)))
+        return step.value
+
     def comm_init(self, world: int, rank: int, id128: bytes):
         buf = (C.c_char * 128).from_buffer_copy(id128)
         L.check(L.lib().rpe_comm_init(self._h, world, rank, buf))

@@ -784,6 +784,18 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
   return RPE_OK;
 }
 
+// `steps` sharded steps in one call (the host loop stays inside the library, as rpe_gn_refine keeps it for one GPU)
+int rpe_gn_steps_dist(rpe_context* c, int kind, int flags, double* pose12, int steps, double* last_step_norm) {
+  if (steps < 0) return fail(RPE_ERR_ARG, "rpe_gn_steps_dist: negative step count");
+  double sn = 0;
+  for (int k = 0; k < steps; k++) {
+    const int rc = rpe_gn_step_dist(c, kind, flags, pose12, nullptr, &sn);
+    if (rc) return rc;
+  }
+  if (last_step_norm) *last_step_norm = sn;
+  return RPE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- K4
 static int vote_arrays(rpe_context* c, int kind) {
   switch (kind) {
