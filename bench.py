@@ -162,6 +162,7 @@ def main():
             if p2p:   # trust, but verify once against the collective library before timing anything
                 chk = pose12(R0, t0)
                 rec = np.zeros(32)
+                dist.barrier()   # ranks arrive here seconds apart (scene generation): the exchange inside the kernel only waits ~2 s
                 try:
                     L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
                     delivered = 1

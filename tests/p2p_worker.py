@@ -34,7 +34,7 @@ def main():
                 import time
                 ctx.gn_step_dist(L.RES_P2P, pose)      # step 0 together ...
                 dist.barrier()
-                time.sleep(1.0)                        # ... then this rank goes missing for longer than the time-out
+                time.sleep(4.0)                        # ... then this rank goes missing for longer than the time-out
                 out["slept"] = True
             elif mode == "device":
                 pose, its, step, cost = ctx.gn_refine_device([(L.RES_P2P, 1.0)], pose, 0, steps, 1e-10)
