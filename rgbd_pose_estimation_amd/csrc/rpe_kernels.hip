@@ -5,11 +5,14 @@
 // the design rules are (1) 16-byte vector loads of the reference's native xyz-interleaved 3 x N arrays --
 // a thread owns P consecutive correspondences (P = 4 for fp32 = three float4, P = 2 for fp64 = three
 // double2), so every byte of every 128-B line is consumed by one lane within three back-to-back loads;
-// (2) per-thread fp64 accumulators, wave64 __shfl_down tree, one LDS hop across the 4 waves of a workgroup,
-// one 256-B partial record per workgroup; (3) a single-workgroup second stage that sums the records in a
-// fixed order (deterministic, no float atomics) and expands them to the 6x6 / 6x1 normal equations;
-// (4) grids of at most a few workgroups per CU with a grid-stride loop, so a launch covers all 8 XCDs and a
-// workgroup re-reads the same slice every Gauss-Newton iteration (slice stays in its XCD's L2 when it fits).
+// (2) per-thread fp64 accumulators fed by per-group sums in the array dtype, a DPP butterfly across the 64 lanes
+// (no LDS traffic), one LDS hop across the waves of a workgroup, one 256-B partial record per workgroup;
+// (3) the second stage inside the SAME launch: write-through records, a two-level arrival count, and the last
+// workgroup sums the records in a fixed order (deterministic, no float atomics), expands them to the 6x6 / 6x1
+// normal equations and publishes them -- to HBM, to pinned host memory, to the peers' mailboxes over xGMI, or
+// straight into an in-kernel 6x6 solve + SE(3) update (reduce_and_finish);
+// (4) grids of at most a few workgroups per CU with a grid-stride, software-pipelined loop, so a launch covers
+// all 8 XCDs and a workgroup re-reads the same slice every Gauss-Newton iteration (it stays cache resident).
 #include "rpe_kernels.h"
 #include "rpe_assoc.h"
 
