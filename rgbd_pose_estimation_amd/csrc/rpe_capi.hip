@@ -114,6 +114,7 @@ struct rpe_context {
   rpe::P2PDesc* d_p2p = nullptr;
   int p2p_world = 0, p2p_rank = 0;
   unsigned long long p2p_step = 0;
+  unsigned long long p2p_vote_step = 0;   // the same for the vote counters of sharded scoring
   void* h_stage = nullptr;        // pinned staging for device -> host copies into caller (pageable) memory
   size_t h_stage_cap = 0;
   // front end (Part 3): the current depth frame's maps and the model it is registered against, all in HBM
@@ -734,7 +735,7 @@ int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
   }
   if (!c->d_p2p) HIP_TRY(hipMalloc((void**)&c->d_p2p, sizeof(rpe::P2PDesc)));
   HIP_TRY(hipMemcpy(c->d_p2p, &d, sizeof(d), hipMemcpyHostToDevice));
-  c->p2p_world = world; c->p2p_rank = rank; c->p2p_step = 0;
+  c->p2p_world = world; c->p2p_rank = rank; c->p2p_step = 0; c->p2p_vote_step = 0;
   return RPE_OK;
 }
 
@@ -845,12 +846,18 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
     stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
-    if (c->comm) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream));  // sharded correspondences
+    if (c->comm && c->p2p_world < 1) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream));  // sharded correspondences
     // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counters into pinned host memory, raises
     // a sequence word the host spins on, and clears the counters for the next launch
     const unsigned long long seq = ++c->vote_seq;
-    HIP_TRY(rpe::launch_publish_votes(c->d_votes, hb, c->h_votes, c->h_flag2, seq, c->stream));
-    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+    if (c->p2p_world >= 1) {   // sharded correspondences, one node: the read-out kernel also exchanges and sums the counters
+      HIP_TRY(rpe::launch_publish_votes_p2p(c->d_votes, hb, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream));
+      if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+      if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP, "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
+    } else {
+      HIP_TRY(rpe::launch_publish_votes(c->d_votes, hb, c->h_votes, c->h_flag2, seq, c->stream));
+      if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+    }
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
   }
   return RPE_OK;

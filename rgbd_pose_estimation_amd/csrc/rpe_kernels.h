@@ -35,7 +35,9 @@ struct GnState {
 // The tag travels WITH the data in one 8-byte store (the "LL" flag-in-data protocol), so no ordering between stores is assumed.
 constexpr int kP2PMaxWorld = 8;
 constexpr int kP2PWords = 64;                                  // 32 doubles = 64 halves
-constexpr size_t kP2PMailboxBytes = (size_t)2 * kP2PMaxWorld * kP2PWords * 8;
+constexpr size_t kP2PRecordWords = (size_t)2 * kP2PMaxWorld * kP2PWords;             // [parity][source rank][64]
+constexpr size_t kP2PVoteWords = (size_t)2 * kP2PMaxWorld * kMaxScoreH;              // [parity][source rank][hypothesis]
+constexpr size_t kP2PMailboxBytes = (kP2PRecordWords + kP2PVoteWords) * 8;           // records first, vote counters behind
 struct P2PDesc {
   int world, rank;
   unsigned long long* peer[kP2PMaxWorld];   // every rank's mailbox as mapped in THIS process; peer[rank] is the own one
@@ -75,6 +77,10 @@ hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const 
 
 // copy `count` reduced values from HBM to pinned host memory and then store `seq` to *h_flag (the host spins on it)
 hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
+// sharded scoring: exchange the `count` vote counters with the peers (same mailbox protocol as the records, one word per
+// hypothesis), add them in rank order, publish the totals, zero the counters.  *h_status is set to 1 if a peer timed out.
+hipError_t launch_publish_votes_p2p(int* d_votes, int count, const P2PDesc* p2p, unsigned long long step, int* h_dst, int* h_status,
+                                    unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 // publish the vote counters to pinned host memory, raise the sequence word, and zero the counters for the next launch_score
 hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);

@@ -1405,6 +1405,52 @@ __global__ void publish_votes_kernel(int* __restrict__ votes, int count, int* __
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// sharded variant: all-reduce(sum) of the counters across the ranks through the peers' mailboxes before publishing (one 8-byte
+// word {count | step tag} per hypothesis and source rank; rank-ordered integer sums; bounded wait like p2p_allreduce32)
+__global__ __launch_bounds__(1024) void publish_votes_p2p_kernel(int* __restrict__ votes, int count, const P2PDesc* __restrict__ desc,
+                                                                 unsigned long long step, int* __restrict__ h_dst, int* __restrict__ h_status,
+                                                                 unsigned long long* __restrict__ h_flag, unsigned long long seq) {
+  const P2PDesc& D = *desc;
+  const unsigned int tag = (unsigned int)(step % 0xFFFFFFFFull) + 1u;
+  const size_t parity = (size_t)(step & 1ull);
+  const size_t base = kP2PRecordWords + parity * kP2PMaxWorld * kMaxScoreH;
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const unsigned long long word = ((unsigned long long)tag << 32) | (unsigned int)votes[i];
+    for (int r = 0; r < D.world; r++)
+      __hip_atomic_store(D.peer[r] + base + (size_t)D.rank * kMaxScoreH + i, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const unsigned long long* box = D.peer[D.rank] + base;
+  const unsigned long long t0 = wall_clock64();
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    int total = 0;
+    for (int r = 0; r < D.world; r++) {
+      unsigned long long w;
+      for (;;) {
+        w = __hip_atomic_load(box + (size_t)r * kMaxScoreH + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned int)(w >> 32) == tag) break;
+        if (wall_clock64() - t0 > 200000000ull) { s_bad = 1; break; }
+      }
+      total += (int)(unsigned int)w;
+    }
+    __hip_atomic_store(h_dst + i, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    votes[i] = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(h_status, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_publish_votes_p2p(int* d_votes, int count, const P2PDesc* p2p, unsigned long long step, int* h_dst, int* h_status,
+                                    unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(publish_votes_p2p_kernel, dim3(1), dim3(count > 256 ? 1024 : 256), 0, s, d_votes, count, p2p, step, h_dst, h_status, h_flag, seq);
+  return hipGetLastError();
+}
 hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
   hipLaunchKernelGGL(publish_votes_kernel, dim3(1), dim3(count > 256 ? 1024 : 256), 0, s, d_votes, count, h_dst, h_flag, seq);
   return hipGetLastError();

@@ -36,6 +36,13 @@ def main():
                 dist.barrier()
                 time.sleep(4.0)                        # ... then this rank goes missing for longer than the time-out
                 out["slept"] = True
+            elif mode == "score":
+                rng = np.random.default_rng(5)
+                import oracle_lib as O
+                from util import perturbed_pose
+                poses = np.array([O.pose7_from_Rt(*perturbed_pose(rng, sc.R, sc.t, ang=0.003 * (h % 7), dt=0.01 * (h % 5)), False) for h in range(steps)])
+                out["votes"] = ctx.score(L.VOTE_33, poses, 0.1, mode=L.SCORE_EXACT).tolist()
+                out["votes2"] = ctx.score(L.VOTE_33, poses[::-1].copy(), 0.1, mode=L.SCORE_EXACT).tolist()   # a second exchange (other parity)
             elif mode == "device":
                 pose, its, step, cost = ctx.gn_refine_device([(L.RES_P2P, 1.0)], pose, 0, steps, 1e-10)
                 out["iters"] = its
@@ -44,7 +51,7 @@ def main():
                     ctx.gn_step_dist(L.RES_P2P, pose)
                     if mode == "straggler" and k == 0:
                         dist.barrier()
-            out["pose"] = pose.tolist()
+            out["pose"] = np.asarray(pose).tolist()
     except L.RpeError as e:
         out["error"] = str(e)
         out["code"] = e.code
@@ -52,6 +59,15 @@ def main():
     dist.all_gather_object(gathered, out)
     if rank == 0:
         ref = None
+        if mode == "score":
+            rng = np.random.default_rng(5)
+            import oracle_lib as O
+            from util import perturbed_pose
+            poses = np.array([O.pose7_from_Rt(*perturbed_pose(rng, sc.R, sc.t, ang=0.003 * (h % 7), dt=0.01 * (h % 5)), False) for h in range(steps)])
+            full = api.Context(0)
+            full.load(L.F32, xw=sc.Q, xc=sc.P)
+            ref = full.score(L.VOTE_33, poses, 0.1, mode=L.SCORE_EXACT).tolist()
+            full.close()
         if mode in ("steps", "device"):
             full = api.Context(0)
             full.load(L.F32, xw=sc.Q, xc=sc.P)

@@ -62,6 +62,17 @@ def test_p2p_sharded_device_resident_loop(world, n):
     assert np.abs(poses[0] - np.array(res["reference"])).max() < 1e-9
 
 
+@pytest.mark.parametrize("world,n,H", [(2, 20000, 70), (8, 100003, 3000)])
+def test_p2p_sharded_scoring_counts_are_exact(world, n, H):
+    """rpe_score after rpe_p2p_init: every rank gets the votes of the WHOLE correspondence set (integer sums, exact)."""
+    res = run_world(world, "score", n, H)
+    ranks = res["ranks"]
+    assert all(r["p2p"] and "error" not in r for r in ranks), ranks
+    for r in ranks:
+        assert r["votes"] == res["reference"]
+        assert r["votes2"] == res["reference"][::-1]
+
+
 def test_p2p_missing_peer_times_out_instead_of_hanging():
     res = run_world(2, "straggler", 20000, 3)
     r0, r1 = res["ranks"]
