@@ -716,6 +716,9 @@ int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
   if (!c || !handles || world < 1 || world > rpe::kP2PMaxWorld || rank < 0 || rank >= world) return fail(RPE_ERR_ARG, "rpe_p2p_init: bad argument (1 <= world <= 8)");
   if (!c->p2p_box) return fail(RPE_ERR_STATE, "rpe_p2p_export first");
   HIP_TRY(hipSetDevice(c->device));
+  for (int r = 0; r < rpe::kP2PMaxWorld; r++)   // a second init: drop the mappings of the first
+    if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]); c->p2p_peer[r] = nullptr; }
+  c->p2p_world = 0;
   rpe::P2PDesc d;
   d.world = world; d.rank = rank;
   for (int r = 0; r < rpe::kP2PMaxWorld; r++) d.peer[r] = nullptr;
