@@ -296,3 +296,33 @@ def test_nl_round_record_vs_numpy(gpu_ctx_factory, n, f64, weighted):
     # rounding, fp32 arrays to the per-term fp32 rounding, which averages out over the sum (relative to the largest entry)
     tol = 1e-11 * max(1.0, np.sqrt(n)) if f64 else 4e-7
     assert np.abs(got - ref).max() <= tol * scale
+
+
+def test_bind_zero_copy_device_buffers():
+    """rpe_bind: arrays that already live in HBM (here: torch tensors) are consumed in place, on the caller's stream; a misaligned
+    pointer is refused (RPE_ERR_ALIGN); rpe_download reads an array back."""
+    import torch
+    sc = util.scene33(5, 10000, np.float32)
+    stream = torch.cuda.Stream(device=0)
+    with torch.cuda.stream(stream):
+        xw = torch.from_numpy(np.ascontiguousarray(sc.Q)).to("cuda:0")
+        xc = torch.from_numpy(np.ascontiguousarray(sc.P)).to("cuda:0")
+        stream.synchronize()
+        ctx = api.Context(0, stream.cuda_stream)
+        ctx.set_problem(len(sc.Q), L.F32)
+        ctx.bind(L.XW, xw.data_ptr())
+        ctx.bind(L.XC, xc.data_ptr())
+        p = api.pose12(sc.R, sc.t)
+        got, _ = ctx.normal_eq(L.RES_P2P, p)
+        ref_ctx = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P)
+        want, _ = ref_ctx.normal_eq(L.RES_P2P, p)
+        assert np.array_equal(got, want)                       # same kernel, same geometry, same bytes -> same bits
+        assert np.array_equal(ctx.download(L.XC), sc.P)
+        xc.mul_(0.5)                                           # the context sees the caller's buffer, not a copy
+        stream.synchronize()
+        got2, _ = ctx.normal_eq(L.RES_P2P, p)
+        assert not np.array_equal(got2, want)
+        with pytest.raises(L.RpeError) as e:
+            ctx.bind(L.XW, xw.data_ptr() + 4)
+        assert e.value.code == L.RPE_ERR_ALIGN
+        ctx.close(); ref_ctx.close()
