@@ -326,3 +326,31 @@ def test_bind_zero_copy_device_buffers():
             ctx.bind(L.XW, xw.data_ptr() + 4)
         assert e.value.code == L.RPE_ERR_ALIGN
         ctx.close(); ref_ctx.close()
+
+
+def test_rccl_communicator_one_rank_and_timing_hooks():
+    """The library-owned RCCL path (rpe_comm_*) with a single rank: the sharded step must equal the plain step bit for bit (an
+    all-reduce over one rank is the identity); and the HIP-event timing hooks bench.py reads."""
+    sc = util.scene33(6, 50000, np.float32)
+    ctx = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P)
+    ctx.comm_init(1, 0, api.comm_unique_id())
+    p1, p2 = api.pose12(np.eye(3), np.zeros(3)), api.pose12(np.eye(3), np.zeros(3))
+    ref = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P)
+    for _ in range(5):
+        s1 = ctx.gn_step_dist(L.RES_P2P, p1)
+        s2 = ref.gn_step(L.RES_P2P, p2)
+        assert s1 == s2
+    assert np.array_equal(p1, p2)
+    assert ctx.gn_steps_dist(L.RES_P2P, p1, 3) >= 0.0
+    v = ctx.score(L.VOTE_33, np.array([api.pose7_from_Rt(sc.R, sc.t, L.F32)]), 0.2)     # votes all-reduced over the one rank
+    assert v[0] == ref.score(L.VOTE_33, np.array([api.pose7_from_Rt(sc.R, sc.t, L.F32)]), 0.2)[0]
+    ctx.comm_destroy()
+    ctx.timing_enable(10, 2)
+    for _ in range(10):
+        ctx.normal_eq(L.RES_P2P, p1)
+    cnt, tot, mn = ctx.timing_collect()
+    assert cnt == 5 and 0 < mn <= tot / cnt < 1.0           # every 2nd launch timed; a launch takes well under a millisecond
+    avg, mn2 = ctx.timing_calibrate(20)
+    assert 0 <= mn2 <= avg < 0.1
+    ctx.timing_enable(0, 1)
+    ctx.close(); ref.close()
