@@ -78,7 +78,21 @@ def cpu_baseline(sc, seconds: float):
         threads = max(1, min(64, (os.cpu_count() or 1)))
         lib.orc_time_gn_p2p_threads.restype = C.c_double
         ga = lib.orc_time_gn_p2p_threads(p(xw), p(xc), C.c_long(n), 200, p(pose), p(out), threads) / 200
-        return {"value": n * reps / spent, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port",
+        # the reference's own default build has no optimisation flag at all (CMakeLists.txt:13-15): the same port compiled that way
+        o0 = None
+        try:
+            o0_path = os.path.join(ROOT, "oracle", "liboracle_O0.so")
+            if os.path.exists(o0_path):
+                lib0 = C.CDLL(o0_path)
+                lib0.orc_time_ao.restype = C.c_double
+                lib0.orc_time_ao(p(xw), p(xc), n, 1, p(R), p(t))
+                r0, s0 = 0, 0.0
+                while s0 < min(2.0, seconds):
+                    s0 += lib0.orc_time_ao(p(xw), p(xc), n, 5, p(R), p(t)); r0 += 5
+                o0 = n * r0 / s0
+        except Exception:
+            o0 = None
+        return {"value": n * reps / spent, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "no_O_flag_value": o0,
                 "sample": f"{reps} calls of the oracle's shinji_ls2<float> (AOOnlyPoseAdapter virtual getters, gather + centroid + covariance "
                           f"passes + 3x3 SVD = Library.cpp ao()) on the same {n}-correspondence scene, g++ -O2, 1 thread, {spent:.1f} s",
                 "gn_pass_fp64_value": n / g, "gn_pass_fp64_all_cores": {"value": n / ga, "threads": threads}, "host_cpus": os.cpu_count()}
