@@ -134,3 +134,37 @@ def test_reduction_is_bit_reproducible_across_geometries(gpu_ctx_factory):
     assert all(np.array_equal(recs[0], r) for r in recs[1:])
     ms = [ctx.p2p_moments() for _ in range(20)]
     assert all(np.array_equal(ms[0], m) for m in ms[1:])
+
+
+@pytest.mark.parametrize("n", [307200, 1000003])
+def test_cross_workgroup_handoff_soak(gpu_ctx_factory, n):
+    """The fence-free hand-off between workgroups (write-through records, arrival counts, last workgroup sums) must never drop or
+    tear a record: tens of thousands of launches of every reduction kernel at a fixed input give bitwise the same record each time."""
+    sc = util.scene_full(3, n, np.float32, nan_frac=0.02)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    p = api.pose12(*util.perturbed_pose(np.random.default_rng(1), sc.R, sc.t, ang=0.01, dt=0.02))
+    q7 = api.pose7_from_Rt(sc.R, sc.t, L.F32)
+    ctx.inlier_mask(L.VOTE_NN_33_23, q7, 0.2, 0.9999, 0.995)
+    lib, h = L.lib(), ctx._h
+    import ctypes as C
+    pp = p.ctypes.data_as(C.c_void_p)
+    def repeat(call, first, reps):
+        out = np.zeros_like(first)
+        op = out.ctypes.data_as(C.c_void_p)
+        for k in range(reps):
+            L.check(call(op))
+            assert np.array_equal(out, first), k
+    reps = 20000 if n <= 307200 else 4000
+    for kind in (L.RES_P2P, L.RES_P2PLANE, L.RES_BEARING):
+        first, _ = ctx.normal_eq(kind, p, L.USE_MASK)
+        repeat(lambda op, kind=kind: lib.rpe_normal_eq(h, kind, L.USE_MASK, pp, op), first, reps)
+    m0 = ctx.p2p_moments(L.USE_MASK | L.SKIP_INVALID)
+    repeat(lambda op: lib.rpe_p2p_moments(h, L.USE_MASK | L.SKIP_INVALID, op), m0, reps)
+    terms = [(L.RES_P2PLANE, 1.0), (L.RES_BEARING, 0.5), (L.RES_NORMAL, 2.0)]
+    j0 = ctx.normal_eq_joint(terms, p, L.USE_MASK)
+    arr = ctx._terms(terms)
+    repeat(lambda op: lib.rpe_normal_eq_joint(h, len(arr), arr, L.USE_MASK, pp, op), j0, reps // 2)
+    a3 = [np.ascontiguousarray(x, np.float64) for x in (-sc.R.T @ sc.t, np.asarray(sc.Q, np.float64).mean(0), np.nanmean(np.asarray(sc.P, np.float64), 0), sc.R.T)]
+    n0 = ctx.nl_round(*a3)
+    ptr = [x.ctypes.data_as(C.c_void_p) for x in a3]
+    repeat(lambda op: lib.rpe_nl_round(h, ptr[0], ptr[1], ptr[2], ptr[3], op), n0, reps // 2)
