@@ -43,6 +43,18 @@ def main():
                 poses = np.array([O.pose7_from_Rt(*perturbed_pose(rng, sc.R, sc.t, ang=0.003 * (h % 7), dt=0.01 * (h % 5)), False) for h in range(steps)])
                 out["votes"] = ctx.score(L.VOTE_33, poses, 0.1, mode=L.SCORE_EXACT).tolist()
                 out["votes2"] = ctx.score(L.VOTE_33, poses[::-1].copy(), 0.1, mode=L.SCORE_EXACT).tolist()   # a second exchange (other parity)
+            elif mode == "soak":   # the exchanged record must be bitwise the same at every one of `steps` steps from a fixed pose
+                import ctypes as C
+                rec, first = np.zeros(32), None
+                bad = 0
+                for k in range(steps):
+                    q = pose.copy()
+                    L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, 0, q.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
+                    if first is None:
+                        first = rec.copy()
+                    bad += int(not np.array_equal(rec, first))
+                out["bad"] = bad
+                out["record"] = first.tolist()
             elif mode == "device":
                 pose, its, step, cost = ctx.gn_refine_device([(L.RES_P2P, 1.0)], pose, 0, steps, 1e-10)
                 out["iters"] = its

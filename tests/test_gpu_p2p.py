@@ -73,6 +73,17 @@ def test_p2p_sharded_scoring_counts_are_exact(world, n, H):
         assert r["votes2"] == res["reference"][::-1]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchange_soak(world):
+    """20 000 exchanges from a fixed pose: every rank sees bitwise the same record every time, and the same as its peers."""
+    res = run_world(world, "soak", 40000, 20000)
+    ranks = res["ranks"]
+    assert all(r["p2p"] and "error" not in r for r in ranks), [{k: v for k, v in r.items() if k != "record"} for r in ranks]
+    assert all(r["bad"] == 0 for r in ranks)
+    for r in ranks[1:]:
+        assert r["record"] == ranks[0]["record"]
+
+
 def test_p2p_missing_peer_times_out_instead_of_hanging():
     res = run_world(2, "straggler", 20000, 3)
     r0, r1 = res["ranks"]
