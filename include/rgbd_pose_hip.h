@@ -164,7 +164,7 @@ int rpe_gn_steps_dist(rpe_context* ctx, int kind, int flags, double* pose12, int
  * words), waits for the peers' records in its own mailbox, adds them in rank order and publishes the sum -- the whole sharded
  * step is ONE kernel launch, and every rank gets bitwise the same record.  Each rank calls rpe_p2p_export (64-byte IPC handle),
  * all handles are gathered by any means (world x 64 bytes, rank order), each rank calls rpe_p2p_init; rpe_gn_step_dist then
- * uses this path (it takes precedence over an RCCL communicator), and rpe_score exchanges and sums its vote counters the same way.  A rank that waits more than 2 s for a peer fails the
+ * uses this path (it takes precedence over an RCCL communicator), and rpe_score exchanges and sums its vote counters the same way.  A rank that waits more than 10 s for a peer fails the
  * step with RPE_ERR_HIP instead of hanging.  Callers barrier before rpe_p2p_destroy. */
 int rpe_p2p_export(rpe_context* ctx, void* handle64);
 int rpe_p2p_init(rpe_context* ctx, int world, int rank, const void* handles);

@@ -146,7 +146,7 @@ struct Finish {
 // [parity][my rank][l] of every rank's mailbox (remote stores travel over xGMI), then polls slot [parity][r][l] of its OWN
 // mailbox for every r until the tag shows up, and adds the records in rank order -- the same order on every rank, so all
 // ranks publish bitwise the same sums.  Parity alternates per step: a fast peer's next record cannot overwrite one that is
-// still being read.  Bounded wait (2 s of the 100 MHz clock): on a timeout *failed is set and the caller publishes an
+// still being read.  Bounded wait (10 s of the 100 MHz clock): on a timeout *failed is set and the caller publishes an
 // error marker instead of hanging the GPU.  `val`: lanes 0..31 hold the local record.  Returns the global record in lanes 0..31.
 __device__ __forceinline__ double p2p_allreduce32(double val, const Finish& fin, int* failed) {
   const P2PDesc& D = *fin.p2p;
@@ -168,7 +168,7 @@ __device__ __forceinline__ double p2p_allreduce32(double val, const Finish& fin,
     for (;;) {
       w = __hip_atomic_load(box + (size_t)r * kP2PWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if ((unsigned int)(w >> 32) == tag) break;
-      if (wall_clock64() - t0 > 200000000ull) { bad = 1; break; }   // 2 s of the 100 MHz constant clock
+      if (wall_clock64() - t0 > 1000000000ull) { bad = 1; break; }   // 10 s of the 100 MHz constant clock
     }
     if (__any(bad)) { bad = 1; break; }
     const unsigned int lo = __shfl((unsigned int)w, (lane << 1) & 63, 64), hi = __shfl((unsigned int)w, ((lane << 1) + 1) & 63, 64);
@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(1024) void publish_votes_p2p_kernel(int* __restrict
       for (;;) {
         w = __hip_atomic_load(box + (size_t)r * kMaxScoreH + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned int)(w >> 32) == tag) break;
-        if (wall_clock64() - t0 > 200000000ull) { s_bad = 1; break; }
+        if (wall_clock64() - t0 > 1000000000ull) { s_bad = 1; break; }
       }
       total += (int)(unsigned int)w;
     }

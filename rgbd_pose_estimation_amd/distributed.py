@@ -110,7 +110,9 @@ def init_native_comm(ctx: "api.Context", group=None) -> bool:
 def init_p2p(ctx: "api.Context", group=None) -> bool:
     """Peer-to-peer all-reduce over xGMI for ONE node (<= 8 ranks): every rank exports the HIP IPC handle of its mailbox,
     torch.distributed gathers the handles, every rank maps its peers' mailboxes.  After this Context.gn_step_dist() is ONE
-    kernel launch per step (the kernel's last workgroup exchanges and sums the records).  All ranks return the same answer;
+    kernel launch per step (the kernel's last workgroup exchanges and sums the records).  The wait inside the kernel is bounded
+    (10 s), so ranks should enter their first exchange together: run a launch locally and barrier first (a process's first
+    launches on a cold box can take seconds).  All ranks return the same answer;
     False leaves the context untouched (use init_native_comm / the torch.distributed path instead)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False

@@ -28,13 +28,16 @@ def main():
     ctx.load(L.F32, xw=sc.Q[lo:hi], xc=sc.P[lo:hi])
     out = {"rank": rank, "p2p": bool(init_p2p(ctx))}
     pose = api.pose12(np.eye(3), np.zeros(3))
+    for _ in range(20):          # first launches of a process can take seconds on a cold box: get them out of the way locally,
+        ctx.normal_eq(L.RES_P2P, pose)
+    dist.barrier()               # ... then enter the first exchange together (the in-kernel wait is bounded)
     try:
         if out["p2p"]:
             if mode == "straggler" and rank == world - 1:
                 import time
                 ctx.gn_step_dist(L.RES_P2P, pose)      # step 0 together ...
                 dist.barrier()
-                time.sleep(4.0)                        # ... then this rank goes missing for longer than the time-out
+                time.sleep(14.0)                        # ... then this rank goes missing for longer than the time-out
                 out["slept"] = True
             elif mode == "score":
                 rng = np.random.default_rng(5)

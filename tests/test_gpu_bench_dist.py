@@ -9,7 +9,12 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+# Several processes share the ONE GPU of the test box here and wait for each other inside kernels.  That works (these tests pass
+# routinely, see profiles/), but it depends on the driver scheduling the processes' queues concurrently, and a rank killed in the
+# middle of an exchange once left the box's GPU unusable for minutes.  The round-end sequence on a single box is tests -> smoke ->
+# bench, so these tests run only on request: RPE_TEST_MULTIPROC=1 (scripts/collect_evidence.sh sets it, after the measurements).
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1",
+                                                  reason="multi-process-on-one-GPU tests run with RPE_TEST_MULTIPROC=1")]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -20,17 +25,23 @@ def test_bench_two_ranks_one_gpu():
     for r in range(2):
         # both ranks on cuda:0: LOCAL_RANK = 0 for both (bench.py reads the device from LOCAL_RANK)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_COLLECTIVE=collective, RPE_BENCH_PREWARM_STEPS="300", RPE_BENCH_BACKEND="gloo")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_COLLECTIVE=collective, RPE_BENCH_PREWARM_STEPS="300", RPE_BENCH_BACKEND="gloo",
+                   RPE_BENCH_STRICT_COLLECTIVE="1")   # two ranks on one device: neither RCCL nor a gloo all-reduce of device tensors can take over
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "300", "--warmup", "30",
                                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
+    import time
+    deadline = time.time() + 600          # a cold box pages the image in: the first import of torch alone can take minutes
+    timed_out = False
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=280))
+            outs.append(p.communicate(timeout=max(1.0, deadline - time.time())))
         except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.fail("bench ranks timed out")
+            timed_out = True
+            p.kill()
+            outs.append(p.communicate())
+    if timed_out:
+        pytest.fail("bench ranks timed out:\n" + "\n".join((o or "")[-600:] + (e or "")[-1500:] for o, e in outs))
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-800:] + e[-1500:] for o, e in outs)
     line = outs[0][0].strip().splitlines()[-1]
     j = json.loads(line)

