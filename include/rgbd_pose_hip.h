@@ -206,6 +206,14 @@ enum { RPE_SCORE_FAST = 0, RPE_SCORE_EXACT = 1 };
  * votes_out[H]: total votes per hypothesis (sum over the modalities of `kind`). */
 int rpe_score(rpe_context* ctx, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl,
               int* votes_out);
+/* One batch of `iters` 3D-3D RANSAC iterations entirely on the device: per iteration a thread draws the 3-point sample from the
+ * PCG32 stream (rng_state, rng_inc: rpe::Rand31's state, Utility.hpp) at its own position (3 draws per iteration, skip-ahead), runs
+ * the closed-form fit shinji() (AbsoluteOrientation.hpp:47-99) on the resident arrays, and the batch is scored by K4 without the
+ * poses ever leaving HBM.  Bitwise the hypotheses, in the order, the host sampler + solver would have produced (same functions,
+ * no FMA contraction).  votes_out[iters]; q7_out[iters x 7] = qw qx qy qz tx ty tz holding Tp values; valid_out[i] = 0 where the
+ * sample hit an invalid (all-NaN) camera point and the reference skips the iteration.  The caller advances its stream by 3*iters. */
+int rpe_ransac33_batch(rpe_context* ctx, uint64_t rng_state, uint64_t rng_inc, int iters, int mode, double thre_3d, int* votes_out,
+                       double* q7_out, unsigned char* valid_out);
 /* K4b: write the winner's inlier masks into the context's device masks (all modalities of `kind`; others
  * untouched) -- what setInlier() stores; returns the vote total. */
 int rpe_inlier_mask(rpe_context* ctx, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,

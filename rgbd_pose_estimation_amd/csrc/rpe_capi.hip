@@ -279,7 +279,7 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_pose, 16 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_state, sizeof(rpe::GnState));
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
-  if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);   // staging for pose uploads; also written directly by the hypothesis generator
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
   if (e == hipSuccess) e = hipMemset(c->d_votes, 0, (size_t)rpe::kMaxScoreH * sizeof(int));   // the scoring kernels accumulate into zeroed counters
   // pinned + device-mapped: the vote read-out kernel stores straight into it; the sequence word sits behind the counters
@@ -862,6 +862,38 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
     }
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
+  }
+  return RPE_OK;
+}
+
+// Device-side generation + scoring of one batch of 3D-3D RANSAC iterations (the vote loop V1/V2 with its hypothesis generator H1)
+int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int iters, int mode, double thre_3d, int* votes_out,
+                       double* q7_out, unsigned char* valid_out) {
+  int rc = need_arrays(c, {RPE_XW, RPE_XC});
+  if (rc) return rc;
+  if (!votes_out || !q7_out || !valid_out || iters < 1 || iters > rpe::kMaxScoreH) return fail(RPE_ERR_ARG, "rpe_ransac33_batch: bad argument (1 <= iters <= %d)", rpe::kMaxScoreH);
+  if (c->n < 3) return fail(RPE_ERR_ARG, "rpe_ransac33_batch: fewer than 3 correspondences");
+  HIP_TRY(hipSetDevice(c->device));
+  const int exact = mode == RPE_SCORE_EXACT;
+  double thr[3];
+  stage_thresholds(c->dtype, exact, thre_3d, 2.0, 2.0, thr);
+  HIP_TRY(rpe::launch_gen_shinji(c->arrays(), rng_state, rng_inc, iters, exact, c->d_poses, c->h_poses, c->stream));
+  HIP_TRY(rpe::launch_score(c->arrays(), RPE_VOTE_33, exact, c->d_poses, iters, thr, c->d_votes, c->score_blocks, c->stream));
+  if (c->comm && c->p2p_world < 1) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)iters, ncclInt32, ncclSum, c->comm, c->stream));
+  const unsigned long long seq = ++c->vote_seq;
+  if (c->p2p_world >= 1) {
+    HIP_TRY(rpe::launch_publish_votes_p2p(c->d_votes, iters, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream));
+    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+    if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP, "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
+  } else {
+    HIP_TRY(rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream));
+    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+  }
+  std::memcpy(votes_out, c->h_votes, (size_t)iters * sizeof(int));
+  // the generator stored the hypotheses into pinned host memory before the scoring kernel ran (same stream): they are complete
+  for (int i = 0; i < iters; i++) {
+    if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }
+    else { const float* h = (const float*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0f; }
   }
   return RPE_OK;
 }

@@ -85,6 +85,12 @@ hipError_t launch_publish_votes_p2p(int* d_votes, int count, const P2PDesc* p2p,
 hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 
+// ---- batched hypothesis generation (rpe_hypotheses.hip): `iters` RANSAC iterations of the 3-point closed form, sampled from the
+// PCG32 stream (state, inc) exactly as the host sampler would; poses to d_poses in the scoring layout of `exact`, and to
+// h_q7 (pinned, 8 values of the array dtype per iteration: qw qx qy qz tx ty tz valid) for the host's replay
+hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
+                             void* h_q7, hipStream_t s);
+
 // ---- front end (rpe_frontend.hip): depth frame -> maps -> projective association; fp32 throughout
 struct Camera { float fx, fy, cx, cy; int width, height; };
 struct PoseF { float R[9]; float t[3]; };   // Xc = R Xw + t, R row-major

@@ -100,7 +100,10 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
     out.push_back(shinji<Tp>(Xw, Xc, K));
   };
   auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
-  ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+  // plain RANSAC consumes exactly K draws per iteration, so every iteration's position in the random stream is known up front and
+  // the whole iteration can run on the device; PROSAC's sampler rejects duplicates (a variable number of draws) and stays on the host
+  if (!prosac && Settings::get().device_hypotheses && N >= K) ransac_engine_device33<Tp>(adapter, spec, commit, Iter, confidence, /*mask_cols=*/2);
+  else ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   adapter.cvtInlier();
 }
 }  // namespace rpe

@@ -43,10 +43,11 @@ template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
 }
 
 // Adapter: any pose adapter (setMaxVotes/getMaxVotes/setRcw/sett/device()).
-// gen(out): advance the sampler by ONE reference iteration and append its 0..3 hypotheses, in the reference's order.
+// produce(iters, hyps, first, votes): advance the sampler by `iters` reference iterations; hyps = their 0..3 hypotheses each, in the
+//   reference's order; first[i] .. first[i+1] = the hypotheses of iteration i (first.size() == iters + 1); votes[h] = score of hyps[h].
 // commit(cols, device_cols): the winner's masks are on the device; the adapter adopts them (setInlierFromDevice).
-template <class Tp, class Adapter, class Gen, class Commit>
-void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+template <class Tp, class Adapter, class Produce, class Commit>
+void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce produce, Commit commit, int& Iter, Tp confidence, int mask_cols) {
   const int N = adapter.getNumberCorrespondences();
   Settings& cfg = Settings::get();
   const bool prof = cfg.profile;
@@ -60,23 +61,14 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
   int batch = std::max(1, cfg.first_batch);
   std::vector<SE3<Tp> > hyps;
   std::vector<int> first;   // first[i] = index into hyps of iteration (it + i)'s first hypothesis
-  std::vector<double> q7;
   std::vector<int> votes;
   while (it < Iter) {
     const int iters = std::min(batch, Iter - it);
-    hyps.clear(); first.assign(1, 0);
+    hyps.clear(); first.clear(); votes.clear();
     if (prof) tp = now_us();
-    for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
-    lap(cfg.prof.generate);
-    if (prof) { cfg.prof.hypotheses += (int)hyps.size(); cfg.prof.batches++; }
-    if (!hyps.empty()) {
-      q7.resize(hyps.size() * 7);
-      for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
-      votes.resize(hyps.size());
-      check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
-                      (double)spec.cos_nl, votes.data()), "rpe_score");
-    }
+    produce(iters, hyps, first, votes);
     lap(cfg.prof.score);
+    if (prof) { cfg.prof.hypotheses += (int)hyps.size(); cfg.prof.batches++; }
     // sequential replay
     for (int i = 0; i < iters && it + i < Iter; i++) {
       for (int h = first[i]; h < first[i + 1]; h++) {
@@ -114,6 +106,61 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
 
     lap(cfg.prof.mask);
   }
+}
+
+// gen(out): advance the sampler by ONE reference iteration and append its 0..3 hypotheses, in the reference's order (host-side
+// minimal solvers); the batch is scored by rpe_score (kernel K4).
+template <class Tp, class Adapter, class Gen, class Commit>
+void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+  Settings& cfg = Settings::get();
+  rpe_context* ctx = adapter.device().ctx();
+  std::vector<double> q7;
+  auto produce = [&](int iters, std::vector<SE3<Tp> >& hyps, std::vector<int>& first, std::vector<int>& votes) {
+    const double t0 = cfg.profile ? now_us() : 0;
+    first.assign(1, 0);
+    for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
+    if (cfg.profile) { const double t1 = now_us(); cfg.prof.generate += t1 - t0; cfg.prof.score -= t1 - t0; }   // the caller books the whole call as "score"
+    if (hyps.empty()) return;
+    q7.resize(hyps.size() * 7);
+    for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
+    votes.resize(hyps.size());
+    check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+                    (double)spec.cos_nl, votes.data()), "rpe_score");
+  };
+  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
+}
+
+// The 3D-3D solvers (shinji_ransac / shinji_ransac2): sampling, the 3-point fit and the scoring all run on the device
+// (rpe_ransac33_batch); the hypotheses are bitwise the ones the host generator above would produce from the same random stream,
+// which is advanced here by the K draws per iteration the host sampler would have consumed.
+template <class Tp, class Adapter, class Commit>
+void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+  Settings& cfg = Settings::get();
+  rpe_context* ctx = adapter.device().ctx();
+  std::vector<double> q7;
+  std::vector<unsigned char> valid;
+  std::vector<int> all_votes;
+  auto produce = [&](int iters, std::vector<SE3<Tp> >& hyps, std::vector<int>& first, std::vector<int>& votes) {
+    Rand31& g = global_rng();
+    q7.resize((size_t)iters * 7); valid.resize((size_t)iters); all_votes.resize((size_t)iters);
+    first.assign(1, 0);
+    for (int done = 0; done < iters;) {   // the device call takes at most kMaxScoreH iterations at a time
+      const int chunk = std::min(iters - done, 8192);
+      check(rpe_ransac33_batch(ctx, g.state(), g.inc(), chunk, cfg.score_mode, (double)spec.thre_3d, all_votes.data() + done,
+                               q7.data() + 7 * (size_t)done, valid.data() + done), "rpe_ransac33_batch");
+      g.advance((uint64_t)spec.model_points * (uint64_t)chunk);
+      done += chunk;
+    }
+    for (int i = 0; i < iters; i++) {
+      if (valid[(size_t)i]) {
+        const double* q = &q7[7 * (size_t)i];
+        hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]), Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
+        votes.push_back(all_votes[(size_t)i]);
+      }
+      first.push_back((int)hyps.size());
+    }
+  };
+  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
 }
 
 }  // namespace rpe

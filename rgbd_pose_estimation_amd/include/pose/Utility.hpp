@@ -26,6 +26,19 @@ class Rand31 {
     step(); _state += seed; step();
   }
   int operator()() { return (int)(step() >> 1); }  // uniform in [0, 2^31)
+  // for samplers that run on the device from this stream's current position (one draw = one LCG step)
+  uint64_t state() const { return _state; }
+  uint64_t inc() const { return _inc; }
+  void advance(uint64_t draws) {   // skip `draws` draws in O(log draws)
+    uint64_t cur_mult = 6364136223846793005ULL, cur_plus = _inc, acc_mult = 1, acc_plus = 0;
+    while (draws > 0) {
+      if (draws & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+      cur_plus = (cur_mult + 1) * cur_plus;
+      cur_mult *= cur_mult;
+      draws >>= 1;
+    }
+    _state = acc_mult * _state + acc_plus;
+  }
  private:
   uint32_t step() {
     const uint64_t old = _state;

@@ -3,6 +3,7 @@
 // There is no CPU path behind these calls: a failing status throws rpe::DeviceError (no fallback, no silent retry).
 #pragma once
 #include <chrono>
+#include <cstdlib>
 #include <cstdint>
 #include <mutex>
 #include <stdexcept>
@@ -34,6 +35,9 @@ struct Settings {
   EngineProfile prof;
   int score_mode = RPE_SCORE_FAST;     // RPE_SCORE_EXACT reproduces the CPU path's votes bit for bit
   int first_batch = 64, max_batch = 2048;  // RANSAC hypotheses scored per launch (grows geometrically)
+  // 3D-3D RANSAC (shinji_ransac / shinji_ransac2): sample + 3-point fit on the device too (rpe_ransac33_batch), bitwise the host's
+  // hypotheses; false = host generation (RPE_HOST_HYPOTHESES=1 sets that default)
+  bool device_hypotheses = std::getenv("RPE_HOST_HYPOTHESES") == nullptr;
   static Settings& get() { static Settings s; return s; }
 };
 

@@ -22,47 +22,47 @@ namespace rpe {
 
 struct Vec3d {
   double v[3];
-  Vec3d() : v{0, 0, 0} {}
-  Vec3d(double a, double b, double c) : v{a, b, c} {}
-  double& operator[](int i) { return v[i]; }
-  double operator[](int i) const { return v[i]; }
+  RPE_HD Vec3d() : v{0, 0, 0} {}
+  RPE_HD Vec3d(double a, double b, double c) : v{a, b, c} {}
+  RPE_HD double& operator[](int i) { return v[i]; }
+  RPE_HD double operator[](int i) const { return v[i]; }
 };
-inline Vec3d operator+(const Vec3d& a, const Vec3d& b) { return Vec3d(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
-inline Vec3d operator-(const Vec3d& a, const Vec3d& b) { return Vec3d(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
-inline Vec3d operator*(double s, const Vec3d& a) { return Vec3d(s * a[0], s * a[1], s * a[2]); }
-inline double dot3(const Vec3d& a, const Vec3d& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-inline Vec3d cross3(const Vec3d& a, const Vec3d& b) {
+RPE_HD inline Vec3d operator+(const Vec3d& a, const Vec3d& b) { return Vec3d(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+RPE_HD inline Vec3d operator-(const Vec3d& a, const Vec3d& b) { return Vec3d(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+RPE_HD inline Vec3d operator*(double s, const Vec3d& a) { return Vec3d(s * a[0], s * a[1], s * a[2]); }
+RPE_HD inline double dot3(const Vec3d& a, const Vec3d& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+RPE_HD inline Vec3d cross3(const Vec3d& a, const Vec3d& b) {
   return Vec3d(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
 }
-inline double norm3(const Vec3d& a) { return std::sqrt(dot3(a, a)); }
+RPE_HD inline double norm3(const Vec3d& a) { return std::sqrt(dot3(a, a)); }
 
 // row-major 3x3
 struct Mat3d {
   double a[9];
-  Mat3d() { std::memset(a, 0, sizeof(a)); }
-  static Mat3d eye() { Mat3d m; m.a[0] = m.a[4] = m.a[8] = 1.0; return m; }
-  double& operator()(int r, int c) { return a[3 * r + c]; }
-  double operator()(int r, int c) const { return a[3 * r + c]; }
-  Vec3d col(int c) const { return Vec3d(a[c], a[3 + c], a[6 + c]); }
-  void setcol(int c, const Vec3d& v) { a[c] = v[0]; a[3 + c] = v[1]; a[6 + c] = v[2]; }
+  RPE_HD Mat3d() { for (int i = 0; i < 9; i++) a[i] = 0.0; }
+  RPE_HD static Mat3d eye() { Mat3d m; m.a[0] = m.a[4] = m.a[8] = 1.0; return m; }
+  RPE_HD double& operator()(int r, int c) { return a[3 * r + c]; }
+  RPE_HD double operator()(int r, int c) const { return a[3 * r + c]; }
+  RPE_HD Vec3d col(int c) const { return Vec3d(a[c], a[3 + c], a[6 + c]); }
+  RPE_HD void setcol(int c, const Vec3d& v) { a[c] = v[0]; a[3 + c] = v[1]; a[6 + c] = v[2]; }
 };
-inline Mat3d mul(const Mat3d& x, const Mat3d& y) {
+RPE_HD inline Mat3d mul(const Mat3d& x, const Mat3d& y) {
   Mat3d r;
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = x(i, 0) * y(0, j) + x(i, 1) * y(1, j) + x(i, 2) * y(2, j);
   return r;
 }
-inline Vec3d mul(const Mat3d& x, const Vec3d& v) {
+RPE_HD inline Vec3d mul(const Mat3d& x, const Vec3d& v) {
   return Vec3d(x(0, 0) * v[0] + x(0, 1) * v[1] + x(0, 2) * v[2], x(1, 0) * v[0] + x(1, 1) * v[1] + x(1, 2) * v[2],
                x(2, 0) * v[0] + x(2, 1) * v[1] + x(2, 2) * v[2]);
 }
-inline Mat3d transposed(const Mat3d& x) { Mat3d r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = x(j, i); return r; }
-inline double det3(const Mat3d& m) {
+RPE_HD inline Mat3d transposed(const Mat3d& x) { Mat3d r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = x(j, i); return r; }
+RPE_HD inline double det3(const Mat3d& m) {
   return m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
          m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
 }
 
 // Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations: S = V diag(l) V^T.
-inline void sym_eig3(const Mat3d& S_in, Mat3d* V, double l[3]) {
+RPE_HD inline void sym_eig3(const Mat3d& S_in, Mat3d* V, double l[3]) {
   Mat3d S = S_in;
   *V = Mat3d::eye();
   for (int sweep = 0; sweep < 64; sweep++) {
@@ -93,11 +93,16 @@ inline void sym_eig3(const Mat3d& S_in, Mat3d* V, double l[3]) {
 
 // A = U diag(s) V^T, s descending, U and V orthogonal (completed when A is rank deficient).
 struct Svd3 { Mat3d U, V; double s[3]; };
-inline Svd3 svd3(const Mat3d& A) {
+RPE_HD inline Svd3 svd3(const Mat3d& A) {
   Mat3d W; double l[3];
   sym_eig3(mul(transposed(A), A), &W, l);
   int ord[3] = {0, 1, 2};
-  std::sort(ord, ord + 3, [&](int i, int j) { return l[i] > l[j]; });
+  for (int i = 1; i < 3; i++) {   // insertion sort, descending, stable: what std::sort does for 3 elements, usable on the device
+    const int o = ord[i];
+    int j = i;
+    while (j > 0 && l[o] > l[ord[j - 1]]) { ord[j] = ord[j - 1]; j--; }
+    ord[j] = o;
+  }
   Svd3 r;
   Vec3d av[3];
   for (int k = 0; k < 3; k++) { r.V.setcol(k, W.col(ord[k])); av[k] = mul(A, r.V.col(k)); r.s[k] = norm3(av[k]); }
@@ -120,7 +125,7 @@ inline Svd3 svd3(const Mat3d& A) {
   for (int k = 0; k < 3; k++) r.U.setcol(k, u[k]);
   return r;
 }
-inline Vec3d svd_solve3(const Mat3d& A, const Vec3d& b) {
+RPE_HD inline Vec3d svd_solve3(const Mat3d& A, const Vec3d& b) {
   Svd3 d = svd3(A);
   Vec3d y = mul(transposed(d.U), b);
   const double thr = 3.0 * std::numeric_limits<double>::epsilon() * d.s[0];
@@ -129,7 +134,7 @@ inline Vec3d svd_solve3(const Mat3d& A, const Vec3d& b) {
 }
 
 // Rotation closest to the cross-covariance M (Kabsch / Umeyama without scale): R = U diag(1,1,det(UV^T)) V^T
-inline Mat3d rotation_from_covariance(const Mat3d& M) {
+RPE_HD inline Mat3d rotation_from_covariance(const Mat3d& M) {
   Svd3 d = svd3(M);
   Mat3d UVt = mul(d.U, transposed(d.V));
   if (det3(UVt) < 0) {
@@ -142,7 +147,7 @@ inline Mat3d rotation_from_covariance(const Mat3d& M) {
 
 // ---- quaternions (w, x, y, z), templated so that Tp-typed adapters can hold a Sophus-like SO3<Tp>
 template <class T> struct Quat { T w, x, y, z; };
-template <class T> Quat<T> quat_from_R(const T* R /*row-major*/) {
+template <class T> RPE_HD Quat<T> quat_from_R(const T* R /*row-major*/) {
   Quat<T> q;
   const T tr = R[0] + R[4] + R[8];
   if (tr > T(0)) {

@@ -3,6 +3,8 @@
 // index lists, invalidateDevice(), host edits pushed back before a least-squares stage.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <limits>
 #include "AbsoluteOrientation.hpp"
 #include "AbsoluteOrientationNormal.hpp"
 #include "GaussNewton.hpp"
@@ -16,7 +18,45 @@ typedef float T;
 template <class A> static int count23(const A& a, int N) { int k = 0; for (int i = 0; i < N; i++) k += a.isInlier23(i); return k; }
 template <class A> static int count33(const A& a, int N) { int k = 0; for (int i = 0; i < N; i++) k += a.isInlier33(i); return k; }
 
+// host generation vs device generation of the 3D-3D RANSAC hypotheses: same random stream -> bitwise the same run
+template <class Tp>
+static void check_device_hypotheses(int N, double nan_frac, int score_mode, unsigned long long seed) {
+  rpe::sim_seed(seed);
+  const rpe::Point3<Tp> t = generate_random_translation_uniform<Tp>(5.0);
+  const rpe::SO3<Tp> R = generate_random_rotation<Tp>(M_PI / 2, false);
+  rpe::MatrixX<Tp> Q, P, U, W(N, 3);
+  simulate_2d_3d_3d_correspondences<Tp>(R, t, N, (Tp)2.0, (Tp)0.03, (Tp)0.2, (Tp)0.4, (Tp)8.0, (Tp)585.0, true, &Q, &U, &P, &W);
+  for (int i = 0; i < N; i++) if ((i * 2654435761u % 1000) < nan_frac * 1000) { P(0, i) = P(1, i) = P(2, i) = std::numeric_limits<Tp>::quiet_NaN(); }
+  rpe::Settings& cfg = rpe::Settings::get();
+  cfg.score_mode = score_mode;
+  struct Out { int votes, iter; rpe::Quat<Tp> q; rpe::Point3<Tp> t; std::vector<short> m33; unsigned long long rng; };
+  Out out[2];
+  for (int dev = 0; dev < 2; dev++) {
+    cfg.device_hypotheses = dev == 1;
+    AOPoseAdapter<Tp> a(U, P, Q);
+    a.setFocal((Tp)585, (Tp)585);
+    rpe::seed(seed + 17);
+    int it = 700;
+    shinji_ransac<Tp>(a, (Tp)0.1, it, (Tp)0.999);
+    out[dev].votes = a.getMaxVotes(); out[dev].iter = it; out[dev].q = a.getRcw().unit_quaternion(); out[dev].t = a.gettw();
+    const AOPoseAdapter<Tp>& ca = a;
+    out[dev].m33 = ca.inlierMask33();
+    out[dev].rng = rpe::global_rng().state();
+  }
+  cfg.device_hypotheses = true; cfg.score_mode = RPE_SCORE_FAST;
+  CHECK(out[0].votes == out[1].votes && out[0].iter == out[1].iter && out[0].votes > 0);
+  CHECK(std::memcmp(&out[0].q, &out[1].q, sizeof(out[0].q)) == 0 && std::memcmp(&out[0].t, &out[1].t, sizeof(out[0].t)) == 0);
+  CHECK(out[0].m33 == out[1].m33);
+  CHECK(out[0].rng == out[1].rng);   // both advanced the random stream by the same number of draws
+}
+
 int main() {
+  for (unsigned long long seed = 1; seed <= 4; seed++) {
+    check_device_hypotheses<float>(5000, 0.0, RPE_SCORE_EXACT, seed);
+    check_device_hypotheses<float>(20011, 0.15, RPE_SCORE_FAST, seed);
+    check_device_hypotheses<double>(3001, 0.1, RPE_SCORE_EXACT, seed);
+    check_device_hypotheses<double>(9, 0.0, RPE_SCORE_FAST, seed);
+  }
   const int N = 20000;
   rpe::sim_seed(3);
   const rpe::Point3<T> t = generate_random_translation_uniform<T>(5.0);
