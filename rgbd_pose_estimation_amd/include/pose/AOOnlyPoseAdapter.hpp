@@ -69,6 +69,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
     if (weights.rows() != 1) {
       _weights_3d.resize(weights.rows());
       for (int i = 0; i < (int)weights.rows(); i++) _weights_3d[i] = weights(i, 1);
+      _idx.clear(); _idx_top = 0;   // the cached PROSAC order belongs to the old weights
       this->device().weight_changed_on_host(RPE_MOD_33);
     }
   }
@@ -77,7 +78,14 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   void cvtInlier() { _vInliersAO.request(); }  // built on first read (rpe::InlierIndex)
   void forgetInlierIdx() { _vInliersAO.drop(); }  // additive, for solvers: see rpe::InlierIndex::drop
   // top_k >= 0: only the first top_k positions of the order are needed now (the rest is sorted on demand)
-  void sortIdx(int top_k = -1) { _idx = sortIndexes<Tp>(_weights_3d, top_k); }
+  // (the order is a pure function of the weights: a prefix at least as long as the one asked for, computed since the last
+  // setWeights, is reused -- several PROSAC solvers on one adapter, TestMain.cpp:186-221, sort once)
+  void sortIdx(int top_k = -1) {
+    const int want = top_k < 0 || top_k > (int)_weights_3d.size() ? (int)_weights_3d.size() : top_k;
+    if (_idx_top >= want && (int)_idx.size() >= want && want > 0) return;
+    _idx = sortIndexes<Tp>(_weights_3d, top_k);
+    _idx_top = (int)_idx.size();
+  }
   void getSortedIdx(std::vector<int>& select_) const { mapSortedIdx<Tp>(_weights_3d, _idx, select_); }
 
   // ---- additive accessors for the device backend
@@ -98,6 +106,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   rpe::HostMask _inliers_3d;
   std::vector<Tp> _weights_3d;
   mutable std::vector<int> _idx;
+  mutable int _idx_top = 0;   // how many leading positions of _idx are valid for the current weights
   rpe::InlierIndex _vInliersAO;
   int _max_votes;
 };

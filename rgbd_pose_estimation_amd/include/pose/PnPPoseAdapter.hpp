@@ -60,7 +60,12 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   bool isInlier23(int index) const { return mask23()[index] == 1; }
   Tp weight23(int index) const { return _weights.empty() ? Tp(1.0) : _weights[index]; }
   // top_k >= 0: only the first top_k positions of the order are needed now (the rest is sorted on demand)
-  void sortIdx(int top_k = -1) { _idx = sortIndexes<Tp>(_weights, top_k); }
+  void sortIdx(int top_k = -1) {   // cached per weight set, see AOOnlyPoseAdapter::sortIdx
+    const int want = top_k < 0 || top_k > (int)_weights.size() ? (int)_weights.size() : top_k;
+    if (_idx_top >= want && (int)_idx.size() >= want && want > 0) return;
+    _idx = sortIndexes<Tp>(_weights, top_k);
+    _idx_top = (int)_idx.size();
+  }
   void getSortedIdx(std::vector<int>& select_) const { mapSortedIdx<Tp>(_weights, _idx, select_); }
 
   // ---- additive accessors for the device backend
@@ -78,6 +83,7 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   void flushInlierIdx23() const { if (_vInliersPnP.pending()) _vInliersPnP.flush(mask23()); }
   template <class M> void setWeights23(const M& weights) {
     _weights.resize(weights.rows());
+    _idx.clear(); _idx_top = 0;   // the cached PROSAC order belongs to the old weights
     for (int i = 0; i < (int)weights.rows(); i++) _weights[i] = weights(i, 0);
     this->device().weight_changed_on_host(RPE_MOD_23);
   }
@@ -85,6 +91,7 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   rpe::HostMask _inliers;
   std::vector<Tp> _weights;
   mutable std::vector<int> _idx;
+  mutable int _idx_top = 0;
   rpe::InlierIndex _vInliersPnP;
   int _max_votes;
 };

@@ -61,6 +61,22 @@ int main() {
   sel = {999, 20};
   a.getSortedIdx(sel);
   CHECK(sel[0] == f1[999] && sel[1] == f1[20]);
+  // the order is cached per weight set: a new setWeights invalidates it
+  {
+    rpe::MatrixX<float> W2(N, 3);
+    for (int i = 0; i < N; i++) { W2(i, 0) = 1.f; W2(i, 1) = (float)(N - i); W2(i, 2) = 1.f; }   // descending: order = identity
+    a.sortIdx(10);
+    a.setWeights(W2);
+    a.sortIdx(10);
+    std::vector<int> s2 = {0, 9};
+    a.getSortedIdx(s2);
+    CHECK(s2[0] == 0 && s2[1] == 9);
+    a.sortIdx(5);                                   // shorter prefix than cached: reused
+    s2 = {4, 700};                                  // 700 is beyond any prefix: extended to the full order
+    a.getSortedIdx(s2);
+    CHECK(s2[0] == 4 && s2[1] == 700);
+    a.setWeights(Wt);                               // back to the first weights for the checks below
+  }
   // cvtInlier lists the mask AS IT WAS when it was called, even though the list is built lazily
   rpe::MatrixXs m(N, 2);
   for (int i = 0; i < N; i++) m(i, 1) = (short)(i % 3 == 0);
