@@ -13,6 +13,7 @@ typedef float T;
 
 int main(int argc, char** argv) {
   const int N = argc > 1 ? std::atoi(argv[1]) : 307200;
+  const bool totals_only = argc > 2;   // any second argument: phase timers off (they also switch off the generate/score overlap)
   rpe::sim_seed(7);
   const rpe::Point3<T> t = generate_random_translation_uniform<T>(5.0);
   const rpe::SO3<T> R = generate_random_rotation<T>(M_PI / 2, false);
@@ -20,7 +21,7 @@ int main(int argc, char** argv) {
   simulate_2d_3d_nl_correspondences<T>(R, t, N, 3.0f, 0.1f, 0.05f, 0.1f, 0.035f, 0.1f, 0.4f, 8.0f, 585.0f, true, &Q, &M, &P, &Nn, &U, &W);
   const T thre_3d = 0.2f, thre_2d = 8.0f, thre_nl = 0.1f, conf = 0.99f;
   rpe::Settings& cfg = rpe::Settings::get();
-  cfg.profile = true;
+  cfg.profile = !totals_only;
   struct Row { const char* name; std::function<void(NormalAOPoseAdapter<T>&, int&)> run; };
   const Row rows[] = {
       {"shinji_ransac", [&](NormalAOPoseAdapter<T>& a, int& it) { shinji_ransac<T>(a, thre_3d, it, conf); }},
