@@ -202,9 +202,34 @@ def main():
                     p2p = False
         if dist_path and not p2p and want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1":
             sys.exit("bench.py: the peer-to-peer collective was requested strictly and is not available")   # every rank agrees on p2p (MIN flag): all exit
-        if dist_path and not p2p and want in ("auto", "rccl", "p2p"):
-            native = init_native_comm(ctx)
-        native = native or p2p
+        rccl_ok = False
+        if dist_path and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1") and want in ("auto", "rccl", "p2p"):
+            # with a peer-to-peer path in place rpe_gn_step_dist prefers it; the communicator is its stand-by
+            rccl_ok = init_native_comm(ctx)
+        if dist_path and p2p and rccl_ok and want == "auto":
+            # both collectives work: keep the faster one (measured here, 400 steps each after a short settling run; every rank reaches
+            # the same verdict because the times are max-reduced).  The wire cannot be exercised on a one-GPU box, so the choice is
+            # made on the machine the benchmark actually runs on.
+            def timed(k):
+                q = pose12(R0, t0)
+                ctx.gn_steps_dist(L.RES_P2P, q, 200, L.USE_MASK)
+                dist.barrier()
+                t0_ = time.perf_counter()
+                ctx.gn_steps_dist(L.RES_P2P, q, k, L.USE_MASK)
+                tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item()) / k
+            t_p2p = timed(400)
+            L.check(L.lib().rpe_p2p_pause(ctx._h, 1))      # stand-by: the same call now takes the RCCL path
+            t_rccl = timed(400)
+            L.check(L.lib().rpe_p2p_pause(ctx._h, 0))
+            if rank == 0:
+                print(f"[bench] sharded step: peer-to-peer {t_p2p * 1e6:.1f} us, RCCL {t_rccl * 1e6:.1f} us", file=sys.stderr, flush=True)
+            if t_rccl < t_p2p:
+                dist.barrier()
+                ctx.p2p_destroy()
+                p2p = False
+        native = rccl_ok or p2p
         collective = "none" if not dist_path else ("peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
                                                    "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
 

@@ -168,6 +168,8 @@ int rpe_gn_steps_dist(rpe_context* ctx, int kind, int flags, double* pose12, int
  * step with RPE_ERR_HIP instead of hanging.  Callers barrier before rpe_p2p_destroy. */
 int rpe_p2p_export(rpe_context* ctx, void* handle64);
 int rpe_p2p_init(rpe_context* ctx, int world, int rank, const void* handles);
+/* pause = 1 keeps the mailboxes but routes rpe_gn_step_dist / rpe_score through the RCCL communicator (stand-by); 0 resumes. */
+int rpe_p2p_pause(rpe_context* ctx, int pause);
 int rpe_p2p_destroy(rpe_context* ctx);
 /* Whole refinement loop on one GPU: up to 3 residual kinds summed with scales; stops when |delta| < tol.
  * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */

@@ -112,7 +112,7 @@ struct rpe_context {
   unsigned long long* p2p_box = nullptr;
   void* p2p_peer[rpe::kP2PMaxWorld] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   rpe::P2PDesc* d_p2p = nullptr;
-  int p2p_world = 0, p2p_rank = 0;
+  int p2p_world = 0, p2p_rank = 0, p2p_world_saved = 0;
   unsigned long long p2p_step = 0;
   unsigned long long p2p_vote_step = 0;   // the same for the vote counters of sharded scoring
   void* h_stage = nullptr;        // pinned staging for device -> host copies into caller (pageable) memory
@@ -718,7 +718,7 @@ int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
   HIP_TRY(hipSetDevice(c->device));
   for (int r = 0; r < rpe::kP2PMaxWorld; r++)   // a second init: drop the mappings of the first
     if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]); c->p2p_peer[r] = nullptr; }
-  c->p2p_world = 0;
+  c->p2p_world = 0; c->p2p_world_saved = 0;
   rpe::P2PDesc d;
   d.world = world; d.rank = rank;
   for (int r = 0; r < rpe::kP2PMaxWorld; r++) d.peer[r] = nullptr;
@@ -738,7 +738,16 @@ int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
   }
   if (!c->d_p2p) HIP_TRY(hipMalloc((void**)&c->d_p2p, sizeof(rpe::P2PDesc)));
   HIP_TRY(hipMemcpy(c->d_p2p, &d, sizeof(d), hipMemcpyHostToDevice));
-  c->p2p_world = world; c->p2p_rank = rank; c->p2p_step = 0; c->p2p_vote_step = 0;
+  c->p2p_world = world; c->p2p_world_saved = world; c->p2p_rank = rank; c->p2p_step = 0; c->p2p_vote_step = 0;
+  return RPE_OK;
+}
+
+// pause = 1: keep the mailboxes mapped but let rpe_gn_step_dist / rpe_score use the RCCL communicator (or nothing); 0 resumes.  Every
+// rank must switch at the same point of its call sequence.
+int rpe_p2p_pause(rpe_context* c, int pause) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (!c->d_p2p || c->p2p_world_saved < 1) return fail(RPE_ERR_STATE, "rpe_p2p_init was not called");
+  c->p2p_world = pause ? 0 : c->p2p_world_saved;
   return RPE_OK;
 }
 
@@ -750,7 +759,7 @@ int rpe_p2p_destroy(rpe_context* c) {
   for (int r = 0; r < rpe::kP2PMaxWorld; r++) if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]); c->p2p_peer[r] = nullptr; }
   if (c->d_p2p) { (void)hipFree(c->d_p2p); c->d_p2p = nullptr; }
   if (c->p2p_box) { (void)hipFree(c->p2p_box); c->p2p_box = nullptr; }
-  c->p2p_world = 0; c->p2p_step = 0;
+  c->p2p_world = 0; c->p2p_world_saved = 0; c->p2p_step = 0;
   return RPE_OK;
 }
 
