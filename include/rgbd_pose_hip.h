@@ -164,8 +164,9 @@ int rpe_gn_steps_dist(rpe_context* ctx, int kind, int flags, double* pose12, int
  * words), waits for the peers' records in its own mailbox, adds them in rank order and publishes the sum -- the whole sharded
  * step is ONE kernel launch, and every rank gets bitwise the same record.  Each rank calls rpe_p2p_export (64-byte IPC handle),
  * all handles are gathered by any means (world x 64 bytes, rank order), each rank calls rpe_p2p_init; rpe_gn_step_dist then
- * uses this path (it takes precedence over an RCCL communicator), and rpe_score exchanges and sums its vote counters the same way.  A rank that waits more than 10 s for a peer fails the
- * step with RPE_ERR_HIP instead of hanging.  Callers barrier before rpe_p2p_destroy. */
+ * uses this path (it takes precedence over an RCCL communicator), and rpe_score exchanges and sums its vote counters the same
+ * way.  A rank that waits more than 10 s for a peer fails the step with RPE_ERR_HIP instead of hanging; ranks should therefore
+ * enter their first exchange together (one local launch + a barrier).  Callers barrier before rpe_p2p_destroy. */
 int rpe_p2p_export(rpe_context* ctx, void* handle64);
 int rpe_p2p_init(rpe_context* ctx, int world, int rank, const void* handles);
 /* pause = 1 keeps the mailboxes but routes rpe_gn_step_dist / rpe_score through the RCCL communicator (stand-by); 0 resumes. */
@@ -182,7 +183,7 @@ int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* 
 int rpe_timing_enable(rpe_context* ctx, int max_records, int stride);
 int rpe_timing_collect(rpe_context* ctx, int* count, double* total_ms, double* min_ms);
 /* Elapsed time an EMPTY event pair reports on this context's stream (average and minimum over `pairs` pairs): what the pair
- * itself adds to every interval rpe_timing_collect returns (about 2 us on MI355X), so that event-based kernel times can be
+ * itself adds to every interval rpe_timing_collect returns (2-5 us on MI355X), so that event-based kernel times can be
  * compared with rocprofv3's dispatch timestamps. */
 int rpe_timing_calibrate(rpe_context* ctx, int pairs, double* avg_ms, double* min_ms);
 
