@@ -404,6 +404,48 @@ def main():
                 pass
             except Exception as e:
                 out["icp_frame_loop"] = {"error": repr(e)}
+            # extra: the other half of the hot path -- batched RANSAC hypothesis scoring (vote loops V1/V2, kernel K4) on the same frame:
+            # 512 hypotheses per pass; the CPU figure is the oracle's vote loop (AOOnlyPoseAdapter virtual getters, 1 thread)
+            try:
+                if args.no_extras:
+                    raise StopIteration
+                rng_s = np.random.default_rng(3)
+                H = 512
+                dq = 0.002 * rng_s.standard_normal((H, 7))
+                base7 = pose7_from_Rt(sc.R, sc.t, L.F32)
+                poses = base7[None, :] + dq
+                poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+                poses = np.ascontiguousarray(poses.astype(np.float32).astype(np.float64))
+                res = {}
+                for mode, name in ((L.SCORE_FAST, "fast"), (L.SCORE_EXACT, "exact")):
+                    t_w = time.perf_counter()
+                    while time.perf_counter() - t_w < 0.2:   # settle: freeing the ICP context above stalls the next launches for ~0.1 s once
+                        ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
+                    t0s = time.perf_counter()
+                    reps = 20
+                    for _ in range(reps):
+                        v = ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
+                    dts = (time.perf_counter() - t0s) / reps
+                    res[name] = {"corr_hyp_per_s": n * H / dts, "us_per_pass": dts * 1e6}
+                    if mode == L.SCORE_EXACT:
+                        v_exact = v
+                cpu = None
+                if not args.no_cpu_baseline:
+                    import oracle_lib as O
+                    votes_cpu = np.zeros(8, np.int32)
+                    xw32, xc32 = np.ascontiguousarray(sc.Q, np.float32), np.ascontiguousarray(sc.P, np.float32)
+                    p8 = np.ascontiguousarray(poses[:8])
+                    O.lib().orc_time_votes33.restype = C.c_double
+                    dtc = O.lib().orc_time_votes33(xw32.ctypes.data_as(C.c_void_p), xc32.ctypes.data_as(C.c_void_p), n, p8.ctypes.data_as(C.c_void_p), 8,
+                                                    C.c_float(THRE_3D), votes_cpu.ctypes.data_as(C.c_void_p))
+                    cpu = {"corr_hyp_per_s": n * 8 / dtc, "cores": 1, "sample": "8 hypotheses through the oracle's vote loop",
+                           "votes_equal_exact_mode": bool(np.array_equal(votes_cpu, v_exact[:8]))}
+                out["ransac_scoring"] = {"hypotheses": H, "kind": "3D-3D (V1/V2)", "fast": res["fast"], "exact": res["exact"], "cpu_port": cpu,
+                                         "note": "wall time per rpe_score call incl. pose upload and vote read-out; beside, not instead of, the headline"}
+            except StopIteration:
+                pass
+            except Exception as e:
+                out["ransac_scoring"] = {"error": repr(e)}
         else:
             if sharded_loop is not None:
                 out["device_resident_loop"] = sharded_loop
