@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs reported beside the headline (profiling runs: only the headline's launches)")
     ap.add_argument("--debug-chunks", action="store_true")
-    ap.add_argument("--time-every", type=int, default=8, help="record a HIP event pair around every k-th K1 launch of the timed region")
+    ap.add_argument("--time-every", type=int, default=16, help="every k-th K1 launch of the timed region carries a HIP event pair (its dispatch begin / end timestamps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -339,9 +339,10 @@ def main():
                          "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
                          "avg_launch_us": k_avg_s * 1e6, "min_launch_us": k_min_ms * 1e3, "launches_timed": cnt,
                          "empty_event_pair_us": ev_avg_ms * 1e3, "rocprofv3_avg_launch_us": rocprof_avg_us,
-                         "note": "HIP events on the kernel's own stream around every stage-1 launch of the timed region; achieved uses that raw interval, which "
-                                 "contains the markers' own latency (an EMPTY pair on the idle stream reads empty_event_pair_us); rocprofv3_avg_launch_us is the "
-                                 "dispatch-timestamp average of the same command from the committed profiles/ summary; 7.99 MB working set is "
+                         "note": "HIP events on the kernel's own stream: every time_every-th stage-1 launch of the timed region is issued with "
+                                 "hipExtLaunchKernelGGL(start, stop), so the pair holds that dispatch's begin / end timestamps (the quantity rocprofv3 "
+                                 "reports; rocprofv3_avg_launch_us is its average for the same command from the committed profiles/ summary; two "
+                                 "marker packets around the launch would add their own latency, empty_event_pair_us); 7.99 MB working set is "
                                  "L2/Infinity-Cache resident after the first step, so this is not an HBM-streaming figure (see DESIGN.md)"},
         }
         # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)

@@ -178,7 +178,8 @@ int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* 
                   double tol, int* iters_out, double* last_step, double* final_cost);
 
 /* HIP-event timing of the normal-equation kernel, on the context's stream: after enable(max_records, stride)
- * every stride-th rpe_normal_eq* call records an event pair around that one kernel launch; collect() synchronises,
+ * every stride-th rpe_normal_eq* call launches its kernel with an event pair that receives the dispatch's own begin / end
+ * timestamps (hipExtLaunchKernelGGL: what rocprofv3 reports for the kernel, no marker packets); collect() synchronises,
  * returns the number of pairs and their total / minimum elapsed milliseconds, and rearms.  enable(0, 1) = off. */
 int rpe_timing_enable(rpe_context* ctx, int max_records, int stride);
 int rpe_timing_collect(rpe_context* ctx, int* count, double* total_ms, double* min_ms);
