@@ -130,6 +130,93 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   return v;
 }
 
+
+// ---- many values at once: a REDUCE-SCATTER across the wave instead of NACC independent butterflies.  At every step a lane
+// keeps one half of its values and hands the other half to its partner, so the number of cross-lane operations halves each
+// time: 32 values cost 31 exchange-and-add steps instead of 32 x 6 (124 VALU instructions instead of 576 for fp64).  The
+// first two steps use gfx950's v_permlane32_swap / v_permlane16_swap, which exchange the halves (rows) of TWO registers in
+// one instruction: after swap(a, b) the sum of the two results holds a's pair sums in the lower half (even rows) and b's in
+// the upper half (odd rows).  The remaining steps pair lanes with DPP moves (row_ror:8, row_half_mirror, quad_perm) and a
+// select on the lane bit that tells the partners apart.  The order of the additions is fixed, so results stay reproducible.
+__device__ __forceinline__ double swap_add32(double x, double y) {   // lower 32 lanes end with x(l) + x(l+32), upper with y(l-32) + y(l)
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double x, double y) {   // even rows end with x's row-pair sums, odd rows with y's
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL> __device__ __forceinline__ double pair_add(double x, double y, bool upper) {   // lanes with upper = 0 keep x, the others y
+  const double keep = upper ? y : x, give = upper ? x : y;
+  return keep + dpp_move<CTRL, 0xf>(give);
+}
+// 32 values -> lane l holds the wave total of value (l >> 1)
+__device__ __forceinline__ double wave_reduce_scatter32(const double (&v)[32], int lane) {
+  double a[16], b[8], c[4], d[2];
+#pragma unroll
+  for (int j = 0; j < 16; j++) a[j] = swap_add32(v[j], v[j + 16]);
+#pragma unroll
+  for (int j = 0; j < 8; j++) b[j] = swap_add16(a[j], a[j + 8]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) c[j] = pair_add<0x128>(b[j], b[j + 4], (lane & 8) != 0);    // row_ror:8         partner l ^ 8
+#pragma unroll
+  for (int j = 0; j < 2; j++) d[j] = pair_add<0x141>(c[j], c[j + 2], (lane & 4) != 0);    // row_half_mirror  partner l ^ 7
+  double e = pair_add<0x1b>(d[0], d[1], (lane & 2) != 0);                                  // quad_perm:[3,2,1,0] partner l ^ 3
+  e += dpp_move<0xb1, 0xf>(e);                                                             // quad_perm:[1,0,3,2] partner l ^ 1
+  return e;
+}
+// 16 values -> lane l holds the wave total of value (l >> 2) & 15
+__device__ __forceinline__ double wave_reduce_scatter16(const double (&v)[16], int lane) {
+  double a[8], b[4], c[2];
+#pragma unroll
+  for (int j = 0; j < 8; j++) a[j] = swap_add32(v[j], v[j + 8]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) b[j] = swap_add16(a[j], a[j + 4]);
+#pragma unroll
+  for (int j = 0; j < 2; j++) c[j] = pair_add<0x128>(b[j], b[j + 2], (lane & 8) != 0);
+  double d = pair_add<0x141>(c[0], c[1], (lane & 4) != 0);
+  d += dpp_move<0x1b, 0xf>(d);
+  d += dpp_move<0xb1, 0xf>(d);
+  return d;
+}
+// wave totals of acc[0 .. NACC) into out[0 .. NACC) (LDS row of this wave)
+template <int NACC>
+__device__ __forceinline__ void wave_reduce_to(const double (&acc)[NACC], double* __restrict__ out, int lane) {
+  int done = 0;
+  if constexpr (NACC >= 24) {          // a block of 32 (padded with zeros) -- 29 and 44 accumulators
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) v[k] = k < NACC ? acc[k] : 0.0;
+    const double r = wave_reduce_scatter32(v, lane);
+    if ((lane & 1) == 0 && (lane >> 1) < NACC) out[lane >> 1] = r;
+    done = 32;
+  } else if constexpr (NACC >= 12) {   // a block of 16 -- 17 accumulators
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = acc[k];
+    const double r = wave_reduce_scatter16(v, lane);
+    if ((lane & 3) == 0) out[(lane >> 2) & 15] = r;
+    done = 16;
+  }
+  if constexpr (NACC > 32 && NACC - 32 > 4) {   // second block for the 44-value record: 12 more in a block of 16
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = 32 + k < NACC ? acc[32 + k < NACC ? 32 + k : 0] : 0.0;
+    const double r = wave_reduce_scatter16(v, lane);
+    if ((lane & 3) == 0 && 32 + ((lane >> 2) & 15) < NACC) out[32 + ((lane >> 2) & 15)] = r;
+    done = 48;
+  }
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {     // the stragglers (1 of 17; everything for tiny records) one butterfly each
+    if (k >= done) {
+      const double t = wave_sum_to_lane63(acc[k]);
+      if (lane == 63) out[k] = t;
+    }
+  }
+}
+
 struct Finish {
   double* partials;            // gridDim.x * LD doubles
   unsigned int* ticket;        // 9 counters, 32 uints apart, zero before the launch; rearmed by the last arrivers
@@ -286,11 +373,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
   __shared__ double tot[LD];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NACC; k++) {
-    const double v = wave_sum_to_lane63(acc[k]);
-    if (lane == 63) red[wave][k] = v;
-  }
+  wave_reduce_to<NACC>(acc, red[wave], lane);
   __syncthreads();
   const int G = gridDim.x;
   if (G > 1) {
