@@ -5,8 +5,8 @@
 // the design rules are (1) 16-byte vector loads of the reference's native xyz-interleaved 3 x N arrays --
 // a thread owns P consecutive correspondences (P = 4 for fp32 = three float4, P = 2 for fp64 = three
 // double2), so every byte of every 128-B line is consumed by one lane within three back-to-back loads;
-// (2) per-thread fp64 accumulators fed by per-group sums in the array dtype, a DPP butterfly across the 64 lanes
-// (no LDS traffic), one LDS hop across the waves of a workgroup, one 256-B partial record per workgroup;
+// (2) per-thread fp64 accumulators fed by per-group sums in the array dtype, a reduce-scatter across the 64 lanes
+// (v_permlane32/16_swap + DPP, no LDS traffic), one LDS hop across the waves of a workgroup, one 256-B partial record per workgroup;
 // (3) the second stage inside the SAME launch: write-through records, a two-level arrival count, and the last
 // workgroup sums the records in a fixed order (deterministic, no float atomics), expands them to the 6x6 / 6x1
 // normal equations and publishes them -- to HBM, to pinned host memory, to the peers' mailboxes over xGMI, or
@@ -105,7 +105,7 @@ __device__ __forceinline__ void load_weight_full(const double* __restrict__ w, i
 template <class T> __device__ __forceinline__ bool all_nan(T x, T y, T z) { return x != x && y != y && z != z; }
 
 // ---- two-stage reduction inside ONE launch.
-// Stage 1 (every workgroup): wave64 __shfl_down tree, one LDS hop across the 4 waves, one LD-double partial record
+// Stage 1 (every workgroup): wave64 reduce-scatter (below), one LDS hop across the waves, one LD-double partial record
 // in HBM.  Stage 2 (the workgroup whose ticket is last): sums the G records IN ROW ORDER -- the result does not
 // depend on which workgroup happens to be last, so it is bitwise reproducible -- expands it to the packed
 // normal-equation record and publishes it to HBM (for a collective) and/or to pinned host memory followed by a
