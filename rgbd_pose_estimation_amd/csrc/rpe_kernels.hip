@@ -1550,13 +1550,15 @@ static inline int grid_for(int64_t n, int P, int max_blocks, int block = kBlock)
   if (g > max_blocks) g = max_blocks;
   return (int)g;
 }
-// Reduction kernels: one partial record per workgroup, so fewer workgroups = a shorter tail.  Give every thread two
-// groups when that still leaves >= 128 workgroups (measured on MI355X: 307 200 correspondences run 7 % faster with 128
-// workgroups of 512 threads than with 150; from 10 M correspondences up the cap of 2 workgroups per CU wins).
+// Reduction kernels: one partial record per workgroup, so fewer workgroups = a shorter tail; but a thread that owns two groups
+// also issues twice the arithmetic, and since the wave stage became a reduce-scatter the arithmetic is what is left of the body.
+// Measured on MI355X: 307 200 correspondences run 6 % faster with one group per thread (150 workgroups of 512: 8.5 us) than with
+// 128 workgroups (9.2 us); from about half a million correspondences every thread gets two groups (>= 128 workgroups), and from
+// 10 M up the cap of 2 workgroups per CU wins.
 static inline int reduce_grid(int64_t n, int P, int max_blocks, int block) {
   const int64_t groups = (n + P - 1) / P;
   const int64_t one = (groups + block - 1) / block, two = (groups + 2 * (int64_t)block - 1) / (2 * (int64_t)block);
-  int64_t g = two < 128 ? (one < 128 ? one : 128) : two;
+  int64_t g = two < 128 ? one : two;
   static const int force = getenv("RPE_REDUCE_GROUPS") ? atoi(getenv("RPE_REDUCE_GROUPS")) : 0;   // experiments: 1 / 2 groups per thread
   if (force == 1) g = one; else if (force == 2) g = two;
   if (g < 1) g = 1;
