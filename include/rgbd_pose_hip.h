@@ -254,6 +254,18 @@ typedef struct {
 int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
             uint64_t seed, int ls, int score_mode, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out);
 
+/* The hypothesis stream of a solver made explicit ("both CPU restatement and GPU consume the same sample
+ * list").  rpe_host_hypotheses runs `method`'s sampler (seeded as rpe_run does) and minimal solvers -- shinji K = 3
+ * (AbsoluteOrientation.hpp:47-99), kneip (P3P.hpp:63-294), nl_2p (AbsoluteOrientationNormal.hpp:77-142), in the order the solver's
+ * loop tries them -- for `iters` iterations WITHOUT scoring anything: no GPU is needed.  q7_out[cap x 7] = qw qx qy qz tx ty tz
+ * (Tp values), first_out[iters + 1]: the hypotheses of iteration i are first_out[i] .. first_out[i+1].  Returns their number.
+ * rpe_run_replay is rpe_run with the hypotheses of iteration i TAKEN from poses7[first[i] .. first[i+1]) instead of being sampled:
+ * scoring on the GPU, best-so-far on strict '>', adaptive Iter, winner's masks and the optional least-squares stage as in rpe_run. */
+int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t seed, double* q7_out, int cap, int* first_out);
+int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d, double thre_2d,
+                   double thre_nl, int* iter_io, double confidence, int ls, int score_mode, double* R9, double* t3, int* max_votes,
+                   short* mask_out);
+
 /* ------------------------------------------------------------------------------------------------
  * Part 3 -- front end (additive): the step BEFORE the hot path.  A depth frame becomes
  * the adapters' arrays directly in HBM: points_c / normal_c / bearingVectors of the frame, points_g / normal_g of the

@@ -220,6 +220,36 @@ int orc_run(int is_f64, int method, const orc_problem* p, double thre_3d, double
                 : run_pipeline<float>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, adapter_kind_for_none, mask_in, R9, t3, max_votes, mask_out);
 }
 
+// ---- explicit hypothesis streams (orc_pose.hpp "explicit hypothesis streams") --------------------------------------------------
+// The hypotheses `method` generates in `iters` iterations from `seed` (its sampler + minimal solvers, nothing voted on):
+// q7_out[cap x 7] = qw qx qy qz tx ty tz, first_out[iters + 1].  Returns the number of hypotheses, or -1 if cap is too small.
+int orc_hypotheses(int is_f64, int method, const orc_problem* p, int iters, uint64_t seed, double* q7_out, int cap, int* first_out) {
+  HypList list;
+  capture_sink() = &list;
+  int it = iters, mv = 0;
+  double R9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t3[3] = {0, 0, 0};
+  if (is_f64) run_pipeline<double>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, 0, 0, nullptr, R9, t3, &mv, nullptr);
+  else run_pipeline<float>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, 0, 0, nullptr, R9, t3, &mv, nullptr);
+  capture_sink() = nullptr;
+  if (list.first.empty()) list.first.assign((size_t)iters + 1, 0);
+  const int H = (int)(list.q7.size() / 7);
+  if (H > cap || (int)list.first.size() != iters + 1) return -1;
+  std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
+  std::memcpy(first_out, list.first.data(), sizeof(int) * list.first.size());
+  return H;
+}
+// orc_run with the hypotheses of iteration i taken from poses7[first[i] .. first[i+1]) instead of the sampler + minimal solvers
+int orc_run_replay(int is_f64, int method, const orc_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d,
+                   double thre_2d, double thre_nl, int* iter_io, double confidence, int ls, double* R9, double* t3, int* max_votes, short* mask_out) {
+  HypList list;
+  list.first.assign(first, first + list_iters + 1);
+  list.q7.assign(poses7, poses7 + 7 * (size_t)first[list_iters]);
+  replay_source() = &list;
+  const int rc = orc_run(is_f64, method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, 1, ls, 0, nullptr, R9, t3, max_votes, mask_out);
+  replay_source() = nullptr;
+  return rc;
+}
+
 // ---- vote loops on an explicit hypothesis list (V1..V8); poses7 = H x (qw qx qy qz tx ty tz) --------
 // thresholds are passed already converted the way the reference does it: cos_thr = cos(atan(thre_2d/f)), cos_nl = cos(nl_thre)
 void orc_votes(int is_f64, int kind, const orc_problem* p, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl,

@@ -111,61 +111,94 @@ template <class T> inline M3<T> hat(const V3<T>& w) {
   return r;
 }
 
-// ---- 3x3 SVD, one-sided (Hestenes) Jacobi; singular values sorted descending like Eigen::JacobiSVD.
-// A = U diag(s) V^T with U, V orthogonal (full bases even when A is rank deficient).
+// ---- 3x3 SVD: the algorithm of Eigen::JacobiSVD (Eigen 3.3.x, Eigen/src/SVD/JacobiSVD.h + Eigen/src/Jacobi/Jacobi.h), restated.
+// Eigen is an un-vendored, version-unpinned dependency of the reference (CMakeLists.txt:17); every SVD on the hot path is
+// JacobiSVD<Matrix<Tp,...>>(M, ComputeFullU | ComputeFullV) on a square 3x3 (AbsoluteOrientation.hpp:79,
+// AbsoluteOrientationNormal.hpp:44,188,512), i.e. no QR preconditioner runs.  The published algorithm:
+//   scale = max |a_ij| (1 if zero);  W = A / scale;  U = V = I;  maxDiag = max_i |W_ii|
+//   sweep until no 2x2 block needed work:  for p = 1..2, q = 0..p-1:
+//     threshold = max(min_positive, 2 eps * maxDiag);  if |W_pq| > threshold or |W_qp| > threshold:
+//       (j_left, j_right) = real_2x2_jacobi_svd(W, p, q);  W <- j_left applied on the left, U <- U j_left^T, W <- W j_right, V <- V j_right
+//       maxDiag = max(maxDiag, |W_pp|, |W_qq|)
+//   s_i = |W_ii| * scale, column i of U multiplied by sign(W_ii); then sorted descending by swapping (selection order).
+// A = U diag(s) V^T with U, V orthogonal full bases also when A is rank deficient (they start from I).
 template <class T> struct SVD3 { M3<T> U, V; T s[3]; };
 
-template <class T> inline V3<T> any_orthogonal(const V3<T>& a) {
-  // unit vector orthogonal to unit vector a
-  V3<T> e = (std::fabs(a.x) <= std::fabs(a.y) && std::fabs(a.x) <= std::fabs(a.z)) ? V3<T>(1, 0, 0)
-          : (std::fabs(a.y) <= std::fabs(a.z) ? V3<T>(0, 1, 0) : V3<T>(0, 0, 1));
-  return normalized(cross(a, e));
+template <class T> struct JacobiRot {   // Eigen::JacobiRotation<T>: the 2x2 matrix [c s; -s c]
+  T c, s;
+  JacobiRot transpose() const { return JacobiRot{c, -s}; }
+  JacobiRot operator*(const JacobiRot& o) const { return JacobiRot{c * o.c - s * o.s, c * o.s + s * o.c}; }
+};
+// Jacobi.h makeJacobi(x, y, z): rotation J with J^T [x y; y z] J diagonal
+template <class T> inline JacobiRot<T> make_jacobi(T x, T y, T z) {
+  const T deno = T(2) * std::fabs(y);
+  if (deno < std::numeric_limits<T>::min()) return JacobiRot<T>{T(1), T(0)};
+  const T tau = (x - z) / deno;
+  const T w = std::sqrt(tau * tau + T(1));
+  const T t = tau > T(0) ? T(1) / (tau + w) : T(1) / (tau - w);
+  const T sign_t = t > T(0) ? T(1) : T(-1);
+  const T n = T(1) / std::sqrt(t * t + T(1));
+  return JacobiRot<T>{n, -sign_t * (y / std::fabs(y)) * std::fabs(t) * n};
+}
+// rows p, q of m <- J^T-style left application (Eigen applyOnTheLeft(p, q, j)): x' = c x + s y ; y' = -s x + c y
+template <class T> inline void rot_left(M3<T>& m, int p, int q, const JacobiRot<T>& j) {
+  for (int k = 0; k < 3; k++) { const T x = m.m[p][k], y = m.m[q][k]; m.m[p][k] = j.c * x + j.s * y; m.m[q][k] = -j.s * x + j.c * y; }
+}
+// columns p, q of m <- m J (Eigen applyOnTheRight(p, q, j)): x' = c x - s y ; y' = s x + c y
+template <class T> inline void rot_right(M3<T>& m, int p, int q, const JacobiRot<T>& j) {
+  for (int k = 0; k < 3; k++) { const T x = m.m[k][p], y = m.m[k][q]; m.m[k][p] = j.c * x - j.s * y; m.m[k][q] = j.s * x + j.c * y; }
 }
 
 template <class T> SVD3<T> svd3(const M3<T>& A_in) {
-  M3<T> A = A_in, V = M3<T>::identity();
-  const T tiny = std::numeric_limits<T>::epsilon();
-  for (int sweep = 0; sweep < 60; sweep++) {
-    bool rotated = false;
-    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
-      T alpha = 0, beta = 0, gamma = 0;
-      for (int i = 0; i < 3; i++) {
-        alpha += A.m[i][p] * A.m[i][p];
-        beta += A.m[i][q] * A.m[i][q];
-        gamma += A.m[i][p] * A.m[i][q];
-      }
-      if (gamma == T(0) || std::fabs(gamma) <= tiny * std::sqrt(alpha * beta)) continue;
-      rotated = true;
-      T zeta = (beta - alpha) / (T(2) * gamma);
-      T t = (zeta >= 0 ? T(1) : T(-1)) / (std::fabs(zeta) + std::sqrt(T(1) + zeta * zeta));
-      T c = T(1) / std::sqrt(T(1) + t * t), s = c * t;
-      for (int i = 0; i < 3; i++) {
-        T ap = A.m[i][p], aq = A.m[i][q];
-        A.m[i][p] = c * ap - s * aq;
-        A.m[i][q] = s * ap + c * aq;
-        T vp = V.m[i][p], vq = V.m[i][q];
-        V.m[i][p] = c * vp - s * vq;
-        V.m[i][q] = s * vp + c * vq;
+  T scale = T(0);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) scale = std::max(scale, std::fabs(A_in.m[i][j]));
+  if (scale == T(0)) scale = T(1);
+  M3<T> W, U = M3<T>::identity(), V = M3<T>::identity();
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) W.m[i][j] = A_in.m[i][j] / scale;
+  const T precision = T(2) * std::numeric_limits<T>::epsilon(), consider_as_zero = std::numeric_limits<T>::min();
+  T max_diag = std::max(std::fabs(W.m[0][0]), std::max(std::fabs(W.m[1][1]), std::fabs(W.m[2][2])));
+  bool finished = false;
+  for (int sweep = 0; !finished && sweep < 1000; sweep++) {   // Eigen has no sweep cap; NaN input would spin, so a generous one
+    finished = true;
+    for (int p = 1; p < 3; p++) for (int q = 0; q < p; q++) {
+      const T threshold = std::max(consider_as_zero, precision * max_diag);
+      if (std::fabs(W.m[p][q]) > threshold || std::fabs(W.m[q][p]) > threshold) {
+        finished = false;
+        // real_2x2_jacobi_svd: first a rotation that makes the 2x2 block symmetric, then the symmetric Jacobi rotation
+        T m00 = W.m[p][p], m01 = W.m[p][q], m10 = W.m[q][p], m11 = W.m[q][q];
+        JacobiRot<T> rot1;
+        const T t = m00 + m11, d = m10 - m01;
+        if (std::fabs(d) < std::numeric_limits<T>::min()) { rot1.s = T(0); rot1.c = T(1); }
+        else { const T u = t / d, tmp = std::sqrt(T(1) + u * u); rot1.s = T(1) / tmp; rot1.c = u / tmp; }
+        { const T x0 = m00, x1 = m01, y0 = m10, y1 = m11;   // m.applyOnTheLeft(0, 1, rot1)
+          m00 = rot1.c * x0 + rot1.s * y0; m01 = rot1.c * x1 + rot1.s * y1; m10 = -rot1.s * x0 + rot1.c * y0; m11 = -rot1.s * x1 + rot1.c * y1; }
+        const JacobiRot<T> j_right = make_jacobi(m00, m01, m11);
+        const JacobiRot<T> j_left = rot1 * j_right.transpose();
+        rot_left(W, p, q, j_left);
+        rot_right(U, p, q, j_left.transpose());
+        rot_right(W, p, q, j_right);
+        rot_right(V, p, q, j_right);
+        max_diag = std::max(max_diag, std::max(std::fabs(W.m[p][p]), std::fabs(W.m[q][q])));
       }
     }
-    if (!rotated) break;
   }
-  T sv[3]; int ord[3] = {0, 1, 2};
-  for (int j = 0; j < 3; j++) sv[j] = norm(A.col(j));
-  std::sort(ord, ord + 3, [&](int a, int b) { return sv[a] > sv[b]; });
   SVD3<T> r;
-  T smax = sv[ord[0]];
-  int rank = 0;
-  for (int k = 0; k < 3; k++) {
-    int j = ord[k];
-    r.s[k] = sv[j];
-    r.V.set_col(k, V.col(j));
-    if (sv[j] > T(0) && sv[j] > smax * tiny * T(4)) { r.U.set_col(k, A.col(j) / sv[j]); rank = k + 1; }
+  for (int i = 0; i < 3; i++) {
+    const T a = std::fabs(W.m[i][i]);
+    r.s[i] = a;
+    if (a != T(0)) { const T sg = W.m[i][i] / a; for (int k = 0; k < 3; k++) U.m[k][i] *= sg; }
   }
-  // complete U to an orthonormal basis when rank deficient
-  if (rank == 0) { r.U = M3<T>::identity(); }
-  else if (rank == 1) { V3<T> u1 = any_orthogonal(r.U.col(0)); r.U.set_col(1, u1); r.U.set_col(2, cross(r.U.col(0), u1)); }
-  else if (rank == 2) { r.U.set_col(2, normalized(cross(r.U.col(0), r.U.col(1)))); }
+  for (int i = 0; i < 3; i++) r.s[i] *= scale;
+  for (int i = 0; i < 3; i++) {   // descending, by swaps with the largest remaining value (first one on ties)
+    int pos = i;
+    for (int k = i + 1; k < 3; k++) if (r.s[k] > r.s[pos]) pos = k;
+    if (r.s[pos] == T(0)) break;
+    if (pos != i) {
+      std::swap(r.s[i], r.s[pos]);
+      for (int k = 0; k < 3; k++) { std::swap(U.m[k][i], U.m[k][pos]); std::swap(V.m[k][i], V.m[k][pos]); }
+    }
+  }
+  r.U = U; r.V = V;
   return r;
 }
 

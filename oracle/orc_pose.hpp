@@ -326,7 +326,7 @@ template <class T> SE3<T> shinji(const MatX<T>& X_w, const MatX<T>& X_c, int K) 
     V3<T> Ac = X_c.col3(n) - Cc; sigma_c += norm(Ac);
     M = M + outer(Ac, Aw);
   }
-  M = (T(1) / (T)X_w.cols()) * M;  // :75 divides by cols(), not K
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = M(i, j) / (T)X_w.cols();  // :75 'M /= (Tp) X_w_.cols()': cols(), not K; Eigen 3.3 divides
   (void)sigma_w; (void)sigma_c;
   SVD3<T> d = svd3(M);
   M3<T> Tmp = d.U * transpose(d.V);
@@ -570,6 +570,38 @@ template <class T> bool kneip(const MatX<T>& X_w, const MatX<T>& bv, SE3<T>* sol
   return false;
 }
 
+// ------------------------------------------------------------------ explicit hypothesis streams (test plumbing, not in the reference)
+// "both CPU restatement and GPU consume the same sample list".  With capture set, the drivers below only
+// generate: the hypotheses of each of the `Iter` iterations are appended (qw qx qy qz tx ty tz) and nothing is voted on.  With
+// replay set, an iteration's hypotheses come from the given list instead of the sampler + minimal solvers; everything after that
+// (vote loop, strict '>', adaptive Iter, masks) is the reference's.
+struct HypList { std::vector<double> q7; std::vector<int> first; };   // first[i] .. first[i+1]: hypotheses of iteration i
+inline HypList*& capture_sink() { static HypList* p = nullptr; return p; }
+inline const HypList*& replay_source() { static const HypList* p = nullptr; return p; }
+template <class T> bool hyp_replay(int ii, std::vector<SE3<T> >* sols) {
+  const HypList* in = replay_source();
+  if (!in) return false;
+  sols->clear();
+  if (ii + 1 < (int)in->first.size())
+    for (int h = in->first[ii]; h < in->first[ii + 1]; h++) {
+      const double* q = &in->q7[7 * (size_t)h];
+      SE3<T> s; s.R.q = Quat<T>((T)q[0], (T)q[1], (T)q[2], (T)q[3]); s.t = V3<T>((T)q[4], (T)q[5], (T)q[6]);
+      sols->push_back(s);
+    }
+  return true;
+}
+template <class T> bool hyp_capture(const std::vector<SE3<T> >& sols) {
+  HypList* out = capture_sink();
+  if (!out) return false;
+  if (out->first.empty()) out->first.push_back(0);
+  for (const SE3<T>& s : sols) {
+    const double q[7] = {(double)s.R.q.w, (double)s.R.q.x, (double)s.R.q.y, (double)s.R.q.z, (double)s.t.x, (double)s.t.y, (double)s.t.z};
+    out->q7.insert(out->q7.end(), q, q + 7);
+  }
+  out->first.push_back((int)(out->q7.size() / 7));
+  return true;
+}
+
 // ------------------------------------------------------------------ RANSAC drivers
 // shinji_ransac (AOPoseAdapter) :101-156, shinji_ransac2 (AOOnly) :158-213
 template <class T, class Ad> void shinji_ransac_impl(Ad& adapter, const T thre_3d, int& Iter, T confidence, Rand31& rnd) {
@@ -579,18 +611,21 @@ template <class T, class Ad> void shinji_ransac_impl(Ad& adapter, const T thre_3
   adapter.setMaxVotes(-1);
   MaskX inliers(N, 2);
   for (int ii = 0; ii < Iter; ii++) {
-    std::vector<int> sel;
-    re.run(K, &sel, rnd);
-    MatX<T> Xw(3, K), Xc(3, K);
-    bool invalid = false;
-    for (int s = 0; s < K; s++) {
-      Xw.set_col3(s, adapter.getPointGlob(sel[s]));
-      if (adapter.isValid(sel[s])) Xc.set_col3(s, adapter.getPointCurr(sel[s]));
-      else invalid = true;
+    std::vector<SE3<T> > sols;
+    if (!hyp_replay<T>(ii, &sols)) {
+      std::vector<int> sel;
+      re.run(K, &sel, rnd);
+      MatX<T> Xw(3, K), Xc(3, K);
+      bool invalid = false;
+      for (int s = 0; s < K; s++) {
+        Xw.set_col3(s, adapter.getPointGlob(sel[s]));
+        if (adapter.isValid(sel[s])) Xc.set_col3(s, adapter.getPointCurr(sel[s]));
+        else invalid = true;
+      }
+      if (!invalid) { SE3<T> fit = shinji<T>(Xw, Xc, K); if (fit.R.ok) sols.push_back(fit); }  // D4
     }
-    if (invalid) continue;
-    SE3<T> sol = shinji<T>(Xw, Xc, K);
-    if (!sol.R.ok) continue;  // D4
+    if (hyp_capture<T>(sols) || sols.empty()) continue;
+    const SE3<T>& sol = sols[0];
     int votes = vote_33<T>(adapter, sol, thre_3d, inliers);
     if (votes > adapter.getMaxVotes()) {
       adapter.setMaxVotes(votes);
@@ -613,19 +648,22 @@ template <class T> void shinji_prosac(AOOnlyPoseAdapter<T>& adapter, const T thr
   adapter.setMaxVotes(-1);
   MaskX inliers(N, 2);
   for (int ii = 0; ii < Iter; ii++) {
-    std::vector<int> sel;
-    ps.sample(&sel, rnd);
-    adapter.getSortedIdx(sel);
-    MatX<T> Xw(3, K), Xc(3, K);
-    bool invalid = false;
-    for (int s = 0; s < K; s++) {
-      Xw.set_col3(s, adapter.getPointGlob(sel[s]));
-      if (adapter.isValid(sel[s])) Xc.set_col3(s, adapter.getPointCurr(sel[s]));
-      else invalid = true;
+    std::vector<SE3<T> > sols;
+    if (!hyp_replay<T>(ii, &sols)) {
+      std::vector<int> sel;
+      ps.sample(&sel, rnd);
+      adapter.getSortedIdx(sel);
+      MatX<T> Xw(3, K), Xc(3, K);
+      bool invalid = false;
+      for (int s = 0; s < K; s++) {
+        Xw.set_col3(s, adapter.getPointGlob(sel[s]));
+        if (adapter.isValid(sel[s])) Xc.set_col3(s, adapter.getPointCurr(sel[s]));
+        else invalid = true;
+      }
+      if (!invalid) { SE3<T> fit = shinji<T>(Xw, Xc, K); if (fit.R.ok) sols.push_back(fit); }
     }
-    if (invalid) continue;
-    SE3<T> sol = shinji<T>(Xw, Xc, K);
-    if (!sol.R.ok) continue;
+    if (hyp_capture<T>(sols) || sols.empty()) continue;
+    const SE3<T>& sol = sols[0];
     int votes = vote_33<T>(adapter, sol, thre_3d, inliers);
     if (votes > adapter.getMaxVotes()) {
       adapter.setMaxVotes(votes);
@@ -648,24 +686,29 @@ template <class T> void kneip_ransac_impl(PnPPoseAdapter<T>& adapter, const T th
   adapter.setMaxVotes(-1);
   MaskX inliers(N, 1);
   for (int it = 0; it < Iter; it++) {
-    std::vector<int> sel;
-    if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); }
-    else re.run(K, &sel, rnd);
-    MatX<T> bv(3, 3), Xw(3, 3);
-    for (int k = 0; k < 3; k++) { bv.set_col3(k, adapter.getBearingVector(sel[k])); Xw.set_col3(k, adapter.getPointGlob(sel[k])); }
-    std::vector<SE3<T> > sols;
-    kneip_main<T>(Xw, bv, &sols);
-    T minScore = 1000000.0;
-    int minIndex = -1;
-    for (int i = 0; i < (int)sols.size(); i++) {
-      V3<T> pw = adapter.getPointGlob(sel[3]);
-      V3<T> pc = sols[i].R.matrix() * pw + sols[i].t;
-      pc = pc / norm(pc);
-      T score = T(1.0) - dot(pc, adapter.getBearingVector(sel[3]));
-      if (score < minScore) { minScore = score; minIndex = i; }
+    std::vector<SE3<T> > picked;   // the iteration's hypothesis: the P3P branch that best reprojects the 4th point
+    if (!hyp_replay<T>(it, &picked)) {
+      std::vector<int> sel;
+      if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); }
+      else re.run(K, &sel, rnd);
+      MatX<T> bv(3, 3), Xw(3, 3);
+      for (int k = 0; k < 3; k++) { bv.set_col3(k, adapter.getBearingVector(sel[k])); Xw.set_col3(k, adapter.getPointGlob(sel[k])); }
+      std::vector<SE3<T> > sols;
+      kneip_main<T>(Xw, bv, &sols);
+      T minScore = 1000000.0;
+      int minIndex = -1;
+      for (int i = 0; i < (int)sols.size(); i++) {
+        V3<T> pw = adapter.getPointGlob(sel[3]);
+        V3<T> pc = sols[i].R.matrix() * pw + sols[i].t;
+        pc = pc / norm(pc);
+        T score = T(1.0) - dot(pc, adapter.getBearingVector(sel[3]));
+        if (score < minScore) { minScore = score; minIndex = i; }
+      }
+      if (minIndex != -1) picked.push_back(sols[minIndex]);
     }
-    if (minIndex != -1) {
-      const SE3<T>& out = sols[minIndex];
+    if (hyp_capture<T>(picked)) continue;
+    if (!picked.empty()) {
+      const SE3<T>& out = picked[0];
       int votes = vote_23<T>(adapter, out, cos_thr, inliers, /*use_matrix=*/!prosac);
       if (votes > adapter.getMaxVotes()) {
         adapter.setMaxVotes(votes);
@@ -707,11 +750,14 @@ template <class T> void shinji_kneip_impl(AOPoseAdapter<T>& adapter, const T thr
   for (int ii = 0; ii < Iter; ii++) {
     SE3<T> sk, ss;
     std::vector<SE3<T> > sols;
-    std::vector<int> sel;
-    if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); }
-    else re.run(K + 1, &sel, rnd);
-    if (assign_sample<T>(adapter, sel, &X_w, &X_c, &bv)) { ss = shinji<T>(X_w, X_c, K); if (ss.R.ok) sols.push_back(ss); }
-    if (kneip<T>(X_w, bv, &sk)) sols.push_back(sk);
+    if (!hyp_replay<T>(ii, &sols)) {
+      std::vector<int> sel;
+      if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); }
+      else re.run(K + 1, &sel, rnd);
+      if (assign_sample<T>(adapter, sel, &X_w, &X_c, &bv)) { ss = shinji<T>(X_w, X_c, K); if (ss.R.ok) sols.push_back(ss); }
+      if (kneip<T>(X_w, bv, &sk)) sols.push_back(sk);
+    }
+    if (hyp_capture<T>(sols)) continue;
     for (size_t h = 0; h < sols.size(); h++) {
       int votes = vote_33_23<T>(adapter, sols[h], thre_3d, cos_thr, inliers);
       if (votes > adapter.getMaxVotes()) {
@@ -805,11 +851,16 @@ template <class T> void nl_kneip_ransac(NormalAOPoseAdapter<T>& adapter, const T
   MaskX inl(N, 3);
   adapter.setMaxVotes(-1);
   for (int ii = 0; ii < Iter; ii++) {
-    SE3<T> sk;
-    std::vector<int> sel;
-    re.run(K + 1, &sel, rnd);
-    assign_sample_nl<T>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv);
-    if (!kneip<T>(Xw, bv, &sk)) continue;
+    std::vector<SE3<T> > sols;
+    if (!hyp_replay<T>(ii, &sols)) {
+      SE3<T> one;
+      std::vector<int> sel;
+      re.run(K + 1, &sel, rnd);
+      assign_sample_nl<T>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv);
+      if (kneip<T>(Xw, bv, &one)) sols.push_back(one);
+    }
+    if (hyp_capture<T>(sols) || sols.empty()) continue;
+    const SE3<T>& sk = sols[0];
     int votes = vote_nn_23<T>(adapter, sk, cos_thr, cos_nl, inl);
     if (votes > adapter.getMaxVotes()) {
       adapter.setMaxVotes(votes);
@@ -834,12 +885,15 @@ template <class T> void nl_shinji_ransac(NormalAOPoseAdapter<T>& adapter, const 
   adapter.setMaxVotes(-1);
   for (int ii = 0; ii < Iter; ii++) {
     SE3<T> ss, sn;
-    std::vector<int> sel;
-    re.run(K + 1, &sel, rnd);
     std::vector<SE3<T> > sols;
-    if (assign_sample_nl<T>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv)) { ss = shinji<T>(Xw, Xc, K); if (ss.R.ok) sols.push_back(ss); }
-    nl_2p<T>(Xc.col3(0), Nc.col3(0), Xc.col3(1), Xw.col3(0), Nw.col3(0), Xw.col3(1), &sn);
-    sols.push_back(sn);
+    if (!hyp_replay<T>(ii, &sols)) {
+      std::vector<int> sel;
+      re.run(K + 1, &sel, rnd);
+      if (assign_sample_nl<T>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv)) { ss = shinji<T>(Xw, Xc, K); if (ss.R.ok) sols.push_back(ss); }
+      nl_2p<T>(Xc.col3(0), Nc.col3(0), Xc.col3(1), Xw.col3(0), Nw.col3(0), Xw.col3(1), &sn);
+      sols.push_back(sn);
+    }
+    if (hyp_capture<T>(sols)) continue;
     for (size_t h = 0; h < sols.size(); h++) {
       int votes = vote_nn_33<T>(adapter, sols[h], thre_3d, cos_nl, inl);
       if (votes > adapter.getMaxVotes()) {
@@ -869,12 +923,15 @@ template <class T> void nl_shinji_kneip_ransac(NormalAOPoseAdapter<T>& adapter, 
   for (int ii = 0; ii < Iter; ii++) {
     SE3<T> sk, ss, sn;
     std::vector<SE3<T> > sols;
-    std::vector<int> sel;
-    re.run(K + 1, &sel, rnd);
-    if (assign_sample_nl<T>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv)) { ss = shinji<T>(Xw, Xc, K); if (ss.R.ok) sols.push_back(ss); }
-    if (kneip<T>(Xw, bv, &sk)) sols.push_back(sk);
-    nl_2p<T>(Xc.col3(0), Nc.col3(0), Xc.col3(1), Xw.col3(0), Nw.col3(0), Xw.col3(1), &sn);
-    sols.push_back(sn);
+    if (!hyp_replay<T>(ii, &sols)) {
+      std::vector<int> sel;
+      re.run(K + 1, &sel, rnd);
+      if (assign_sample_nl<T>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv)) { ss = shinji<T>(Xw, Xc, K); if (ss.R.ok) sols.push_back(ss); }
+      if (kneip<T>(Xw, bv, &sk)) sols.push_back(sk);
+      nl_2p<T>(Xc.col3(0), Nc.col3(0), Xc.col3(1), Xw.col3(0), Nw.col3(0), Xw.col3(1), &sn);
+      sols.push_back(sn);
+    }
+    if (hyp_capture<T>(sols)) continue;
     for (size_t h = 0; h < sols.size(); h++) {
       int votes = vote_nn_33_23<T>(adapter, sols[h], thre_3d, cos_thr, cos_nl, inl);
       if (votes > adapter.getMaxVotes()) {

@@ -389,3 +389,38 @@ def run(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weight
     L.check(L.lib().rpe_run(method, C.byref(prob), thre_3d, thre_2d, thre_nl, C.byref(it), confidence, seed, ls, score_mode, _p(mi), _p(R),
                             _p(t), C.byref(mv), _p(mo)))
     return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mo)
+
+
+def _problem(dtype, xw, xc, bv, nw, nc, weights, f):
+    dt = _np_dtype(dtype)
+    arrs = {k: (None if a is None else np.ascontiguousarray(a, dtype=dt)) for k, a in dict(xw=xw, xc=xc, bv=bv, nw=nw, nc=nc).items()}
+    n = len(arrs["xw"])
+    w = None if weights is None else np.asfortranarray(weights, dtype=dt)
+    prob = L.RpeProblem(n, dtype, _p(arrs["bv"]), _p(arrs["xc"]), _p(arrs["nc"]), _p(arrs["xw"]), _p(arrs["nw"]), _p(w),
+                        0 if w is None else w.shape[1], f, f)
+    return prob, n, (arrs, w)   # the last item keeps the buffers alive
+
+
+def host_hypotheses(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weights=None, f=585.0, iters=0, seed=1):
+    """rpe_host_hypotheses: the hypothesis stream `method` generates in `iters` iterations (no GPU).  Returns (q7[H, 7], first[iters + 1])."""
+    prob, n, keep = _problem(dtype, xw, xc, bv, nw, nc, weights, f)
+    cap = 3 * iters + 1
+    q7, first = np.zeros((cap, 7)), np.zeros(iters + 1, np.int32)
+    H = L.lib().rpe_host_hypotheses(method, C.byref(prob), iters, seed, _p(q7), cap, _p(first))
+    if H < 0:
+        L.check(H)
+    return q7[:H].copy(), first
+
+
+def run_replay(method, poses7, first, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weights=None, f=585.0, thre_3d=0.0, thre_2d=0.0,
+               thre_nl=0.0, iters=0, confidence=0.99, ls=LS_NONE, score_mode=L.SCORE_EXACT):
+    """rpe_run_replay: rpe_run with the hypotheses of iteration i taken from poses7[first[i]:first[i+1]]."""
+    prob, n, keep = _problem(dtype, xw, xc, bv, nw, nc, weights, f)
+    poses7 = np.ascontiguousarray(poses7, np.float64).reshape(-1, 7)
+    first = np.ascontiguousarray(first, np.int32)
+    R, t = np.eye(3).reshape(9).copy(), np.zeros(3)
+    it, mv = C.c_int(iters), C.c_int(0)
+    mo = np.zeros((3, n), np.int16)
+    L.check(L.lib().rpe_run_replay(method, C.byref(prob), _p(poses7), _p(first), len(first) - 1, thre_3d, thre_2d, thre_nl, C.byref(it), confidence, ls,
+                                   score_mode, _p(R), _p(t), C.byref(mv), _p(mo)))
+    return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mo)

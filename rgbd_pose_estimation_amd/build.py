@@ -15,6 +15,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librgbdpose_hip.so")
 SOURCES = ["rpe_kernels.hip", "rpe_frontend.hip", "rpe_hypotheses.hip", "rpe_capi.hip", "library.cpp"]
 ARCH = "gfx950"
+LINK_RT = "--rtlib=libgcc"
 
 
 def _deps():
@@ -42,17 +43,43 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            # pure host code over the C ABI (the drop-in headers, ao / ao_ransac / rpe_run): the host C++ compiler, IEEE arithmetic
+            # without contraction -- the minimal solvers in pose/*.hpp evaluate the reference's expressions operation by operation
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
+        else:
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+                   "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    # --rtlib=libgcc: the complex multiply / divide helpers (__divdc3 ...) that std::complex code in the P3P solver calls must be the
+    # host toolchain's (libgcc), as in any g++-built caller of the headers; clang's compiler-rt copies round differently
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", LINK_RT, "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     return LIB
+
+
+def build_stamps(level: int = 1, verbose: bool = False) -> str:
+    """DIAGNOSTIC build (never loaded by the product): the same library with -DRPE_STAMPS=<level>, whose reduction kernels stamp the
+    100 MHz clock at their phase boundaries (scripts/tail_timeline.py).  Only rpe_kernels.hip is recompiled."""
+    build()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = os.path.join(LIBDIR, f"librgbdpose_hip_stamps{level}.so")
+    obj = os.path.join(LIBDIR, f"rpe_kernels_stamps{level}.o")
+    if os.path.exists(out) and all(os.path.getmtime(p) <= os.path.getmtime(out) for p in _deps()):
+        return out
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", f"-DRPE_STAMPS={level}",
+           "-x", "hip", "-c", os.path.join(CSRC, "rpe_kernels.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    objs = [obj] + [os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o") for src in SOURCES if src != "rpe_kernels.hip"]
+    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", LINK_RT, "-o", out] + objs)
+    return out
 
 
 EXAMPLES = ["simple_main", "test_main", "icp_main", "engine_profile"]

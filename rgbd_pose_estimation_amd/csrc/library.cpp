@@ -294,4 +294,39 @@ int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, do
   return rc;
 }
 
+
+// ---- explicit hypothesis streams (rpe::Settings::capture / replay, rpe/device.hpp)
+int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t seed, double* q7_out, int cap, int* first_out) {
+  if (!p || p->n <= 0 || !p->xw || iters < 0 || !q7_out || !first_out || method < 0 || method > 9) return rpe::set_error(RPE_ERR_ARG, "rpe_host_hypotheses: bad argument");
+  rpe::Settings::HypothesisList list;
+  rpe::Settings::get().capture = &list;
+  int it = iters, mv = 0, rc = RPE_OK;
+  double R9[9], t3[3];
+  try {
+    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, 0, nullptr, R9, t3, &mv, nullptr)
+                             : run_t<float>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, 0, nullptr, R9, t3, &mv, nullptr);
+  } catch (const std::exception& e) { rc = rpe::set_error(RPE_ERR_STATE, e.what()); }
+  rpe::Settings::get().capture = nullptr;
+  if (rc != RPE_OK) return rc;
+  if (list.first.empty()) list.first.assign((size_t)iters + 1, 0);
+  const int H = (int)(list.q7.size() / 7);
+  if (H > cap || (int)list.first.size() != iters + 1) return rpe::set_error(RPE_ERR_ARG, "rpe_host_hypotheses: output capacity too small");
+  std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
+  std::memcpy(first_out, list.first.data(), sizeof(int) * list.first.size());
+  return H;
+}
+
+int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d, double thre_2d,
+                   double thre_nl, int* iter_io, double confidence, int ls, int score_mode, double* R9, double* t3, int* max_votes,
+                   short* mask_out) {
+  if (!poses7 || !first || list_iters < 0) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: bad argument");
+  rpe::Settings::HypothesisList list;
+  list.first.assign(first, first + list_iters + 1);
+  list.q7.assign(poses7, poses7 + 7 * (size_t)first[list_iters]);
+  rpe::Settings::get().replay = &list;
+  const int rc = rpe_run(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, 1, ls, score_mode, nullptr, R9, t3, max_votes, mask_out);
+  rpe::Settings::get().replay = nullptr;
+  return rc;
+}
+
 }  // extern "C"

@@ -271,7 +271,7 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)4096 * rpe::kNlLd * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)(4096 + 8) * rpe::kNlLd * sizeof(double));   // + 8 shard records
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 9 * 128); }

@@ -2,8 +2,9 @@
 // shinji_ransac2 -- the core of ao_ransac): one thread per RANSAC iteration draws its minimal sample from the SAME random stream
 // the host sampler would have used (PCG32 skip-ahead to its position; RandomElements' partial Fisher-Yates over the identity
 // table), gathers the three correspondences from the HBM-resident arrays, and runs the closed-form fit shinji() for K = 3
-// (pose/AbsoluteOrientation.hpp; reference :47-99) -- by compiling the very functions the host path runs (rpe/linalg.hpp,
-// __host__ __device__) with FMA contraction off, so that every hypothesis is BITWISE the one the host would have produced and the
+// (pose/AbsoluteOrientation.hpp; reference :47-99) -- by compiling the very function the host path runs (rpe::rigid_fit<T>,
+// rpe/linalg.hpp, __host__ __device__: T arithmetic in the reference's operation order, Jacobi SVD) with FMA contraction off and
+// IEEE division / square root, so that every hypothesis is BITWISE the one the host would have produced and the
 // sequential replay in pose/RansacEngine.hpp reaches the same pose, votes, Iter and mask.  The poses land in HBM in the scoring
 // kernel's layout (no staging, no H2D copy) and, as quaternion + translation, in pinned host memory for the replay.
 #pragma clang fp contract(off)
@@ -60,31 +61,18 @@ __global__ __launch_bounds__(64) void gen_shinji_kernel(const T* __restrict__ xw
     set(top, vp);
     sel[s] = vp;
   }
-  T X_w[3][K], X_c[3][K];
+  T X_w[3 * K], X_c[3 * K];   // 3 x K column-major, as the host's MatrixX
   bool valid = true;
   for (int s = 0; s < K; s++) {
     const T cx = xc[3 * (size_t)sel[s]], cy = xc[3 * (size_t)sel[s] + 1], cz = xc[3 * (size_t)sel[s] + 2];
     valid = valid && (cx == cx || cy == cy || cz == cz);   // isValid: not all three NaN
-    X_c[0][s] = cx; X_c[1][s] = cy; X_c[2][s] = cz;
-    X_w[0][s] = xw[3 * (size_t)sel[s]]; X_w[1][s] = xw[3 * (size_t)sel[s] + 1]; X_w[2][s] = xw[3 * (size_t)sel[s] + 2];
+    X_c[3 * s] = cx; X_c[3 * s + 1] = cy; X_c[3 * s + 2] = cz;
+    X_w[3 * s] = xw[3 * (size_t)sel[s]]; X_w[3 * s + 1] = xw[3 * (size_t)sel[s] + 1]; X_w[3 * s + 2] = xw[3 * (size_t)sel[s] + 2];
   }
   T q[4] = {T(1), T(0), T(0), T(0)}, t[3] = {T(0), T(0), T(0)};
-  if (valid) {   // shinji<T>(X_w, X_c, 3), statement for statement
-    Vec3d Cw, Cc;
-    for (int c = 0; c < K; c++) for (int k = 0; k < 3; k++) { Cw[k] += X_w[k][c]; Cc[k] += X_c[k][c]; }
-    for (int k = 0; k < 3; k++) { Cw[k] /= K; Cc[k] /= K; }
-    Mat3d M;
-    for (int c = 0; c < K; c++)
-      for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) M(r, cc) += (X_c[r][c] - Cc[r]) * (X_w[cc][c] - Cw[cc]);
-    const Mat3d R = rotation_from_covariance(M);
-    const Vec3d tt = Cc - mul(R, Cw);
-    T Rt[9];
-    for (int k = 0; k < 9; k++) Rt[k] = (T)R.a[k];
-    const Quat<T> qq = quat_from_R<T>(Rt);
-    const T nrm = sqrt(qq.w * qq.w + qq.x * qq.x + qq.y * qq.y + qq.z * qq.z);
-    if (nrm >= Eps<T>::value()) { q[0] = qq.w / nrm; q[1] = qq.x / nrm; q[2] = qq.y / nrm; q[3] = qq.z / nrm; }   // SO3::fromQuaternion
-    t[0] = (T)tt[0]; t[1] = (T)tt[1]; t[2] = (T)tt[2];
-  }
+  // shinji<T>(X_w, X_c, 3): the host's own function (rpe/linalg.hpp rigid_fit, T arithmetic in the reference's order).  A fit whose
+  // rotation fails the SO3 constructor's test is skipped by the host solvers, so it is reported as not valid here too.
+  if (valid) valid = rigid_fit<T>(X_w, X_c, K, K, Eps<T>::value(), q, t);
   T* hq = h_q7 + 8 * (size_t)i;
   hq[0] = q[0]; hq[1] = q[1]; hq[2] = q[2]; hq[3] = q[3]; hq[4] = t[0]; hq[5] = t[1]; hq[6] = t[2]; hq[7] = valid ? T(1) : T(0);
   if (exact) {

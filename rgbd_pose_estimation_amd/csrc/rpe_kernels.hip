@@ -19,6 +19,24 @@
 
 namespace rpe {
 
+// ---- diagnostic build only (-DRPE_STAMPS, scripts/tail_timeline.py): thread 0 of every workgroup stamps the 100 MHz constant clock at the
+// phase boundaries of the reduction kernels into a buffer of its own (16 words per workgroup); no stamp exists in the product build.
+#ifdef RPE_STAMPS
+__device__ unsigned long long g_stamps[4096 * 16];
+#define RPE_STAMP(k)                                                                                             \
+  do {                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (threadIdx.x == 0) {                                                                                      \
+      unsigned long long t_;                                                                                     \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");                          \
+      g_stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                                              \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  } while (0)
+#else
+#define RPE_STAMP(k) do {} while (0)
+#endif
+
 enum { KIND_P2P = 0, KIND_P2PLANE = 1, KIND_BEARING = 2 };
 enum { F_USE_MASK = 1, F_USE_WEIGHT = 2, F_SKIP_INVALID = 4 };
 
@@ -227,6 +245,7 @@ struct Finish {
   GnState* gn;                 // and its state
   const P2PDesc* p2p;          // multi-GPU peer-to-peer all-reduce of the record (null = single GPU / collective done elsewhere)
   unsigned long long p2p_step;
+  int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
 };
 
 // ---- all-reduce(sum) of the 32-double record across <= 8 GPUs, by the first wave of the LAST workgroup, without leaving the
@@ -364,6 +383,37 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
   return true;
 }
 
+// fixed-order column sums of `count` partial records, rows first, first + step, ...: thread (j, rg) takes every RG-th of them,
+// U independent sc1 loads in flight, then the RG row-group sums are added in row-group order -> tot[j] (valid for threadIdx.x < LD
+// after the caller's barrier).  The order depends on (first, step, count) only, never on which workgroup runs it.
+template <int NACC, int LD, int BLK, int U>
+__device__ __forceinline__ void sum_records(const double* __restrict__ partials, int first, int step, int count, double (*part)[LD],
+                                            double* __restrict__ tot) {
+  constexpr int RG = BLK / LD;
+  const int j = threadIdx.x % LD, rg = threadIdx.x / LD;
+  double s = 0.0;
+  if (j < NACC) {
+    for (int r0 = rg; r0 < count; r0 += RG * U) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = r0 + u * RG;
+        v[u] = r < count ? __hip_atomic_load(partials + (size_t)(first + r * step) * LD + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) s += v[u];
+    }
+  }
+  part[rg][j] = s;
+  __syncthreads();
+  if (threadIdx.x < LD) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < RG; k++) t += part[k][threadIdx.x];
+    tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
+  }
+}
+
 template <int NACC, int LD, int MODE, int BLK>
 __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Finish& fin) {
   constexpr int NW = BLK / 64;
@@ -374,7 +424,9 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   wave_reduce_to<NACC>(acc, red[wave], lane);
+  RPE_STAMP(2);
   __syncthreads();
+  RPE_STAMP(3);
   const int G = gridDim.x;
   if (G > 1) {
     // Hand-off without fences (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms"): EVERY byte of
@@ -388,49 +440,66 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
       __hip_atomic_store(fin.partials + (size_t)blockIdx.x * LD + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RPE_STAMP(4);
     __syncthreads();
-    if (threadIdx.x == 0) {
-      // two-level arrival count: 8 shard counters (one 128-B line each) + a top counter.  A single counter costs
-      // ~12 ns per arrival at the memory side (MI355X_MICROARCH.md "fanin"), i.e. 3+ us for a few hundred workgroups.
-      const int shard = blockIdx.x & 7;
-      const unsigned int in_shard = (unsigned int)((G - shard + 7) >> 3), shards = (unsigned int)(G < 8 ? G : 8);
-      int last = 0;
-      unsigned int* sc = fin.ticket + 32 * shard;
-      if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-        __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rearm for the next launch
+    RPE_STAMP(5);
+    const int shard = blockIdx.x & 7;
+    const int in_shard = (G - shard + 7) >> 3, shards = G < 8 ? G : 8;
+    const int tailv = fin.tail & 3;
+    if (tailv != 1) {
+      if (threadIdx.x == 0) {
+        // two-level arrival count: 8 shard counters (one 128-B line each) + a top counter.  A single counter costs
+        // ~12 ns per arrival at the memory side (MI355X_MICROARCH.md "fanin"), i.e. 3+ us for a few hundred workgroups.
+        int last = 0;
+        unsigned int* sc = fin.ticket + 32 * shard;
+        if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)in_shard - 1) {
+          __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // rearm for the next launch
+          unsigned int* top = fin.ticket + 32 * 8;
+          if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)shards - 1) {
+            __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = 1;
+          }
+        }
+        s_last = last;
+      }
+      RPE_STAMP(6);
+      __syncthreads();
+      if (!s_last) return;
+      RPE_STAMP(7);
+      if (tailv == 2) sum_records<NACC, LD, BLK, 16>(fin.partials, 0, 1, G, part, tot);
+      else sum_records<NACC, LD, BLK, 8>(fin.partials, 0, 1, G, part, tot);
+      RPE_STAMP(8);
+    } else {
+      // hierarchical tail: the last arriver of each shard sums ITS shard's records (rows shard, shard + 8, ...) into one shard
+      // record behind the G workgroup records, then arrives at the top counter; the last shard to arrive sums the <= 8 shard
+      // records in shard order.  Same hand-off rules at both levels; the result is a fixed function of (G, records).
+      if (threadIdx.x == 0) {
+        unsigned int* sc = fin.ticket + 32 * shard;
+        const int last = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)in_shard - 1;
+        if (last) __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+      }
+      RPE_STAMP(6);
+      __syncthreads();
+      if (!s_last) return;
+      RPE_STAMP(7);
+      sum_records<NACC, LD, BLK, 4>(fin.partials, shard, 8, in_shard, part, tot);
+      __syncthreads();
+      if (threadIdx.x < LD) __hip_atomic_store(fin.partials + (size_t)(G + shard) * LD + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      RPE_STAMP(8);
+      if (threadIdx.x == 0) {
         unsigned int* top = fin.ticket + 32 * 8;
-        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
-          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last = 1;
-        }
+        const int last = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)shards - 1;
+        if (last) __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
       }
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // fixed-order column sums: thread (j, rg) takes rows rg, rg + RG, ... ; U independent loads in flight
-    const int j = threadIdx.x % LD, rg = threadIdx.x / LD;
-    double s = 0.0;
-    if (j < NACC) {
-      constexpr int U = 8;
-      for (int r0 = rg; r0 < G; r0 += RG * U) {
-        double v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int r = r0 + u * RG;
-          v[u] = r < G ? __hip_atomic_load(fin.partials + (size_t)r * LD + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) s += v[u];
-      }
-    }
-    part[rg][j] = s;
-    __syncthreads();
-    if (threadIdx.x < LD) {
-      double t = 0.0;
-#pragma unroll
-      for (int k = 0; k < RG; k++) t += part[k][threadIdx.x];
-      tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
+      __syncthreads();
+      if (!s_last) return;
+      RPE_STAMP(12);
+      sum_records<NACC, LD, BLK, 1>(fin.partials, G, 1, shards, part, tot);
+      RPE_STAMP(13);
     }
   } else {
     if (threadIdx.x < LD) {
@@ -508,10 +577,12 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
   }
   if (fin.out_host) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RPE_STAMP(9);
     __syncthreads();
     if (threadIdx.x == 0) {
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    RPE_STAMP(10);
   }
 }
 
@@ -655,6 +726,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
 #pragma unroll
     for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
   }
+  RPE_STAMP(0);
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
@@ -675,6 +747,20 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     if (KIND == KIND_P2PLANE) { c0 = c4[3 * g]; c1 = c4[3 * g + 1]; c2 = c4[3 * g + 2]; }
     if (MASK) load_mask_full(mask, g, m);
     if (WEIGHT) load_weight_full(weight, g, wv);
+  }
+#if defined(RPE_STAMPS) && RPE_STAMPS >= 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
+  RPE_STAMP(11);
+#endif
+  if (stride >= full && !(fin.tail & 8)) {   // frame-sized problems: one group per thread (reduce_grid), nothing to pipeline -- straight-line body
+    if (g < full) {
+      T vw[3 * P], vb[3 * P], vc[3 * P];
+      unpack3(a0, a1, a2, vw);
+      unpack3(b0, b1, b2, vb);
+      if (KIND == KIND_P2PLANE) unpack3(c0, c1, c2, vc);
+      normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, P, acc);
+    }
+    g = full;
   }
   while (g < full) {
     const int64_t gn = g + stride;
@@ -709,6 +795,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     if (WEIGHT) load_scalars<T, T>(weight, full, n, wv, T(0));
     normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, (int)(n - full * P), acc);
   }
+  RPE_STAMP(1);
   reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
 }
 
@@ -1540,6 +1627,19 @@ hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned lo
   return hipGetLastError();
 }
 
+#ifdef RPE_STAMPS
+}  // namespace rpe
+// diagnostic build only: copy the stamp buffer to the host (after a stream synchronise) and clear it
+extern "C" int rpe_debug_read_stamps(unsigned long long* out, int nwords) {
+  if (nwords > 4096 * 16) nwords = 4096 * 16;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rpe::g_stamps), (size_t)nwords * 8) != hipSuccess) return -1;
+  static unsigned long long zeros[4096 * 16];
+  return hipMemcpyToSymbol(HIP_SYMBOL(rpe::g_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
+}
+namespace rpe {
+#endif
+
 // ================================================================================================
 // launchers
 // ================================================================================================
@@ -1576,6 +1676,8 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.partials = rt.d_partials; f.ticket = rt.d_ticket; f.out_dev = rt.d_out; f.out_host = rt.h_out; f.seq = rt.seq;
   f.gn_pose = rt.gn_pose; f.gn = rt.gn;
   f.p2p = rt.p2p; f.p2p_step = rt.p2p_step;
+  static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 0;   // experiments (scripts/tail_timeline.py)
+  f.tail = env_tail;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

@@ -39,23 +39,17 @@ rpe::Point3<Tp> calc_err(const rpe::SE3<Tp>& GT_cw_, const rpe::SE3<Tp>& SE_cw_)
   return rpe::Point3<Tp>(td.norm(), angle, Tp(0));
 }
 
-// Closed-form rigid fit on the first K columns (Umeyama 1991 without scale; reference :47-99).  Host code: inside
-// RANSAC K = 3; the O(N) uses go through rpe::pose_from_device_moments instead.
+// Closed-form rigid fit on the first K columns (Umeyama 1991 without scale; reference :47-99), evaluated in Tp in the reference's
+// operation order (rpe::rigid_fit, rpe/linalg.hpp): inside RANSAC, K = 3, the hypothesis must be the reference's own Tp values or the
+// consensus sets differ at the thresholds.  The O(N) uses go through rpe::pose_from_device_moments instead (one GPU pass, fp64 sums).
+// so3().valid() is false where the reference's SO3(Matrix3) constructor would abort (SOPHUS_ENSURE): the solvers skip such a sample.
 template <typename Tp>
 rpe::SE3<Tp> shinji(const rpe::MatrixX<Tp>& X_w_, const rpe::MatrixX<Tp>& X_c_, int K) {
-  rpe::Vec3d Cw, Cc;
-  for (int i = 0; i < K; i++) for (int k = 0; k < 3; k++) { Cw[k] += X_w_(k, i); Cc[k] += X_c_(k, i); }
-  for (int k = 0; k < 3; k++) { Cw[k] /= K; Cc[k] /= K; }
-  rpe::Mat3d M;
-  for (int i = 0; i < K; i++)
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M(r, c) += (X_c_(r, i) - Cc[r]) * (X_w_(c, i) - Cw[c]);
-  const rpe::Mat3d R = rpe::rotation_from_covariance(M);
-  const rpe::Vec3d t = Cc - rpe::mul(R, Cw);
-  rpe::Matrix3<Tp> Rt;
-  for (int i = 0; i < 9; i++) Rt.a[i] = (Tp)R.a[i];
-  // Tp-rounded entries are orthogonal only to Tp precision: take the quaternion and renormalise, as SO3(quaternion) does
-  const rpe::Quat<Tp> q = rpe::quat_from_R<Tp>(Rt.a);
-  return rpe::SE3<Tp>(rpe::SO3<Tp>::fromQuaternion(q.w, q.x, q.y, q.z), rpe::Point3<Tp>((Tp)t[0], (Tp)t[1], (Tp)t[2]));
+  Tp q[4], t[3];
+  const bool ok = rpe::rigid_fit<Tp>(X_w_.data(), X_c_.data(), K, X_w_.cols(), rpe::LieEps<Tp>::value(), q, t);
+  rpe::SO3<Tp> R = rpe::SO3<Tp>::fromQuaternionRaw(q[0], q[1], q[2], q[3]);
+  if (!ok) R.invalidate();
+  return rpe::SE3<Tp>(R, rpe::Point3<Tp>(t[0], t[1], t[2]));
 }
 
 namespace rpe {
@@ -97,12 +91,13 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
       Xw.setCol(s, adapter.getPointGlob(sel[s]));
       Xc.setCol(s, adapter.getPointCurr(sel[s]));
     }
-    out.push_back(shinji<Tp>(Xw, Xc, K));
+    const SE3<Tp> fit = shinji<Tp>(Xw, Xc, K);
+    if (fit.so3().valid()) out.push_back(fit);
   };
   auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
   // plain RANSAC consumes exactly K draws per iteration, so every iteration's position in the random stream is known up front and
   // the whole iteration can run on the device; PROSAC's sampler rejects duplicates (a variable number of draws) and stays on the host
-  if (!prosac && Settings::get().device_hypotheses && N >= K) ransac_engine_device33<Tp>(adapter, spec, commit, Iter, confidence, /*mask_cols=*/2);
+  if (!prosac && Settings::get().device_hypotheses && N >= K && !Settings::get().capture && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, commit, Iter, confidence, /*mask_cols=*/2);
   else ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   adapter.cvtInlier();
 }
@@ -166,7 +161,7 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
   auto gen = [&](std::vector<SE3<Tp> >& out) {
     std::vector<int> sel;
     if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K + 1, &sel);
-    if (assign_sample<Tp>(adapter, sel, &X_w, &X_c, &bv)) out.push_back(shinji<Tp>(X_w, X_c, K));
+    if (assign_sample<Tp>(adapter, sel, &X_w, &X_c, &bv)) { const SE3<Tp> fit = shinji<Tp>(X_w, X_c, K); if (fit.so3().valid()) out.push_back(fit); }
     SE3<Tp> sk;
     if (kneip<Tp>(X_w, bv, &sk)) out.push_back(sk);
   };

@@ -132,7 +132,7 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
       if (kneip<Tp>(Xw, bv, &sk)) out.push_back(sk);
       return;
     }
-    if (all_valid) out.push_back(shinji<Tp>(Xw, Xc, K));
+    if (all_valid) { const SE3<Tp> fit = shinji<Tp>(Xw, Xc, K); if (fit.so3().valid()) out.push_back(fit); }
     if (which == 2) { SE3<Tp> sk; if (kneip<Tp>(Xw, bv, &sk)) out.push_back(sk); }
     SE3<Tp> sn;  // NB the reference runs nl_2p on whatever Xc/Nc hold, also when the sample was not all valid (:315, :389)
     nl_2p<Tp>(Xc.col(0), Nc.col(0), Xc.col(1), Xw.col(0), Nw.col(0), Xw.col(1), &sn);

@@ -16,81 +16,95 @@
 
 // Real parts of the four roots of a[0] x^4 + a[1] x^3 + a[2] x^2 + a[3] x + a[4] by Ferrari's method with complex
 // intermediates (reference :11-60): depressed quartic y^4 + alpha y^2 + beta y + gamma, resolvent cubic via Cardano.
+// The P3P hypotheses feed threshold tests, so the evaluation keeps the reference's operation order in Tp: powers by repeated
+// multiplication, every quotient formed as there, and -- a C++ detail of the reference -- pow(beta, 2) / 8 in the resolvent is a
+// double expression (pow(Tp, int) promotes), so for Tp = float that term is subtracted in double before rounding.
 template <typename Tp>
 std::vector<Tp> o4_roots(const Tp a[5]) {
   typedef std::complex<Tp> Cx;
   const Tp A = a[0], B = a[1], C = a[2], D = a[3], E = a[4];
-  const Tp ia = Tp(1) / A;
-  const Tp b = B * ia, c = C * ia, d = D * ia, e = E * ia;  // monic coefficients
-  const Tp b2 = b * b;
-  const Tp alpha = c - Tp(3) * b2 / Tp(8);
-  const Tp beta = b2 * b / Tp(8) - b * c / Tp(2) + d;
-  const Tp gamma = -Tp(3) * b2 * b2 / Tp(256) + b2 * c / Tp(16) - b * d / Tp(4) + e;
-  const Cx P(-alpha * alpha / Tp(12) - gamma, 0);
-  const Cx Q(-alpha * alpha * alpha / Tp(108) + alpha * gamma / Tp(3) - beta * beta / Tp(8), 0);
-  const Cx R = -Q / Tp(2) + std::sqrt(Q * Q / Tp(4) + P * P * P / Tp(27));
+  const Tp A2 = A * A, B2 = B * B;
+  const Tp A3 = A2 * A, B3 = B2 * B;
+  const Tp A4 = A3 * A, B4 = B3 * B;
+  const Tp alpha = -3 * B2 / (8 * A2) + C / A;
+  const Tp beta = B3 / (8 * A3) - B * C / (2 * A2) + D / A;
+  const Tp gamma = -3 * B4 / (256 * A4) + B2 * C / (16 * A3) - B * D / (4 * A2) + E / A;
+  const Tp alpha2 = alpha * alpha, alpha3 = alpha2 * alpha;
+  const Cx P(-alpha2 / 12 - gamma, 0);
+  const Cx Q((Tp)((double)(-alpha3 / 108 + alpha * gamma / 3) - (double)beta * (double)beta / 8), 0);
+  const Cx R = -Q / Tp(2.0) + std::sqrt(std::pow(Q, Tp(2.)) / Tp(4.) + std::pow(P, Tp(3.)) / Tp(27.));
   const Cx U = std::pow(R, Tp(1.0 / 3.0));
-  const Cx y = U.real() == 0 ? Cx(-Tp(5) * alpha / Tp(6)) - std::pow(Q, Tp(1.0 / 3.0))
-                             : Cx(-Tp(5) * alpha / Tp(6)) - P / (Tp(3) * U) + U;
-  const Cx w = std::sqrt(Cx(alpha) + Tp(2) * y);
-  const Cx sp = std::sqrt(-(Cx(Tp(3) * alpha) + Tp(2) * y + Tp(2) * beta / w));
-  const Cx sm = std::sqrt(-(Cx(Tp(3) * alpha) + Tp(2) * y - Tp(2) * beta / w));
-  const Tp shift = -b / Tp(4);
+  Cx y;
+  if (U.real() == 0) y = -Tp(5.0) * alpha / Tp(6.) - std::pow(Q, Tp(1.0 / 3.0));
+  else y = -Tp(5.0) * alpha / Tp(6.) - P / (Tp(3.) * U) + U;
+  const Cx w = std::sqrt(alpha + Tp(2.) * y);
+  const Cx up = std::sqrt(-(Tp(3.) * alpha + Tp(2.) * y + Tp(2.) * beta / w));
+  const Cx um = std::sqrt(-(Tp(3.) * alpha + Tp(2.) * y - Tp(2.) * beta / w));
+  const Tp shift = -B / (Tp(4.) * A);
   std::vector<Tp> roots(4);
-  roots[0] = (Cx(shift) + Tp(0.5) * (w + sp)).real();
-  roots[1] = (Cx(shift) + Tp(0.5) * (w - sp)).real();
-  roots[2] = (Cx(shift) + Tp(0.5) * (-w + sm)).real();
-  roots[3] = (Cx(shift) + Tp(0.5) * (-w - sm)).real();
+  roots[0] = (shift + Tp(0.5) * (w + up)).real();
+  roots[1] = (shift + Tp(0.5) * (w - up)).real();
+  roots[2] = (shift + Tp(0.5) * (-w + um)).real();
+  roots[3] = (shift + Tp(0.5) * (-w - um)).real();
   return roots;
 }
 
 // Kneip, Scaramuzza, Siegwart: "A novel parametrization of the P3P problem" (CVPR 2011); reference :63-232.
-// X_w, bv: 3 x (>= 3) column-major; up to four (R_cw, t) with Xc = R Xw + t.
+// X_w, bv: 3 x (>= 3) column-major; up to four (R_cw, t) with Xc = R Xw + t.  Operation order of the reference throughout
+// (products and sums left to right as written there; `1 / (1 - cos_beta^2) - 1` in double because pow(Tp, int) promotes).
 template <typename Tp>
 void kneip_main(const rpe::MatrixX<Tp>& X_w, const rpe::MatrixX<Tp>& bv, std::vector<rpe::SE3<Tp> >* p_solutions_) {
   typedef rpe::Point3<Tp> V3;
   typedef rpe::Matrix3<Tp> M3;
   p_solutions_->clear();
   V3 P1 = X_w.col(0), P2 = X_w.col(1), P3 = X_w.col(2);
-  const V3 edge12 = P2 - P1;
-  if (edge12.cross(P3 - P1).norm() == 0) return;  // collinear world points
+  const V3 edge12 = P2 - P1;                           // kept from BEFORE any swap (:129 reads its norm afterwards)
+  if (edge12.cross(P3 - P1).norm() == 0) return;       // collinear world points
   V3 f1 = bv.col(0), f2 = bv.col(1), f3 = bv.col(2);
 
-  // intermediate camera frame tau = (f1, (f1 x f2) x f1, f1 x f2)
+  // intermediate camera frame tau = (f1, (f1 x f2) x f1, f1 x f2), rows of Tcam
   M3 Tcam;
   auto camera_frame = [&]() {
-    V3 e3 = f1.cross(f2); e3 /= e3.norm();
-    Tcam.setRow(0, f1); Tcam.setRow(1, e3.cross(f1)); Tcam.setRow(2, e3);
-    return Tcam * f3;
+    V3 e3 = f1.cross(f2);
+    e3 = e3 / e3.norm();
+    const V3 e2 = e3.cross(f1);
+    Tcam.setRow(0, f1); Tcam.setRow(1, e2); Tcam.setRow(2, e3);
+    f3 = Tcam * f3;
   };
-  V3 f3t = camera_frame();
-  if (f3t[2] > 0) {  // keep theta in [0, pi]: swap the roles of points 1 and 2
-    std::swap(f1, f2); std::swap(P1, P2);
-    f3 = bv.col(2);
-    f3t = camera_frame();
+  camera_frame();
+  if (f3[2] > 0) {  // keep theta in [0, pi]: swap the roles of points 1 and 2
+    f1 = bv.col(1); f2 = bv.col(0); f3 = bv.col(2);
+    camera_frame();
+    P1 = X_w.col(1); P2 = X_w.col(0); P3 = X_w.col(2);
   }
-  // intermediate world frame eta
-  V3 n1 = P2 - P1; n1 /= n1.norm();
-  V3 n3 = n1.cross(P3 - P1); n3 /= n3.norm();
-  M3 Nw; Nw.setRow(0, n1); Nw.setRow(1, n3.cross(n1)); Nw.setRow(2, n3);
-  const V3 P3e = Nw * (P3 - P1);
+  // intermediate world frame eta, rows of Nw
+  V3 n1 = P2 - P1;
+  n1 = n1 / n1.norm();
+  V3 n3 = n1.cross(P3 - P1);
+  n3 = n3 / n3.norm();
+  const V3 n2 = n3.cross(n1);
+  M3 Nw; Nw.setRow(0, n1); Nw.setRow(1, n2); Nw.setRow(2, n3);
+  P3 = Nw * (P3 - P1);
 
   const Tp d12 = edge12.norm();
-  const Tp f_1 = f3t[0] / f3t[2], f_2 = f3t[1] / f3t[2], p_1 = P3e[0], p_2 = P3e[1];
+  const Tp f_1 = f3[0] / f3[2], f_2 = f3[1] / f3[2], p_1 = P3[0], p_2 = P3[1];
   const Tp cos_beta = f1.dot(f2);
-  Tp b = Tp(1) / (Tp(1) - cos_beta * cos_beta) - Tp(1);
+  Tp b = (Tp)(1 / (1 - (double)cos_beta * (double)cos_beta) - 1);
   b = cos_beta < 0 ? -std::sqrt(b) : std::sqrt(b);
 
-  // quartic in cos(theta), coefficients grouped by common factors
-  const Tp f1s = f_1 * f_1, f2s = f_2 * f_2, p1s = p_1 * p_1, p2s = p_2 * p_2, ds = d12 * d12, bs = b * b;
+  // quartic in cos(theta): the reference's 5 coefficient sums, term by term
+  const Tp f1s = f_1 * f_1, f2s = f_2 * f_2;
+  const Tp p1s = p_1 * p_1, p1c = p1s * p_1, p1q = p1c * p_1;
+  const Tp p2s = p_2 * p_2, p2c = p2s * p_2, p2q = p2c * p_2;
+  const Tp ds = d12 * d12, bs = b * b;
   Tp q[5];
-  q[0] = -p2s * p2s * (f2s + f1s + Tp(1));
-  q[1] = Tp(2) * p2s * p_2 * d12 * (b + f2s * b - f_1 * f_2);
-  q[2] = p2s * (-f2s * p1s - f2s * ds * bs - f2s * ds + f2s * p2s + p2s * f1s + Tp(2) * p_1 * d12 + Tp(2) * f_1 * f_2 * p_1 * d12 * b -
-                p1s * f1s + Tp(2) * p_1 * f2s * d12 - ds * bs - Tp(2) * p1s);
-  q[3] = Tp(2) * p_2 * d12 * (p1s * b + f_1 * f_2 * p2s - f2s * p2s * b - p_1 * d12 * b);
-  q[4] = -Tp(2) * f_2 * p2s * f_1 * p_1 * d12 * b + f2s * p2s * ds + Tp(2) * p1s * p_1 * d12 - p1s * ds + f2s * p2s * p1s - p1s * p1s -
-         Tp(2) * f2s * p2s * p_1 * d12 + p2s * f1s * p1s + f2s * p2s * ds * bs;
+  q[0] = -f2s * p2q - p2q * f1s - p2q;
+  q[1] = 2 * p2c * d12 * b + 2 * f2s * p2c * d12 * b - 2 * f_2 * p2c * f_1 * d12;
+  q[2] = -f2s * p2s * p1s - f2s * p2s * ds * bs - f2s * p2s * ds + f2s * p2q + p2q * f1s + 2 * p_1 * p2s * d12 +
+         2 * f_1 * f_2 * p_1 * p2s * d12 * b - p2s * p1s * f1s + 2 * p_1 * p2s * f2s * d12 - p2s * ds * bs - 2 * p1s * p2s;
+  q[3] = 2 * p1s * p_2 * d12 * b + 2 * f_2 * p2c * f_1 * d12 - 2 * f2s * p2c * d12 * b - 2 * p_1 * p_2 * ds * b;
+  q[4] = -2 * f_2 * p2s * f_1 * p_1 * d12 * b + f2s * p2s * ds + 2 * p1c * d12 - p1s * ds + f2s * p2s * p1s - p1q -
+         2 * f2s * p2s * p_1 * d12 + p2s * f1s * p1s + f2s * p2s * ds * bs;
   const std::vector<Tp> roots = o4_roots<Tp>(q);
 
   for (int i = 0; i < 4; i++) {
@@ -98,13 +112,13 @@ void kneip_main(const rpe::MatrixX<Tp>& X_w, const rpe::MatrixX<Tp>& bv, std::ve
     if (cos_theta != cos_theta) continue;
     const Tp cot_alpha = (-f_1 * p_1 / f_2 - cos_theta * p_2 + d12 * b) / (-f_1 * cos_theta * p_2 / f_2 + p_1 - d12);
     if (cos_theta > Tp(1) || cos_theta < Tp(-1)) continue;
-    const Tp sin_theta = std::sqrt(Tp(1) - cos_theta * cos_theta);
-    const Tp sin_alpha = std::sqrt(Tp(1) / (cot_alpha * cot_alpha + Tp(1)));
-    Tp cos_alpha = std::sqrt(Tp(1) - sin_alpha * sin_alpha);
+    const Tp sin_theta = std::sqrt(1 - cos_theta * cos_theta);
+    const Tp sin_alpha = std::sqrt(1 / (cot_alpha * cot_alpha + 1));
+    Tp cos_alpha = std::sqrt(1 - sin_alpha * sin_alpha);
     if (cot_alpha < 0) cos_alpha = -cos_alpha;
-    const Tp k = d12 * (sin_alpha * b + cos_alpha);
-    const V3 C_eta(k * cos_alpha, k * cos_theta * sin_alpha, k * sin_theta * sin_alpha);
-    const V3 C = P1 + Nw.transpose() * C_eta;  // camera centre in the world frame
+    V3 C(d12 * cos_alpha * (sin_alpha * b + cos_alpha), cos_theta * d12 * sin_alpha * (sin_alpha * b + cos_alpha),
+         sin_theta * d12 * sin_alpha * (sin_alpha * b + cos_alpha));
+    C = P1 + Nw.transpose() * C;  // camera centre in the world frame
     M3 Q;
     Q(0, 0) = -cos_alpha; Q(0, 1) = -sin_alpha * cos_theta; Q(0, 2) = -sin_alpha * sin_theta;
     Q(1, 0) = sin_alpha;  Q(1, 1) = -cos_alpha * cos_theta; Q(1, 2) = -cos_alpha * sin_theta;

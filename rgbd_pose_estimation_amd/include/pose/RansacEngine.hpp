@@ -113,11 +113,36 @@ void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce p
 template <class Tp, class Adapter, class Gen, class Commit>
 void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
   Settings& cfg = Settings::get();
+  if (cfg.capture) {   // generation only (rpe_host_hypotheses): the stream of `Iter` iterations, no device
+    std::vector<SE3<Tp> > hyps;
+    Settings::HypothesisList& out = *cfg.capture;
+    if (out.first.empty()) out.first.push_back(0);
+    for (int i = 0; i < Iter; i++) {
+      hyps.clear();
+      gen(hyps);
+      for (const SE3<Tp>& h : hyps) { double q[7]; pose7<Tp>(h, q); out.q7.insert(out.q7.end(), q, q + 7); }
+      out.first.push_back((int)(out.q7.size() / 7));
+    }
+    return;
+  }
   rpe_context* ctx = adapter.device().ctx();
   std::vector<double> q7;
+  int replay_pos = 0;
   auto produce = [&](int iters, std::vector<SE3<Tp> >& hyps, std::vector<int>& first, std::vector<int>& votes) {
     const double t0 = cfg.profile ? now_us() : 0;
     first.assign(1, 0);
+    if (cfg.replay) {   // a GIVEN hypothesis list (rpe_run_replay); iterations past its end have no hypotheses
+      const Settings::HypothesisList& in = *cfg.replay;
+      const int have = (int)in.first.size() - 1;
+      for (int i = 0; i < iters; i++, replay_pos++) {
+        if (replay_pos < have)
+          for (int h = in.first[replay_pos]; h < in.first[replay_pos + 1]; h++) {
+            const double* q = &in.q7[7 * (size_t)h];
+            hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]), Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
+          }
+        first.push_back((int)hyps.size());
+      }
+    } else
     for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
     if (cfg.profile) { const double t1 = now_us(); cfg.prof.generate += t1 - t0; cfg.prof.score -= t1 - t0; }   // the caller books the whole call as "score"
     if (hyps.empty()) return;

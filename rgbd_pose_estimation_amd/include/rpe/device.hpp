@@ -38,6 +38,14 @@ struct Settings {
   // 3D-3D RANSAC (shinji_ransac / shinji_ransac2): sample + 3-point fit on the device too (rpe_ransac33_batch), bitwise the host's
   // hypotheses; false = host generation (RPE_HOST_HYPOTHESES=1 sets that default)
   bool device_hypotheses = std::getenv("RPE_HOST_HYPOTHESES") == nullptr;
+  // Hypothesis streams made explicit (parity tests, SURVEY.md section 8d "both sides consume the same sample list"):
+  //   capture != null: the RANSAC / PROSAC engines only GENERATE -- the hypotheses of `Iter` iterations are appended to *capture,
+  //                    nothing is scored and no device is touched (rpe_host_hypotheses);
+  //   replay  != null: the engines take their hypotheses from *replay instead of sampling (rpe_run_replay); scoring, the
+  //                    best-so-far / adaptive-Iter replay and the winner's masks run as usual.
+  struct HypothesisList { std::vector<double> q7; std::vector<int> first; };   // first[i] .. first[i+1]: hypotheses of iteration i; 7 doubles each
+  HypothesisList* capture = nullptr;
+  const HypothesisList* replay = nullptr;
   static Settings& get() { static Settings s; return s; }
 };
 
@@ -96,6 +104,7 @@ class DeviceSet {
   }
   // make sure array `slot` in HBM is the host array at `host` (3 x n of Tp)
   template <class Tp> void ensure(int slot, const Tp* host, int64_t n) {
+    if (Settings::get().capture) return;   // generation only: nothing runs on the device
     if (_n != n || _dtype != (int)DType<Tp>::value) {  // first use of this set (a recycled context still holds its last frame)
       check(rpe_set_problem(ctx(), n, DType<Tp>::value), "rpe_set_problem");
       _n = n; _dtype = DType<Tp>::value;

@@ -61,68 +61,97 @@ RPE_HD inline double det3(const Mat3d& m) {
          m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
 }
 
-// Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations: S = V diag(l) V^T.
-RPE_HD inline void sym_eig3(const Mat3d& S_in, Mat3d* V, double l[3]) {
-  Mat3d S = S_in;
-  *V = Mat3d::eye();
-  for (int sweep = 0; sweep < 64; sweep++) {
-    double off = S(0, 1) * S(0, 1) + S(0, 2) * S(0, 2) + S(1, 2) * S(1, 2);
-    double dia = S(0, 0) * S(0, 0) + S(1, 1) * S(1, 1) + S(2, 2) * S(2, 2);
-    if (off <= 1e-34 * dia || off == 0.0) break;
-    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
-      if (S(p, q) == 0.0) continue;
-      double theta = (S(q, q) - S(p, p)) / (2.0 * S(p, q));
-      double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-      double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-      for (int k = 0; k < 3; k++) {  // S <- S J
-        double skp = S(k, p), skq = S(k, q);
-        S(k, p) = c * skp - s * skq; S(k, q) = s * skp + c * skq;
+// ---- 3x3 SVD in T = float / double, host and device: the two-sided Jacobi iteration that Eigen::JacobiSVD runs on a square
+// matrix (the reference's only SVD: JacobiSVD<Matrix<Tp,-1,-1>>(M, ComputeFullU | ComputeFullV), pose/AbsoluteOrientation.hpp:79,
+// pose/AbsoluteOrientationNormal.hpp:44,188,512; Eigen 3.3: SVD/JacobiSVD.h, Jacobi/Jacobi.h).  Following that published algorithm
+// step for step -- and not a mathematically equivalent one -- is what makes a minimal-sample hypothesis here the SAME Tp values the
+// reference's arithmetic yields, so that RANSAC consensus sets can be compared exactly and not "up to rounding at the threshold":
+//   W = A / max|a_ij| ; U = V = I ; repeat sweeps over (p, q) = (1,0) (2,0) (2,1) while some |W_pq| or |W_qp| exceeds
+//   max(min_normal, 2 eps max_k |W_kk|):  G1 symmetrises the 2x2 block, J diagonalises the symmetric block (Jacobi),
+//   W <- (G1 J^T) W J ; U <- U (G1 J^T)^T ; V <- V J ;  finally s_k = |W_kk| scale, sign into U's column, descending by swaps.
+// Matrices are ROW-major 9-arrays.  U and V are full orthogonal bases whatever the rank (they start from I).
+template <class T> struct SvdJ { T U[9], V[9], s[3]; };
+template <class T> struct Givens { T c, s; };   // [c s; -s c]
+template <class T> RPE_HD inline T absv(T x) { return std::fabs(x); }
+template <class T> RPE_HD inline T maxv(T a, T b) { return a < b ? b : a; }   // std::max(a, b)
+// rows p, q:  x' = c x + s y ; y' = -s x + c y
+template <class T> RPE_HD inline void givens_rows(T* M, int p, int q, const Givens<T>& g) {
+  for (int k = 0; k < 3; k++) { const T x = M[3 * p + k], y = M[3 * q + k]; M[3 * p + k] = g.c * x + g.s * y; M[3 * q + k] = -g.s * x + g.c * y; }
+}
+// columns p, q:  x' = c x - s y ; y' = s x + c y
+template <class T> RPE_HD inline void givens_cols(T* M, int p, int q, const Givens<T>& g) {
+  for (int k = 0; k < 3; k++) { const T x = M[3 * k + p], y = M[3 * k + q]; M[3 * k + p] = g.c * x - g.s * y; M[3 * k + q] = g.s * x + g.c * y; }
+}
+template <class T> RPE_HD inline SvdJ<T> jacobi_svd3(const T* A) {
+  const T tiny = std::numeric_limits<T>::min(), prec = T(2) * std::numeric_limits<T>::epsilon();
+  T scale = T(0);
+  for (int i = 0; i < 9; i++) scale = maxv(scale, absv(A[i]));
+  if (scale == T(0)) scale = T(1);
+  SvdJ<T> r;
+  T W[9];
+  for (int i = 0; i < 9; i++) { W[i] = A[i] / scale; r.U[i] = r.V[i] = (i % 4 == 0) ? T(1) : T(0); }
+  T big = maxv(absv(W[0]), maxv(absv(W[4]), absv(W[8])));
+  bool done = false;
+  for (int sweep = 0; !done && sweep < 1000; sweep++) {
+    done = true;
+    for (int p = 1; p < 3; p++) for (int q = 0; q < p; q++) {
+      const T thr = maxv(tiny, prec * big);
+      if (!(absv(W[3 * p + q]) > thr || absv(W[3 * q + p]) > thr)) continue;
+      done = false;
+      // 2x2 block [a b; c d] = rows/cols (p, q)
+      T a = W[4 * p], b = W[3 * p + q], c = W[3 * q + p], d = W[4 * q];
+      Givens<T> g1;
+      const T tr = a + d, df = c - b;
+      if (absv(df) < tiny) { g1.s = T(0); g1.c = T(1); }
+      else { const T u = tr / df, h = std::sqrt(T(1) + u * u); g1.s = T(1) / h; g1.c = u / h; }
+      { const T a0 = a, b0 = b, c0 = c, d0 = d; a = g1.c * a0 + g1.s * c0; b = g1.c * b0 + g1.s * d0; c = -g1.s * a0 + g1.c * c0; d = -g1.s * b0 + g1.c * d0; }
+      (void)c;
+      Givens<T> jr;   // Jacobi rotation of the now symmetric block [a b; b d]
+      const T two_b = T(2) * absv(b);
+      if (two_b < tiny) { jr.c = T(1); jr.s = T(0); }
+      else {
+        const T tau = (a - d) / two_b, w = std::sqrt(tau * tau + T(1));
+        const T t = tau > T(0) ? T(1) / (tau + w) : T(1) / (tau - w);
+        const T sgn = t > T(0) ? T(1) : T(-1), n = T(1) / std::sqrt(t * t + T(1));
+        jr.s = -sgn * (b / absv(b)) * absv(t) * n;
+        jr.c = n;
       }
-      for (int k = 0; k < 3; k++) {  // S <- J^T S
-        double spk = S(p, k), sqk = S(q, k);
-        S(p, k) = c * spk - s * sqk; S(q, k) = s * spk + c * sqk;
-      }
-      for (int k = 0; k < 3; k++) {
-        double vkp = (*V)(k, p), vkq = (*V)(k, q);
-        (*V)(k, p) = c * vkp - s * vkq; (*V)(k, q) = s * vkp + c * vkq;
+      const Givens<T> jl{g1.c * jr.c - g1.s * (-jr.s), g1.c * (-jr.s) + g1.s * jr.c};   // g1 * jr^T
+      givens_rows(W, p, q, jl);
+      givens_cols(r.U, p, q, Givens<T>{jl.c, -jl.s});
+      givens_cols(W, p, q, jr);
+      givens_cols(r.V, p, q, jr);
+      big = maxv(big, maxv(absv(W[4 * p]), absv(W[4 * q])));
+    }
+  }
+  for (int k = 0; k < 3; k++) {
+    const T m = absv(W[4 * k]);
+    r.s[k] = m;
+    if (m != T(0)) { const T sg = W[4 * k] / m; for (int i = 0; i < 3; i++) r.U[3 * i + k] *= sg; }
+  }
+  for (int k = 0; k < 3; k++) r.s[k] *= scale;
+  for (int k = 0; k < 3; k++) {
+    int best = k;
+    for (int j = k + 1; j < 3; j++) if (r.s[j] > r.s[best]) best = j;
+    if (r.s[best] == T(0)) break;
+    if (best != k) {
+      const T ts = r.s[k]; r.s[k] = r.s[best]; r.s[best] = ts;
+      for (int i = 0; i < 3; i++) {
+        const T tu = r.U[3 * i + k]; r.U[3 * i + k] = r.U[3 * i + best]; r.U[3 * i + best] = tu;
+        const T tv = r.V[3 * i + k]; r.V[3 * i + k] = r.V[3 * i + best]; r.V[3 * i + best] = tv;
       }
     }
   }
-  l[0] = S(0, 0); l[1] = S(1, 1); l[2] = S(2, 2);
+  return r;
 }
 
-// A = U diag(s) V^T, s descending, U and V orthogonal (completed when A is rank deficient).
+// A = U diag(s) V^T, s descending, U and V orthogonal (double; the O(N) least-squares paths)
 struct Svd3 { Mat3d U, V; double s[3]; };
 RPE_HD inline Svd3 svd3(const Mat3d& A) {
-  Mat3d W; double l[3];
-  sym_eig3(mul(transposed(A), A), &W, l);
-  int ord[3] = {0, 1, 2};
-  for (int i = 1; i < 3; i++) {   // insertion sort, descending, stable: what std::sort does for 3 elements, usable on the device
-    const int o = ord[i];
-    int j = i;
-    while (j > 0 && l[o] > l[ord[j - 1]]) { ord[j] = ord[j - 1]; j--; }
-    ord[j] = o;
-  }
+  const SvdJ<double> d = jacobi_svd3<double>(A.a);
   Svd3 r;
-  Vec3d av[3];
-  for (int k = 0; k < 3; k++) { r.V.setcol(k, W.col(ord[k])); av[k] = mul(A, r.V.col(k)); r.s[k] = norm3(av[k]); }
-  // modified Gram-Schmidt on A V: exact orthogonality of U even when V is only accurate to rounding
-  const double tiny = 4.0 * std::numeric_limits<double>::epsilon() * (r.s[0] > 0 ? r.s[0] : 1.0);
-  Vec3d u[3];
-  int have = 0;
-  for (int k = 0; k < 3; k++) {
-    Vec3d w = av[k];
-    for (int j = 0; j < have; j++) w = w - dot3(u[j], w) * u[j];
-    double nw = norm3(w);
-    if (nw > tiny && have == k) { u[have++] = (1.0 / nw) * w; }
-    else break;
-  }
-  if (have == 0) { u[0] = Vec3d(1, 0, 0); u[1] = Vec3d(0, 1, 0); u[2] = Vec3d(0, 0, 1); }
-  else if (have == 1) {
-    Vec3d e = std::fabs(u[0][0]) < 0.6 ? Vec3d(1, 0, 0) : Vec3d(0, 1, 0);
-    Vec3d w = cross3(u[0], e); u[1] = (1.0 / norm3(w)) * w; u[2] = cross3(u[0], u[1]);
-  } else if (have == 2) { u[2] = cross3(u[0], u[1]); }
-  for (int k = 0; k < 3; k++) r.U.setcol(k, u[k]);
+  for (int i = 0; i < 9; i++) { r.U.a[i] = d.U[i]; r.V.a[i] = d.V[i]; }
+  for (int k = 0; k < 3; k++) r.s[k] = d.s[k];
   return r;
 }
 RPE_HD inline Vec3d svd_solve3(const Mat3d& A, const Vec3d& b) {
@@ -177,15 +206,67 @@ template <class T> RPE_HD void quat_to_R(const Quat<T>& q, T* R /*row-major*/) {
   R[3] = txy + twz; R[4] = T(1) - (txx + tzz); R[5] = tyz - twx;
   R[6] = txz - twy; R[7] = tyz + twx; R[8] = T(1) - (txx + tyy);
 }
-template <class T> void quat_rotate(const Quat<T>& q, const T* v, T* out) {
+template <class T> RPE_HD void quat_rotate(const Quat<T>& q, const T* v, T* out) {
   T ux = q.y * v[2] - q.z * v[1], uy = q.z * v[0] - q.x * v[2], uz = q.x * v[1] - q.y * v[0];
   ux += ux; uy += uy; uz += uz;
   const T cx = q.y * uz - q.z * uy, cy = q.z * ux - q.x * uz, cz = q.x * uy - q.y * ux;
   out[0] = (v[0] + q.w * ux) + cx; out[1] = (v[1] + q.w * uy) + cy; out[2] = (v[2] + q.w * uz) + cz;
 }
-template <class T> Quat<T> quat_mul(const Quat<T>& a, const Quat<T>& b) {
+template <class T> RPE_HD Quat<T> quat_mul(const Quat<T>& a, const Quat<T>& b) {
   return Quat<T>{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
                  a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+
+// ---- closed-form rigid fit Xc ~ R Xw + t on K columns (Umeyama 1991 without scale: the reference's shinji(),
+// pose/AbsoluteOrientation.hpp:47-99), every operation in T and in the reference's order: column sums / K, centred outer products
+// summed column by column, the sum divided by `cols` (the reference divides by X_w_.cols(), :75 -- equal to K at every call site),
+// Jacobi SVD, R = U V^T, or U diag(1,1,-1) V^T when det(U V^T) < 0, quaternion taken from R without renormalising (what
+// Sophus::SO3(Matrix3) does, sophus/so3.hpp:561-566), t = Cc - q * Cw with the quaternion rotation.  Returns false where
+// SOPHUS_ENSURE would have aborted the reference (R not orthogonal to LieEps, or det(R) <= 0); q and t are filled either way.
+// Xw, Xc: 3 x K column-major.  Host and device (the batched 3-point generator of csrc/rpe_hypotheses.hip runs this very function).
+template <class T> RPE_HD inline void mat3_mul(const T* X, const T* Y, T* Z) {   // row-major, terms added in column order
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Z[3 * i + j] = X[3 * i] * Y[j] + X[3 * i + 1] * Y[3 + j] + X[3 * i + 2] * Y[6 + j];
+}
+template <class T> RPE_HD inline T mat3_det(const T* a) {
+  return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+}
+// |R R^T - I|_F < eps and det R > 0: the two SOPHUS_ENSUREs of SO3(Matrix3) (sophus/rotation_matrix.hpp:13-24)
+template <class T> RPE_HD inline bool is_rotation(const T* R, T eps) {
+  T Rt[9], E[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+  mat3_mul(R, Rt, E);
+  T f = T(0);
+  for (int i = 0; i < 9; i++) { const T d = E[i] - ((i % 4 == 0) ? T(1) : T(0)); f += d * d; }
+  return (std::sqrt(f) < eps) && (mat3_det(R) > T(0));
+}
+template <class T> RPE_HD inline bool rigid_fit(const T* Xw, const T* Xc, int K, int cols, T eps, T q[4], T t[3]) {
+  T Cw[3] = {T(0), T(0), T(0)}, Cc[3] = {T(0), T(0), T(0)};
+  for (int n = 0; n < K; n++) for (int k = 0; k < 3; k++) { Cw[k] += Xw[3 * n + k]; Cc[k] += Xc[3 * n + k]; }
+  for (int k = 0; k < 3; k++) { Cw[k] /= (T)K; Cc[k] /= (T)K; }
+  T M[9];
+  for (int i = 0; i < 9; i++) M[i] = T(0);
+  for (int n = 0; n < K; n++) {
+    T Aw[3], Ac[3];
+    for (int k = 0; k < 3; k++) { Aw[k] = Xw[3 * n + k] - Cw[k]; Ac[k] = Xc[3 * n + k] - Cc[k]; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[3 * r + c] += Ac[r] * Aw[c];
+  }
+  for (int i = 0; i < 9; i++) M[i] /= (T)cols;
+  const SvdJ<T> d = jacobi_svd3<T>(M);
+  T Vt[9], R[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Vt[3 * i + j] = d.V[3 * j + i];
+  mat3_mul(d.U, Vt, R);
+  if (mat3_det(R) < T(0)) {
+    const T F[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(-1)};
+    T UF[9];
+    mat3_mul(d.U, F, UF);
+    mat3_mul(UF, Vt, R);
+  }
+  const Quat<T> qq = quat_from_R<T>(R);
+  q[0] = qq.w; q[1] = qq.x; q[2] = qq.y; q[3] = qq.z;
+  T rc[3];
+  quat_rotate<T>(qq, Cw, rc);
+  for (int k = 0; k < 3; k++) t[k] = Cc[k] - rc[k];
+  return is_rotation(R, eps);
 }
 
 // ---- SE(3) exponential, tangent (upsilon, omega), as Sophus (se3.hpp:321-342 / so3.hpp:322-355)

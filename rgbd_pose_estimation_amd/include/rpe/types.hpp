@@ -117,7 +117,7 @@ template <class Tp> class SO3 {
   }
   static SO3 fromQuaternion(Tp w, Tp x, Tp y, Tp z) {
     SO3 r; Tp n = std::sqrt(w * w + x * x + y * y + z * z);
-    if (!(n >= LieEps<Tp>::value())) { r._ok = false; return r; }
+    if (!(n >= LieEps<Tp>::value())) { r._q = Quat<Tp>{w, x, y, z}; r._ok = false; return r; }   // the reference aborts here (SOPHUS_ENSURE); the values are kept
     r._q = Quat<Tp>{w / n, x / n, y / n, z / n};
     return r;
   }
@@ -134,6 +134,7 @@ template <class Tp> class SO3 {
     return fromQuaternionRaw(real, imag * omega[0], imag * omega[1], imag * omega[2]);
   }
   bool valid() const { return _ok; }
+  void invalidate() { _ok = false; }
   const Quat<Tp>& unit_quaternion() const { return _q; }
   SO3 inverse() const { SO3 r = fromQuaternionRaw(_q.w, -_q.x, -_q.y, -_q.z); r._ok = _ok; return r; }
   Matrix3<Tp> matrix() const { Matrix3<Tp> m; quat_to_R<Tp>(_q, m.a); return m; }

@@ -123,6 +123,26 @@ def run(prob: Problem, method, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0, iters=0, c
     return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mask_out)
 
 
+def hypotheses(prob: Problem, method, iters, seed=1):
+    """orc_hypotheses: the hypothesis stream of `method` over `iters` iterations -> (q7[H, 7], first[iters + 1])."""
+    cap = 3 * iters + 1
+    q7, first = np.zeros((cap, 7)), np.zeros(iters + 1, np.int32)
+    H = lib().orc_hypotheses(prob.is_f64, method, C.byref(prob.c), iters, C.c_uint64(seed), _p(q7), cap, _p(first))
+    assert H >= 0
+    return q7[:H].copy(), first
+
+
+def run_replay(prob: Problem, method, poses7, first, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0, iters=0, confidence=0.99, ls=LS_NONE):
+    poses7 = np.ascontiguousarray(poses7, np.float64).reshape(-1, 7)
+    first = np.ascontiguousarray(first, np.int32)
+    R, t = np.zeros(9), np.zeros(3)
+    it, mv = C.c_int(iters), C.c_int(0)
+    mask_out = np.zeros((3, prob.n), np.int16)
+    lib().orc_run_replay(prob.is_f64, method, C.byref(prob.c), _p(poses7), _p(first), len(first) - 1, C.c_double(thre_3d), C.c_double(thre_2d),
+                         C.c_double(thre_nl), C.byref(it), C.c_double(confidence), ls, _p(R), _p(t), C.byref(mv), _p(mask_out))
+    return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mask_out)
+
+
 def votes(prob: Problem, kind, poses7, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mask_for=-1):
     poses7 = np.ascontiguousarray(poses7, dtype=np.float64).reshape(-1, 7)
     H = len(poses7)

@@ -53,26 +53,68 @@ PIPELINES = [
 ]
 
 
+def _pose_close(got, ref):
+    # the least-squares stages sum in fp64 on the GPU and in Tp on the CPU: poses agree to BASELINE.json's tolerance, not bit for bit
+    return util.rot_err(got["R"], ref["R"]) < util.ROT_TOL_RAD and util.trans_rel_err(got["t"], ref["t"]) < util.TRANS_REL_TOL
+
+
 @pytest.mark.parametrize("f64", [False, True])
-@pytest.mark.parametrize("n", [100, 2000])
+@pytest.mark.parametrize("n", [100, 2000, 32767, 307200])
 @pytest.mark.parametrize("pl", PIPELINES, ids=[p[0] for p in PIPELINES])
 def test_pipelines_agree_with_oracle(oracle, pl, n, f64):
-    """Noisy scenes: the host-side minimal solvers of product and oracle are separate implementations, so hypotheses
-    agree to rounding, not bit for bit; the pipelines must land on equally good consensus sets and the same pose
-    to well within the RANSAC noise (both within tolerance of the truth)."""
+    """NOISY scenes (2D / 3D / normal noise, 20 % gross outliers, 5 % missing camera points), whole pipelines, same seed.
+    The minimal solvers are the reference's arithmetic in Tp on both sides (tests/test_hypothesis_streams.py: identical streams) and
+    the scoring kernels are bit-exact (RPE_SCORE_EXACT), so every integer output must be EQUAL: consensus size, adapted Iter, and all
+    three inlier masks.  The RANSAC pose (a hypothesis) must be the same hypothesis."""
     name, method, arrays, ls, thr = pl
+    if n == 307200 and f64 and name not in ("shinji_ransac", "shinji_kneip_ransac", "nl_shinji_kneip_ransac"):
+        pytest.skip("full-size fp64 runs: one solver per adapter family keeps the CPU oracle's share of the suite to seconds")
     dt = np.float64 if f64 else np.float32
     sc = util.scene_full(500 + n, n, dt, n2d=1.0, n3d=0.05, nnl_deg=2.0, outliers=0.2, nan_frac=0.05)
     data = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
     sel = {k: data[k] for k in arrays}
     kw = dict(iters=300, confidence=0.9999, seed=5, **thr)
-    got = api.run(getattr(api, method), L.F64 if f64 else L.F32, weights=sc.weights, ls=getattr(api, ls), score_mode=L.SCORE_EXACT, **sel, **kw)
-    ref = oracle.run(oracle.Problem(f64, weights=sc.weights, **sel), getattr(oracle, method), ls=getattr(oracle, ls), **kw)
-    assert got["max_votes"] > 0 and ref["max_votes"] > 0
-    assert abs(got["max_votes"] - ref["max_votes"]) <= max(3, 0.03 * ref["max_votes"])
-    e_got, e_ref = util.rot_err(got["R"], sc.R), util.rot_err(ref["R"], sc.R)
-    assert e_got < max(3 * e_ref, 0.02)
-    assert np.linalg.norm(got["t"] - sc.t) < max(3 * np.linalg.norm(ref["t"] - sc.t), 0.15)
+    got = api.run(getattr(api, method), L.F64 if f64 else L.F32, weights=sc.weights, ls=api.LS_NONE, score_mode=L.SCORE_EXACT, **sel, **kw)
+    ref = oracle.run(oracle.Problem(f64, weights=sc.weights, **sel), getattr(oracle, method), ls=oracle.LS_NONE, **kw)
+    assert ref["max_votes"] > 0
+    assert got["max_votes"] == ref["max_votes"]
+    assert got["iters"] == ref["iters"]
+    assert np.array_equal(got["masks"], ref["masks"])
+    assert np.array_equal(got["R"], ref["R"]) and np.array_equal(got["t"], ref["t"])   # the winning hypothesis itself
+    if ls != "LS_NONE" and n <= 32767:   # ... and the least-squares stage on those inliers lands on the oracle's pose
+        got = api.run(getattr(api, method), L.F64 if f64 else L.F32, weights=sc.weights, ls=getattr(api, ls), score_mode=L.SCORE_EXACT, **sel, **kw)
+        ref = oracle.run(oracle.Problem(f64, weights=sc.weights, **sel), getattr(oracle, method), ls=getattr(oracle, ls), **kw)
+        assert np.array_equal(got["masks"], ref["masks"]) and got["iters"] == ref["iters"]
+        tol = (1e-9, 1e-9) if f64 else (util.ROT_TOL_RAD, util.TRANS_REL_TOL)
+        if ls == "LS_NL_BUGCOMPAT" and not f64:
+            tol = (5e-5, 5e-4)   # three accumulate-across-rounds SVDs in float on the CPU side (reference quirk E3): the oracle itself moves by this much between float and double
+        assert util.rot_err(got["R"], ref["R"]) < tol[0] and util.trans_rel_err(got["t"], ref["t"]) < tol[1]
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("pl", [PIPELINES[0], PIPELINES[3], PIPELINES[7]], ids=[PIPELINES[i][0] for i in (0, 3, 7)])
+def test_replay_of_the_oracles_hypothesis_list(oracle, pl, f64):
+    """rpe_run_replay: the ORACLE's hypothesis list (its sampler, its minimal solvers) fed through the product's engine -- scoring on the
+    GPU, strict '>' best-so-far, adaptive Iter, winner's masks -- against the oracle replaying the same list on the CPU."""
+    name, method, arrays, ls, thr = pl
+    n = 20000
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(900 + len(name), n, dt, n2d=1.0, n3d=0.05, nnl_deg=2.0, outliers=0.25, nan_frac=0.05)
+    data = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    sel = {k: data[k] for k in arrays}
+    prob = oracle.Problem(f64, weights=sc.weights, **sel)
+    q7, first = oracle.hypotheses(prob, getattr(oracle, method), 300, seed=21)
+    kw = dict(iters=300, confidence=0.9999, **thr)
+    got = api.run_replay(getattr(api, method), q7, first, L.F64 if f64 else L.F32, weights=sc.weights, **sel, **kw)
+    ref = oracle.run_replay(prob, getattr(oracle, method), q7, first, **kw)
+    assert ref["max_votes"] > 0 and ref["iters"] < 300   # the adaptive bound did shrink: the replay semantics are exercised
+    assert got["max_votes"] == ref["max_votes"] and got["iters"] == ref["iters"]
+    assert np.array_equal(got["masks"], ref["masks"])
+    assert np.array_equal(got["R"], ref["R"]) and np.array_equal(got["t"], ref["t"])
+    # a list shorter than Iter: the missing iterations simply have no hypotheses
+    got = api.run_replay(getattr(api, method), q7[:first[5]], first[:6], L.F64 if f64 else L.F32, weights=sc.weights, **sel, **kw)
+    ref = oracle.run_replay(prob, getattr(oracle, method), q7[:first[5]], first[:6], **kw)
+    assert got["max_votes"] == ref["max_votes"] and got["iters"] == ref["iters"] and np.array_equal(got["masks"], ref["masks"])
 
 
 @pytest.mark.parametrize("f64", [False, True])
@@ -132,13 +174,16 @@ def test_gn_adapter_level(oracle):
         assert util.trans_rel_err(got["t"], po[9:]) < util.TRANS_REL_TOL
 
 
-def test_ao_ransac_ffi(oracle):
-    """Library.cpp ao_ransac(): hard-coded Iter=1000, thre_3d=0.1, confidence=0.99999; result next to the oracle's."""
-    sc = util.scene33(900, 20000, np.float32, noise=0.02, outliers=0.2)
+@pytest.mark.parametrize("n", [20000, 307200])
+def test_ao_ransac_ffi(oracle, n):
+    """Library.cpp ao_ransac(): hard-coded Iter=1000, thre_3d=0.1, confidence=0.99999, then shinji_ls1 over the inliers.  Same
+    sampler stream, same hypotheses, same consensus set as the CPU restatement => the least-squares poses agree to BASELINE.json's
+    tolerance (the sums run in fp64 on the GPU, in float on the CPU)."""
+    sc = util.scene33(900, n, np.float32, noise=0.02, outliers=0.2)
     R, t = api.ao_ransac(sc.Q, sc.P)
     Ro, to, it, votes = oracle.ao_ransac(sc.Q, sc.P, seed=1)
-    assert util.rot_err(R, sc.R) < 2e-3 and util.rot_err(Ro.astype(np.float64), sc.R) < 2e-3
-    assert util.rot_err(R, Ro.astype(np.float64)) < 2e-3
+    assert util.rot_err(R, sc.R) < 2e-3
+    assert util.rot_err(R, Ro.astype(np.float64)) < util.ROT_TOL_RAD and util.trans_rel_err(t, to.astype(np.float64)) < util.TRANS_REL_TOL
 
 
 def test_nan_columns_never_vote(oracle):
