@@ -1,40 +1,122 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric: correspondence-residuals/s + pose error vs the CPU path).
 
-A "step" is ONE Gauss-Newton iteration of the point-to-point absolute-orientation refinement over one batch of
-synthetic correspondences resident in HBM: stage-1 normal-equation kernel (K1) + stage-2 reduction, [all-reduce
-of the 32-double record over RCCL when --gpus > 1], D2H of the record, 6x6 solve and SE(3) exp-map update on the
-host.  Workload at N=1 = BASELINE.json configs[1]: 640x480 dense depth = 307 200 3D-3D correspondences, fp32.
-Weak scaling: every rank holds its own 307 200-correspondence shard (global problem = N x 307 200), same pose.
+A "step" is ONE Gauss-Newton iteration of the point-to-point absolute-orientation refinement over one batch of synthetic
+correspondences resident in HBM: normal-equation kernel (K1: residuals + 6-DoF Jacobians + two-stage reduction to the 27
+scalars), [all-reduce of the 32-double record over RCCL when --gpus > 1], record to the host, 6x6 solve and SE(3) exp-map
+update ON THE HOST (north star), next pose back to the GPU.
+
+  N = 1   workload = BASELINE.json configs[1]: 640x480 dense depth = 307 200 3D-3D correspondences, fp32, refinement over
+          the RANSAC inlier mask.  The host loop is rpe_gn_refine (C++, inside the library); on one GPU its kernel is RESIDENT:
+          ONE launch serves all steps of a refinement, every new pose reaches the waiting grid through device memory.
+  N > 1   workload = configs[4]: 10 000 000 correspondences sharded N ways (contiguous ranges), one all-reduce(sum) of the
+          32-double record per iteration over RCCL (library-owned communicator); strong scaling.  `python bench.py --gpus N`
+          starts its own N rank processes (no GPU is touched by the parent); under torch.distributed.run it is one rank.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  Nothing here reads /root/reference.
+The timed region (barrier + synchronize, K steps, synchronize + barrier, MAX over ranks) is repeated --repeats times from the
+same start pose; ms_per_step is the MEDIAN repetition (p10 / p90 beside it).  Rank 0 prints ONE JSON line.
+Nothing here reads /root/reference.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PER_GPU = 307200           # 640 x 480
+N_FRAME = 307200             # 640 x 480 (configs[1])
+N_SHARDED = 10_000_000       # configs[4]
 BYTES_PER_CORR = 24 + 2      # Xw 12 + Xc 12 + short inlier mask 2 (p2p fp32 + mask)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 THRE_3D = 0.2                # Parameters.yml thre_3d
+PMC_FILE = "profiles/r02_pmc_traffic.json"
+ROCPROF_FILE = "profiles/r02_bench_rocprofv3_kernel_stats.csv"
 
 
+# ------------------------------------------------------------------------------------------------ launcher (no GPU, no torch)
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(base: dict, rank: int, world: int, port: int) -> dict:
+    env = dict(base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return env
+
+
+def launch_children(argv: list[str], gpus: int) -> int:
+    """`python bench.py --gpus N` from a bare shell: N fresh rank processes (one per GPU), started BEFORE anything in this process
+    has touched HIP -- this parent never does.  Rank 0's stdout is forwarded (its last line is the JSON line); any failing child
+    fails the run."""
+    port = free_port()
+    procs = []
+    for r in range(gpus):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=rank_env(os.environ, r, gpus, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def pin_to_gpu_numa_node(local_rank: int):
+    """The host thread that waits for every record and hands every pose over should sit next to the GPU's PCIe root.  Plain
+    sched_setaffinity on this process, before any GPU call (no exec, no wrapper).  Best effort: returns what it did."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        cards = []
+        base = "/sys/class/drm"
+        for name in sorted(os.listdir(base)):
+            if not name.startswith("renderD"):
+                continue
+            dev = os.path.join(base, name, "device")
+            try:
+                if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                    continue
+                cards.append(dev)
+            except OSError:
+                continue
+        if not cards:
+            return {"pinned": False, "reason": "no amdgpu render node in sysfs"}
+        dev = cards[min(local_rank, len(cards) - 1)]
+        cpus = []
+        for part in open(os.path.join(dev, "local_cpulist")).read().strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        cand = [c for c in cpus if c in allowed] or allowed
+        # one CPU per rank, away from CPU 0 (interrupts), spread so that ranks do not share a core
+        cpu = cand[(1 + 2 * local_rank) % len(cand)]
+        os.sched_setaffinity(0, {cpu})
+        return {"pinned": True, "cpu": cpu, "numa_node": open(os.path.join(dev, "numa_node")).read().strip(), "gpu_local_cpus": len(cpus)}
+    except Exception as e:  # noqa: BLE001
+        return {"pinned": False, "reason": repr(e)}
+
+
+# ------------------------------------------------------------------------------------------------ workload
 def make_shard(rank: int, n: int):
     """Same ground-truth pose on every rank, different points per rank (Simulator.hpp model, Parameters.yml values)."""
+    import numpy as np
     from rgbd_pose_estimation_amd import simulator as S
     R, t = S.random_pose(np.random.default_rng(20260101))
     rng = np.random.default_rng(1000 + rank)
@@ -43,6 +125,7 @@ def make_shard(rank: int, n: int):
 
 def initial_pose(sc):
     """Start 0.02 rad / 5 cm away from the truth (what a RANSAC winner looks like)."""
+    import numpy as np
     w = np.array([0.012, -0.010, 0.0125]); th = np.linalg.norm(w)
     K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
     dR = np.eye(3) + math.sin(th) / th * K + (1 - math.cos(th)) / th ** 2 * K @ K
@@ -50,6 +133,7 @@ def initial_pose(sc):
 
 
 def rot_err(Ra, Rb):
+    import numpy as np
     D = Ra @ Rb.T
     s = np.linalg.norm([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]]) / 2
     return math.atan2(s, (np.trace(D) - 1) / 2)
@@ -58,6 +142,7 @@ def rot_err(Ra, Rb):
 def cpu_baseline(sc, seconds: float):
     """Oracle (CPU restatement of the reference) timed on this host: shinji_ls2<float> through AOOnlyPoseAdapter's
     virtual getters, exactly what Library.cpp ao() runs; 1 thread because the reference is single-threaded."""
+    import numpy as np
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes as C
@@ -100,44 +185,46 @@ def cpu_baseline(sc, seconds: float):
         return {"value": None, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e!r}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the legs reported beside the headline (profiling runs: only the headline's launches)")
-    ap.add_argument("--debug-chunks", action="store_true")
-    ap.add_argument("--time-every", type=int, default=16, help="every k-th K1 launch of the timed region carries a HIP event pair (its dispatch begin / end timestamps)")
-    args = ap.parse_args()
+def percentile(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
+
+# ------------------------------------------------------------------------------------------------ one rank
+def worker(args, affinity):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("RPE_BENCH_DRY_RUN") == "1":
+        # launcher test on a CPU box: the rank reports the environment it was started with and leaves BEFORE anything touches a GPU
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus, "steps": args.steps,
+                              "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+        sys.exit(int(os.environ.get("RPE_BENCH_DRY_EXIT", "0")) if rank == int(os.environ.get("RPE_BENCH_DRY_EXIT_RANK", "-1")) else 0)
+    import ctypes as C
+    import numpy as np
     force_dist = os.environ.get("RPE_BENCH_FORCE_DIST") == "1"   # exercise the collective path with one rank
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
 
     # Load librgbdpose_hip.so (and let it register its gfx950 code objects) BEFORE torch initialises HIP: measured on
     # MI355X / ROCm 7.x, a library whose fat binary is registered after hipInit() pays 2-3x the launch latency per
-    # kernel (62 us vs 20 us per step here).  torch's bundled libamdhip64 is the one runtime of the process (_lib.py).
+    # kernel.  torch's bundled libamdhip64 is the one runtime of the process (_lib.py).
     from rgbd_pose_estimation_amd import _lib as L, api
     L.lib()
     n_dev = L.device_count()
     import torch
     import torch.distributed as dist
-    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_native_comm, init_p2p
+    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_native_comm, init_p2p, shard_range
 
     if n_dev < 1 or not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
+    if local_rank >= n_dev and os.environ.get("RPE_BENCH_SHARE_GPU") == "1":
+        local_rank = 0   # test rig: several ranks on the one GPU of the box
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("RPE_BENCH_BACKEND", "nccl")
     cdev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"   # where tensors handed to torch.distributed live
-    if world > 1 or force_dist:
+    dist_path = world > 1 or force_dist
+    if dist_path:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         # plumbing backend: "nccl" (= RCCL) in production; "gloo" lets the tests run two ranks on ONE GPU (RCCL refuses that)
@@ -146,9 +233,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    n = args.n_per_gpu
+    # ---- workload
+    if world > 1:
+        total_n = args.n_total if args.n_total > 0 else N_SHARDED
+        lo, hi = shard_range(total_n, rank, world)
+        n = hi - lo
+        workload = (f"configs[4]: {total_n} 3D-3D correspondences sharded over {world} GPUs (contiguous ranges, {n} on rank 0), point-to-point "
+                    "Gauss-Newton step over the RANSAC inlier mask, ONE all-reduce(sum) of the 32-double record per iteration")
+        scaling = "strong"
+    else:
+        n = args.n_per_gpu
+        total_n = n
+        workload = (f"configs[1]: 640x480 dense depth, {n} 3D-3D correspondences, point-to-point absolute orientation, Gauss-Newton "
+                    "step (K1 normal equations + host 6x6 solve + SE3 exp-map update) over the RANSAC inlier mask")
+        scaling = "weak"
     sc = make_shard(rank, n)
-    dist_path = world > 1 or force_dist
     # the collective needs the kernel on the stream torch orders the all-reduce after; one GPU uses the library's own stream
     stream = torch.cuda.Stream(device=local_rank) if dist_path else None
     import contextlib
@@ -160,33 +259,31 @@ def main():
         from rgbd_pose_estimation_amd.api import pose12, pose7_from_Rt
         # untimed prologue: one scoring pass at the initial pose writes the 3D-3D inlier mask (K4b), as RANSAC would
         q0 = pose7_from_Rt(R0, t0, L.F32)
-        inl = ctx.inlier_mask(L.VOTE_33, q0, thre_3d=THRE_3D)
+        inl = int(ctx.inlier_mask(L.VOTE_33, q0, thre_3d=THRE_3D))
         shard.kind, shard.flags = L.RES_P2P, L.USE_MASK
         gn = ShardedGaussNewton(shard.normal_eq)
         pose = pose12(R0, t0)
-        # N > 1, in order of preference (every rank takes the same branch; RPE_BENCH_COLLECTIVE=p2p|rccl|torch forces one):
-        #   p2p   the kernel's last workgroup exchanges the 32-double record with its peers over xGMI (HIP IPC mailboxes) and sums
-        #         in rank order: the sharded step is ONE launch, no collective library on the critical path
-        #   rccl  kernel -> in-place ncclAllReduce on the library's own communicator -> publish kernel
-        #   torch kernel -> torch.distributed.all_reduce -> .cpu()   (fallback)
-        want = os.environ.get("RPE_BENCH_COLLECTIVE", "torch" if os.environ.get("RPE_BENCH_TORCH_ALLREDUCE") == "1" else "auto")
-        p2p = native = False
+
+        # ---- N > 1: the collective.  Default = RCCL on a library-owned communicator.  The in-kernel peer-to-peer exchange over
+        # xGMI is tried only on request (RPE_BENCH_COLLECTIVE=auto|p2p): verified against the all-reduced record first, timed
+        # against RCCL, kept only if faster; both times go into the JSON line.
+        want = os.environ.get("RPE_BENCH_COLLECTIVE", "rccl")
+        p2p = native = rccl_ok = False
+        coll_times = {}
         if dist_path:
-            # every rank first runs the kernel on its own (code-object load, clock ramp: the first launches of a process on a cold box
-            # can take seconds), so that the ranks enter the first exchange together and not one of them seconds late
-            for _ in range(200):
+            for _ in range(200):   # first launches of a process on a cold box can take seconds: ranks enter the first collective together
                 ctx.normal_eq(L.RES_P2P, pose12(R0, t0), L.USE_MASK)
             dist.barrier()
         if dist_path and want in ("auto", "p2p"):
             p2p = init_p2p(ctx)
-            if p2p:   # trust, but verify once against the collective library before timing anything
+            if p2p:
                 chk = pose12(R0, t0)
                 rec = np.zeros(32)
-                dist.barrier()   # ranks arrive here at different times: the exchange inside the kernel has a bounded wait
+                dist.barrier()
                 try:
                     L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
                     delivered = 1
-                except L.RpeError as e:   # e.g. a peer's record never arrived (bounded wait inside the kernel)
+                except L.RpeError as e:
                     delivered = 0
                     print(f"[bench] rank {rank}: peer-to-peer step failed: {e}", file=sys.stderr, flush=True)
                 ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
@@ -201,15 +298,10 @@ def main():
                     ctx.p2p_destroy()
                     p2p = False
         if dist_path and not p2p and want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1":
-            sys.exit("bench.py: the peer-to-peer collective was requested strictly and is not available")   # every rank agrees on p2p (MIN flag): all exit
-        rccl_ok = False
-        if dist_path and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1") and want in ("auto", "rccl", "p2p"):
-            # with a peer-to-peer path in place rpe_gn_step_dist prefers it; the communicator is its stand-by
-            rccl_ok = init_native_comm(ctx)
-        if dist_path and p2p and rccl_ok and want == "auto":
-            # both collectives work: keep the faster one (measured here, 400 steps each after a short settling run; every rank reaches
-            # the same verdict because the times are max-reduced).  The wire cannot be exercised on a one-GPU box, so the choice is
-            # made on the machine the benchmark actually runs on.
+            sys.exit("bench.py: the peer-to-peer collective was requested strictly and is not available")
+        if dist_path and want in ("auto", "rccl", "p2p") and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1"):
+            rccl_ok = init_native_comm(ctx)   # with a peer-to-peer path in place rpe_gn_step_dist prefers it; the communicator is its stand-by
+        if dist_path and p2p and rccl_ok:
             def timed(k):
                 q = pose12(R0, t0)
                 ctx.gn_steps_dist(L.RES_P2P, q, 200, L.USE_MASK)
@@ -219,13 +311,11 @@ def main():
                 tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 return float(tt.item()) / k
-            t_p2p = timed(400)
+            coll_times["p2p_us"] = timed(400) * 1e6
             L.check(L.lib().rpe_p2p_pause(ctx._h, 1))      # stand-by: the same call now takes the RCCL path
-            t_rccl = timed(400)
+            coll_times["rccl_us"] = timed(400) * 1e6
             L.check(L.lib().rpe_p2p_pause(ctx._h, 0))
-            if rank == 0:
-                print(f"[bench] sharded step: peer-to-peer {t_p2p * 1e6:.1f} us, RCCL {t_rccl * 1e6:.1f} us", file=sys.stderr, flush=True)
-            if t_rccl < t_p2p:
+            if coll_times["rccl_us"] < coll_times["p2p_us"] or want == "rccl":
                 dist.barrier()
                 ctx.p2p_destroy()
                 p2p = False
@@ -233,62 +323,85 @@ def main():
         collective = "none" if not dist_path else ("peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
                                                    "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
 
-        # The host side of the loop (launch, wait for the published record, 6x6 solve, SE(3) exp-map update) is C++ inside the
-        # library -- rpe_gn_refine / rpe_gn_steps_dist with tol = 0 run exactly k iterations -- so that the timed region contains
-        # no Python per step (a ctypes call per step costs 2-3 us of the ~18).  The torch fallback keeps its Python loop.
+        # The host side of the loop (wait for the record, 6x6 solve, SE(3) exp-map update, next pose out) is C++ inside the library:
+        # rpe_gn_refine / rpe_gn_steps_dist with tol = 0 run exactly k iterations, so the timed region contains no Python per step.
+        resident = (not dist_path) and os.environ.get("RPE_RESIDENT", "1") != "0"
+
         def run_steps(p, k):
             if k <= 0:
                 return p
             if not dist_path:
-                q, its, _, _ = ctx.gn_refine([L.RES_P2P], p, None, L.USE_MASK, k, 0.0)   # k x (kernel + publish + solve + exp-map)
+                q, its, _, _ = ctx.gn_refine([L.RES_P2P], p, None, L.USE_MASK, k, 0.0)
                 assert its == k
                 return q
             if native:
-                ctx.gn_steps_dist(L.RES_P2P, p, k, L.USE_MASK)   # k x (kernel [+ peer exchange | RCCL all-reduce + publish] + solve + exp-map)
+                ctx.gn_steps_dist(L.RES_P2P, p, k, L.USE_MASK)
                 return p
             for _ in range(k):
                 p = gn.step(p)[0]
             return p
 
-        # untimed pre-warm, independent of --warmup: the first ~25 ms of launches after torch has initialised HIP contain a
-        # one-off ~35 ms stall (measured; runtime lazy initialisation), and the FIRST process on a freshly booted box runs its
-        # kernels ~25 % slower for about a second (measured: 16.4 us vs 12.7 us per launch; 1 s of pre-warm removes it) --
-        # neither may land in the timed region
+        # untimed pre-warm, independent of --warmup: the first process on a freshly booted box runs its kernels slower for about a
+        # second, and the runtime's lazy initialisation stalls once -- neither may land in the timed region
         if dist_path:
-            pose = run_steps(pose, int(os.environ.get("RPE_BENCH_PREWARM_STEPS", "60000")))   # a FIXED count: every rank must issue the same number of collective steps
+            pose = run_steps(pose, int(os.environ.get("RPE_BENCH_PREWARM_STEPS", "20000")))   # a FIXED count: every rank issues the same number of collective steps
         else:
             t_pre = time.perf_counter()
             while time.perf_counter() - t_pre < float(os.environ.get("RPE_BENCH_PREWARM_S", "1.5")):
                 pose = run_steps(pose, 500)
-        pose = run_steps(pose12(R0, t0), args.warmup)
-        if args.time_every > 0:
-            ctx.timing_enable(args.steps // args.time_every + 1, args.time_every)   # HIP events around every time_every-th K1 launch
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t_start = time.perf_counter()
-        chunk_t = []
-        if args.debug_chunks:
-            for k in range(0, args.steps, 250):
-                pose = run_steps(pose, min(250, args.steps - k))
-                chunk_t.append(time.perf_counter())
-        else:
-            pose = run_steps(pose, args.steps)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t_start
-        cnt, k_total_ms, k_min_ms = ctx.timing_collect()
-        ctx.timing_enable(0, 1)
-        ev_avg_ms, ev_min_ms = ctx.timing_calibrate(200)   # what an empty event pair reads: the marker latency inside every interval
+        run_steps(pose12(R0, t0), args.warmup)
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # ---- timed: `repeats` repetitions of EXACTLY `steps` steps, each bracketed by barrier + synchronize, MAX over ranks
+        launches_per_rep = 1 if resident else args.steps
+        time_every = 1 if (resident or args.steps < 256) else 16
+        per_rep_records = (launches_per_rep + time_every - 1) // time_every
+        budget = 4096
+        timed_reps = max(1, min(args.repeats, budget // max(per_rep_records, 1)))
+        samples, k_cnt, k_total_ms, k_min_ms = [], 0, 0.0, 1e30
+        for rep in range(args.repeats):
+            timing = rep < timed_reps
+            if timing:
+                ctx.timing_enable(per_rep_records + 1, time_every)
+            p_start = pose12(R0, t0)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
+            pose = run_steps(p_start, args.steps)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t_start
+            if world > 1:
+                tmax = torch.tensor([el], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            samples.append(el)
+            if timing:
+                cnt, tot_ms, mn_ms = ctx.timing_collect()
+                k_cnt += cnt; k_total_ms += tot_ms
+                if cnt:
+                    k_min_ms = min(k_min_ms, mn_ms)
+                ctx.timing_enable(0, 1)
+        ev_avg_ms, ev_min_ms = ctx.timing_calibrate(200)
+        elapsed = percentile(samples, 0.5)
 
-    # extra on the collective path (every rank takes part): the sharded device-resident loop -- exchange + sum + 6x6 solve + exp-map
-    # in the kernel's last workgroup, one launch per iteration on every GPU, one host wait per refinement
+        # where a step's time goes, seen from the host thread (resident loop only): waiting for the GPU vs its own work
+        loop_prof = None
+        if not dist_path and hasattr(L.lib(), "rpe_debug_loop_profile"):
+            try:
+                gpu_us, host_us, cnt = C.c_double(0), C.c_double(0), C.c_longlong(0)
+                L.lib().rpe_debug_loop_profile(ctx._h, 1, None, None, None)
+                run_steps(pose12(R0, t0), args.steps)
+                L.lib().rpe_debug_loop_profile(ctx._h, 0, C.byref(gpu_us), C.byref(host_us), C.byref(cnt))
+                if cnt.value:
+                    loop_prof = {"steps": cnt.value, "host_waits_for_record_us": gpu_us.value / cnt.value, "host_solve_update_handover_us": host_us.value / cnt.value,
+                                 "note": "per step, host clock inside rpe_gn_refine: waiting = pose hand-over in flight + kernel iteration + record in flight; "
+                                         "host = 6x6 LDL^T solve + SE(3) exp-map update + 13 stores into the control block"}
+            except Exception as e:  # noqa: BLE001
+                loop_prof = {"error": repr(e)}
+
+    # extra on the collective path (every rank takes part): the sharded device-resident loop
     sharded_loop = None
     if world > 1 and p2p and not args.no_extras:
         try:
@@ -300,54 +413,71 @@ def main():
             td = torch.tensor([time.perf_counter() - t0d], dtype=torch.float64, device=cdev)
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
             dtd = float(td.item())
-            sharded_loop = {"value": float(n) * world * K / dtd, "unit": "correspondence-residuals/s", "us_per_iteration": dtd / K * 1e6, "iterations": itd,
-                            "rot_rad_vs_host_loop": rot_err(pd[:9].reshape(3, 3), pose[:9].reshape(3, 3)),
+            sharded_loop = {"value": float(total_n) * K / dtd, "unit": "correspondence-residuals/s", "us_per_iteration": dtd / K * 1e6, "iterations": itd,
                             "note": "rpe_gn_refine_device after rpe_p2p_init: one launch per iteration on every GPU; beside, not instead of, the headline"}
-        except Exception as e:
+        except Exception as e:  # noqa: BLE001
             sharded_loop = {"error": repr(e)}
 
+    # global inlier count (valid correspondences) for the headline value
+    inl_total = inl
+    if world > 1:
+        ti = torch.tensor([inl], dtype=torch.int64, device=cdev)
+        dist.all_reduce(ti)
+        inl_total = int(ti.item())
+
+    out = None
     if rank == 0:
-        total = float(n) * world * args.steps
-        k_avg_s = (k_total_ms / max(cnt, 1)) * 1e-3
-        achieved = BYTES_PER_CORR * n / k_avg_s / 1e9 if k_avg_s > 0 else None
-        traffic = None
-        rocprof_avg_us = None
-        try:   # the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), for side-by-side reading
-            import csv
-            with open(os.path.join(ROOT, "profiles", "r01_bench_rocprofv3_kernel_stats.csv")) as fh:
-                for row in csv.DictReader(fh):
-                    if "normal_eq_kernel<float, 0" in row["Name"]:
-                        rocprof_avg_us = float(row["AverageNs"]) * 1e-3
-        except Exception:
-            rocprof_avg_us = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("normal_eq_p2p_f32_bytes_per_launch")
+        steps_per_launch = args.steps if resident else 1
+        k_avg_s = (k_total_ms / max(k_cnt, 1)) * 1e-3
+        bytes_per_launch = BYTES_PER_CORR * n * steps_per_launch
+        achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else None
+        traffic, traffic_src, rocprof_avg_us, rocprof_src = None, None, None, None
+        kernel_name = "rpe::normal_eq_resident_kernel<float, 0, 512, true, false, true>" if resident else "rpe::normal_eq_kernel<float, 0, 512, true, false>"
+        if world == 1 and resident:
+            try:   # the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), for side-by-side reading
+                import csv
+                with open(os.path.join(ROOT, ROCPROF_FILE)) as fh:
+                    for row in csv.DictReader(fh):
+                        if "normal_eq_resident_kernel<float, 0" in row["Name"]:
+                            rocprof_avg_us = float(row["AverageNs"]) * 1e-3
+                            rocprof_src = ROCPROF_FILE
             except Exception:
-                traffic = None
-        out = {
-            "metric": "correspondence-residuals/sec", "value": total / elapsed, "unit": "correspondence-residuals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: 640x480 dense depth, {n} 3D-3D correspondences per GPU, point-to-point absolute "
-                                   "orientation, Gauss-Newton step (K1 normal equations + host SE3 exp-map update) over the RANSAC inlier mask",
-                       "corr_per_gpu": n, "global_corr": n * world, "inliers_rank0": int(inl), "accumulate": "fp64",
-                       "collective": collective},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "rpe::normal_eq_kernel<float, 0>", "algorithmic_bytes_per_launch": BYTES_PER_CORR * n,
-                         "avg_launch_us": k_avg_s * 1e6, "min_launch_us": k_min_ms * 1e3, "launches_timed": cnt,
-                         "empty_event_pair_us": ev_avg_ms * 1e3, "rocprofv3_avg_launch_us": rocprof_avg_us,
-                         "note": "HIP events on the kernel's own stream: every time_every-th stage-1 launch of the timed region is issued with "
-                                 "hipExtLaunchKernelGGL(start, stop), so the pair holds that dispatch's begin / end timestamps (the quantity rocprofv3 "
-                                 "reports; rocprofv3_avg_launch_us is its average for the same command from the committed profiles/ summary; two "
-                                 "marker packets around the launch would add their own latency, empty_event_pair_us); 7.99 MB working set is "
-                                 "L2/Infinity-Cache resident after the first step, so this is not an HBM-streaming figure (see DESIGN.md)"},
-        }
-        # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)
-        if world == 1:
+                pass
             try:
+                j = json.load(open(os.path.join(ROOT, PMC_FILE)))
+                traffic = j.get("normal_eq_resident_p2p_f32_bytes_per_launch")
+                traffic_src = PMC_FILE
+            except Exception:
+                pass
+        ms_med = elapsed / args.steps * 1e3
+        out = {
+            "metric": "correspondence-residuals/sec", "value": float(inl_total) * args.steps / elapsed, "unit": "correspondence-residuals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
+                       "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
+                       "streamed_corr_per_s": float(total_n) * args.steps / elapsed, "accumulate": "fp64", "collective": collective,
+                       "collective_step_us": coll_times or None, "rccl_ranks": world if (dist_path and rccl_ok and not p2p) else 0,
+                       "host_loop": "rpe_gn_refine: ONE resident launch per refinement, poses handed over through device memory" if resident else
+                                    ("rpe_gn_steps_dist: one launch + one collective per step" if dist_path else "rpe_gn_refine: one launch per step")},
+            "timing": {"repeats": args.repeats, "statistic": "median over repetitions of the whole K-step region (MAX over ranks each)",
+                       "ms_per_step_p10": percentile(samples, 0.1) / args.steps * 1e3, "ms_per_step_p90": percentile(samples, 0.9) / args.steps * 1e3,
+                       "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": affinity, "loop_profile": loop_prof},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_launch, "steps_per_launch": steps_per_launch,
+                         "avg_launch_us": k_avg_s * 1e6, "avg_launch_us_per_step": k_avg_s * 1e6 / steps_per_launch, "min_launch_us": (k_min_ms * 1e3) if k_cnt else None,
+                         "launches_timed": k_cnt, "empty_event_pair_us": ev_avg_ms * 1e3, "rocprofv3_avg_launch_us": rocprof_avg_us,
+                         "rocprofv3_source": rocprof_src,
+                         "note": "HIP events on the kernel's own stream (hipExtLaunchKernelGGL start / stop = the dispatch's begin / end timestamps, what "
+                                 "rocprofv3 reports).  One launch of the resident kernel serves steps_per_launch iterations; its duration INCLUDES the host's "
+                                 "turn of every iteration (record over PCIe, 6x6 solve, exp-map, next pose over PCIe): algorithmic bytes = 26 B x "
+                                 "correspondences x iterations.  The correspondences of a frame-sized problem stay in registers between iterations, so "
+                                 "this is not an HBM-streaming figure (DESIGN.md section 5); traffic / rocprofv3_* are read from the named profiles/ files "
+                                 "(collected with the same command on another box), not measured in this run"},
+        }
+        if world == 1:
+            try:   # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import oracle_lib as O
                 m = ctx.download_mask(L.MOD_33)
@@ -356,111 +486,24 @@ def main():
                                             "trans_rel": float(np.linalg.norm(pose[9:] - to) / np.linalg.norm(to)),
                                             "tolerance": {"rot_rad": 1e-5, "trans_rel": 1e-4},
                                             "reference": "oracle shinji() fp64 on the same fp32 inputs and inlier set"}
-            except Exception as e:
+            except Exception as e:  # noqa: BLE001
                 out["pose_error_vs_cpu"] = {"error": repr(e)}
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(sc, args.cpu_seconds)
-            # extra (not the headline: the north star keeps the exp-map on the host): the same iterations with the 6x6 solve and
-            # the SE(3) update done by the kernel's last workgroup, one launch per iteration, one host wait at the end
-            try:
-                if args.no_extras:
-                    raise StopIteration
-                K = 500
-                p0d = pose12(R0, t0)
-                ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0d, L.USE_MASK, 50, 0.0)
-                t0d = time.perf_counter()
-                pd, itd, _, _ = ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0d, L.USE_MASK, K, 0.0)
-                dtd = time.perf_counter() - t0d
-                out["device_resident_loop"] = {"value": n * K / dtd, "unit": "correspondence-residuals/s", "us_per_iteration": dtd / K * 1e6,
-                                               "iterations": itd, "rot_rad_vs_host_loop": rot_err(pd[:9].reshape(3, 3), pose[:9].reshape(3, 3)),
-                                               "note": "rpe_gn_refine_device: solve + exp-map on the GPU; reported beside, not instead of, the host-update headline"}
-            except StopIteration:
-                pass
-            except Exception as e:
-                out["device_resident_loop"] = {"error": repr(e)}
-            # extra: the step BEFORE the path -- two rendered 640x480 depth frames of the reference camera,
-            # dense projective ICP with association and normal equations fused in one kernel per round, pose kept on the GPU
-            try:
-                if args.no_extras:
-                    raise StopIteration
-                from rgbd_pose_estimation_amd import simulator as S
-                Ra, ta = S._rot_zyx(0.05, -0.1, 0.02), np.array([0.1, -0.05, 0.2])
-                dR = S._rot_zyx(0.02, -0.015, 0.01)
-                Rb, tb = dR @ Ra, dR @ ta + np.array([0.03, -0.02, 0.025])
-                fctx = api.Context(local_rank)
-                fctx.frame_set_depth(S.render_depth(Ra, ta, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
-                fctx.model_from_frame(pose12(Ra, ta))
-                fctx.frame_set_depth(S.render_depth(Rb, tb, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
-                K, reps = 20, 25
-                fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
-                t0i = time.perf_counter()
-                for _ in range(reps):
-                    pi, iti, _, _, pairs = fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
-                dti = (time.perf_counter() - t0i) / reps
-                out["icp_frame_loop"] = {"value": pairs * K / dti, "unit": "pixel-residuals/s", "us_per_round": dti / K * 1e6, "rounds": K,
-                                         "pairs": pairs, "pixels": 307200, "rot_err_rad_vs_truth": rot_err(pi[:9].reshape(3, 3), Rb),
-                                         "trans_err_m_vs_truth": float(np.linalg.norm(pi[9:] - tb)),
-                                         "note": "rpe_icp fused + device-resident: projective association + point-to-plane normal equations in one kernel per round"}
-                fctx.close()
-            except StopIteration:
-                pass
-            except Exception as e:
-                out["icp_frame_loop"] = {"error": repr(e)}
-            # extra: the other half of the hot path -- batched RANSAC hypothesis scoring (vote loops V1/V2, kernel K4) on the same frame:
-            # 512 hypotheses per pass; the CPU figure is the oracle's vote loop (AOOnlyPoseAdapter virtual getters, 1 thread)
-            try:
-                if args.no_extras:
-                    raise StopIteration
-                rng_s = np.random.default_rng(3)
-                H = 512
-                dq = 0.002 * rng_s.standard_normal((H, 7))
-                base7 = pose7_from_Rt(sc.R, sc.t, L.F32)
-                poses = base7[None, :] + dq
-                poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
-                poses = np.ascontiguousarray(poses.astype(np.float32).astype(np.float64))
-                res = {}
-                for mode, name in ((L.SCORE_FAST, "fast"), (L.SCORE_EXACT, "exact")):
-                    t_w = time.perf_counter()
-                    while time.perf_counter() - t_w < 0.2:   # settle: freeing the ICP context above stalls the next launches for ~0.1 s once
-                        ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
-                    t0s = time.perf_counter()
-                    reps = 20
-                    for _ in range(reps):
-                        v = ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
-                    dts = (time.perf_counter() - t0s) / reps
-                    res[name] = {"corr_hyp_per_s": n * H / dts, "us_per_pass": dts * 1e6}
-                    if mode == L.SCORE_EXACT:
-                        v_exact = v
-                cpu = None
-                if not args.no_cpu_baseline:
-                    import oracle_lib as O
-                    votes_cpu = np.zeros(8, np.int32)
-                    xw32, xc32 = np.ascontiguousarray(sc.Q, np.float32), np.ascontiguousarray(sc.P, np.float32)
-                    p8 = np.ascontiguousarray(poses[:8])
-                    O.lib().orc_time_votes33.restype = C.c_double
-                    dtc = O.lib().orc_time_votes33(xw32.ctypes.data_as(C.c_void_p), xc32.ctypes.data_as(C.c_void_p), n, p8.ctypes.data_as(C.c_void_p), 8,
-                                                    C.c_float(THRE_3D), votes_cpu.ctypes.data_as(C.c_void_p))
-                    cpu = {"corr_hyp_per_s": n * 8 / dtc, "cores": 1, "sample": "8 hypotheses through the oracle's vote loop",
-                           "votes_equal_exact_mode": bool(np.array_equal(votes_cpu, v_exact[:8]))}
-                out["ransac_scoring"] = {"hypotheses": H, "kind": "3D-3D (V1/V2)", "fast": res["fast"], "exact": res["exact"], "cpu_port": cpu,
-                                         "note": "wall time per rpe_score call incl. pose upload and vote read-out; beside, not instead of, the headline"}
-            except StopIteration:
-                pass
-            except Exception as e:
-                out["ransac_scoring"] = {"error": repr(e)}
+            if not args.no_extras:
+                extras(out, args, ctx, sc, n, R0, t0, pose, local_rank)
         else:
             if sharded_loop is not None:
                 out["device_resident_loop"] = sharded_loop
             out["pose_error_vs_truth"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), sc.R), "trans_abs_m": float(np.linalg.norm(pose[9:] - sc.t))}
             out["cpu_baseline"] = None
-        if args.debug_chunks:
-            ts = [t_start] + chunk_t
-            out["chunk_us_per_step"] = [round((b - a) / 250 * 1e6, 1) for a, b in zip(ts[:-1], ts[1:])]
+            # the weak-scaling figure beside the strong-scaling headline: every rank's own frame-sized shard at the same step rate
+            out["weak_scaling_note"] = "strong scaling (fixed 10 M total) is the headline for N > 1; per-GPU work at N = 1 is configs[1] (307 200)"
     # tear everything down first: RCCL prints its version banner on stdout around communicator life-cycle events, and
     # the JSON line must be the LAST line rank 0 prints
     if world > 1:
         dist.barrier()   # no rank may unmap its mailbox / destroy its communicator while a peer can still reach it
     ctx.close()
-    if world > 1 or force_dist:
+    if dist_path:
         dist.destroy_process_group()
     sys.stdout.flush()
     try:  # RCCL's banner sits in the C stdio buffer until exit: push it out before the JSON line
@@ -470,6 +513,136 @@ def main():
         pass
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
+    """Legs reported BESIDE the headline (never part of `value`)."""
+    import ctypes as C
+    import numpy as np
+    from rgbd_pose_estimation_amd import _lib as L, api
+    from rgbd_pose_estimation_amd.api import pose12, pose7_from_Rt
+    # (1) the same iterations with one launch per step (RPE_RESIDENT=0 behaviour), for the step-time budget
+    try:
+        K = 2000
+        p0 = pose12(R0, t0)
+        best = 1e9
+        for _ in range(3):
+            t0s = time.perf_counter()
+            for _k in range(K // 500):
+                api_steps = 500
+                q = p0.copy()
+                for _s in range(api_steps):   # rpe_gn_step: one launch + wait + host solve per call (ctypes per step: ~2 us of it)
+                    ctx.gn_step(L.RES_P2P, q, L.USE_MASK)
+            best = min(best, (time.perf_counter() - t0s) / K)
+        out["launch_per_step_loop"] = {"us_per_step": best * 1e6, "note": "rpe_gn_step per iteration (kernel launch + record + host solve each step), Python-driven"}
+    except Exception as e:  # noqa: BLE001
+        out["launch_per_step_loop"] = {"error": repr(e)}
+    # (2) solve + exp-map on the GPU too (not the headline: the north star keeps the exp-map on the host)
+    try:
+        K = 500
+        p0d = pose12(R0, t0)
+        ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0d, L.USE_MASK, 50, 0.0)
+        t0d = time.perf_counter()
+        pd, itd, _, _ = ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0d, L.USE_MASK, K, 0.0)
+        dtd = time.perf_counter() - t0d
+        out["device_resident_loop"] = {"value": out["config"]["valid_corr_per_step"] * K / dtd, "unit": "correspondence-residuals/s", "us_per_iteration": dtd / K * 1e6,
+                                       "iterations": itd, "rot_rad_vs_host_loop": rot_err(pd[:9].reshape(3, 3), pose[:9].reshape(3, 3)),
+                                       "note": "rpe_gn_refine_device: solve + exp-map on the GPU, one launch per iteration; reported beside, not instead of, the host-update headline"}
+    except Exception as e:  # noqa: BLE001
+        out["device_resident_loop"] = {"error": repr(e)}
+    # (3) the step BEFORE the path (SURVEY 8f rank 3): dense projective ICP on two rendered 640x480 depth frames
+    try:
+        from rgbd_pose_estimation_amd import simulator as S
+        Ra, ta = S._rot_zyx(0.05, -0.1, 0.02), np.array([0.1, -0.05, 0.2])
+        dR = S._rot_zyx(0.02, -0.015, 0.01)
+        Rb, tb = dR @ Ra, dR @ ta + np.array([0.03, -0.02, 0.025])
+        fctx = api.Context(local_rank)
+        fctx.frame_set_depth(S.render_depth(Ra, ta, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
+        fctx.model_from_frame(pose12(Ra, ta))
+        fctx.frame_set_depth(S.render_depth(Rb, tb, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
+        K, reps = 20, 25
+        fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
+        t0i = time.perf_counter()
+        for _ in range(reps):
+            pi, iti, _, _, pairs = fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
+        dti = (time.perf_counter() - t0i) / reps
+        out["icp_frame_loop"] = {"value": pairs * K / dti, "unit": "pixel-residuals/s", "us_per_round": dti / K * 1e6, "rounds": K,
+                                 "pairs": pairs, "pixels": 307200, "rot_err_rad_vs_truth": rot_err(pi[:9].reshape(3, 3), Rb),
+                                 "trans_err_m_vs_truth": float(np.linalg.norm(pi[9:] - tb)),
+                                 "note": "rpe_icp fused + device-resident: projective association + point-to-plane normal equations in one kernel per round"}
+        fctx.close()
+    except Exception as e:  # noqa: BLE001
+        out["icp_frame_loop"] = {"error": repr(e)}
+    # (4) the other half of the hot path: batched RANSAC hypothesis scoring (vote loops V1/V2, kernel K4), 512 hypotheses per pass
+    try:
+        rng_s = np.random.default_rng(3)
+        H = 512
+        dq = 0.002 * rng_s.standard_normal((H, 7))
+        base7 = pose7_from_Rt(sc.R, sc.t, L.F32)
+        poses = base7[None, :] + dq
+        poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+        poses = np.ascontiguousarray(poses.astype(np.float32).astype(np.float64))
+        res = {}
+        v_exact = None
+        for mode, name in ((L.SCORE_FAST, "fast"), (L.SCORE_EXACT, "exact")):
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.2:
+                ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
+            t0s = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                v = ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
+            dts = (time.perf_counter() - t0s) / reps
+            res[name] = {"corr_hyp_per_s": n * H / dts, "us_per_pass": dts * 1e6}
+            if mode == L.SCORE_EXACT:
+                v_exact = v
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            votes_cpu = np.zeros(8, np.int32)
+            xw32, xc32 = np.ascontiguousarray(sc.Q, np.float32), np.ascontiguousarray(sc.P, np.float32)
+            p8 = np.ascontiguousarray(poses[:8])
+            O.lib().orc_time_votes33.restype = C.c_double
+            dtc = O.lib().orc_time_votes33(xw32.ctypes.data_as(C.c_void_p), xc32.ctypes.data_as(C.c_void_p), n, p8.ctypes.data_as(C.c_void_p), 8,
+                                            C.c_float(THRE_3D), votes_cpu.ctypes.data_as(C.c_void_p))
+            cpu = {"corr_hyp_per_s": n * 8 / dtc, "cores": 1, "sample": "8 hypotheses through the oracle's vote loop",
+                   "votes_equal_exact_mode": bool(np.array_equal(votes_cpu, v_exact[:8]))}
+        out["ransac_scoring"] = {"hypotheses": H, "kind": "3D-3D (V1/V2)", "fast": res["fast"], "exact": res["exact"], "cpu_port": cpu,
+                                 "note": "wall time per rpe_score call incl. pose upload and vote read-out; beside, not instead of, the headline"}
+    except Exception as e:  # noqa: BLE001
+        out["ransac_scoring"] = {"error": repr(e)}
+    # (5) configs[2] exactly as SURVEY 8d states it: 307 200 3D-3D + 2 000 bearings, 300 RANSAC iterations of shinji + kneip from a
+    # fixed seeded sample list, scored in batches, best-so-far / adaptive-Iter replay, joint GN refine -- GPU pipeline and CPU oracle
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import config3_case
+        out["config3_pipeline"] = config3_case.run(with_cpu=not args.no_cpu_baseline)
+    except Exception as e:  # noqa: BLE001
+        out["config3_pipeline"] = {"error": repr(e)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=50, help="repetitions of the timed K-step region; the median is reported")
+    ap.add_argument("--n-per-gpu", type=int, default=N_FRAME, help="correspondences at N = 1 (configs[1])")
+    ap.add_argument("--n-total", type=int, default=0, help="total correspondences at N > 1 (default configs[4]: 10 000 000)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs reported beside the headline (profiling runs: only the headline's launches)")
+    args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
+        sys.exit("bench.py: --gpus, --steps and --repeats must be positive")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_children(sys.argv[1:], args.gpus))   # this process never initialises HIP
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and "WORLD_SIZE" in os.environ:
+        args.gpus = world
+    affinity = pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0"))) if os.environ.get("RPE_BENCH_NO_PIN") != "1" else {"pinned": False, "reason": "RPE_BENCH_NO_PIN=1"}
+    worker(args, affinity)
 
 
 if __name__ == "__main__":

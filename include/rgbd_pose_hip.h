@@ -144,6 +144,11 @@ int rpe_gn_refine_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int
 int rpe_gn_refine_device(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
                          int* iters_out, double* last_step, double* final_cost);
 
+/* Test hook for the device-resident loop: ONE application, ON THE GPU, of what its last workgroup does with a record -- the register
+ * LDL^T solve of H delta = -g and pose <- exp(delta) * pose with the kernel's own SE(3) exponential (sophus/se3.hpp:321-342) -- to a
+ * record and pose of the caller's.  RPE_ERR_DEGENERATE where the device solve refuses the system. */
+int rpe_debug_device_gn_update(rpe_context* ctx, const double* ne32, double* pose12, double* step_norm);
+
 /* One Gauss-Newton step on one GPU (kernel -> D2H of the 32-double record -> solve -> exp-map update of pose12).
  * ne32_out / step_norm may be NULL. */
 int rpe_gn_step(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
@@ -176,6 +181,11 @@ int rpe_p2p_destroy(rpe_context* ctx);
  * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */
 int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
                   double tol, int* iters_out, double* last_step, double* final_cost);
+
+/* Host-clock profile of rpe_gn_refine's resident loop (one GPU): enable = 1 clears and starts; enable = 0 stops and returns the sums, in
+ * microseconds over `steps` steady-state iterations, of the host's WAIT for a record (pose hand-over in flight + one iteration of the
+ * resident kernel + record in flight) and of the host's own turn (6x6 solve + SE(3) update + hand-over stores). */
+int rpe_debug_loop_profile(rpe_context* ctx, int enable, double* wait_us, double* host_us, long long* steps);
 
 /* HIP-event timing of the normal-equation kernel, on the context's stream: after enable(max_records, stride)
  * every stride-th rpe_normal_eq* call launches its kernel with an event pair that receives the dispatch's own begin / end

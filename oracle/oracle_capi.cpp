@@ -234,7 +234,7 @@ int orc_hypotheses(int is_f64, int method, const orc_problem* p, int iters, uint
   if (list.first.empty()) list.first.assign((size_t)iters + 1, 0);
   const int H = (int)(list.q7.size() / 7);
   if (H > cap || (int)list.first.size() != iters + 1) return -1;
-  std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
+  if (!list.q7.empty()) std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
   std::memcpy(first_out, list.first.data(), sizeof(int) * list.first.size());
   return H;
 }

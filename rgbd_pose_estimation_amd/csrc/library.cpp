@@ -311,7 +311,7 @@ int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t se
   if (list.first.empty()) list.first.assign((size_t)iters + 1, 0);
   const int H = (int)(list.q7.size() / 7);
   if (H > cap || (int)list.first.size() != iters + 1) return rpe::set_error(RPE_ERR_ARG, "rpe_host_hypotheses: output capacity too small");
-  std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
+  if (!list.q7.empty()) std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
   std::memcpy(first_out, list.first.data(), sizeof(int) * list.first.size());
   return H;
 }

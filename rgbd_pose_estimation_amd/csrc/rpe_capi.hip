@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>   // types only: the RCCL entry points are resolved with dlopen/dlsym (no DT_NEEDED on librccl)
 
 #include <cstdarg>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -27,6 +28,16 @@ int fail(int code, const char* fmt, ...) {
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RPE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 size_t elem_size(int dtype) { return dtype == RPE_F64 ? 8 : 4; }
+inline double clock_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+
+// orders the host's stores into BAR-mapped device memory (possibly write-combining): data before tags, tags out at once
+inline void store_fence() {
+#if defined(__x86_64__)
+  __asm__ __volatile__("sfence" ::: "memory");
+#else
+  __sync_synchronize();
+#endif
+}
 
 }  // namespace
 
@@ -115,6 +126,15 @@ struct rpe_context {
   int p2p_world = 0, p2p_rank = 0, p2p_world_saved = 0;
   unsigned long long p2p_step = 0;
   unsigned long long p2p_vote_step = 0;   // the same for the vote counters of sharded scoring
+  // resident Gauss-Newton loop (rpe_gn_refine on one GPU): control block in fine-grained device memory that the HOST writes through
+  // the PCIe BAR and every workgroup of the resident kernel polls (layout: rpe_kernels.hip).  Null when the device memory is not
+  // host-accessible (no large BAR): the loop then launches one kernel per iteration.
+  volatile unsigned long long* ctl = nullptr;
+  bool resident = false;
+  // optional host-clock profile of the resident loop (rpe_debug_loop_profile): time spent waiting for records vs the host's own turn
+  bool loop_prof = false;
+  double prof_wait_us = 0, prof_host_us = 0;
+  long long prof_steps = 0;
   void* h_stage = nullptr;        // pinned staging for device -> host copies into caller (pageable) memory
   size_t h_stage_cap = 0;
   // front end (Part 3): the current depth frame's maps and the model it is registered against, all in HBM
@@ -214,6 +234,33 @@ int wait_host(rpe_context* c, int ld) {
   }
 }
 
+// Tagged form (resident loop): the record arrives as `ld` pairs {value, seq}, each written by ONE 16-byte store; it is complete
+// when every pair carries the wanted sequence value.  A pair's value is read after its tag (acquire): both came in one write.
+int wait_host_tagged(rpe_context* c, int ld, double* out) {
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_out);
+  const unsigned long long want = c->seq;
+  for (unsigned long long spins = 0;; spins++) {
+    int have = 0;
+    for (int i = ld - 1; i >= 0; i--) {
+      if (__atomic_load_n(pairs + 2 * i + 1, __ATOMIC_ACQUIRE) != want) break;
+      have++;
+    }
+    if (have == ld) {
+      for (int i = 0; i < ld; i++) { const unsigned long long w = __atomic_load_n(pairs + 2 * i, __ATOMIC_RELAXED); std::memcpy(out + i, &w, 8); }
+      return RPE_OK;
+    }
+    if ((spins & 0xFFFFF) == 0xFFFFF) {
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+      if (q == hipSuccess) {   // the resident kernel is gone (it gives up after ~2 s without a new pose): did the record still arrive?
+        int all = 1;
+        for (int i = 0; i < ld; i++) all = all && __atomic_load_n(pairs + 2 * i + 1, __ATOMIC_ACQUIRE) == want;
+        if (!all) return fail(RPE_ERR_HIP, "the resident kernel ended without publishing record %llu", want);
+      }
+    }
+  }
+}
+
 // same spin on an arbitrary pinned sequence word
 int wait_flag(rpe_context* c, unsigned long long* flag, unsigned long long want) {
   for (unsigned long long spins = 0;; spins++) {
@@ -286,6 +333,17 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { std::memset(c->h_votes, 0, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int)); c->h_flag2 = reinterpret_cast<unsigned long long*>(c->h_votes + rpe::kMaxScoreH); }
   if (e != hipSuccess) { rpe_destroy(c); return fail(RPE_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e)); }
+  {  // resident loop: needs device memory the CPU can store into (large BAR); RPE_RESIDENT=0 switches it off
+    int large_bar = 0;
+    const char* env = getenv("RPE_RESIDENT");
+    if (!(env && env[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
+      void* p = nullptr;
+      if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+        c->ctl = (volatile unsigned long long*)p;
+        c->resident = true;
+      } else { (void)hipGetLastError(); if (p) (void)hipFree(p); }
+    } else (void)hipGetLastError();
+  }
   *out = c;
   return RPE_OK;
 }
@@ -308,6 +366,7 @@ void rpe_destroy(rpe_context* c) {
   if (c->h_votes) (void)hipHostFree(c->h_votes);
   (void)rpe_p2p_destroy(c);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->ctl) (void)hipFree((void*)c->ctl);
   if (c->fe.d_depth) (void)hipFree(c->fe.d_depth);
   for (float* m : c->fe.fmap) if (m) (void)hipFree(m);
   for (float* m : c->fe.mmap) if (m) (void)hipFree(m);
@@ -621,6 +680,26 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   return RPE_OK;
 }
 
+// Test hook: what ONE iteration of the device-resident loop does with a record -- solve H delta = -g by the kernel's register LDL^T and
+// apply pose <- exp(delta) pose by the kernel's own exponential map (sophus/se3.hpp:321-342) -- on the GPU, for a record and pose of
+// the caller's.  Returns RPE_ERR_DEGENERATE where the device solve refuses the system.
+int rpe_debug_device_gn_update(rpe_context* c, const double* ne32, double* pose12, double* step_norm) {
+  if (!c || !ne32 || !pose12) return fail(RPE_ERR_ARG, "rpe_debug_device_gn_update: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  double buf[48];
+  for (int i = 0; i < 32; i++) buf[i] = ne32[i];
+  for (int i = 0; i < 12; i++) buf[32 + i] = pose12[i];
+  buf[44] = buf[45] = 0;
+  HIP_TRY(hipMemcpyAsync(c->d_out, buf, sizeof(buf), hipMemcpyHostToDevice, c->stream));   // d_out holds 64 doubles
+  HIP_TRY(rpe::launch_gn_update_probe(c->d_out, c->d_out + 32, c->d_out + 44, c->stream));
+  HIP_TRY(hipMemcpyAsync(buf, c->d_out, sizeof(buf), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (buf[45] == 0.0) return fail(RPE_ERR_DEGENERATE, "device solve: normal equations are not positive definite");
+  for (int i = 0; i < 12; i++) pose12[i] = buf[32 + i];
+  if (step_norm) *step_norm = buf[44];
+  return RPE_OK;
+}
+
 int rpe_gn_solve(const double* ne32, double* delta6) {
   if (!ne32 || !delta6) return fail(RPE_ERR_ARG, "null argument");
   if (!rpe::solve_normal_eq6(ne32, delta6)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite");
@@ -630,6 +709,19 @@ int rpe_gn_solve(const double* ne32, double* delta6) {
 int rpe_gn_apply(const double* delta6, double* pose12) {
   if (!delta6 || !pose12) return fail(RPE_ERR_ARG, "null argument");
   rpe::se3_left_update(delta6, pose12);
+  return RPE_OK;
+}
+
+// Host-clock profile of the resident loop: enable = 1 clears and starts, enable = 0 stops and reports the per-loop sums (microseconds)
+// of (a) waiting for a record = hand-over in flight + one kernel iteration + record in flight, (b) the host's turn = solve + update +
+// hand-over stores, over `steps` steady-state iterations (the first one of every call, which contains the launch, is left out).
+int rpe_debug_loop_profile(rpe_context* c, int enable, double* wait_us, double* host_us, long long* steps) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (enable) { c->loop_prof = true; c->prof_wait_us = c->prof_host_us = 0; c->prof_steps = 0; return RPE_OK; }
+  c->loop_prof = false;
+  if (wait_us) *wait_us = c->prof_wait_us;
+  if (host_us) *host_us = c->prof_host_us;
+  if (steps) *steps = c->prof_steps;
   return RPE_OK;
 }
 
@@ -644,6 +736,55 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   int it = 0;
   double step = 0, cost = 0;
   const double sc = scales ? scales[0] : 1.0;
+  if (c->resident && max_iter >= 2 && kinds[0] != RPE_RES_BEARING && !c->comm && c->p2p_world_saved < 1) {
+    // ONE launch for the whole loop: the grid stays resident, the host hands every new pose to it through the control block in
+    // device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration) and solves / updates as before.
+    int rc = kind_arrays(c, kinds[0]);
+    if (rc) return rc;
+    if ((rc = check_flags(c, kinds[0], flags))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const unsigned long long base = c->seq;   // record i carries sequence base + i; pose i carries tag base + i
+    auto hand_over = [&](const double* p, unsigned long long tag) {
+      if (p) for (int k = 0; k < 12; k++) { unsigned long long w; std::memcpy(&w, &p[k], 8); c->ctl[1 + k] = w; }   // words 1..7 | 8..12
+      store_fence();
+      c->ctl[0] = tag; c->ctl[15] = tag;
+      store_fence();
+    };
+    hand_over(pose12, base + 1);
+    rpe::ReduceTarget rt = host_target(c);
+    rt.seq = base;
+    static const bool tagged = !(getenv("RPE_RESIDENT_TAGGED") && getenv("RPE_RESIDENT_TAGGED")[0] == '0');   // experiments: 0 = record + drained sequence word
+    rt.tagged = tagged ? 1 : 0;
+    c->seq = base;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+    HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), kinds[0], flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream, e0, e1));
+    int status = RPE_OK, received = 0;   // records received so far = poses the grid has consumed
+    double tp = c->loop_prof ? clock_us() : 0;
+    for (;;) {
+      c->seq = base + (unsigned long long)received + 1;
+      double ne[32], d[6];
+      if (tagged) { if ((rc = wait_host_tagged(c, rpe::kNeLd, ne))) { status = rc; break; } }
+      else { if ((rc = wait_host(c, rpe::kNeLd))) { status = rc; break; } for (int i = 0; i < 32; i++) ne[i] = c->h_out[i]; }
+      received++;
+      if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
+      cost = sc * ne[27];
+      if (!rpe::solve_normal_eq6(ne, d)) { status = fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, ne[28]); break; }
+      rpe::se3_left_update(d, pose12);
+      step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+      it = received;
+      if (step < tol || received == max_iter) break;
+      hand_over(pose12, base + (unsigned long long)received + 1);
+      if (c->loop_prof) { const double t = clock_us(); c->prof_host_us += t - tp; tp = t; }
+    }
+    if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);   // the grid is still waiting: release it
+    c->seq = base + (unsigned long long)max_iter + 1;   // stays ahead of every tag / sequence value this launch could use
+    if (iters_out) *iters_out = it;
+    if (status != RPE_OK) return status;
+    if (last_step) *last_step = step;
+    if (final_cost) *final_cost = cost;
+    return RPE_OK;
+  }
   for (; it < max_iter; it++) {
     double ne[32], d[6];
     int rc = rpe_normal_eq(c, kinds[0], flags, pose12, ne);
@@ -719,6 +860,12 @@ int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
   for (int r = 0; r < rpe::kP2PMaxWorld; r++)   // a second init: drop the mappings of the first
     if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]); c->p2p_peer[r] = nullptr; }
   c->p2p_world = 0; c->p2p_world_saved = 0;
+  // A new session restarts the step counters at 0, so the mailbox must not hold the tags of an earlier one (tag 1 left in the
+  // parity-0 slots would make the new step 0 accept stale records).  Peers write here only inside an exchange, and ranks enter their
+  // first exchange together (a barrier after init, see the header), i.e. after every rank has passed this point.
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemset(c->p2p_box, 0, rpe::kP2PMailboxBytes));
+  HIP_TRY(hipDeviceSynchronize());
   rpe::P2PDesc d;
   d.world = world; d.rank = rank;
   for (int r = 0; r < rpe::kP2PMaxWorld; r++) d.peer[r] = nullptr;
@@ -844,6 +991,20 @@ static void stage_thresholds(int dtype, int exact, double thre_3d, double cos_th
   thr[1] = cos_thr; thr[2] = cos_nl;
 }
 
+// The scoring kernels ACCUMULATE into c->d_votes and rely on the read-out kernel to leave the counters zero.  If anything between
+// launch_score and the read-out fails (a collective, a launch), the counters would stay dirty and every later scoring call would be
+// silently wrong: clear them on the way out.
+static int votes_or_clear(rpe_context* c, hipError_t e, int count) {
+  if (e == hipSuccess) return RPE_OK;
+  (void)hipMemsetAsync(c->d_votes, 0, (size_t)count * sizeof(int), c->stream);
+  return fail(RPE_ERR_HIP, "vote read-out: %s", hipGetErrorString(e));
+}
+static int nccl_votes_or_clear(rpe_context* c, ncclResult_t r, int count) {
+  if (r == ncclSuccess) return RPE_OK;
+  (void)hipMemsetAsync(c->d_votes, 0, (size_t)count * sizeof(int), c->stream);
+  return fail(RPE_ERR_HIP, "all-reduce of the vote counters: %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
+}
+
 int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
   int rc = vote_arrays(c, kind);
   if (rc) return rc;
@@ -858,16 +1019,16 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
     stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
-    if (c->comm && c->p2p_world < 1) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream));  // sharded correspondences
+    if (c->comm && c->p2p_world < 1 && (rc = nccl_votes_or_clear(c, rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream), hb))) return rc;  // sharded correspondences
     // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counters into pinned host memory, raises
     // a sequence word the host spins on, and clears the counters for the next launch
     const unsigned long long seq = ++c->vote_seq;
     if (c->p2p_world >= 1) {   // sharded correspondences, one node: the read-out kernel also exchanges and sums the counters
-      HIP_TRY(rpe::launch_publish_votes_p2p(c->d_votes, hb, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream));
+      if ((rc = votes_or_clear(c, rpe::launch_publish_votes_p2p(c->d_votes, hb, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream), hb))) return rc;
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
       if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP, "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
     } else {
-      HIP_TRY(rpe::launch_publish_votes(c->d_votes, hb, c->h_votes, c->h_flag2, seq, c->stream));
+      if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, hb, c->h_votes, c->h_flag2, seq, c->stream), hb))) return rc;
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
     }
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
@@ -882,22 +1043,20 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
   if (rc) return rc;
   if (!votes_out || !q7_out || !valid_out || iters < 1 || iters > rpe::kMaxScoreH) return fail(RPE_ERR_ARG, "rpe_ransac33_batch: bad argument (1 <= iters <= %d)", rpe::kMaxScoreH);
   if (c->n < 3) return fail(RPE_ERR_ARG, "rpe_ransac33_batch: fewer than 3 correspondences");
+  // The generator samples THIS context's arrays: on a sharded context (rpe_comm_init / rpe_p2p_init) iteration i would be a different
+  // pose on every rank and the summed votes would mix unrelated hypotheses.  Sharded RANSAC = host hypotheses (every rank the same
+  // list) + rpe_score, which all-reduces the votes of IDENTICAL poses.
+  if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1)
+    return fail(RPE_ERR_STATE, "rpe_ransac33_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
   HIP_TRY(hipSetDevice(c->device));
   const int exact = mode == RPE_SCORE_EXACT;
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, 2.0, 2.0, thr);
   HIP_TRY(rpe::launch_gen_shinji(c->arrays(), rng_state, rng_inc, iters, exact, c->d_poses, c->h_poses, c->stream));
   HIP_TRY(rpe::launch_score(c->arrays(), RPE_VOTE_33, exact, c->d_poses, iters, thr, c->d_votes, c->score_blocks, c->stream));
-  if (c->comm && c->p2p_world < 1) NCCL_TRY(rccl().AllReduce(c->d_votes, c->d_votes, (size_t)iters, ncclInt32, ncclSum, c->comm, c->stream));
   const unsigned long long seq = ++c->vote_seq;
-  if (c->p2p_world >= 1) {
-    HIP_TRY(rpe::launch_publish_votes_p2p(c->d_votes, iters, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream));
-    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
-    if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP, "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
-  } else {
-    HIP_TRY(rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream));
-    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
-  }
+  if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream), iters))) return rc;
+  if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
   std::memcpy(votes_out, c->h_votes, (size_t)iters * sizeof(int));
   // the generator stored the hypotheses into pinned host memory before the scoring kernel ran (same stream): they are complete
   for (int i = 0; i < iters; i++) {
@@ -934,6 +1093,9 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
 int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const double* Cc3, const double* Rwc9, double* out44) {
   int rc = need_arrays(c, {RPE_XW});
   if (rc) return rc;
+  // the kernel reads the normal arrays as a PAIR (one without the other would dereference a null pointer on the device)
+  if ((c->arr[RPE_NW] != nullptr) != (c->arr[RPE_NC] != nullptr))
+    return fail(RPE_ERR_STATE, "rpe_nl_round: NW (normal_g) and NC (normal_c) must be uploaded together (have %s only)", c->arr[RPE_NW] ? "NW" : "NC");
   if (!c_opt3 || !Cw3 || !Cc3 || !Rwc9 || !out44) return fail(RPE_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   // masks default to all ones, exactly as a freshly constructed adapter

@@ -56,10 +56,19 @@ struct ReduceTarget {
   GnState* gn = nullptr;       // its state (null = ordinary launch: pose from the kernel argument, record published)
   const P2PDesc* p2p = nullptr;   // multi-GPU: exchange + sum the record with the peers before publishing (h_out path only)
   unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
+  int tagged = 0;              // h_out receives LD pairs {value, seq} (16 bytes, one store each) instead of the record + a sequence word
 };
 // ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+// RESIDENT form of the same kernels: one launch serves up to max_iters Gauss-Newton iterations; between iterations every workgroup
+// waits for the next pose in `ctl` (16 words in fine-grained device memory written by the host: layout in rpe_kernels.hip), tagged
+// first_tag + i; record i is published with sequence value rt.seq + i.  Needs host-writable device memory (large BAR).
+constexpr unsigned long long kResidentStopBit = 1ull << 63;
+hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
+                                     int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+// test hook: one application of the device-resident loop's 6x6 LDL^T solve + SE(3) exp-map update (d_step_ok: |delta|, ok flag)
+hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, hipStream_t s);
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s);
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
 hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,

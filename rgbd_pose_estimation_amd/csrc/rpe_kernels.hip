@@ -128,8 +128,18 @@ template <class T> __device__ __forceinline__ bool all_nan(T x, T y, T z) { retu
 // depend on which workgroup happens to be last, so it is bitwise reproducible -- expands it to the packed
 // normal-equation record and publishes it to HBM (for a collective) and/or to pinned host memory followed by a
 // sequence word the host spins on (no D2H copy kernel, no stream synchronise on the critical path).
-// Hand-off protocol = cdna_hip_programming.md Guideline 16: plain stores -> storing wave's vmcnt(0) -> barrier ->
-// lane-0 agent release -> vmcnt(0) -> relaxed agent ticket add; last arriver: agent acquire -> vmcnt(0) -> barrier.
+// Hand-off protocol = the FENCE-FREE form of cdna_hip_programming.md Guideline 16 ("sc1 loads in place of the acquire", the valid-forms
+// table of MI355X_MICROARCH.md, first row): every byte of a partial record is stored write-through (relaxed agent-scope atomic store =
+// global_store ... sc1) by ONE wave, that wave drains vmcnt(0), the workgroup barriers, ONE lane adds to the arrival counter (relaxed,
+// agent scope), and the workgroup whose add came last reads the records -- after a workgroup barrier -- with relaxed agent-scope
+// atomic loads (= global_load ... sc1, L1-bypassing) and nothing else.  There is NO release / acquire fence: under the HIP / LLVM
+// memory model alone this would be a data race; what makes it a hand-off is the gfx942 / gfx950 lowering of those accesses (sc1 write-
+// through to the memory side, sc1 loads served past the per-CU L1, vmcnt covering write-through completion), measured in the guide.
+// It saves the ~1.7 us a release fence and the ~1.7 us an acquire fence cost per launch (the whole kernel takes ~8 us).  The guard
+// below keeps the file from being compiled for an architecture where that lowering has not been established.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "rpe_kernels.hip: the fence-free cross-workgroup hand-off (reduce_and_finish) is only established for gfx942 / gfx950"
+#endif
 // wave64 sum by DPP cross-lane moves (no LDS traffic): butterfly inside each row of 16 lanes (quad_perm, row_ror),
 // then row_bcast:15 / row_bcast:31 fold the four rows; the total lands in lane 63.
 template <int CTRL, int ROW_MASK>
@@ -246,6 +256,7 @@ struct Finish {
   const P2PDesc* p2p;          // multi-GPU peer-to-peer all-reduce of the record (null = single GPU / collective done elsewhere)
   unsigned long long p2p_step;
   int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
+  int tagged;                  // 1: publish to out_host as LD pairs {value, seq} of 16 bytes, one store each, no drain and no separate sequence word
 };
 
 // ---- all-reduce(sum) of the 32-double record across <= 8 GPUs, by the first wave of the LAST workgroup, without leaving the
@@ -386,6 +397,26 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
 // fixed-order column sums of `count` partial records, rows first, first + step, ...: thread (j, rg) takes every RG-th of them,
 // U independent sc1 loads in flight, then the RG row-group sums are added in row-group order -> tot[j] (valid for threadIdx.x < LD
 // after the caller's barrier).  The order depends on (first, step, count) only, never on which workgroup runs it.
+// test hook (rpe_debug_device_gn_update): the device-resident loop's solve + SE(3) update on a record and pose of the caller's, so that
+// the LDL^T solve and the exponential map the last workgroup runs can be checked against the oracle / golden values in isolation
+__global__ void gn_update_probe_kernel(const double* __restrict__ rec, double* __restrict__ pose, double* __restrict__ step_ok) {
+  __shared__ double s_rec[32];
+  __shared__ double s_pose[12];
+  if (threadIdx.x < 32) s_rec[threadIdx.x] = rec[threadIdx.x];
+  if (threadIdx.x < 12) s_pose[threadIdx.x] = pose[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double step = 0.0;
+    const bool ok = gn_solve_update(s_rec, s_pose, &step);
+    step_ok[0] = step; step_ok[1] = ok ? 1.0 : 0.0;
+    if (ok) for (int k = 0; k < 12; k++) pose[k] = s_pose[k];
+  }
+}
+hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d_step_ok, hipStream_t s) {
+  hipLaunchKernelGGL(gn_update_probe_kernel, dim3(1), dim3(64), 0, s, d_rec, d_pose, d_step_ok);
+  return hipGetLastError();
+}
+
 template <int NACC, int LD, int BLK, int U>
 __device__ __forceinline__ void sum_records(const double* __restrict__ partials, int first, int step, int count, double (*part)[LD],
                                             double* __restrict__ tot) {
@@ -537,6 +568,22 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     int failed = 0;
     val = p2p_allreduce32(val, fin, &failed);
     if (failed && threadIdx.x == 31) val = 1e300;   // error marker in the last (padding) entry of the record: the host checks it
+  }
+  if (fin.tagged) {
+    // resident loop: every value travels WITH the sequence number in ONE 16-byte store (one PCIe write), so the host needs no
+    // ordering between stores: it waits until all LD pairs carry the sequence value.  No drain of the posted writes (~1.3 us saved).
+    // The store must be a SYSTEM-scope one (sc0 sc1: straight out to the host, like the 8-byte atomic stores of the untagged form);
+    // a plain or nt 16-byte store to this memory was observed never to reach the host while the kernel stays resident.  There is no
+    // 16-byte atomic builtin, hence the instruction itself (s_nop 1: the data registers must not be reused before the store reads them).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (threadIdx.x < LD) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
+      u32x4 pr;
+      pr.x = (unsigned int)bits; pr.y = (unsigned int)(bits >> 32); pr.z = (unsigned int)fin.seq; pr.w = (unsigned int)(fin.seq >> 32);
+      const unsigned long long* dst = reinterpret_cast<const unsigned long long*>(fin.out_host) + 2 * threadIdx.x;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(pr) : "memory");
+    }
+    return;
   }
   if (threadIdx.x < LD) {
     if (fin.gn == nullptr) {
@@ -797,6 +844,116 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   }
   RPE_STAMP(1);
   reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
+}
+
+// ================================================================================================
+// K1 / K2 / K3, RESIDENT form: the host-driven Gauss-Newton loop in ONE launch.
+// The north-star loop keeps the 6x6 solve and the SE(3) exp-map on the host, so every iteration needs a host round trip; with one
+// launch per iteration that round trip also pays a kernel launch, the dispatch ramp of the grid (1.3 - 2.3 us for 150 workgroups,
+// profiles/r02_tail_timeline.jsonl) and a re-read of the arrays.  Here the grid stays resident between iterations: every workgroup
+// waits for the next pose in a control block that lives in fine-grained DEVICE memory and that the host writes through the PCIe BAR
+// (MI355X: 1.9 us host -> 256 polling workgroups -> host, scripts/ubench/hostmailbox.hip; polling pinned HOST memory from 150
+// workgroups costs 13 us), evaluates its slice, and the last workgroup publishes the record exactly as normal_eq_kernel does.
+// Frame-sized problems (one group per thread) keep their correspondences IN REGISTERS across the iterations -- the arrays are read
+// from memory once per refinement, not once per iteration.
+// Control block: 16 words of 8 bytes = two 64-byte halves, each carrying its own copy of the tag so that no ordering between the
+// host's stores to the two halves is assumed:   [0] tag | [1..7] pose[0..6]   ||   [8..12] pose[7..11] | [13,14] - | [15] tag.
+// The host writes the pose, then both tags (= first_tag + iteration; bit 63 set = stop).  Co-residency: the grid has at most one
+// workgroup per CU (reduce_grid, max_blocks <= 256) and no workgroup waits for another one -- only for the host, and only for a
+// bounded time (~2 s of the 100 MHz clock, then the kernel exits without publishing and the host reports an error).
+// ================================================================================================
+constexpr unsigned long long kResidentStop = 1ull << 63;
+// one group of P correspondences through the bounds-checked loaders when it is the ragged last one (g == full), plain 16-byte loads otherwise
+template <class T, int KIND, bool MASK, bool WEIGHT>
+__device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c, const short* __restrict__ mask,
+                                               const T* __restrict__ weight, int64_t g, int64_t full, int64_t n, T (&vw)[3 * Pk<T>::P],
+                                               T (&vb)[3 * Pk<T>::P], T (&vc)[3 * Pk<T>::P], short (&m)[Pk<T>::P], T (&wv)[Pk<T>::P]) {
+  typedef typename Pk<T>::V V;
+  if (g < full) {
+    const V* xw4 = reinterpret_cast<const V*>(xw);
+    const V* b4 = reinterpret_cast<const V*>(b);
+    const V x0 = xw4[3 * g], x1 = xw4[3 * g + 1], x2 = xw4[3 * g + 2];
+    const V y0 = b4[3 * g], y1 = b4[3 * g + 1], y2 = b4[3 * g + 2];
+    unpack3(x0, x1, x2, vw);
+    unpack3(y0, y1, y2, vb);
+    if (KIND == KIND_P2PLANE) { const V* c4 = reinterpret_cast<const V*>(c); const V z0 = c4[3 * g], z1 = c4[3 * g + 1], z2 = c4[3 * g + 2]; unpack3(z0, z1, z2, vc); }
+    if (MASK) load_mask_full(mask, g, m);
+    if (WEIGHT) load_weight_full(weight, g, wv);
+  } else {
+    load_group<T>(xw, g, n, vw);
+    load_group<T>(b, g, n, vb);
+    if (KIND == KIND_P2PLANE) load_group<T>(c, g, n, vc);
+    if (MASK) load_scalars<T, short>(mask, g, n, m, (short)0);
+    if (WEIGHT) load_scalars<T, T>(weight, g, n, wv, T(0));
+  }
+}
+
+// IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
+// loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS>
+__global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
+                                                                 const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
+                                                                 const unsigned long long* __restrict__ ctl, unsigned long long first_tag,
+                                                                 int max_iters, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
+  __shared__ double s_pose[12];
+  __shared__ int s_go;
+  const int64_t full = n / P, groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  const int64_t g0 = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  T rw[3 * P], rb[3 * P], rc[3 * P];
+  short rm[P];
+  T rwv[P];
+  int rpresent = 0;
+  if (IN_REGS && g0 < groups) {
+    load_any_group<T, KIND, MASK, WEIGHT>(xw, b, c, mask, weight, g0, full, n, rw, rb, rc, rm, rwv);
+    rpresent = g0 < full ? P : (int)(n - full * P);
+  }
+  for (int it = 1; it <= max_iters; it++) {
+    // ---- wait for pose number `it`: the first 16 lanes read the control block (one 8-byte word each), until both tags match
+    if (threadIdx.x < 64) {
+      const unsigned long long want = first_tag + (unsigned long long)it;
+      const int lane = threadIdx.x;
+      const unsigned long long t0 = wall_clock64();
+      int go = 0;
+      unsigned long long w = 0;
+      for (;;) {
+        if (lane < 16) w = __hip_atomic_load(ctl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long ta = __shfl(w, 0, 64), tb = __shfl(w, 15, 64);
+        if (ta == tb && (ta & ~kResidentStop) == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
+        if (wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // the host went away: give up (2 s)
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (lane >= 1 && lane <= 12) s_pose[lane - 1] = __longlong_as_double((long long)w);
+      if (lane == 0) s_go = go;
+    }
+    __syncthreads();
+    if (s_go != 1) return;   // stop requested (2) or no host (3): uniform for the workgroup
+    PoseK<double> pose;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose.t[k] = s_pose[9 + k];
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+    if (IN_REGS) {
+      if (rpresent > 0) normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, rw, rb, rc, rm, rwv, rpresent, acc);
+    } else {
+      for (int64_t g = g0; g < groups; g += stride) {
+        T vw[3 * P], vb[3 * P], vc[3 * P];
+        short mm[P];
+        T ww[P];
+        load_any_group<T, KIND, MASK, WEIGHT>(xw, b, c, mask, weight, g, full, n, vw, vb, vc, mm, ww);
+        normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, mm, ww, g < full ? P : (int)(n - full * P), acc);
+      }
+    }
+    Finish f = fin;
+    f.seq = fin.seq + (unsigned long long)it;
+    reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, f);
+    __syncthreads();   // the reduction's LDS scratch and s_pose are reused by the next iteration
+  }
 }
 
 // ================================================================================================
@@ -1678,6 +1835,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.p2p = rt.p2p; f.p2p_step = rt.p2p_step;
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 0;   // experiments (scripts/tail_timeline.py)
   f.tail = env_tail;
+  f.tagged = rt.tagged;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)
@@ -1736,6 +1894,50 @@ static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const 
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev0, hipEvent_t ev1) {
   return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s, ev0, ev1);
+}
+
+// resident form: ONE launch for up to max_iters iterations; ctl = the control block in fine-grained device memory, first_tag + i =
+// tag of pose i (i = 1 ...), rt.seq + i = sequence value published with record i
+template <class T, int KIND, int BLK>
+static void resident_launch(const DeviceArrays& A, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
+                            const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  const T* xw = (const T*)A.a[0];
+  const T* b = (const T*)(KIND == KIND_BEARING ? A.a[2] : A.a[1]);
+  const T* c = (const T*)A.a[4];
+  const int mod = KIND == KIND_BEARING ? 0 : 1;
+  const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
+  const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < 256 ? rt.max_blocks : 256, BLK);   // at most one workgroup per CU: all co-resident
+  const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
+  const bool in_regs = (int64_t)G * BLK >= groups;
+  const Finish fin = make_finish(rt);
+#define RPE_RES_LAUNCH2(M, W, R)                                                                                                             \
+  do {                                                                                                                                       \
+    if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
+    else hipLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R>), dim3(G), dim3(BLK), 0, s, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin);     \
+  } while (0)
+#define RPE_RES_LAUNCH(M, W) do { if (in_regs) RPE_RES_LAUNCH2(M, W, true); else RPE_RES_LAUNCH2(M, W, false); } while (0)
+  if (mask && weight) RPE_RES_LAUNCH(true, true);
+  else if (mask) RPE_RES_LAUNCH(true, false);
+  else if (weight) RPE_RES_LAUNCH(false, true);
+  else RPE_RES_LAUNCH(false, false);
+#undef RPE_RES_LAUNCH
+#undef RPE_RES_LAUNCH2
+}
+template <class T>
+static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
+                             const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  // the two 3D-3D kinds only: the bearing residual's register footprint (fp64 normalisation, three Jacobian rows) leaves no room
+  // for a resident group without spilling; it keeps one launch per iteration
+  if (kind == KIND_P2P) resident_launch<T, KIND_P2P, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
+  else if (kind == KIND_P2PLANE) resident_launch<T, KIND_P2PLANE, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
+                                     int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  return A.dtype ? resident_t<double>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1)
+                 : resident_t<float>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
 }
 
 hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam,

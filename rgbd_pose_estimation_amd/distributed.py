@@ -132,6 +132,7 @@ def init_p2p(ctx: "api.Context", group=None) -> bool:
     if ok:
         try:
             ctx.p2p_init(world, rank, b"".join(handles))
+            ctx.p2p_handles = b"".join(handles)   # a later re-initialisation of the same mailboxes (rpe_p2p_init clears the own one)
         except Exception as e:  # noqa: BLE001
             ok = 0
             print(f"[rgbd_pose_estimation_amd] rank {rank}: peers' mailboxes cannot be mapped ({e})", flush=True)

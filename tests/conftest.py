@@ -35,3 +35,14 @@ def gpu_ctx_factory():
     yield make
     for c in made:
         c.close()
+
+
+@pytest.fixture(scope="session")
+def G():
+    """The committed golden vectors (tests/golden/make_golden.py): expected values as JSON, inputs as npz."""
+    import json
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = json.load(open(os.path.join(here, "golden", "golden.json")))
+    g["arr"] = dict(np.load(os.path.join(here, "golden", "golden_inputs.npz")))
+    return g

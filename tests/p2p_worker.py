@@ -66,6 +66,12 @@ def main():
                     ctx.gn_step_dist(L.RES_P2P, pose)
                     if mode == "straggler" and k == 0:
                         dist.barrier()
+                    if mode == "reinit" and k == 0:
+                        # a second rpe_p2p_init after a session of ONE step (tag 1 sits in the parity-0 slots): the step counters restart
+                        # at 0, so the own mailbox must come back empty or the new step 0 would accept the stale records
+                        dist.barrier()
+                        ctx.p2p_init(world, rank, ctx.p2p_handles)
+                        dist.barrier()
             out["pose"] = np.asarray(pose).tolist()
     except L.RpeError as e:
         out["error"] = str(e)
@@ -83,11 +89,11 @@ def main():
             full.load(L.F32, xw=sc.Q, xc=sc.P)
             ref = full.score(L.VOTE_33, poses, 0.1, mode=L.SCORE_EXACT).tolist()
             full.close()
-        if mode in ("steps", "device"):
+        if mode in ("steps", "device", "reinit"):
             full = api.Context(0)
             full.load(L.F32, xw=sc.Q, xc=sc.P)
             ref = api.pose12(np.eye(3), np.zeros(3))
-            if mode == "steps":
+            if mode in ("steps", "reinit"):
                 for _ in range(steps):
                     full.gn_step(L.RES_P2P, ref)
             else:

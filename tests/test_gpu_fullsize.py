@@ -32,10 +32,22 @@ def _big_scene(seed, n, full=False):
     return R, t, {k: tile(getattr(sc, k)) for k in ("Q", "P", "U", "M", "N")}
 
 
-def test_config3_sparse_bearings_plus_dense_depth(gpu_ctx_factory, oracle):
-    """configs[2]: 2 000 2D-3D bearings + 307 200 3D-3D points.  AOPoseAdapter has one N (F5), so bearings beyond the first
-    2 000 rows are NaN: they never vote (NaN > x is false) and the bearing residual skips them.  Votes must equal the
-    CPU path exactly; the joint GN must land on the oracle's."""
+def test_config3_exactly_as_surveyed(oracle):
+    """configs[2] as SURVEY.md 8(d) "Config 3" states it (tests/config3_case.py): 307 200 3D-3D + 2 000 bearings, 300 iterations of
+    shinji + kneip hypotheses from a fixed seeded sample list, consumed by BOTH the CPU restatement and the GPU path; votes, adapted
+    Iter, all masks and the winning hypothesis must be exactly equal; the joint GN refinement must land on the oracle's fp64 GN."""
+    import config3_case
+    r = config3_case.run(with_cpu=True)
+    assert r["hypotheses"] >= 300                       # every iteration yields the 3-point fit; P3P only where 4 sampled rows carry bearings
+    assert r["lists_identical"]
+    assert r["votes_equal"] and r["iter_equal"] and r["masks_equal"] and r["winner_equal"], r
+    assert r["gpu"]["inliers_33"] > 0.8 * config3_case.N and 0 < r["gpu"]["inliers_23"] <= config3_case.N2D
+    assert r["refined_pose_vs_cpu"]["rot_rad"] < util.ROT_TOL_RAD and r["refined_pose_vs_cpu"]["trans_rel"] < util.TRANS_REL_TOL, r
+    assert r["gpu"]["rot_err_rad_vs_truth"] < 2e-3
+
+
+def test_config3_scoring_of_300_perturbed_poses(gpu_ctx_factory, oracle):
+    """The scoring kernel alone at the config's size and array mix: 300 poses around the truth, votes equal to the CPU vote loop."""
     n, n2d = 307200, 2000
     rng = np.random.default_rng(3)
     R, t = S.random_pose(rng)
@@ -47,24 +59,6 @@ def test_config3_sparse_bearings_plus_dense_depth(gpu_ctx_factory, oracle):
     v = ctx.score(L.VOTE_33_23, poses, thr3, cthr, mode=L.SCORE_EXACT)
     vo = oracle.votes(oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=U), oracle.V_33_23, poses, thr3, cthr)
     assert np.array_equal(v, vo)
-    best = int(np.argmax(v))
-    tot = ctx.inlier_mask(L.VOTE_33_23, poses[best], thr3, cthr, mode=L.SCORE_EXACT)
-    assert tot == v[best]
-    m23, m33 = ctx.download_mask(L.MOD_23), ctx.download_mask(L.MOD_33)
-    assert m23[n2d:].sum() == 0 and m23[:n2d].sum() > 0.08 * n2d and m33.sum() > 0.8 * n  # 15 px noise vs an 8 px gate (Parameters.yml): ~13 % pass
-    # joint refinement over both inlier sets, from the RANSAC winner
-    q = poses[best]
-    R0 = np.array(oracle.se3_exp(np.zeros(6))[0])  # identity, placeholder to keep numpy happy
-    from scipy.spatial.transform import Rotation
-    R0 = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
-    p0 = api.pose12(R0, q[4:])
-    p, its, step, cost = ctx.gn_refine([L.RES_P2P, L.RES_BEARING], p0, scales=[1.0, 1.0], flags=L.USE_MASK, max_iter=30, tol=1e-9)
-    po, itso, _, _ = oracle.gn_refine([dict(kind=oracle.GN_P2P, a=sc.Q, b=sc.P, mask=m33), dict(kind=oracle.GN_BEARING, a=sc.Q, b=U, mask=m23)],
-                                      n, p0, max_iter=30, tol=1e-9)
-    assert its > 0 and itso > 0
-    assert util.rot_err(p[:9].reshape(3, 3), po[:9].reshape(3, 3)) < util.ROT_TOL_RAD
-    assert util.trans_rel_err(p[9:], po[9:]) < util.TRANS_REL_TOL
-    assert util.rot_err(p[:9].reshape(3, 3), R) < 2e-3
 
 
 def test_config4_point_to_plane_1M(gpu_ctx_factory, oracle):

@@ -128,3 +128,69 @@ def test_device_resident_loop_reports_degenerate(gpu_ctx_factory):
     ctx.load(L.F32, xw=sc.Q, xc=sc.P)
     p, it, _, _ = ctx.gn_refine_device([(L.RES_P2P, 1.0)], api.pose12(sc.R, sc.t), max_iter=10, tol=1e-8)
     assert it > 0
+
+
+@pytest.mark.parametrize("case", ["p2p", "p2plane", "p2p+bearing"])
+def test_device_resident_loop_against_the_oracle(gpu_ctx_factory, oracle, case):
+    """(f)1 checked DIRECTLY against the CPU restatement (not against the repo's own host loop): rpe_gn_refine_device -- solve and
+    SE(3) exp-map in the kernel's last workgroup -- and the oracle's fp64 Gauss-Newton of the same objective on the same inliers
+    (oracle/orc_gn.hpp; update T <- exp(delta) T with Sophus' exponential, sophus/se3.hpp:321-342), 307 200 correspondences: same
+    iteration count, pose within BASELINE.json's tolerance (1e-5 rad, 1e-4 relative translation)."""
+    n = 307200
+    sc = util.scene_full(610, n, np.float32, n2d=2.0, n3d=0.03, outliers=0.1)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    ctx.inlier_mask(L.VOTE_NN_33_23, api.pose7_from_Rt(sc.R, sc.t), 0.15, math.cos(math.atan(8 / 585)), math.cos(0.1))
+    m23, m33 = ctx.download_mask(L.MOD_23), ctx.download_mask(L.MOD_33)
+    p0 = api.pose12(*util.perturbed_pose(np.random.default_rng(3), sc.R, sc.t, 0.02, 0.05))
+    if case == "p2p":
+        terms, oterms = [(L.RES_P2P, 1.0)], [dict(kind=oracle.GN_P2P, a=sc.Q, b=sc.P, mask=m33)]
+    elif case == "p2plane":
+        terms, oterms = [(L.RES_P2PLANE, 1.0)], [dict(kind=oracle.GN_P2PLANE, a=sc.Q, b=sc.P, c=sc.N, mask=m33)]
+    else:
+        terms = [(L.RES_P2P, 1.0), (L.RES_BEARING, 2.0)]
+        oterms = [dict(kind=oracle.GN_P2P, a=sc.Q, b=sc.P, mask=m33), dict(kind=oracle.GN_BEARING, a=sc.Q, b=sc.U, mask=m23, scale=2.0)]
+    tol = 1e-7   # above the fp32-product step floor of the kernels (~1e-9), so both loops stop on the same iteration
+    pd, itd, stepd, costd = ctx.gn_refine_device(terms, p0, flags=L.USE_MASK, max_iter=25, tol=tol)
+    po, ito, stepo, costo = oracle.gn_refine(oterms, n, p0, max_iter=25, tol=tol)
+    assert 0 < itd < 25 and itd == ito
+    assert util.rot_err(pd[:9].reshape(3, 3), po[:9].reshape(3, 3)) < util.ROT_TOL_RAD
+    assert util.trans_rel_err(pd[9:], po[9:]) < util.TRANS_REL_TOL
+    assert abs(costd - costo) <= 1e-5 * abs(costo)
+
+
+def test_device_exp_map_and_solve_against_golden(gpu_ctx_factory, oracle, G):
+    """The exponential map and the 6x6 solve the device-resident loop runs ON THE GPU (rpe_debug_device_gn_update), in isolation:
+    exp against the scipy.linalg.expm golden of sophus/se3.hpp:321-342 (tests/golden), the solve against numpy, and one combined
+    update against the oracle's gn_apply."""
+    import ctypes as C
+    ctx = gpu_ctx_factory()
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ident = api.pose12(np.eye(3), np.zeros(3))
+
+    def device_update(H, g, pose):
+        rec = np.zeros(32); k = 0
+        for i in range(6):
+            for j in range(i, 6):
+                rec[k] = H[i, j]; k += 1
+        rec[21:27] = g
+        p = np.array(pose, np.float64).copy()
+        step = C.c_double(0)
+        L.check(L.lib().rpe_debug_device_gn_update(ctx._h, _p(rec), _p(p), C.byref(step)))
+        return p, step.value
+
+    for e in G["se3_exp"]:   # H = I, g = -a  =>  delta = a  =>  pose = exp(a)
+        a = np.array(e["a"])
+        p, step = device_update(np.eye(6), -a, ident)
+        assert np.allclose(p[:9].reshape(3, 3), e["R"], atol=1e-13) and np.allclose(p[9:], e["t"], atol=1e-13)
+        assert abs(step - np.linalg.norm(a)) < 1e-14
+    rng = np.random.default_rng(11)
+    J = rng.standard_normal((40, 6)); r = 0.01 * rng.standard_normal(40)
+    H, g = J.T @ J, J.T @ r
+    p0 = oracle.pose12(np.array(G["full_R"]), np.array(G["full_t"]))
+    p, step = device_update(H, g, p0)
+    d = np.linalg.solve(H, -g)
+    assert abs(step - np.linalg.norm(d)) < 1e-12
+    assert np.allclose(p, oracle.gn_apply(d, p0), atol=1e-12)
+    with pytest.raises(L.RpeError) as err:   # not positive definite: refused, like the host solve
+        device_update(np.zeros((6, 6)), g, p0)
+    assert err.value.code == L.RPE_ERR_DEGENERATE

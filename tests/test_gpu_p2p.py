@@ -13,8 +13,10 @@ import pytest
 # routinely, see profiles/), but it depends on the driver scheduling the processes' queues concurrently, and a rank killed in the
 # middle of an exchange once left the box's GPU unusable for minutes.  The round-end sequence on a single box is tests -> smoke ->
 # bench, so these tests run only on request: RPE_TEST_MULTIPROC=1 (scripts/collect_evidence.sh sets it, after the measurements).
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1",
-                                                  reason="multi-process-on-one-GPU tests run with RPE_TEST_MULTIPROC=1")]
+# The smallest case -- two ranks, a handful of exchanges, every wait bounded -- is part of the default -m gpu suite, so that the
+# exchange protocol (IPC mappings, tagged words, rank-ordered sums, re-initialisation) is observed on every run.
+pytestmark = [pytest.mark.gpu]
+multiproc = pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1", reason="the larger multi-process-on-one-GPU cases run with RPE_TEST_MULTIPROC=1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -41,7 +43,7 @@ def run_world(world, mode, n, steps, timeout=240):
     return json.loads(line[0][7:])
 
 
-@pytest.mark.parametrize("world,n", [(2, 20000), (3, 100003), (8, 307200)])
+@pytest.mark.parametrize("world,n", [(2, 20000), pytest.param(3, 100003, marks=multiproc), pytest.param(8, 307200, marks=multiproc)])
 def test_p2p_sharded_steps_match_the_single_gpu_run(world, n):
     res = run_world(world, "steps", n, 6)
     ranks = res["ranks"]
@@ -54,6 +56,17 @@ def test_p2p_sharded_steps_match_the_single_gpu_run(world, n):
     assert np.abs(poses[0] - ref).max() < 1e-9         # shards add up to the whole (different summation order only)
 
 
+def test_p2p_reinit_after_an_odd_session():
+    """rpe_p2p_init a second time after ONE step: the restarted step 0 must not take the first session's records for delivered."""
+    res = run_world(2, "reinit", 20000, 5)
+    ranks = res["ranks"]
+    assert all(r["p2p"] and "error" not in r for r in ranks), ranks
+    poses = [np.array(r["pose"]) for r in ranks]
+    assert np.array_equal(poses[0], poses[1])
+    assert np.abs(poses[0] - np.array(res["reference"])).max() < 1e-9
+
+
+@multiproc
 @pytest.mark.parametrize("world,n", [(2, 20000), (8, 307200)])
 def test_p2p_sharded_device_resident_loop(world, n):
     """One launch per iteration on every rank: exchange + sum + solve + exp-map in the kernel's last workgroup."""
@@ -67,6 +80,7 @@ def test_p2p_sharded_device_resident_loop(world, n):
     assert np.abs(poses[0] - np.array(res["reference"])).max() < 1e-9
 
 
+@multiproc
 @pytest.mark.parametrize("world,n,H", [(2, 20000, 70), (8, 100003, 3000)])
 def test_p2p_sharded_scoring_counts_are_exact(world, n, H):
     """rpe_score after rpe_p2p_init: every rank gets the votes of the WHOLE correspondence set (integer sums, exact)."""
@@ -78,6 +92,7 @@ def test_p2p_sharded_scoring_counts_are_exact(world, n, H):
         assert r["votes2"] == res["reference"][::-1]
 
 
+@multiproc
 @pytest.mark.parametrize("world", [2, 4])
 def test_p2p_exchange_soak(world):
     """20 000 exchanges from a fixed pose: every rank sees bitwise the same record every time, and the same as its peers."""
@@ -89,6 +104,7 @@ def test_p2p_exchange_soak(world):
         assert r["record"] == ranks[0]["record"]
 
 
+@multiproc
 def test_p2p_missing_peer_times_out_instead_of_hanging():
     res = run_world(2, "straggler", 20000, 3)
     r0, r1 = res["ranks"]
