@@ -233,6 +233,13 @@ int rpe_ransac33_batch(rpe_context* ctx, uint64_t rng_state, uint64_t rng_inc, i
 int rpe_inlier_mask(rpe_context* ctx, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,
                     int* votes_out);
 
+/* ---- PROSAC order: the first top_k (<= 4096) entries of "indices sorted by weight, descending" (pose/Utility.hpp:107-118 sortIndexes as
+ * PROSAC consumes it through getSortedIdx, pose/AOOnlyPoseAdapter.hpp:233-254) for n float weights (host pointer), computed on the GPU:
+ * two-level radix select of the cut + LDS bitonic sort of the candidates.  Equal weights are ordered by index (the reference's
+ * comparator leaves their order to std::sort), which makes the order unique and the prefix well defined.  RPE_ERR_STATE when more than
+ * 8192 (near-)equal weights surround the cut: the caller then sorts on the host (the C++ adapters do). */
+int rpe_prosac_order(rpe_context* ctx, const float* weights, int n, int top_k, int* order_out);
+
 /* ---- K5 one round of nl_shinji_kneip_ls (AbsoluteOrientationNormal.hpp:484-505) + find_opt_cc (:24-39),
  * fused into one pass over up to 60 B/corr.  in: c_opt[3], Cw[3], Cc[3], Rwc9 (row-major, rotation used by
  * find_opt_cc).  out44: M23 (9) TW K | M33 (9) sigma | MNN (9) TL M | AA (6: xx xy xz yy yz zz) bb (3) | pad.

@@ -297,13 +297,13 @@ class Context:
                                       C.byref(cost)))
         return p, it.value, step.value, cost.value
 
-    def score(self, kind: int, poses7, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mode=L.SCORE_FAST) -> np.ndarray:
+    def score(self, kind: int, poses7, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mode=L.SCORE_EXACT) -> np.ndarray:
         q = np.ascontiguousarray(poses7, np.float64).reshape(-1, 7)
         v = np.zeros(len(q), np.int32)
         L.check(L.lib().rpe_score(self._h, kind, mode, _p(q), len(q), thre_3d, cos_thr, cos_nl, _p(v)))
         return v
 
-    def inlier_mask(self, kind: int, pose7, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mode=L.SCORE_FAST) -> int:
+    def inlier_mask(self, kind: int, pose7, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mode=L.SCORE_EXACT) -> int:
         q = np.ascontiguousarray(pose7, np.float64).reshape(7)
         v = C.c_int(0)
         L.check(L.lib().rpe_inlier_mask(self._h, kind, mode, _p(q), thre_3d, cos_thr, cos_nl, C.byref(v)))
@@ -368,7 +368,7 @@ LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL, LS_GN_P
 
 
 def run(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weights=None, f=585.0, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0,
-        iters=0, confidence=0.99, seed=1, ls=LS_NONE, score_mode=L.SCORE_FAST, mask_in=None, pose_in=None, max_votes_in=1):
+        iters=0, confidence=0.99, seed=1, ls=LS_NONE, score_mode=L.SCORE_EXACT, mask_in=None, pose_in=None, max_votes_in=1):
     """Run one solver of pose/*.hpp on a freshly built adapter (AOOnly / PnP / AO / NormalAO chosen like the
     reference's demos do).  Returns dict(R, t, iters, max_votes, masks[3, n])."""
     dt = _np_dtype(dtype)

@@ -131,6 +131,11 @@ struct rpe_context {
   // host-accessible (no large BAR): the loop then launches one kernel per iteration.
   volatile unsigned long long* ctl = nullptr;
   bool resident = false;
+  // PROSAC order on the device (rpe_prosac_order): scratch
+  float* ps_w = nullptr; size_t ps_w_cap = 0;
+  unsigned int* ps_hist = nullptr;        // 2048 + 8 uints (histogram | control words)
+  unsigned long long* ps_cand = nullptr;  // kProsacSortCap keys
+  int* ps_order = nullptr;                // kProsacMaxTopK + 1 ints (order | status)
   // optional host-clock profile of the resident loop (rpe_debug_loop_profile): time spent waiting for records vs the host's own turn
   bool loop_prof = false;
   double prof_wait_us = 0, prof_host_us = 0;
@@ -332,6 +337,11 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   // pinned + device-mapped: the vote read-out kernel stores straight into it; the sequence word sits behind the counters
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { std::memset(c->h_votes, 0, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int)); c->h_flag2 = reinterpret_cast<unsigned long long*>(c->h_votes + rpe::kMaxScoreH); }
+  // PROSAC order scratch (rpe_prosac_order): histogram + control words (zero between calls), candidate keys, order + status
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ps_hist, (2048 + 8) * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemset(c->ps_hist, 0, (2048 + 8) * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ps_cand, (size_t)rpe::kProsacSortCap * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->ps_order, ((size_t)rpe::kProsacMaxTopK + 1) * sizeof(int));
   if (e != hipSuccess) { rpe_destroy(c); return fail(RPE_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e)); }
   {  // resident loop: needs device memory the CPU can store into (large BAR); RPE_RESIDENT=0 switches it off
     int large_bar = 0;
@@ -367,6 +377,10 @@ void rpe_destroy(rpe_context* c) {
   (void)rpe_p2p_destroy(c);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ctl) (void)hipFree((void*)c->ctl);
+  if (c->ps_w) (void)hipFree(c->ps_w);
+  if (c->ps_hist) (void)hipFree(c->ps_hist);
+  if (c->ps_cand) (void)hipFree(c->ps_cand);
+  if (c->ps_order) (void)hipFree(c->ps_order);
   if (c->fe.d_depth) (void)hipFree(c->fe.d_depth);
   for (float* m : c->fe.fmap) if (m) (void)hipFree(m);
   for (float* m : c->fe.mmap) if (m) (void)hipFree(m);
@@ -1086,6 +1100,29 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   c->h_votes[0] = (int)c->h_out[0];
   if (votes_out) *votes_out = c->h_votes[0];
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- PROSAC order
+int rpe_prosac_order(rpe_context* c, const float* weights, int n, int top_k, int* order_out) {
+  if (!c || !weights || !order_out || n < 1 || top_k < 1) return fail(RPE_ERR_ARG, "rpe_prosac_order: bad argument");
+  if (top_k > n) top_k = n;
+  if (top_k > rpe::kProsacMaxTopK) return fail(RPE_ERR_ARG, "rpe_prosac_order: top_k %d exceeds %d (sort the longer prefix on the host)", top_k, rpe::kProsacMaxTopK);
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->ps_w_cap < (size_t)n) {
+    if (c->ps_w) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->ps_w)); c->ps_w = nullptr; c->ps_w_cap = 0; }
+    HIP_TRY(hipMalloc((void**)&c->ps_w, (size_t)n * sizeof(float)));
+    c->ps_w_cap = (size_t)n;
+  }
+  HIP_TRY(hipMemcpyAsync(c->ps_w, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(rpe::launch_prosac_order(c->ps_w, n, top_k, c->ps_hist, c->ps_hist + 2048, c->ps_cand, c->ps_order, c->ps_order + rpe::kProsacMaxTopK, c->stream));
+  std::vector<int> host((size_t)rpe::kProsacMaxTopK + 1);
+  int rc = copy_to_host(c, host.data(), c->ps_order, host.size() * sizeof(int));
+  if (rc) return rc;
+  const int status = host[(size_t)rpe::kProsacMaxTopK];
+  if (status != 0) return fail(RPE_ERR_STATE, status == 1 ? "rpe_prosac_order: too many (near-)equal weights around the cut for the device sort; use the host order"
+                                                          : "rpe_prosac_order: fewer candidates than top_k");
+  std::memcpy(order_out, host.data(), (size_t)top_k * sizeof(int));
   return RPE_OK;
 }
 

@@ -100,6 +100,14 @@ hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned 
 hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
                              void* h_q7, hipStream_t s);
 
+// ---- PROSAC order (rpe_prosac.hip): the first top_k (<= kProsacMaxTopK) positions of "indices by weight descending, ties to the lower
+// index" for n float weights in HBM.  d_hist: 2048 uints, zero on entry and on exit; d_ctl: 8 uints; d_cand: kProsacSortCap keys;
+// d_status: 0 ok, 1 = more candidates than the LDS sort holds (heavy ties around the cut): use the host order.
+constexpr int kProsacSortCap = 8192;
+constexpr int kProsacMaxTopK = 4096;
+hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl, unsigned long long* d_cand, int* d_order,
+                               int* d_status, hipStream_t s);
+
 // ---- front end (rpe_frontend.hip): depth frame -> maps -> projective association; fp32 throughout
 struct Camera { float fx, fy, cx, cy; int width, height; };
 struct PoseF { float R[9]; float t[3]; };   // Xc = R Xw + t, R row-major

@@ -1833,7 +1833,9 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.partials = rt.d_partials; f.ticket = rt.d_ticket; f.out_dev = rt.d_out; f.out_host = rt.h_out; f.seq = rt.seq;
   f.gn_pose = rt.gn_pose; f.gn = rt.gn;
   f.p2p = rt.p2p; f.p2p_step = rt.p2p_step;
-  static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 0;   // experiments (scripts/tail_timeline.py)
+  // default 2: the last workgroup reads all records in ONE batch of loads (measured against 0 = two batches and 1 = per-shard sums
+  // first, profiles/r02_tail_timeline.jsonl: 7.9 / 8.1 / 8.7 us per launch at 307 200 points); RPE_TAIL overrides for experiments
+  static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
   f.tail = env_tail;
   f.tagged = rt.tagged;
   return f;

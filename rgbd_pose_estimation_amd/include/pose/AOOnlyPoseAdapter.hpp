@@ -83,7 +83,8 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   void sortIdx(int top_k = -1) {
     const int want = top_k < 0 || top_k > (int)_weights_3d.size() ? (int)_weights_3d.size() : top_k;
     if (_idx_top >= want && (int)_idx.size() >= want && want > 0) return;
-    _idx = sortIndexes<Tp>(_weights_3d, top_k);
+    _idx = rpe::device_prosac_order<Tp>(this->device(), _weights_3d, top_k);   // top-k select + sort on the GPU for a dense frame's weights ...
+    if (_idx.empty()) _idx = sortIndexes<Tp>(_weights_3d, top_k);                  // ... the same prefix on the host otherwise
     _idx_top = (int)_idx.size();
   }
   void getSortedIdx(std::vector<int>& select_) const { mapSortedIdx<Tp>(_weights_3d, _idx, select_); }

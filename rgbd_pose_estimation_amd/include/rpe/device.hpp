@@ -2,6 +2,7 @@
 // (include/rgbd_pose_hip.h).  The host side stays C++; every device call goes through the extern "C" shim.
 // There is no CPU path behind these calls: a failing status throws rpe::DeviceError (no fallback, no silent retry).
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstdint>
@@ -33,8 +34,15 @@ struct Settings {
   int device = 0;
   bool profile = false;
   EngineProfile prof;
-  int score_mode = RPE_SCORE_FAST;     // RPE_SCORE_EXACT reproduces the CPU path's votes bit for bit
-  int first_batch = 64, max_batch = 2048;  // RANSAC hypotheses scored per launch (grows geometrically)
+  // RPE_SCORE_EXACT (default): the vote kernels replay the reference's operation sequence in Tp, so consensus sets, adapted Iter and
+  // inlier masks are THE reference's, bit for bit.  RPE_SCORE_FAST (opt-in, RPE_SCORE_FAST=1 in the environment sets the default):
+  // rotation-matrix FMA form, 2.7x the scoring rate; votes can differ for correspondences within rounding of a threshold.
+  int score_mode = std::getenv("RPE_SCORE_FAST") && std::getenv("RPE_SCORE_FAST")[0] == '1' ? RPE_SCORE_FAST : RPE_SCORE_EXACT;
+  // RANSAC iterations generated + scored per round trip: starts at first_batch and doubles up to max_batch.  The adaptive bound
+  // usually drops below a few dozen iterations as soon as one all-inlier sample has been scored, so a small first batch ends most
+  // runs after ONE round (307 200 points, RPE_SCORE_EXACT: shinji_kneip_ransac 68 us with 8 against 291 us with 64; every run of
+  // profiles/r02_engine_profile.txt ended in its first batch).  RPE_FIRST_BATCH overrides.
+  int first_batch = std::getenv("RPE_FIRST_BATCH") ? std::atoi(std::getenv("RPE_FIRST_BATCH")) : 8, max_batch = 2048;
   // 3D-3D RANSAC (shinji_ransac / shinji_ransac2): sample + 3-point fit on the device too (rpe_ransac33_batch), bitwise the host's
   // hypotheses; false = host generation (RPE_HOST_HYPOTHESES=1 sets that default)
   bool device_hypotheses = std::getenv("RPE_HOST_HYPOTHESES") == nullptr;
@@ -151,5 +159,19 @@ class DeviceSet {
   bool _mask_fresh[3], _weight_fresh[3];
   bool _borrowed;
 };
+
+// PROSAC order on the device (rpe_prosac_order): the first top_k positions of "indices by weight, descending, ties to the lower index"
+// for a dense frame's weights -- the very prefix sortIndexes<float>(w, top_k) (pose/Utility.hpp) returns.  Empty result = not done
+// here (other Tp, short arrays, long prefixes, capture mode, heavy ties around the cut, RPE_HOST_PROSAC=1): the caller sorts on the host.
+template <class Tp> inline std::vector<int> device_prosac_order(DeviceSet&, const std::vector<Tp>&, int) { return std::vector<int>(); }
+template <> inline std::vector<int> device_prosac_order<float>(DeviceSet& dev, const std::vector<float>& w, int top_k) {
+  static const bool host_only = std::getenv("RPE_HOST_PROSAC") != nullptr;
+  if (host_only || Settings::get().capture || w.size() < 65536 || top_k < 1 || top_k > 4096) return std::vector<int>();
+  std::vector<int> order((size_t)std::min<size_t>((size_t)top_k, w.size()));
+  const int rc = rpe_prosac_order(dev.ctx(), w.data(), (int)w.size(), top_k, order.data());
+  if (rc == RPE_ERR_STATE) return std::vector<int>();   // heavy ties: host order
+  check(rc, "rpe_prosac_order");
+  return order;
+}
 
 }  // namespace rpe

@@ -1,30 +1,40 @@
 """Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/<tag>_pmc_traffic.json.
-usage: python scripts/pmc_summary.py gpurun_out/<tag> <tag>"""
+usage: python scripts/pmc_summary.py gpurun_out/<tag> <tag> [steps_per_launch]
+The bench command of the passes launches the RESIDENT normal-equation kernel once per repetition, every launch serving the same number
+of Gauss-Newton iterations (scripts/collect_evidence_r02.sh: --steps 2000 --warmup 2000, no pre-warm)."""
 import csv, glob, json, os, sys
 src, tag = sys.argv[1], sys.argv[2]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "normal_eq_resident_kernel"
+
 
 def mean_counter(sub, counter, trim_to):
     f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
-    rows = [r for r in csv.DictReader(open(f)) if "normal_eq_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter]
     vals = [float(r["Counter_Value"]) for r in rows]
-    # keep the head of the file as the committed evidence (the full trace is tens of MB)
     with open(f) as fh, open(os.path.join(root, "profiles", f"{tag}_pmc_{sub.split('_')[1]}_counter_collection.csv"), "w") as out:
-        for i, line in enumerate(fh):
-            if i >= trim_to: break
+        for i, line in enumerate(fh):   # the head of the file as committed evidence (the full trace is large)
+            if i >= trim_to:
+                break
             out.write(line)
-    vals = vals[len(vals) // 10:]  # drop the cold first launches
+    vals = vals[1:] if len(vals) > 1 else vals   # drop the first (cold) launch
     return sum(vals) / len(vals), len(vals)
+
 
 fetch, nf = mean_counter("pmc_fetch", "FETCH_SIZE", 60)
 write, nw = mean_counter("pmc_write", "WRITE_SIZE", 60)
-alg = 307200 * 26
+alg = 307200 * 26 * steps
 out = {
-    "normal_eq_p2p_f32_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
-    "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write, "launches_averaged": [nf, nw],
-    "correction": "gfx950: FETCH_SIZE reads half the bytes of a 16-B/lane coalesced stream (MI355X_MICROARCH.md, HBM); traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; the 8-B/lane mask loads are uncalibrated",
+    "normal_eq_resident_p2p_f32_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
+    "bytes_per_iteration": (2 * fetch * 1024 + write * 1024) / steps,
+    "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write, "launches_averaged": [nf, nw], "iterations_per_launch": steps,
+    "correction": "gfx950: FETCH_SIZE reads half the bytes of a 16-B/lane coalesced stream (MI355X_MICROARCH.md, HBM); traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; "
+                  "the 8-B sc1 / system-scope accesses of the hand-off, the control-block polls and the mask loads are uncalibrated",
     "algorithmic_bytes_per_launch": alg,
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras",
+    "reading": "a frame-sized problem is read ONCE per launch into registers (7.99 MB) and every later iteration touches only the control block, "
+               "the 150 partial records and the published pairs: traffic far BELOW the algorithmic 26 B x correspondences x iterations",
+    "command": "RPE_BENCH_PREWARM_S=0 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2000 --warmup 2000 --repeats 5 --no-cpu-baseline --no-extras",
 }
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out))
