@@ -81,8 +81,10 @@ def launch_children(argv: list[str], gpus: int) -> int:
 def pin_to_gpu_numa_node(local_rank: int):
     """The host thread that waits for every record and hands every pose over should sit next to the GPU's PCIe root.  Plain
     sched_setaffinity on this process, before any GPU call (no exec, no wrapper).  Best effort: returns what it did."""
+    global ORIG_AFFINITY
     try:
         allowed = sorted(os.sched_getaffinity(0))
+        ORIG_AFFINITY = set(allowed)
         cards = []
         base = "/sys/class/drm"
         for name in sorted(os.listdir(base)):
@@ -139,6 +141,9 @@ def rot_err(Ra, Rb):
     return math.atan2(s, (np.trace(D) - 1) / 2)
 
 
+ORIG_AFFINITY = None
+
+
 def cpu_baseline(sc, seconds: float):
     """Oracle (CPU restatement of the reference) timed on this host: shinji_ls2<float> through AOOnlyPoseAdapter's
     virtual getters, exactly what Library.cpp ao() runs; 1 thread because the reference is single-threaded."""
@@ -159,10 +164,15 @@ def cpu_baseline(sc, seconds: float):
         pose = np.concatenate([np.eye(3).reshape(9), np.zeros(3)])
         out = np.zeros(29)
         g = lib.orc_time_gn_p2p(p(xw), p(xc), C.c_long(n), 20, p(pose), p(out)) / 20
-        # all-core variant of the same pass: the reference itself is single-threaded, so this is beside, not instead
-        threads = max(1, min(64, (os.cpu_count() or 1)))
+        # all-core variant of the same pass: the reference itself is single-threaded, so this is beside, not instead.
+        # The bench's host thread is pinned to one CPU; the worker threads of this leg get the process's original CPU set back.
+        pinned = os.sched_getaffinity(0)
+        if ORIG_AFFINITY:
+            os.sched_setaffinity(0, ORIG_AFFINITY)
+        threads = max(1, min(64, len(os.sched_getaffinity(0))))
         lib.orc_time_gn_p2p_threads.restype = C.c_double
         ga = lib.orc_time_gn_p2p_threads(p(xw), p(xc), C.c_long(n), 200, p(pose), p(out), threads) / 200
+        os.sched_setaffinity(0, pinned)
         # the reference's own default build has no optimisation flag at all (CMakeLists.txt:13-15): the same port compiled that way
         o0 = None
         try:
