@@ -131,6 +131,7 @@ struct rpe_context {
   // host-accessible (no large BAR): the loop then launches one kernel per iteration.
   volatile unsigned long long* ctl = nullptr;
   bool resident = false;
+  double* h_big = nullptr;        // pinned + mapped: 256 workgroups x 32 pairs of 16 bytes (the per-workgroup records of the resident kernel, summed here on the host)
   // PROSAC order on the device (rpe_prosac_order): scratch
   float* ps_w = nullptr; size_t ps_w_cap = 0;
   unsigned int* ps_hist = nullptr;        // 2048 + 8 uints (histogram | control words)
@@ -266,6 +267,41 @@ int wait_host_tagged(rpe_context* c, int ld, double* out) {
   }
 }
 
+// Host-side final sum (resident loop, frame-sized problems): `grid` workgroups each sent `nacc` pairs {value, seq}; add them in
+// workgroup order as they arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps
+// the arrival of the later ones.
+int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals) {
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big);
+  const unsigned long long want = c->seq;
+  for (int k = 0; k < nacc; k++) totals[k] = 0.0;
+  unsigned long long spins = 0;
+  for (int g = 0; g < grid; g++) {
+    unsigned long long* rec = pairs + 2 * (size_t)g * nacc;
+    for (int k = nacc - 1; k >= 0; k--) {
+      while (__atomic_load_n(rec + 2 * k + 1, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 0xFFFFF) == 0) {
+          hipError_t q = hipStreamQuery(c->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+          if (q == hipSuccess && __atomic_load_n(rec + 2 * k + 1, __ATOMIC_ACQUIRE) != want)
+            return fail(RPE_ERR_HIP, "the resident kernel ended without publishing record %llu (workgroup %d)", want, g);
+        }
+      }
+    }
+    for (int k = 0; k < nacc; k++) { double v; const unsigned long long w = __atomic_load_n(rec + 2 * k, __ATOMIC_RELAXED); std::memcpy(&v, &w, 8); totals[k] += v; }
+  }
+  return RPE_OK;
+}
+// the 17 structured point-to-point sums -> the packed record (same map as record_entry<1> in rpe_kernels.hip)
+void expand_p2p17(const double* t, double* ne) {
+  for (int i = 0; i < 32; i++) ne[i] = 0.0;
+  const double nn = t[0], Sx = t[1], Sy = t[2], Sz = t[3], xx = t[4], xy = t[5], xz = t[6], yy = t[7], yz = t[8], zz = t[9];
+  ne[0] = ne[6] = ne[11] = ne[28] = nn;
+  ne[4] = Sz; ne[5] = -Sy; ne[8] = -Sz; ne[10] = Sx; ne[12] = Sy; ne[13] = -Sx;
+  ne[15] = yy + zz; ne[16] = -xy; ne[17] = -xz; ne[18] = xx + zz; ne[19] = -yz; ne[20] = xx + yy;
+  for (int i = 21; i <= 26; i++) ne[i] = t[i - 11];
+  ne[27] = t[16];
+}
+
 // same spin on an arbitrary pinned sequence word
 int wait_flag(rpe_context* c, unsigned long long* flag, unsigned long long want) {
   for (unsigned long long spins = 0;; spins++) {
@@ -350,7 +386,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
       void* p = nullptr;
       if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
         c->ctl = (volatile unsigned long long*)p;
-        c->resident = true;
+        c->resident = hipHostMalloc((void**)&c->h_big, (size_t)256 * 32 * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+        if (c->resident) std::memset(c->h_big, 0, (size_t)256 * 32 * 16); else { (void)hipGetLastError(); (void)hipFree(p); c->ctl = nullptr; }
       } else { (void)hipGetLastError(); if (p) (void)hipFree(p); }
     } else (void)hipGetLastError();
   }
@@ -377,6 +414,7 @@ void rpe_destroy(rpe_context* c) {
   (void)rpe_p2p_destroy(c);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ctl) (void)hipFree((void*)c->ctl);
+  if (c->h_big) (void)hipHostFree(c->h_big);
   if (c->ps_w) (void)hipFree(c->ps_w);
   if (c->ps_hist) (void)hipFree(c->ps_hist);
   if (c->ps_cand) (void)hipFree(c->ps_cand);
@@ -767,8 +805,18 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     hand_over(pose12, base + 1);
     rpe::ReduceTarget rt = host_target(c);
     rt.seq = base;
-    static const bool tagged = !(getenv("RPE_RESIDENT_TAGGED") && getenv("RPE_RESIDENT_TAGGED")[0] == '0');   // experiments: 0 = record + drained sequence word
-    rt.tagged = tagged ? 1 : 0;
+    rt.tagged = 1;
+    // cross-workgroup stage of the resident kernel: a handful of small records (grid x sums <= 1024 pairs, e.g. a few thousand
+    // correspondences) -> every workgroup's record goes to the host, which adds them in workgroup order (no GPU-side hand-off at all:
+    // 5.4 us per step at 10 000 points); more -> 16-byte granules read by workgroup 0 on the GPU (41 KB of 16-byte PCIe writes per
+    // iteration cost more than the GPU-side hand-off: 10.6 vs 7.5 us at 307 200 points).  RPE_RESIDENT_TAIL = 16 | 32 forces one.
+    int grid = 0, nacc = 0;
+    rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc);
+    static const int env_rt = getenv("RPE_RESIDENT_TAIL") ? atoi(getenv("RPE_RESIDENT_TAIL")) : -1;
+    const int rtail = (env_rt == 16 || env_rt == 32) ? env_rt : (grid * nacc <= 1024 ? 32 : 16);
+    const bool host_sum = rtail == 32;
+    rt.tail = rtail;
+    if (host_sum) rt.h_out = c->h_big;
     c->seq = base;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
@@ -778,8 +826,8 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     for (;;) {
       c->seq = base + (unsigned long long)received + 1;
       double ne[32], d[6];
-      if (tagged) { if ((rc = wait_host_tagged(c, rpe::kNeLd, ne))) { status = rc; break; } }
-      else { if ((rc = wait_host(c, rpe::kNeLd))) { status = rc; break; } for (int i = 0; i < 32; i++) ne[i] = c->h_out[i]; }
+      if (host_sum) { double tot[32]; if ((rc = wait_host_partials(c, grid, nacc, tot))) { status = rc; break; } if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; } }
+      else if ((rc = wait_host_tagged(c, rpe::kNeLd, ne))) { status = rc; break; }
       received++;
       if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
       cost = sc * ne[27];

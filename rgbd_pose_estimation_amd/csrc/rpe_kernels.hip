@@ -417,6 +417,53 @@ hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d
   return hipGetLastError();
 }
 
+// the packed 32-entry record entry `i` from the totals (LDS): MODE 0 = the totals are the record, MODE 1 = the 17 structured
+// point-to-point sums expanded to H upper triangle (21) | g (6) | cost | weight
+template <int MODE> __device__ __forceinline__ double record_entry(const double* __restrict__ tot, int i) {
+  if (MODE == 0) return tot[i];
+  const double nn = tot[0], Sx = tot[1], Sy = tot[2], Sz = tot[3];
+  const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
+  switch (i) {
+    case 0: case 6: case 11: case 28: return nn;     // (0,0) (1,1) (2,2) ; weight sum
+    case 4: return Sz;    case 5: return -Sy;          // (0,4) (0,5)
+    case 8: return -Sz;   case 10: return Sx;          // (1,3) (1,5)
+    case 12: return Sy;   case 13: return -Sx;         // (2,3) (2,4)
+    case 15: return yy + zz; case 16: return -xy; case 17: return -xz;   // row 3
+    case 18: return xx + zz; case 19: return -yz;                         // row 4
+    case 20: return xx + yy;                                              // row 5
+    case 21: case 22: case 23: case 24: case 25: case 26: return tot[i - 11];   // g = (sum r, sum p x r)
+    case 27: return tot[16];
+    default: return 0.0;
+  }
+}
+// one value to the host WITH the sequence number in ONE 16-byte SYSTEM-scope store (sc0 sc1: straight out over PCIe); the host waits
+// until every pair carries the sequence value, so no ordering between the stores, no drain and no separate flag are needed.
+// (A plain or nt 16-byte store to this memory was observed never to reach the host while the kernel stays resident.  There is no
+// 16-byte atomic builtin, hence the instruction itself; s_nop 1: the data registers must not be reused before the store reads them.)
+__device__ __forceinline__ void store_tagged_pair(double* __restrict__ out_host, int slot, double val, unsigned long long seq) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
+  u32x4 pr;
+  pr.x = (unsigned int)bits; pr.y = (unsigned int)(bits >> 32); pr.z = (unsigned int)seq; pr.w = (unsigned int)(seq >> 32);
+  const unsigned long long* dst = reinterpret_cast<const unsigned long long*>(out_host) + 2 * slot;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(pr) : "memory");
+}
+// 16-byte granules {value, tag} between workgroups of one launch (agent scope): written by ONE sc1 (write-through) store, read by ONE
+// sc1 load -- the tag travels with the value, so neither a drain nor an arrival counter is needed (cdna_hip_programming.md Guideline 16,
+// recipe R2, with 16-byte granules: observed untorn on gfx950).
+typedef unsigned int granule_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_granule16(unsigned long long* __restrict__ g, double val, unsigned long long tag) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
+  granule_t pr;
+  pr.x = (unsigned int)bits; pr.y = (unsigned int)(bits >> 32); pr.z = (unsigned int)tag; pr.w = (unsigned int)(tag >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(g), "v"(pr) : "memory");
+}
+__device__ __forceinline__ granule_t load_granule16(const unsigned long long* __restrict__ g) {
+  granule_t pr;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(pr) : "v"(g) : "memory");
+  return pr;
+}
+
 template <int NACC, int LD, int BLK, int U>
 __device__ __forceinline__ void sum_records(const double* __restrict__ partials, int first, int step, int count, double (*part)[LD],
                                             double* __restrict__ tot) {
@@ -545,44 +592,14 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
   __syncthreads();
   // publish
   double val = 0.0;
-  if (threadIdx.x < LD) {
-    if (MODE == 0) val = tot[threadIdx.x];
-    else {  // expand the 17 structured p2p sums into the packed record (H upper triangle 21 | g 6 | cost | weight)
-      const double nn = tot[0], Sx = tot[1], Sy = tot[2], Sz = tot[3];
-      const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
-      switch (threadIdx.x) {
-        case 0: case 6: case 11: case 28: val = nn; break;  // (0,0) (1,1) (2,2) ; weight sum
-        case 4: val = Sz; break;    case 5: val = -Sy; break;    // (0,4) (0,5)
-        case 8: val = -Sz; break;   case 10: val = Sx; break;    // (1,3) (1,5)
-        case 12: val = Sy; break;   case 13: val = -Sx; break;   // (2,3) (2,4)
-        case 15: val = yy + zz; break; case 16: val = -xy; break; case 17: val = -xz; break;  // row 3
-        case 18: val = xx + zz; break; case 19: val = -yz; break;                              // row 4
-        case 20: val = xx + yy; break;                                                         // row 5
-        case 21: case 22: case 23: case 24: case 25: case 26: val = tot[threadIdx.x - 11]; break;  // g = (sum r, sum p x r)
-        case 27: val = tot[16]; break;
-        default: val = 0.0;
-      }
-    }
-  }
+  if (threadIdx.x < LD) val = record_entry<MODE>(tot, threadIdx.x);
   if (LD == 32 && fin.p2p != nullptr && threadIdx.x < 64) {   // wave 0 (uniform branch): all 64 lanes take part in the exchange
     int failed = 0;
     val = p2p_allreduce32(val, fin, &failed);
     if (failed && threadIdx.x == 31) val = 1e300;   // error marker in the last (padding) entry of the record: the host checks it
   }
-  if (fin.tagged) {
-    // resident loop: every value travels WITH the sequence number in ONE 16-byte store (one PCIe write), so the host needs no
-    // ordering between stores: it waits until all LD pairs carry the sequence value.  No drain of the posted writes (~1.3 us saved).
-    // The store must be a SYSTEM-scope one (sc0 sc1: straight out to the host, like the 8-byte atomic stores of the untagged form);
-    // a plain or nt 16-byte store to this memory was observed never to reach the host while the kernel stays resident.  There is no
-    // 16-byte atomic builtin, hence the instruction itself (s_nop 1: the data registers must not be reused before the store reads them).
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    if (threadIdx.x < LD) {
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
-      u32x4 pr;
-      pr.x = (unsigned int)bits; pr.y = (unsigned int)(bits >> 32); pr.z = (unsigned int)fin.seq; pr.w = (unsigned int)(fin.seq >> 32);
-      const unsigned long long* dst = reinterpret_cast<const unsigned long long*>(fin.out_host) + 2 * threadIdx.x;
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(pr) : "memory");
-    }
+  if (fin.tagged) {   // resident loop: tagged pairs, no drain, no flag
+    if (threadIdx.x < LD) store_tagged_pair(fin.out_host, threadIdx.x, val, fin.seq);
     return;
   }
   if (threadIdx.x < LD) {
@@ -930,6 +947,10 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     }
     __syncthreads();
     if (s_go != 1) return;   // stop requested (2) or no host (3): uniform for the workgroup
+#ifdef RPE_STAMPS
+    const bool stamp_it = it == 1000;
+    if (stamp_it) RPE_STAMP(0);
+#endif
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
@@ -949,10 +970,112 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
         normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, mm, ww, g < full ? P : (int)(n - full * P), acc);
       }
     }
-    Finish f = fin;
-    f.seq = fin.seq + (unsigned long long)it;
-    reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, f);
-    __syncthreads();   // the reduction's LDS scratch and s_pose are reused by the next iteration
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(1);
+#endif
+    if (fin.tail & 32) {
+      // ---- host-side final sum (frame-sized problems): the wave + LDS stages end in one NACC-value record per workgroup, and every
+      // workgroup sends ITS record straight to the host as tagged 16-byte pairs; the host thread that already owns the 6x6 solve adds
+      // the G records in workgroup order (a fixed order: bitwise reproducible).  No cross-workgroup traffic on the GPU at all: neither
+      // write-through + re-read through memory (~2 us) nor arrival counters.  G x NACC x 16 B cross PCIe per iteration (41 KB at 640x480).
+      constexpr int NW = BLK / 64;
+      __shared__ double h_red[NW][NACC];
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      wave_reduce_to<NACC>(acc, h_red[wave], lane);
+      __syncthreads();
+      if (threadIdx.x < NACC) {
+        double own = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) own += h_red[w][threadIdx.x];
+        store_tagged_pair(fin.out_host, blockIdx.x * NACC + threadIdx.x, own, fin.seq + (unsigned long long)it);
+      }
+      __syncthreads();
+    } else {
+      // ---- granule hand-off (resident loop): every workgroup stores its NACC sums as 16-byte granules {value, iteration tag} -- one sc1
+      // store per lane, no drain, no arrival counter -- and returns to wait for the next pose; workgroup 0, after its own slice, reads
+      // all granules (sc1 loads, re-read until the tag is this iteration's) and adds them in row order, so the sums are a fixed function
+      // of the records whichever workgroup finishes first.  A workgroup overwrites its granules only in the next iteration, which the
+      // host starts after it has received this iteration's record, i.e. after workgroup 0 has read them.
+      constexpr int NW = BLK / 64;
+      constexpr int RGN = BLK / NACC;                       // row groups of the reading workgroup
+      __shared__ double g_red[NW][NACC];
+      __shared__ double g_part[RGN][NACC];
+      __shared__ double g_tot[kNeLd];
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const unsigned long long tag = first_tag + (unsigned long long)it;
+      unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
+      wave_reduce_to<NACC>(acc, g_red[wave], lane);
+      __syncthreads();
+      double own = 0.0;
+      if (threadIdx.x < NACC) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
+        if (blockIdx.x != 0) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+      }
+#ifdef RPE_STAMPS
+      if (stamp_it) RPE_STAMP(2);
+#endif
+      if (blockIdx.x == 0) {
+        const int G = gridDim.x;
+        const int j = threadIdx.x % NACC, rg = threadIdx.x / NACC;
+        constexpr int MAXR = (256 + RGN - 1) / RGN;          // rows per reading thread (the resident grid has <= 256 workgroups)
+        double sum = 0.0;
+        bool lost = false;
+        if (rg < RGN) {
+          // buffer loads with the sc1 bit (aux 16): counted by the compiler, so a whole sweep of this thread's rows is in flight at once
+          const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(gran), 0, G * NACC * 16, 0x00020000);
+          const unsigned long long t0 = wall_clock64();
+          constexpr int CH = 8;                                  // granules in flight per thread and sweep (32 VGPRs)
+          for (int u0 = 0; u0 < MAXR && !lost; u0 += CH) {       // rows in increasing order: a fixed summation order
+            if (1 + rg + u0 * RGN >= G) break;
+            granule_t q[CH];
+            for (;;) {
+              bool pending = false;
+#pragma unroll
+              for (int u = 0; u < CH; u++) {
+                const int r = 1 + rg + (u0 + u) * RGN;
+                if (r < G) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r * NACC + j) * 16, 0, 16);
+              }
+#pragma unroll
+              for (int u = 0; u < CH; u++) {
+                const int r = 1 + rg + (u0 + u) * RGN;
+                if (r < G && (((unsigned long long)q[u].w << 32) | q[u].z) != tag) pending = true;
+              }
+              if (!pending) break;
+              if (wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+              const int r = 1 + rg + (u0 + u) * RGN;
+              if (r < G && !lost) sum += __longlong_as_double((long long)(((unsigned long long)q[u].y << 32) | q[u].x));
+            }
+          }
+          g_part[rg][j] = sum;
+        }
+#ifdef RPE_STAMPS
+        if (stamp_it) RPE_STAMP(3);
+#endif
+        if (__syncthreads_or(lost)) return;   // no record: the host reports the kernel as having ended without publishing
+#ifdef RPE_STAMPS
+        if (stamp_it) RPE_STAMP(4);
+#endif
+        if (threadIdx.x < kNeLd) {
+          double t = 0.0;
+          if (threadIdx.x < NACC) {
+            t = own;
+#pragma unroll
+            for (int k = 0; k < RGN; k++) t += g_part[k][threadIdx.x];
+          }
+          g_tot[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < kNeLd) store_tagged_pair(fin.out_host, threadIdx.x, record_entry<KIND == KIND_P2P ? 1 : 0>(g_tot, threadIdx.x), fin.seq + (unsigned long long)it);
+#ifdef RPE_STAMPS
+        if (stamp_it) RPE_STAMP(5);
+#endif
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -1836,7 +1959,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   // default 2: the last workgroup reads all records in ONE batch of loads (measured against 0 = two batches and 1 = per-shard sums
   // first, profiles/r02_tail_timeline.jsonl: 7.9 / 8.1 / 8.7 us per launch at 307 200 points); RPE_TAIL overrides for experiments
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
-  f.tail = env_tail;
+  f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.tagged = rt.tagged;
   return f;
 }
@@ -1935,6 +2058,12 @@ static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const u
   else if (kind == KIND_P2PLANE) resident_launch<T, KIND_P2PLANE, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+// grid the resident kernel runs with, and the number of sums per workgroup record (what a host-side final sum has to expect)
+void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc) {
+  const int P = A.dtype ? 2 : 4;
+  *grid = reduce_grid(A.n, P, max_blocks < 256 ? max_blocks : 256, 512);
+  *nacc = kind == KIND_P2P ? 17 : 29;
 }
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {

@@ -1,5 +1,7 @@
 """A/B of the host-driven Gauss-Newton loop (rpe_gn_refine): RESIDENT kernel (one launch, poses handed over through device memory) against
-one launch per iteration (RPE_RESIDENT=0).  Wall time per step of the library's loop, pose agreement between the two.  Development aid."""
+one launch per iteration (RPE_RESIDENT=0), and the resident kernel's cross-workgroup stage (RPE_RESIDENT_TAIL: 16 granules read by
+workgroup 0, 32 every workgroup's record to the host, which adds them).  Wall time per step of the library's
+loop, pose agreement.  Development aid."""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,10 +21,9 @@ def worker(n, kind, steps):
         t0 = time.perf_counter()
         q, its, step, cost = ctx.gn_refine([kind], p, max_iter=steps, tol=0.0)
         best = min(best, (time.perf_counter() - t0) / steps)
-    # a converging run from a perturbed pose: iterations and pose
     p0 = p.copy(); p0[9:] += 0.02
     qc, itc, stepc, _ = ctx.gn_refine([kind], p0, max_iter=30, tol=1e-9)
-    print(json.dumps(dict(resident=os.environ.get("RPE_RESIDENT", "1"), n=n, kind=kind, us_per_step=best * 1e6, iters=its, pose=list(q), conv_iters=itc, conv_pose=list(qc))), flush=True)
+    print(json.dumps(dict(resident=os.environ.get("RPE_RESIDENT", "1"), tail=os.environ.get("RPE_RESIDENT_TAIL", "auto"), n=n, kind=kind, us_per_step=best * 1e6, iters=its, pose=list(q), conv_iters=itc, conv_pose=list(qc))), flush=True)
     ctx.close()
 
 
@@ -30,7 +31,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     else:
+        variants = [dict(RPE_RESIDENT="0")] + [dict(RPE_RESIDENT="1", RPE_RESIDENT_TAIL=t) for t in (sys.argv[1:] or ["16", "32"])]
         for n, kind in ((307200, 0), (1000000, 1), (1250000, 0), (10000, 0), (10000000, 0)):
-            for res in ("1", "0"):
-                e = dict(os.environ, RPE_RESIDENT=res)
+            for v in variants:
+                e = dict(os.environ, **v)
                 subprocess.run(["timeout", "120", sys.executable, os.path.abspath(__file__), "--worker", str(n), str(kind), "2000"], env=e, check=False)
