@@ -242,7 +242,7 @@ int wait_host(rpe_context* c, int ld) {
 
 // Tagged form (resident loop): the record arrives as `ld` pairs {value, seq}, each written by ONE 16-byte store; it is complete
 // when every pair carries the wanted sequence value.  A pair's value is read after its tag (acquire): both came in one write.
-int wait_host_tagged(rpe_context* c, int ld, double* out) {
+[[maybe_unused]] int wait_host_tagged(rpe_context* c, int ld, double* out) {
   unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_out);
   const unsigned long long want = c->seq;
   for (unsigned long long spins = 0;; spins++) {
@@ -267,9 +267,9 @@ int wait_host_tagged(rpe_context* c, int ld, double* out) {
   }
 }
 
-// Host-side final sum (resident loop, frame-sized problems): `grid` workgroups each sent `nacc` pairs {value, seq}; add them in
-// workgroup order as they arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps
-// the arrival of the later ones.
+// Host-side final sum (resident loop): `grid` collecting workgroups each sent `nacc` pairs {value, seq}; add them in run order as they
+// arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps the arrival of the
+// later ones.
 int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals) {
   unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big);
   const unsigned long long want = c->seq;
@@ -806,17 +806,18 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     rpe::ReduceTarget rt = host_target(c);
     rt.seq = base;
     rt.tagged = 1;
-    // cross-workgroup stage of the resident kernel: a handful of small records (grid x sums <= 1024 pairs, e.g. a few thousand
-    // correspondences) -> every workgroup's record goes to the host, which adds them in workgroup order (no GPU-side hand-off at all:
-    // 5.4 us per step at 10 000 points); more -> 16-byte granules read by workgroup 0 on the GPU (41 KB of 16-byte PCIe writes per
-    // iteration cost more than the GPU-side hand-off: 10.6 vs 7.5 us at 307 200 points).  RPE_RESIDENT_TAIL = 16 | 32 forces one.
-    int grid = 0, nacc = 0;
-    rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc);
-    static const int env_rt = getenv("RPE_RESIDENT_TAIL") ? atoi(getenv("RPE_RESIDENT_TAIL")) : -1;
-    const int rtail = (env_rt == 16 || env_rt == 32) ? env_rt : (grid * nacc <= 1024 ? 32 : 16);
-    const bool host_sum = rtail == 32;
-    rt.tail = rtail;
-    if (host_sum) rt.h_out = c->h_big;
+    // cross-workgroup stage of the resident kernel: runs of `rows` workgroups are added by the first workgroup of the run (granule
+    // hand-off, one hop), the run records come to the host, which adds them in run order.  A handful of small records (grid x sums <=
+    // 1024 pairs, i.e. a few thousand correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the
+    // GPU at all; otherwise the largest run a collecting workgroup can take with one granule per thread (30 for point-to-point: 5 run
+    // records at 640 x 480), which keeps the PCIe side to a few hundred bytes.  RPE_RESIDENT_ROWS forces a run length.
+    int grid = 0, nacc = 0, max_rows = 1;
+    rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc, &max_rows);
+    static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
+    const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : max_rows);
+    const int runs = (grid + rows - 1) / rows;
+    rt.rows = rows;
+    rt.h_out = c->h_big;
     c->seq = base;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
@@ -826,8 +827,9 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     for (;;) {
       c->seq = base + (unsigned long long)received + 1;
       double ne[32], d[6];
-      if (host_sum) { double tot[32]; if ((rc = wait_host_partials(c, grid, nacc, tot))) { status = rc; break; } if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; } }
-      else if ((rc = wait_host_tagged(c, rpe::kNeLd, ne))) { status = rc; break; }
+      double tot[32];
+      if ((rc = wait_host_partials(c, runs, nacc, tot))) { status = rc; break; }
+      if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; }
       received++;
       if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
       cost = sc * ne[27];

@@ -57,17 +57,19 @@ struct ReduceTarget {
   const P2PDesc* p2p = nullptr;   // multi-GPU: exchange + sum the record with the peers before publishing (h_out path only)
   unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
   int tagged = 0;              // h_out receives LD pairs {value, seq} (16 bytes, one store each) instead of the record + a sequence word
-  int tail = -1;               // cross-workgroup stage: -1 = default / RPE_TAIL; resident kernel: 16 = granule hand-off to workgroup 0, 32 = every
-                               // workgroup sends its record to the host (h_out must hold grid x nacc pairs), which adds them in workgroup order
+  int tail = -1;               // cross-workgroup stage of the ordinary kernels: -1 = default / RPE_TAIL
+  int rows = 0;                // resident kernel: workgroups per collecting workgroup (1 = every workgroup sends its own record); h_out must hold
+                               // ceil(grid / rows) x nacc pairs, which the host adds in order
 };
 // ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // RESIDENT form of the same kernels: one launch serves up to max_iters Gauss-Newton iterations; between iterations every workgroup
 // waits for the next pose in `ctl` (16 words in fine-grained device memory written by the host: layout in rpe_kernels.hip), tagged
-// first_tag + i; record i is published with sequence value rt.seq + i.  Needs host-writable device memory (large BAR).
+// first_tag + i; the run records of iteration i (rt.rows) are published with sequence value rt.seq + i.  Needs host-writable device
+// memory (large BAR).
 constexpr unsigned long long kResidentStopBit = 1ull << 63;
-void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc);
+void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows);
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // test hook: one application of the device-resident loop's 6x6 LDL^T solve + SE(3) exp-map update (d_step_ok: |delta|, ok flag)

@@ -257,6 +257,7 @@ struct Finish {
   unsigned long long p2p_step;
   int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
   int tagged;                  // 1: publish to out_host as LD pairs {value, seq} of 16 bytes, one store each, no drain and no separate sequence word
+  int rows;                    // resident kernel: workgroups per collecting workgroup
 };
 
 // ---- all-reduce(sum) of the 32-double record across <= 8 GPUs, by the first wave of the LAST workgroup, without leaving the
@@ -973,84 +974,50 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(1);
 #endif
-    if (fin.tail & 32) {
-      // ---- host-side final sum (frame-sized problems): the wave + LDS stages end in one NACC-value record per workgroup, and every
-      // workgroup sends ITS record straight to the host as tagged 16-byte pairs; the host thread that already owns the 6x6 solve adds
-      // the G records in workgroup order (a fixed order: bitwise reproducible).  No cross-workgroup traffic on the GPU at all: neither
-      // write-through + re-read through memory (~2 us) nor arrival counters.  G x NACC x 16 B cross PCIe per iteration (41 KB at 640x480).
+    // ---- cross-workgroup stage: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the first of a run
+    // collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no drain, no arrival
+    // counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls ONE granule (sc1 load until the
+    // tag is this iteration's), the rows are added in row order, and the run's NACC sums go to the host as tagged 16-byte pairs.  The
+    // host thread that owns the 6x6 solve adds the ceil(G / R) run records in run order.  So one hand-off hop on the GPU (about 1 us: a
+    // collecting wave reads a few hundred bytes, MI355X_MICROARCH.md "handoff-1to1"), a few hundred bytes over PCIe, and sums that are
+    // a fixed function of (G, R) whichever workgroup finishes first.  R = 1: every workgroup sends its own record (tiny problems).
+    // A workgroup overwrites its granules only in the next iteration, which the host starts after it has received every run record,
+    // i.e. after the granules have been read.
+    {
       constexpr int NW = BLK / 64;
-      __shared__ double h_red[NW][NACC];
+      constexpr int RGN = BLK / NACC;                       // rows a collecting workgroup can take, one granule per thread
+      __shared__ double g_red[NW][NACC];
+      __shared__ double g_part[RGN][NACC];
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      wave_reduce_to<NACC>(acc, h_red[wave], lane);
+      const unsigned long long tag = first_tag + (unsigned long long)it;
+      unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
+      const int R = fin.rows, run = blockIdx.x / R, leader = run * R;
+      wave_reduce_to<NACC>(acc, g_red[wave], lane);
       __syncthreads();
       if (threadIdx.x < NACC) {
         double own = 0.0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) own += h_red[w][threadIdx.x];
-        store_tagged_pair(fin.out_host, blockIdx.x * NACC + threadIdx.x, own, fin.seq + (unsigned long long)it);
-      }
-      __syncthreads();
-    } else {
-      // ---- granule hand-off (resident loop): every workgroup stores its NACC sums as 16-byte granules {value, iteration tag} -- one sc1
-      // store per lane, no drain, no arrival counter -- and returns to wait for the next pose; workgroup 0, after its own slice, reads
-      // all granules (sc1 loads, re-read until the tag is this iteration's) and adds them in row order, so the sums are a fixed function
-      // of the records whichever workgroup finishes first.  A workgroup overwrites its granules only in the next iteration, which the
-      // host starts after it has received this iteration's record, i.e. after workgroup 0 has read them.
-      constexpr int NW = BLK / 64;
-      constexpr int RGN = BLK / NACC;                       // row groups of the reading workgroup
-      __shared__ double g_red[NW][NACC];
-      __shared__ double g_part[RGN][NACC];
-      __shared__ double g_tot[kNeLd];
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      const unsigned long long tag = first_tag + (unsigned long long)it;
-      unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
-      wave_reduce_to<NACC>(acc, g_red[wave], lane);
-      __syncthreads();
-      double own = 0.0;
-      if (threadIdx.x < NACC) {
-#pragma unroll
         for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
-        if (blockIdx.x != 0) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+        if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+        else g_part[0][threadIdx.x] = own;
       }
 #ifdef RPE_STAMPS
       if (stamp_it) RPE_STAMP(2);
 #endif
-      if (blockIdx.x == 0) {
-        const int G = gridDim.x;
-        const int j = threadIdx.x % NACC, rg = threadIdx.x / NACC;
-        constexpr int MAXR = (256 + RGN - 1) / RGN;          // rows per reading thread (the resident grid has <= 256 workgroups)
-        double sum = 0.0;
+      if ((int)blockIdx.x == leader) {
+        const int rows = min(R, (int)gridDim.x - leader);
+        const int j = threadIdx.x % NACC, r = threadIdx.x / NACC;
         bool lost = false;
-        if (rg < RGN) {
-          // buffer loads with the sc1 bit (aux 16): counted by the compiler, so a whole sweep of this thread's rows is in flight at once
-          const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(gran), 0, G * NACC * 16, 0x00020000);
+        if (r >= 1 && r < rows) {
+          const unsigned long long* src = gran + 2 * ((size_t)(leader + r) * NACC + j);
           const unsigned long long t0 = wall_clock64();
-          constexpr int CH = 8;                                  // granules in flight per thread and sweep (32 VGPRs)
-          for (int u0 = 0; u0 < MAXR && !lost; u0 += CH) {       // rows in increasing order: a fixed summation order
-            if (1 + rg + u0 * RGN >= G) break;
-            granule_t q[CH];
-            for (;;) {
-              bool pending = false;
-#pragma unroll
-              for (int u = 0; u < CH; u++) {
-                const int r = 1 + rg + (u0 + u) * RGN;
-                if (r < G) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r * NACC + j) * 16, 0, 16);
-              }
-#pragma unroll
-              for (int u = 0; u < CH; u++) {
-                const int r = 1 + rg + (u0 + u) * RGN;
-                if (r < G && (((unsigned long long)q[u].w << 32) | q[u].z) != tag) pending = true;
-              }
-              if (!pending) break;
-              if (wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
-            }
-#pragma unroll
-            for (int u = 0; u < CH; u++) {
-              const int r = 1 + rg + (u0 + u) * RGN;
-              if (r < G && !lost) sum += __longlong_as_double((long long)(((unsigned long long)q[u].y << 32) | q[u].x));
-            }
+          granule_t q;
+          for (unsigned int spins = 1;; spins++) {
+            q = load_granule16(src);
+            if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
+            if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
           }
-          g_part[rg][j] = sum;
+          g_part[r][j] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
         }
 #ifdef RPE_STAMPS
         if (stamp_it) RPE_STAMP(3);
@@ -1059,17 +1026,11 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #ifdef RPE_STAMPS
         if (stamp_it) RPE_STAMP(4);
 #endif
-        if (threadIdx.x < kNeLd) {
+        if (threadIdx.x < NACC) {
           double t = 0.0;
-          if (threadIdx.x < NACC) {
-            t = own;
-#pragma unroll
-            for (int k = 0; k < RGN; k++) t += g_part[k][threadIdx.x];
-          }
-          g_tot[threadIdx.x] = t;
+          for (int k = 0; k < rows; k++) t += g_part[k][threadIdx.x];
+          store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, t, fin.seq + (unsigned long long)it);
         }
-        __syncthreads();
-        if (threadIdx.x < kNeLd) store_tagged_pair(fin.out_host, threadIdx.x, record_entry<KIND == KIND_P2P ? 1 : 0>(g_tot, threadIdx.x), fin.seq + (unsigned long long)it);
 #ifdef RPE_STAMPS
         if (stamp_it) RPE_STAMP(5);
 #endif
@@ -1961,6 +1922,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.tagged = rt.tagged;
+  f.rows = rt.rows > 0 ? rt.rows : 1;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)
@@ -2035,7 +1997,9 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < 256 ? rt.max_blocks : 256, BLK);   // at most one workgroup per CU: all co-resident
   const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
   const bool in_regs = (int64_t)G * BLK >= groups;
-  const Finish fin = make_finish(rt);
+  Finish fin = make_finish(rt);
+  constexpr int kMaxRows = BLK / (KIND == KIND_P2P ? 17 : 29);
+  if (fin.rows > kMaxRows) fin.rows = kMaxRows;
 #define RPE_RES_LAUNCH2(M, W, R)                                                                                                             \
   do {                                                                                                                                       \
     if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
@@ -2059,11 +2023,12 @@ static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const u
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
-// grid the resident kernel runs with, and the number of sums per workgroup record (what a host-side final sum has to expect)
-void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc) {
+// grid the resident kernel runs with, the number of sums per record, and the largest run of workgroups one collecting workgroup can take
+void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows) {
   const int P = A.dtype ? 2 : 4;
   *grid = reduce_grid(A.n, P, max_blocks < 256 ? max_blocks : 256, 512);
   *nacc = kind == KIND_P2P ? 17 : 29;
+  *max_rows = 512 / *nacc;
 }
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {

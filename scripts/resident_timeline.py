@@ -1,6 +1,6 @@
 """Where one iteration of the RESIDENT Gauss-Newton kernel spends its time (development aid; diagnostic build -DRPE_STAMPS): thread 0 of
 every workgroup stamps the 100 MHz clock in iteration 1000 of a 2000-iteration refinement -- pose seen, slice done, granules stored,
-(workgroup 0) all granules read, sums done, record stored towards the host.  Reported relative to the first workgroup's "pose seen"."""
+(collecting workgroup 0) its granule read, all read, run record stored towards the host.  Reported relative to the first workgroup's "pose seen"."""
 import ctypes as C, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,7 +36,7 @@ def worker(n, kind):
                 row[name] = float((w0[0, c] - t0) * 0.01)
         rows.append(row)
     keys = sorted({k for r in rows for k in r})
-    print(json.dumps(dict(what="resident_stamps", tail=os.environ.get("RPE_TAIL", ""), n=n, kind=kind, unit="us after the first workgroup saw the pose; medians over 30 refinements",
+    print(json.dumps(dict(what="resident_stamps", rows=os.environ.get("RPE_RESIDENT_ROWS", "auto"), n=n, kind=kind, unit="us after the first workgroup saw the pose; medians over 30 refinements",
                           **{k: float(np.median([r[k] for r in rows if k in r])) for k in keys})), flush=True)
     ctx.close()
 
@@ -50,4 +50,4 @@ if __name__ == "__main__":
         if not os.path.exists(so):
             so = B.build_stamps(1)
         for n, kind in ((307200, 0), (1000000, 1)):
-            subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(n), str(kind)], env=dict(os.environ, RPE_LIBRARY=so, RPE_TAIL="18"), check=False)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(n), str(kind)], env=dict(os.environ, RPE_LIBRARY=so), check=False)
