@@ -131,7 +131,9 @@ struct rpe_context {
   // host-accessible (no large BAR): the loop then launches one kernel per iteration.
   volatile unsigned long long* ctl = nullptr;
   bool resident = false;
-  double* h_big = nullptr;        // pinned + mapped: 256 workgroups x 32 pairs of 16 bytes (the per-workgroup records of the resident kernel, summed here on the host)
+  double* h_big = nullptr;        // pinned + mapped: tagged 16-byte pairs {value, sequence} -- the run records of collecting launches, added here on the host
+  size_t h_big_pairs = 0;
+  bool collecting = false;        // the launch in flight publishes run records into h_big (collect_target)
   // PROSAC order on the device (rpe_prosac_order): scratch
   float* ps_w = nullptr; size_t ps_w_cap = 0;
   unsigned int* ps_hist = nullptr;        // 2048 + 8 uints (histogram | control words)
@@ -217,16 +219,28 @@ rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
   rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
+  c->collecting = false;
+  return rt;
+}
+// host-consumed result of ONE launch on a single GPU: collecting workgroups + host-side final sum (rpe_kernels.hip collect_and_send);
+// wait_host then assembles the record in c->h_out.  RPE_COLLECT=0: the arrival-counter tail (as the device / collective targets use)
+rpe::ReduceTarget collect_target(rpe_context* c) {
+  rpe::ReduceTarget rt = host_target(c);
+  static const bool on = !(getenv("RPE_COLLECT") && atoi(getenv("RPE_COLLECT")) == 0);
+  if (on) { rt.h_out = c->h_big; rt.rows = 1 << 20; c->collecting = true; }
   return rt;
 }
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
   rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
+  c->collecting = false;
   return rt;
 }
 // Spin on the sequence word the kernel's last workgroup stores after the record (pinned, coherent host memory).
+int wait_collect(rpe_context* c, int ld);
 int wait_host(rpe_context* c, int ld) {
+  if (c->collecting) { c->collecting = false; return wait_collect(c, ld); }
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_out + ld);
   const unsigned long long want = c->seq;
   for (unsigned long long spins = 0;; spins++) {
@@ -270,8 +284,8 @@ int wait_host(rpe_context* c, int ld) {
 // Host-side final sum (resident loop): `grid` collecting workgroups each sent `nacc` pairs {value, seq}; add them in run order as they
 // arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps the arrival of the
 // later ones.
-int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals) {
-  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big);
+int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int first_slot = 0) {
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big) + 2 * (size_t)first_slot;
   const unsigned long long want = c->seq;
   for (int k = 0; k < nacc; k++) totals[k] = 0.0;
   unsigned long long spins = 0;
@@ -300,6 +314,31 @@ void expand_p2p17(const double* t, double* ne) {
   ne[15] = yy + zz; ne[16] = -xy; ne[17] = -xz; ne[18] = xx + zz; ne[19] = -yz; ne[20] = xx + yy;
   for (int i = 21; i <= 26; i++) ne[i] = t[i - 11];
   ne[27] = t[16];
+}
+
+// Result of a collecting launch (collect_target): the header pair says how many run records of how many sums to expect; add them in
+// run order and lay the record out in c->h_out as the flag path would have left it.
+int wait_collect(rpe_context* c, int ld) {
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big);
+  const unsigned long long want = c->seq;
+  for (unsigned long long spins = 1; __atomic_load_n(pairs + 1, __ATOMIC_ACQUIRE) != want; spins++) {
+    if ((spins & 0xFFFFF) == 0) {
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+      if (q == hipSuccess && __atomic_load_n(pairs + 1, __ATOMIC_ACQUIRE) != want)
+        return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu; header %llx %llu, first pair %llx %llu)", want,
+                    pairs[0], pairs[1], pairs[2], pairs[3]);
+    }
+  }
+  const unsigned long long hdr = __atomic_load_n(pairs, __ATOMIC_RELAXED);
+  const int runs = (int)(hdr & 0xFFFF), nacc = (int)((hdr >> 16) & 0xFF), mode = (int)((hdr >> 24) & 0xFF);
+  if (runs < 1 || nacc < 1 || nacc > 64 || nacc > ld || (size_t)(1 + runs * nacc) > c->h_big_pairs) return fail(RPE_ERR_HIP, "malformed result header (%d runs of %d sums)", runs, nacc);
+  double tot[64];
+  int rc = wait_host_partials(c, runs, nacc, tot, 1);
+  if (rc) return rc;
+  if (mode == 1) expand_p2p17(tot, c->h_out);
+  else { for (int i = 0; i < ld; i++) c->h_out[i] = i < nacc ? tot[i] : 0.0; }
+  return RPE_OK;
 }
 
 // same spin on an arbitrary pinned sequence word
@@ -360,7 +399,11 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)(4096 + 8) * rpe::kNlLd * sizeof(double));   // + 8 shard records
+  if (e == hipSuccess) e = hipMemset(c->d_partials, 0, (size_t)(4096 + 8) * rpe::kNlLd * sizeof(double));   // granule tags start below every sequence value
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
+  c->h_big_pairs = 8192 + 64;
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_big, c->h_big_pairs * 16, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) std::memset(c->h_big, 0, c->h_big_pairs * 16);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 9 * 128); }
   if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * 128);
@@ -386,8 +429,7 @@ int rpe_create(rpe_context** out, int device, void* stream) {
       void* p = nullptr;
       if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
         c->ctl = (volatile unsigned long long*)p;
-        c->resident = hipHostMalloc((void**)&c->h_big, (size_t)256 * 32 * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-        if (c->resident) std::memset(c->h_big, 0, (size_t)256 * 32 * 16); else { (void)hipGetLastError(); (void)hipFree(p); c->ctl = nullptr; }
+        c->resident = true;
       } else { (void)hipGetLastError(); if (p) (void)hipFree(p); }
     } else (void)hipGetLastError();
   }
@@ -518,7 +560,7 @@ int rpe_p2p_moments(rpe_context* c, int flags, double* out18) {
   if (!out18) return fail(RPE_ERR_ARG, "null out18");
   if ((rc = check_flags(c, RPE_RES_P2P, flags))) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_moments(c->arrays(), flags, host_target(c), c->stream));
+  HIP_TRY(rpe::launch_moments(c->arrays(), flags, collect_target(c), c->stream));
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   for (int i = 0; i < 18; i++) out18[i] = c->h_out[i];
   return RPE_OK;
@@ -553,7 +595,7 @@ static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* p
   HIP_TRY(hipSetDevice(c->device));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
-  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : host_target(c), c->stream, e0, e1));
+  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : collect_target(c), c->stream, e0, e1));
   return RPE_OK;
 }
 
@@ -651,7 +693,7 @@ static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* term
   }
   if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, host_target(c), c->stream));
+  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, collect_target(c), c->stream));
   return RPE_OK;
 }
 
@@ -1146,7 +1188,7 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   double staged[12];
   stage_poses(RPE_F64, exact, pose7, 1, staged);  // layout only; the launcher rounds to the array dtype
-  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, staged, thr, host_target(c), c->stream));
+  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, staged, thr, collect_target(c), c->stream));
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   c->h_votes[0] = (int)c->h_out[0];
   if (votes_out) *votes_out = c->h_votes[0];
@@ -1193,7 +1235,7 @@ int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const 
   for (int i = 0; i < 3; i++) { prm[i] = c_opt3[i]; prm[3 + i] = Cw3[i]; prm[6 + i] = Cc3[i]; }
   for (int i = 0; i < 9; i++) prm[9 + i] = Rwc9[i];
   for (int i = 18; i < 24; i++) prm[i] = 0;
-  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, host_target(c), c->stream));
+  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, collect_target(c), c->stream));
   if ((rc = wait_host(c, rpe::kNlLd))) return rc;
   for (int i = 0; i < 44; i++) out44[i] = c->h_out[i];
   return RPE_OK;
@@ -1387,7 +1429,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
   } else {
     for (; it < o->max_iter; it++) {
-      if ((rc = round(pose12, host_target(c), false))) return rc;
+      if ((rc = round(pose12, collect_target(c), false))) return rc;
       if ((rc = wait_host(c, rpe::kNeLd))) return rc;
       double ne[32], d[6];
       for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];

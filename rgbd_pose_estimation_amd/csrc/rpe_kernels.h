@@ -58,8 +58,9 @@ struct ReduceTarget {
   unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
   int tagged = 0;              // h_out receives LD pairs {value, seq} (16 bytes, one store each) instead of the record + a sequence word
   int tail = -1;               // cross-workgroup stage of the ordinary kernels: -1 = default / RPE_TAIL
-  int rows = 0;                // resident kernel: workgroups per collecting workgroup (1 = every workgroup sends its own record); h_out must hold
-                               // ceil(grid / rows) x nacc pairs, which the host adds in order
+  int rows = 0;                // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
+                               // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out must hold
+                               // 1 + ceil(grid / run length) x sums pairs), and the host adds them in order.  Host-consumed, single-GPU results only
 };
 // ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,

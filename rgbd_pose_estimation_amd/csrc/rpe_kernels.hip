@@ -257,7 +257,7 @@ struct Finish {
   unsigned long long p2p_step;
   int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
   int tagged;                  // 1: publish to out_host as LD pairs {value, seq} of 16 bytes, one store each, no drain and no separate sequence word
-  int rows;                    // resident kernel: workgroups per collecting workgroup
+  int rows;                    // > 0: collecting workgroups + host-side final sum (collect_and_send / the resident kernel): cap on the run length
 };
 
 // ---- all-reduce(sum) of the 32-double record across <= 8 GPUs, by the first wave of the LAST workgroup, without leaving the
@@ -493,6 +493,120 @@ __device__ __forceinline__ void sum_records(const double* __restrict__ partials,
   }
 }
 
+// ---- cross-workgroup stage for results the HOST consumes (single GPU): collecting workgroups + a host-side final sum.
+// Workgroups are taken in runs of R = min(fin.rows, BLK / NACC); the first of a run collects: the others store their NACC sums as
+// 16-byte granules {value, launch sequence number} (one sc1 store per lane; no drain, no arrival counter) and are done; every thread of
+// the collecting workgroup polls ONE granule (sc1 load until the tag is this launch's), the rows are added in row order, and the run's
+// NACC sums go to pinned host memory as tagged 16-byte pairs (slot 1 + run * NACC + j; slot 0 = a header pair from workgroup 0 that
+// tells the host how many runs and sums to expect).  The host adds the runs in run order and expands the record (rpe_capi.hip
+// wait_collect).  One hand-off hop of ~1 us replaces the arrival counters + the last workgroup's re-read of all G records + the
+// drain before the flag (profiles/r02_tail_timeline.jsonl); the sums are a fixed function of (G, R) whichever workgroup finishes first.
+// Placement-independent: only the ceil(G / R) collecting workgroups ever wait, and only for workgroups that never wait themselves.
+// the collecting workgroup's read: thread (r, j) = (tid / NACC, tid % NACC) takes rows r, r + RGN, r + 2 RGN ... of the run (row 0 is the
+// workgroup's own record, already in part[0]), up to CH granules in flight at once (buffer loads with the sc1 bit, aux 16, re-issued
+// until every tag is this launch's), added in increasing row order into part[r][j].  Returns true if a granule never arrived (2 s).
+#ifndef RPE_RESIDENT_CH
+#define RPE_RESIDENT_CH 1
+#endif
+template <int NACC, int BLK, int CH = 4>
+__device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gran, int G, int leader, int rows, unsigned long long tag,
+                                             double (*part)[NACC]) {
+  constexpr int RGN = BLK / NACC;
+  const int j = threadIdx.x % NACC, r = threadIdx.x / NACC;
+  bool lost = false;
+  if (CH == 1) {   // runs of at most RGN rows (the resident kernel): one granule per thread, polled by itself
+    if (r >= 1 && r < rows) {
+      const unsigned long long* src = gran + 2 * ((size_t)(leader + r) * NACC + j);
+      const unsigned long long t0 = wall_clock64();
+      granule_t q;
+      for (unsigned int spins = 1;; spins++) {
+        q = load_granule16(src);
+        if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
+        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
+      }
+      part[r][j] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
+    }
+  } else if (r < RGN && r < rows) {
+    double sum = r == 0 ? part[0][j] : 0.0;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(gran), 0, G * NACC * 16, 0x00020000);
+    const unsigned long long t0 = wall_clock64();
+    for (int k0 = r == 0 ? RGN : r; k0 < rows && !lost; k0 += CH * RGN) {
+      granule_t q[CH];
+      for (unsigned int spins = 1;; spins++) {
+        bool pending = false;
+        asm volatile("" ::: "memory");   // the loads below are re-issued every sweep (to the compiler they read memory nobody writes)
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+          const int row = k0 + u * RGN;
+          if (row < rows) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((leader + row) * NACC + j) * 16, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+          const int row = k0 + u * RGN;
+          if (row < rows && (((unsigned long long)q[u].w << 32) | q[u].z) != tag) pending = true;
+        }
+        if (!pending) break;
+        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
+      }
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int row = k0 + u * RGN;
+        if (row < rows && !lost) sum += __longlong_as_double((long long)(((unsigned long long)q[u].y << 32) | q[u].x));
+      }
+    }
+    part[r][j] = sum;
+  }
+  return lost;
+}
+
+// ---- cross-workgroup stage for results the HOST consumes (single GPU): collecting workgroups + a host-side final sum.
+// Workgroups are taken in runs of R; the first of a run collects: the others store their NACC sums as 16-byte granules {value, launch
+// sequence number} (one sc1 store per lane; no drain, no arrival counter) and are done; the collecting workgroup reads its run's
+// granules (collect_rows), adds the rows in a fixed order and sends the run's NACC sums to pinned host memory as tagged 16-byte pairs
+// (slot 1 + run * NACC + j; slot 0 = a header pair from workgroup 0 that tells the host how many runs of how many sums to expect).
+// The host adds the runs in run order and expands the record (rpe_capi.hip wait_collect).  R = one granule per collecting thread
+// (BLK / NACC rows), lengthened until the runs fit in ~512 pairs.  One hand-off hop of ~1 us replaces the arrival counters + the last
+// workgroup's re-read of all G records + the drain before the flag (profiles/r02_tail_timeline.jsonl); the sums are a fixed function
+// of G whichever workgroup finishes first.  Placement-independent: only the collecting workgroups ever wait, and only for workgroups
+// that never wait themselves.
+template <int NACC, int MODE, int BLK>
+__device__ __forceinline__ void collect_and_send(const double (*red)[NACC], const Finish& fin) {
+  constexpr int NW = BLK / 64;
+  constexpr int RGN = BLK / NACC;
+  constexpr int kMaxRuns = 512 / NACC > 0 ? 512 / NACC : 1;
+  __shared__ double c_part[RGN][NACC];
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
+  const int G = gridDim.x;
+  int R = RGN * ((G + RGN * kMaxRuns - 1) / (RGN * kMaxRuns));
+  if (R > fin.rows) R = fin.rows;
+  const int run = blockIdx.x / R, leader = run * R;
+  if (threadIdx.x < NACC) {
+    double own = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NW; w++) own += red[w][threadIdx.x];
+    if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, fin.seq);
+    else c_part[0][threadIdx.x] = own;
+  }
+  RPE_STAMP(4);
+  if ((int)blockIdx.x != leader) return;
+  const int rows = min(R, G - leader);
+  const bool lost = collect_rows<NACC, BLK>(gran, G, leader, rows, fin.seq, c_part);
+  RPE_STAMP(7);
+  if (__syncthreads_or(lost)) return;   // nothing published: the host reports the kernel as having finished without its result
+  RPE_STAMP(8);
+  if (threadIdx.x < NACC) {
+    double t = 0.0;
+    const int nr = rows < RGN ? rows : RGN;
+    for (int k = 0; k < nr; k++) t += c_part[k][threadIdx.x];
+    store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x, t, fin.seq);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 64) {   // header: runs | sums per run << 16 | record layout << 24
+    const unsigned long long hdr = (unsigned long long)((G + R - 1) / R) | ((unsigned long long)NACC << 16) | ((unsigned long long)MODE << 24);
+    store_tagged_pair(fin.out_host, 0, __longlong_as_double((long long)hdr), fin.seq);
+  }
+  RPE_STAMP(9);
+}
+
 template <int NACC, int LD, int MODE, int BLK>
 __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Finish& fin) {
   constexpr int NW = BLK / 64;
@@ -506,6 +620,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
   RPE_STAMP(2);
   __syncthreads();
   RPE_STAMP(3);
+  if (fin.rows > 0) { collect_and_send<NACC, MODE, BLK>(red, fin); return; }
   const int G = gridDim.x;
   if (G > 1) {
     // Hand-off without fences (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms"): EVERY byte of
@@ -1006,19 +1121,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #endif
       if ((int)blockIdx.x == leader) {
         const int rows = min(R, (int)gridDim.x - leader);
-        const int j = threadIdx.x % NACC, r = threadIdx.x / NACC;
-        bool lost = false;
-        if (r >= 1 && r < rows) {
-          const unsigned long long* src = gran + 2 * ((size_t)(leader + r) * NACC + j);
-          const unsigned long long t0 = wall_clock64();
-          granule_t q;
-          for (unsigned int spins = 1;; spins++) {
-            q = load_granule16(src);
-            if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
-            if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
-          }
-          g_part[r][j] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
-        }
+        const bool lost = collect_rows<NACC, BLK, RPE_RESIDENT_CH>(gran, (int)gridDim.x, leader, rows, tag, g_part);
 #ifdef RPE_STAMPS
         if (stamp_it) RPE_STAMP(3);
 #endif
@@ -1922,7 +2025,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.tagged = rt.tagged;
-  f.rows = rt.rows > 0 ? rt.rows : 1;
+  f.rows = rt.rows > 0 ? rt.rows : 0;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)
@@ -2000,6 +2103,7 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   Finish fin = make_finish(rt);
   constexpr int kMaxRows = BLK / (KIND == KIND_P2P ? 17 : 29);
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
+  if (fin.rows < 1) fin.rows = 1;
 #define RPE_RES_LAUNCH2(M, W, R)                                                                                                             \
   do {                                                                                                                                       \
     if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
