@@ -1123,6 +1123,16 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
   for (int h0 = 0; h0 < H; h0 += rpe::kMaxScoreH) {
     const int hb = std::min(rpe::kMaxScoreH, H - h0);
     stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
+    if (!c->comm && c->p2p_world < 1 && hb <= rpe::score_small_cap(c->dtype, exact)) {
+      // short list on one GPU: ONE launch -- the hypotheses ride in the kernel argument, the counts come back as run records
+      rpe::ReduceTarget rt = collect_target(c);
+      if (rt.rows > 0) {
+        HIP_TRY(rpe::launch_score_small(c->arrays(), kind, exact, c->h_poses, nullptr, hb, thr, rt, c->stream));
+        if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+        for (int i = 0; i < hb; i++) votes_out[h0 + i] = (int)c->h_out[i];
+        continue;
+      }
+    }
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
     if (c->comm && c->p2p_world < 1 && (rc = nccl_votes_or_clear(c, rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream), hb))) return rc;  // sharded correspondences
@@ -1159,11 +1169,18 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, 2.0, 2.0, thr);
   HIP_TRY(rpe::launch_gen_shinji(c->arrays(), rng_state, rng_inc, iters, exact, c->d_poses, c->h_poses, c->stream));
-  HIP_TRY(rpe::launch_score(c->arrays(), RPE_VOTE_33, exact, c->d_poses, iters, thr, c->d_votes, c->score_blocks, c->stream));
-  const unsigned long long seq = ++c->vote_seq;
-  if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream), iters))) return rc;
-  if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
-  std::memcpy(votes_out, c->h_votes, (size_t)iters * sizeof(int));
+  rpe::ReduceTarget rt = iters <= rpe::score_small_cap(c->dtype, exact) ? collect_target(c) : host_target(c);
+  if (rt.rows > 0) {   // short batch: the scoring kernel itself hands the counts to the host (no read-out kernel)
+    HIP_TRY(rpe::launch_score_small(c->arrays(), RPE_VOTE_33, exact, nullptr, c->d_poses, iters, thr, rt, c->stream));
+    if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+    for (int i = 0; i < iters; i++) votes_out[i] = (int)c->h_out[i];
+  } else {
+    HIP_TRY(rpe::launch_score(c->arrays(), RPE_VOTE_33, exact, c->d_poses, iters, thr, c->d_votes, c->score_blocks, c->stream));
+    const unsigned long long seq = ++c->vote_seq;
+    if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream), iters))) return rc;
+    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+    std::memcpy(votes_out, c->h_votes, (size_t)iters * sizeof(int));
+  }
   // the generator stored the hypotheses into pinned host memory before the scoring kernel ran (same stream): they are complete
   for (int i = 0; i < iters; i++) {
     if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }

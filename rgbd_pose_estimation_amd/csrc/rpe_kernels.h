@@ -84,6 +84,12 @@ hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, c
 // d_votes[0..H) must be zero on entry (launch_publish_votes leaves them so)
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s);
+// single-launch form for short lists (H <= score_small_cap): the hypotheses, staged in HOST memory in the layout above, travel as a kernel
+// argument (h_poses), or are read from HBM (d_poses: a device-generated batch; exactly one of the two is non-null); rt must be a
+// collecting target (rt.rows > 0); record[h] of the result = votes of hypothesis h
+int score_small_cap(int dtype, int exact);
+hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H, const double* thr3,
+                              const ReduceTarget& rt, hipStream_t s);
 // pose12: fast = R row-major (9) t (3); exact = qw qx qy qz tx ty tz (rest ignored).  The vote total is record[0] of rt.
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
                        hipStream_t s);

@@ -14,6 +14,8 @@
 // (4) grids of at most a few workgroups per CU with a grid-stride, software-pipelined loop, so a launch covers
 // all 8 XCDs and a workgroup re-reads the same slice every Gauss-Newton iteration (it stays cache resident).
 #include "rpe_kernels.h"
+#include <cstring>
+#include <algorithm>
 #include <hip/hip_ext.h>
 #include "rpe_assoc.h"
 
@@ -1622,6 +1624,71 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
   }
 }
 
+// Small batches (the first RANSAC batches: 8 .. 32 hypotheses): ONE launch and no device-side staging at all -- the hypotheses arrive as
+// a kernel argument (no H2D copy), every wave counts as above (lane h holds hypothesis h's count), the per-wave counts go straight into
+// the collecting stage (collect_and_send: integers < 2^53 as doubles, exact), and the host adds the run records.  Replaces copy +
+// scoring kernel + read-out kernel + flag (42 us per batch of 16 at 640 x 480) for lists of up to HB hypotheses.
+template <class T, int HB, int STRIDE> struct SmallPoses { T v[HB * STRIDE]; };
+template <class T, int KIND, bool EXACT, int HB>
+__global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                             const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                             SmallPoses<T, HB, Hyp<T, EXACT>::STRIDE> sp, const T* __restrict__ dposes, int H, int hs,
+                                                             T thr33, T cthr, T cnl, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // hs (1, 2 or 4) waves share a tile of correspondences and split the list between them (wave copy c takes hypotheses c, c + hs, ...):
+  // a frame-sized problem then runs as 4 x as many, 4 x shorter waves -- the pass is a long serial chain per wave (every predicate of
+  // every hypothesis on the wave's points), so with one group per thread it is bound by that chain, not by memory or issue rate
+  const int per_copy = (kBlock / 64) / hs, copy = wave / per_copy;
+  const int tile = kBlock / hs;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * tile;
+  int mine = 0;
+  // loop bound is workgroup-uniform so that every lane of a wave takes part in the per-hypothesis ballots
+  for (int64_t gb = (int64_t)blockIdx.x * tile; gb < groups; gb += stride) {
+    const int64_t g = gb + (wave % per_copy) * 64 + lane;
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    bool present[P], valid[P];
+    load_group<T>(xw, g, n, vw);
+    if (MD::need_xc) load_group<T>(xc, g, n, vc);
+    if (MD::m23) load_group<T>(bv, g, n, vb);
+    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      present[i] = (g * P + i) < n;
+      valid[i] = present[i] & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+    }
+    for (int hl = copy; hl < H; hl += hs) {
+      Hyp<T, EXACT> hyp;
+      if (dposes) hyp.load(dposes + (size_t)hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);   // a list generated on the device
+      else hyp.load(sp.v + hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+        if (MD::mnn) {
+          const bool v = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
+          cnt += __popcll(__ballot(v));
+        }
+        if (MD::m33) {
+          const bool v = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
+          cnt += __popcll(__ballot(v));
+        }
+        if (MD::m23) {
+          const bool v = present[i] & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
+          cnt += __popcll(__ballot(v));
+        }
+      }
+      mine += (lane == hl) ? cnt : 0;
+    }
+  }
+  __shared__ double red[kBlock / 64][HB];
+  if (lane < HB) red[wave][lane] = (double)mine;
+  __syncthreads();
+  collect_and_send<HB, 0, kBlock>(red, fin);
+}
+
 // P flags of one group as ONE store (8 bytes for fp32 / P = 4, 4 bytes for fp64 / P = 2): a thread owns P consecutive
 // correspondences, so its shorts are contiguous; 2-byte scattered stores cost an order of magnitude more per byte.
 __device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[4]) {
@@ -2281,6 +2348,48 @@ hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* 
     const int G = grid_for(A.n, 4, max_blocks);
     if (exact) { RPE_KIND_SWITCH(score_launch, float, true, A, d_poses, H, thr3, d_votes, G, s) }
     else { RPE_KIND_SWITCH(score_launch, float, false, A, d_poses, H, thr3, d_votes, G, s) }
+  }
+  return hipGetLastError();
+}
+template <class T, int KIND, bool EXACT>
+static void score_small_launch(const DeviceArrays& A, const void* h_poses, const void* d_poses, int H, const double* thr, const ReduceTarget& rt, int cap,
+                               hipStream_t s) {
+  constexpr int STRIDE = Hyp<T, EXACT>::STRIDE;
+  const Finish fin = make_finish(rt);
+  // up to a million correspondences the list is split over the 4 waves of a workgroup (RPE_SCORE_SPLIT = 1 | 2 | 4 overrides)
+  static const int env_hs = getenv("RPE_SCORE_SPLIT") ? atoi(getenv("RPE_SCORE_SPLIT")) : 0;
+  const int hs = (env_hs == 1 || env_hs == 2 || env_hs == 4) ? env_hs : (A.n <= (int64_t)1 << 20 ? 4 : 1);
+  const int64_t tiles = ((A.n + Pk<T>::P - 1) / Pk<T>::P + kBlock / hs - 1) / (kBlock / hs);
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cap));
+#define RPE_SMALL(HB)                                                                                                                        \
+  do {                                                                                                                                       \
+    SmallPoses<T, HB, STRIDE> sp;                                                                                                            \
+    std::memset(&sp, 0, sizeof(sp));                                                                                                         \
+    if (h_poses) std::memcpy(sp.v, h_poses, (size_t)H * STRIDE * sizeof(T));                                                                 \
+    hipLaunchKernelGGL((score_small_kernel<T, KIND, EXACT, HB>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], \
+                       (const T*)A.a[3], (const T*)A.a[4], A.n, sp, (const T*)d_poses, H, hs, (T)thr[0], (T)thr[1], (T)thr[2], fin);                                 \
+  } while (0)
+  if (H <= 16) RPE_SMALL(16); else RPE_SMALL(32);
+#undef RPE_SMALL
+}
+// largest list the single-launch form takes for this dtype / mode (the hypotheses travel as a kernel argument of at most 2 KB)
+int score_small_cap(int dtype, int exact) {
+  const int bytes = (exact ? 8 : 12) * (dtype ? 8 : 4);
+  return 32 * bytes <= 2048 ? 32 : 16;
+}
+// h_poses: H hypotheses staged in HOST memory in the scoring layout of `exact`, values of the array dtype (they travel in the kernel
+// argument) -- or null and d_poses: the same list in HBM (a device-generated batch).  The vote counts arrive through rt (a collecting
+// target): record[h] = votes of hypothesis h.
+hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H, const double* thr3,
+                              const ReduceTarget& rt, hipStream_t s) {
+  if (H < 1 || H > score_small_cap(A.dtype, exact) || rt.rows < 1 || (!h_poses == !d_poses)) return hipErrorInvalidValue;
+  const int cap = 2048;   // workgroups (grid-stride beyond)
+  if (A.dtype) {
+    if (exact) { RPE_KIND_SWITCH(score_small_launch, double, true, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+    else { RPE_KIND_SWITCH(score_small_launch, double, false, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+  } else {
+    if (exact) { RPE_KIND_SWITCH(score_small_launch, float, true, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+    else { RPE_KIND_SWITCH(score_small_launch, float, false, A, h_poses, d_poses, H, thr3, rt, cap, s) }
   }
   return hipGetLastError();
 }

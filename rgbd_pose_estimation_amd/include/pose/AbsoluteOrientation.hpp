@@ -97,7 +97,7 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
   auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
   // plain RANSAC consumes exactly K draws per iteration, so every iteration's position in the random stream is known up front and
   // the whole iteration can run on the device; PROSAC's sampler rejects duplicates (a variable number of draws) and stays on the host
-  if (!prosac && Settings::get().device_hypotheses && N >= K && !Settings::get().capture && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, commit, Iter, confidence, /*mask_cols=*/2);
+  if (!prosac && Settings::get().device_hypotheses && N >= K && !Settings::get().capture && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   else ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   adapter.cvtInlier();
 }

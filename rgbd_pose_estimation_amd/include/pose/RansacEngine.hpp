@@ -158,17 +158,33 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
 // The 3D-3D solvers (shinji_ransac / shinji_ransac2): sampling, the 3-point fit and the scoring all run on the device
 // (rpe_ransac33_batch); the hypotheses are bitwise the ones the host generator above would produce from the same random stream,
 // which is advanced here by the K draws per iteration the host sampler would have consumed.
-template <class Tp, class Adapter, class Commit>
-void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+// Short batches (the first ones: at most kHostBatch iterations) are generated by the host's `gen` instead -- eight 3-point fits take the
+// CPU 4 us, while a device batch of eight is one thread per fit running a 3x3 Jacobi SVD (25 us of latency) -- and scored by rpe_score's
+// single-launch form; the random stream is the same either way, so the two can alternate batch by batch.
+template <class Tp, class Adapter, class Gen, class Commit>
+void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+  constexpr int kHostBatch = 32;
   Settings& cfg = Settings::get();
   rpe_context* ctx = adapter.device().ctx();
   std::vector<double> q7;
   std::vector<unsigned char> valid;
   std::vector<int> all_votes;
   auto produce = [&](int iters, std::vector<SE3<Tp> >& hyps, std::vector<int>& first, std::vector<int>& votes) {
+    first.assign(1, 0);
+    if (iters <= kHostBatch) {
+      const double t0 = cfg.profile ? now_us() : 0;
+      for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
+      if (cfg.profile) { const double t1 = now_us(); cfg.prof.generate += t1 - t0; cfg.prof.score -= t1 - t0; }
+      if (hyps.empty()) return;
+      q7.resize(hyps.size() * 7);
+      for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
+      votes.resize(hyps.size());
+      check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+                      (double)spec.cos_nl, votes.data()), "rpe_score");
+      return;
+    }
     Rand31& g = global_rng();
     q7.resize((size_t)iters * 7); valid.resize((size_t)iters); all_votes.resize((size_t)iters);
-    first.assign(1, 0);
     for (int done = 0; done < iters;) {   // the device call takes at most kMaxScoreH iterations at a time
       const int chunk = std::min(iters - done, 8192);
       check(rpe_ransac33_batch(ctx, g.state(), g.inc(), chunk, cfg.score_mode, (double)spec.thre_3d, all_votes.data() + done,
