@@ -3,9 +3,10 @@
   python scripts/tail_timeline.py            -> JSON lines on stdout:
      * "stamps": the DIAGNOSTIC build (-DRPE_STAMPS, rgbd_pose_estimation_amd/build.py:build_stamps) stamps the 100 MHz clock in thread 0
        of every workgroup at the phase boundaries; reported per launch relative to the earliest workgroup start, medians over launches
-     * "timing": the PRODUCT build under RPE_TAIL = 0 (all records summed by the last workgroup), 1 (per-shard sums first),
+     * "timing": the PRODUCT build with its default stage for host-consumed results (collecting workgroups + host-side final sum) and,
+       under RPE_COLLECT=0, the arrival-counter tails RPE_TAIL = 0 (all records summed by the last workgroup), 1 (per-shard sums first),
        2 (0 with one batch of loads), +8 (pipelined loop even for one group per thread): dispatch-timestamp kernel time and the wall
-       time per Gauss-Newton step of the library's host loop
+       time per Gauss-Newton step of the library's launch-per-step host loop (RPE_RESIDENT=0)
 Every variant runs in its own process (the knobs are read once per process)."""
 import ctypes as C
 import json
@@ -53,7 +54,7 @@ def worker_timing(n, kind, steps):
     ctx.gn_refine([kind], p0, max_iter=2000, tol=0.0)
     wall_loop = (time.perf_counter() - t0) / 2000
     bpc = 36 if kind == L.RES_P2PLANE else 24
-    print(json.dumps(dict(what="timing", tail=os.environ.get("RPE_TAIL", "0"), block=os.environ.get("RPE_BLOCK", ""), groups=os.environ.get("RPE_REDUCE_GROUPS", ""),
+    print(json.dumps(dict(what="timing", tail=os.environ.get("RPE_TAIL", "0"), collect=os.environ.get("RPE_COLLECT", "1"), block=os.environ.get("RPE_BLOCK", ""), groups=os.environ.get("RPE_REDUCE_GROUPS", ""),
                           n=n, kind=kind, kernel_avg_us=tot / cnt * 1e3, kernel_min_us=mn * 1e3, wall_us_python_step=wall_py * 1e6, wall_us_library_step=wall_loop * 1e6,
                           achieved_GBs=bpc * n / (tot / cnt * 1e-3) / 1e9)), flush=True)
     ctx.close()
@@ -88,6 +89,15 @@ def worker_stamps(n, kind, launches):
         if (s[:, 11] > 0).any():
             row["loads_landed_med"] = float(np.median(rel(11)))
             row["loads_landed_max"] = float(rel(11).max())
+        lead = s[:, 9] > 0   # collecting workgroups (collect_and_send): 4 = own sums stored / kept, 7 = its granules read, 8 = all read, 9 = run record sent
+        if lead.any() and not (s[:, 10] > 0).any():
+            row["collecting_workgroups"] = int(lead.sum())
+            row["granules_stored_med"] = float(np.median(rel(4)))
+            row["granules_stored_max"] = float(rel(4).max())
+            row["run_read_max"] = float(((s[lead, 8] - t0) * 0.01).max())
+            row["run_record_sent_max"] = float(((s[lead, 9] - t0) * 0.01).max())
+            for k in ("record_stored_med", "record_stored_max", "wg_barrier2_med", "wg_barrier2_max", "arrived_med", "arrived_max"):
+                row.pop(k, None)
         fin = s[:, 10] > 0   # the workgroup that published
         if fin.any():
             i = int(np.argmax(fin))
@@ -98,7 +108,7 @@ def worker_stamps(n, kind, launches):
         rows.append(row)
     keys = sorted({k for r in rows for k in r})
     med = {k: float(np.median([r[k] for r in rows if k in r])) for k in keys}
-    print(json.dumps(dict(what="stamps", level=os.environ.get("RPE_STAMP_LEVEL", "1"), tail=os.environ.get("RPE_TAIL", "0"), n=n, kind=kind, launches=launches,
+    print(json.dumps(dict(what="stamps", level=os.environ.get("RPE_STAMP_LEVEL", "1"), tail=os.environ.get("RPE_TAIL", "0"), collect=os.environ.get("RPE_COLLECT", "1"), n=n, kind=kind, launches=launches,
                           unit="us after the first workgroup's start; medians over launches", **med)), flush=True)
     ctx.close()
 
@@ -117,17 +127,20 @@ def main():
         so = os.path.join(ROOT, 'rgbd_pose_estimation_amd', 'lib', f'librgbdpose_hip_stamps{level}.so')
         if not os.path.exists(so):
             so = B.build_stamps(level)
-        for tail in ("0", "1", "2"):
+        for n, kind in cases[:2]:   # the product's stage for host-consumed results: collecting workgroups + host-side final sum
+            run({"RPE_LIBRARY": so, "RPE_STAMP_LEVEL": str(level)}, "stamps", n, kind, 200)
+        for tail in ("0", "1", "2"):   # the arrival-counter tails (device / collective targets; RPE_COLLECT=0 forces them for host results too)
             for n, kind in cases[:2]:
-                run({"RPE_LIBRARY": so, "RPE_TAIL": tail, "RPE_STAMP_LEVEL": str(level)}, "stamps", n, kind, 200)
+                run({"RPE_LIBRARY": so, "RPE_TAIL": tail, "RPE_COLLECT": "0", "RPE_STAMP_LEVEL": str(level)}, "stamps", n, kind, 200)
     for rep in range(2):
+        for n, kind in cases:
+            run({"RPE_RESIDENT": "0"}, "timing", n, kind, 2000)
         for tail in ("0", "1", "2", "8", "10"):
             for n, kind in cases:
-                run({"RPE_TAIL": tail}, "timing", n, kind, 2000)
+                run({"RPE_TAIL": tail, "RPE_COLLECT": "0", "RPE_RESIDENT": "0"}, "timing", n, kind, 2000)
     for blk, groups in (("256", "1"), ("1024", "1"), ("512", "2"), ("256", "2")):
         for n, kind in cases:
-            run({"RPE_TAIL": "2", "RPE_BLOCK": blk, "RPE_REDUCE_GROUPS": groups}, "timing", n, kind, 2000)
-
+            run({"RPE_BLOCK": blk, "RPE_REDUCE_GROUPS": groups, "RPE_RESIDENT": "0"}, "timing", n, kind, 2000)
 
 if __name__ == "__main__":
     main()

@@ -202,6 +202,53 @@ def test_score_fast_differs_only_at_threshold(gpu_ctx_factory, oracle, n, kind):
         assert abs(int(vf[h]) - int(ve[h])) <= band
 
 
+@pytest.mark.parametrize("n", [1, 4099, 307200])
+@pytest.mark.parametrize("kind", VOTE_KINDS)
+@pytest.mark.parametrize("f64", [False, True])
+def test_score_short_lists_single_launch(gpu_ctx_factory, oracle, n, kind, f64):
+    """Lists of up to 32 hypotheses take the single-launch form (hypotheses in the kernel argument, run records to the host): the
+    counts must be the long-list kernel's -- and the oracle's -- for every list length around the 16 / 32 slot boundaries, in both
+    scoring modes."""
+    if n == 307200 and f64:
+        pytest.skip("oracle time")
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(170 + n, n, dt, nan_frac=0.1 if n > 10 else 0.0)
+    poses = _hypotheses(oracle, sc, 70, f64, n)
+    thr3, cthr, cnl = 0.2, oracle.cos_thr(f64, 8.0, 585.0), oracle.cos_nl(f64, 0.1)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    long_exact = ctx.score(kind, poses, thr3, cthr, cnl, mode=L.SCORE_EXACT)   # 70 hypotheses: the table kernel
+    long_fast = ctx.score(kind, poses, thr3, cthr, cnl, mode=L.SCORE_FAST)
+    if n <= 4099:
+        prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+        orc_kind = {L.VOTE_33: oracle.V_33, L.VOTE_23: oracle.V_23, L.VOTE_33_23: oracle.V_33_23, L.VOTE_NN_23: oracle.V_NN_23,
+                    L.VOTE_NN_33: oracle.V_NN_33, L.VOTE_NN_33_23: oracle.V_NN_33_23, L.VOTE_23_MATRIX: oracle.V_23_MATRIX}[kind]
+        vo, _ = oracle.votes(prob, orc_kind, poses, thr3, cthr, cnl, mask_for=0)
+        assert np.array_equal(long_exact, vo)
+    for H in (1, 7, 16, 17, 32):
+        for first in (0, 70 - H):
+            sub = poses[first:first + H]
+            assert np.array_equal(ctx.score(kind, sub, thr3, cthr, cnl, mode=L.SCORE_EXACT), long_exact[first:first + H])
+            assert np.array_equal(ctx.score(kind, sub, thr3, cthr, cnl, mode=L.SCORE_FAST), long_fast[first:first + H])
+
+
+def test_score_short_list_grid_stride(gpu_ctx_factory, oracle):
+    """Beyond a million correspondences the single-launch form runs one wave copy and a grid-stride loop; counts stay exact."""
+    n = 2_500_003
+    base = util.scene33(91, 50_000, np.float32)
+    reps = (n + 49_999) // 50_000
+    Q = np.ascontiguousarray(np.tile(base.Q, (reps, 1))[:n]); P = np.ascontiguousarray(np.tile(base.P, (reps, 1))[:n])
+    rng = np.random.default_rng(3)
+    poses = np.array([oracle.pose7_from_Rt(*util.perturbed_pose(rng, base.R, base.t, ang=0.004 * h, dt=0.01 * h), False) for h in range(12)])
+    ctx = gpu_ctx_factory().load(L.F32, xw=Q, xc=P)
+    v = ctx.score(L.VOTE_33, poses, 0.2, mode=L.SCORE_EXACT)
+    long_list = ctx.score(L.VOTE_33, np.concatenate([poses, poses, poses, poses]), 0.2, mode=L.SCORE_EXACT)   # 48: the table kernel
+    assert np.array_equal(v, long_list[:12]) and np.array_equal(v, long_list[36:])
+    vo = oracle.votes(oracle.Problem(False, xw=base.Q, xc=base.P), oracle.V_33, poses, 0.2)
+    full, rem = divmod(n, 50_000)
+    vr = oracle.votes(oracle.Problem(False, xw=base.Q[:rem], xc=base.P[:rem]), oracle.V_33, poses, 0.2)
+    assert np.array_equal(v, full * np.asarray(vo) + np.asarray(vr))
+
+
 def test_score_many_hypotheses_batches(gpu_ctx_factory, oracle):
     """H larger than one launch's LDS table (kMaxScoreH = 8192) is split; counts stay exact."""
     n = 2000
