@@ -224,7 +224,7 @@ def worker(args, affinity):
     n_dev = L.device_count()
     import torch
     import torch.distributed as dist
-    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_native_comm, init_p2p, shard_range
+    from rgbd_pose_estimation_amd.distributed import HipShard, ShardedGaussNewton, init_host_exchange, init_native_comm, init_p2p, shard_range
 
     if n_dev < 1 or not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible (the HIP path has no CPU fallback)")
@@ -274,17 +274,25 @@ def worker(args, affinity):
         gn = ShardedGaussNewton(shard.normal_eq)
         pose = pose12(R0, t0)
 
-        # ---- N > 1: the collective.  Default = RCCL on a library-owned communicator.  The in-kernel peer-to-peer exchange over
-        # xGMI is tried only on request (RPE_BENCH_COLLECTIVE=auto|p2p): verified against the all-reduced record first, timed
-        # against RCCL, kept only if faster; both times go into the JSON line.
-        want = os.environ.get("RPE_BENCH_COLLECTIVE", "rccl")
-        p2p = native = rccl_ok = False
+        # ---- N > 1: how the shards' 32-double records meet every iteration.  RPE_BENCH_COLLECTIVE =
+        #   auto (default): RCCL all-reduce on a library-owned communicator AND the host-side exchange (the rank processes' host threads
+        #                   add the records through shared memory; every rank keeps its resident kernel) are both set up, the
+        #                   exchange is verified against the all-reduced record, both are timed in this run, the faster one carries
+        #                   the measurement and both times go into the JSON line;
+        #   rccl | host   : that one only;
+        #   p2p | auto_p2p: the in-kernel peer-to-peer exchange over xGMI (only on request: it has never run on real xGMI), alone or
+        #                   timed against RCCL.
+        want = os.environ.get("RPE_BENCH_COLLECTIVE", "auto")
+        if want not in ("auto", "rccl", "host", "p2p", "auto_p2p"):
+            sys.exit(f"bench.py: unknown RPE_BENCH_COLLECTIVE={want}")
+        want_p2p = want in ("p2p", "auto_p2p")
+        p2p = native = rccl_ok = hostex = False
         coll_times = {}
         if dist_path:
             for _ in range(200):   # first launches of a process on a cold box can take seconds: ranks enter the first collective together
                 ctx.normal_eq(L.RES_P2P, pose12(R0, t0), L.USE_MASK)
             dist.barrier()
-        if dist_path and want in ("auto", "p2p"):
+        if dist_path and want_p2p:
             p2p = init_p2p(ctx)
             if p2p:
                 chk = pose12(R0, t0)
@@ -309,38 +317,74 @@ def worker(args, affinity):
                     p2p = False
         if dist_path and not p2p and want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1":
             sys.exit("bench.py: the peer-to-peer collective was requested strictly and is not available")
-        if dist_path and want in ("auto", "rccl", "p2p") and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1"):
+        if dist_path and want != "host" and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1"):
             rccl_ok = init_native_comm(ctx)   # with a peer-to-peer path in place rpe_gn_step_dist prefers it; the communicator is its stand-by
+        def timed(k, refine=False):
+            q = pose12(R0, t0)
+            run = (lambda kk: ctx.gn_refine([L.RES_P2P], q, None, L.USE_MASK, kk, 0.0)) if refine else (lambda kk: ctx.gn_steps_dist(L.RES_P2P, q, kk, L.USE_MASK))
+            run(200)
+            dist.barrier()
+            t0_ = time.perf_counter()
+            run(k)
+            tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / k
         if dist_path and p2p and rccl_ok:
-            def timed(k):
-                q = pose12(R0, t0)
-                ctx.gn_steps_dist(L.RES_P2P, q, 200, L.USE_MASK)
-                dist.barrier()
-                t0_ = time.perf_counter()
-                ctx.gn_steps_dist(L.RES_P2P, q, k, L.USE_MASK)
-                tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                return float(tt.item()) / k
             coll_times["p2p_us"] = timed(400) * 1e6
             L.check(L.lib().rpe_p2p_pause(ctx._h, 1))      # stand-by: the same call now takes the RCCL path
             coll_times["rccl_us"] = timed(400) * 1e6
             L.check(L.lib().rpe_p2p_pause(ctx._h, 0))
-            if coll_times["rccl_us"] < coll_times["p2p_us"] or want == "rccl":
+            if coll_times["rccl_us"] < coll_times["p2p_us"]:
                 dist.barrier()
                 ctx.p2p_destroy()
                 p2p = False
+        if dist_path and want in ("auto", "host"):
+            if rccl_ok:
+                coll_times["rccl_us"] = timed(400) * 1e6   # before the exchange exists: rpe_gn_steps_dist = kernel + ncclAllReduce + publish
+            hostex = init_host_exchange(ctx)
+            if hostex:   # verify: one sharded step's record against the all-reduced local records
+                chk, rec = pose12(R0, t0), np.zeros(32)
+                try:
+                    L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
+                    delivered = 1
+                except L.RpeError as e:
+                    delivered = 0
+                    print(f"[bench] rank {rank}: host-exchange step failed: {e}", file=sys.stderr, flush=True)
+                ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
+                dist.all_reduce(ref)
+                ref = ref.cpu().numpy()
+                good = int(delivered and np.all(np.abs(rec[:29] - ref[:29]) <= 1e-9 * (1.0 + np.abs(ref[:29]))))
+                flag = torch.tensor([good], dtype=torch.int32, device=cdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if rank == 0:
+                        print("[bench] host-exchange record differs from the all-reduced one: falling back to RCCL", file=sys.stderr, flush=True)
+                    ctx.hostex_destroy()
+                    hostex = False
+            if hostex:
+                coll_times["host_us"] = timed(400, refine=True) * 1e6   # rpe_gn_refine: resident kernel per rank + exchange between the hosts
+                if want == "auto" and rccl_ok and coll_times["rccl_us"] < coll_times["host_us"]:
+                    dist.barrier()
+                    ctx.hostex_destroy()
+                    hostex = False
+            if not hostex and want == "host":
+                sys.exit("bench.py: the host-side exchange was requested and is not available")
         native = rccl_ok or p2p
-        collective = "none" if not dist_path else ("peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
-                                                   "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
+        collective = "none" if not dist_path else (
+            "host-side exchange: every rank's host thread adds the peers' 32 fp64 records (shared memory, rank order) each iteration" if hostex else
+            "peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
+            "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
 
         # The host side of the loop (wait for the record, 6x6 solve, SE(3) exp-map update, next pose out) is C++ inside the library:
         # rpe_gn_refine / rpe_gn_steps_dist with tol = 0 run exactly k iterations, so the timed region contains no Python per step.
-        resident = (not dist_path) and os.environ.get("RPE_RESIDENT", "1") != "0"
+        # sharded + host exchange: rpe_gn_refine on every rank (resident kernel when every rank has its own GPU)
+        shared_gpu = os.environ.get("RPE_BENCH_SHARE_GPU") == "1"
+        resident = ((not dist_path) or (hostex and not shared_gpu)) and os.environ.get("RPE_RESIDENT", "1") != "0"
 
         def run_steps(p, k):
             if k <= 0:
                 return p
-            if not dist_path:
+            if not dist_path or hostex:
                 q, its, _, _ = ctx.gn_refine([L.RES_P2P], p, None, L.USE_MASK, k, 0.0)
                 assert its == k
                 return q
@@ -467,9 +511,10 @@ def worker(args, affinity):
             "config": {"workload": workload, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
                        "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
                        "streamed_corr_per_s": float(total_n) * args.steps / elapsed, "accumulate": "fp64", "collective": collective,
-                       "collective_step_us": coll_times or None, "rccl_ranks": world if (dist_path and rccl_ok and not p2p) else 0,
+                       "collective_step_us": coll_times or None, "rccl_ranks": world if (dist_path and rccl_ok and not p2p and not hostex) else 0,
                        "host_loop": "rpe_gn_refine: ONE resident launch per refinement, poses handed over through device memory" if resident else
-                                    ("rpe_gn_steps_dist: one launch + one collective per step" if dist_path else "rpe_gn_refine: one launch per step")},
+                                    ("rpe_gn_refine on every rank: one launch per step + exchange between the host threads (ranks share a GPU)" if hostex else
+                                     "rpe_gn_steps_dist: one launch + one collective per step" if dist_path else "rpe_gn_refine: one launch per step")},
             "timing": {"repeats": args.repeats, "statistic": "median over repetitions of the whole K-step region (MAX over ranks each)",
                        "ms_per_step_p10": percentile(samples, 0.1) / args.steps * 1e3, "ms_per_step_p90": percentile(samples, 0.9) / args.steps * 1e3,
                        "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": affinity, "loop_profile": loop_prof},
@@ -480,6 +525,8 @@ def worker(args, affinity):
                          "launches_timed": k_cnt, "empty_event_pair_us": ev_avg_ms * 1e3, "rocprofv3_avg_launch_us": rocprof_avg_us,
                          "rocprofv3_source": rocprof_src,
                          "note": "HIP events on the kernel's own stream (hipExtLaunchKernelGGL start / stop = the dispatch's begin / end timestamps, what "
+                                 "rocprofv3 reports); one launch per step, 26 B x correspondences of this rank per launch" if not resident else
+                                 "HIP events on the kernel's own stream (hipExtLaunchKernelGGL start / stop = the dispatch's begin / end timestamps, what "
                                  "rocprofv3 reports).  One launch of the resident kernel serves steps_per_launch iterations; its duration INCLUDES the host's "
                                  "turn of every iteration (record over PCIe, 6x6 solve, exp-map, next pose over PCIe): algorithmic bytes = 26 B x "
                                  "correspondences x iterations.  The correspondences of a frame-sized problem stay in registers between iterations, so "

@@ -177,6 +177,28 @@ int rpe_p2p_init(rpe_context* ctx, int world, int rank, const void* handles);
 /* pause = 1 keeps the mailboxes but routes rpe_gn_step_dist / rpe_score through the RCCL communicator (stand-by); 0 resumes. */
 int rpe_p2p_pause(rpe_context* ctx, int pause);
 int rpe_p2p_destroy(rpe_context* ctx);
+/* Host-side exchange for ONE node (the third way to all-reduce; csrc/rpe_hostex.cpp): on one GPU a reduction's final sum already
+ * happens on the host (a few run records per launch, added by the calling thread), so with sharded correspondences every rank's host
+ * thread holds its shard's record microseconds after its kernel -- and the rank processes share the node's memory.  The records are
+ * exchanged between the host threads through a POSIX shared-memory segment and added in RANK ORDER (bitwise the same sums on every
+ * rank): no collective kernel, no GPU-side wait for a peer.  rpe_hostex_init(ctx, world, rank, name, create): `name` ("/...") is
+ * agreed by any means; exactly one rank passes create = 1 and must do so before the others open (they wait up to the time-out for the
+ * segment to appear).  With an exchange set,
+ * rpe_gn_step_dist / rpe_gn_steps_dist / rpe_gn_refine are sharded steps (the exchange takes precedence over rpe_p2p_* and
+ * rpe_comm_*), rpe_gn_refine keeps its RESIDENT kernel per rank (one GPU per rank; ranks that share a GPU fall back to one launch per
+ * iteration, because two resident grids that wait for each other's hosts cannot both be resident), and rpe_score adds the vote counters
+ * the same way.  Every wait is bounded (10 s): a missing peer fails the call with RPE_ERR_STATE. */
+int rpe_hostex_init(rpe_context* ctx, int world, int rank, const char* name, int create);
+int rpe_hostex_destroy(rpe_context* ctx);
+/* The exchange by itself (no GPU involved; what the two calls above wrap): */
+typedef struct rpe_host_exchange rpe_host_exchange;
+int rpe_host_exchange_open(const char* name, int world, int rank, int create, double timeout_s, rpe_host_exchange** out);
+int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n);   /* in place, 1 <= n <= 64, sums in rank order */
+int rpe_host_exchange_allreduce_i32(rpe_host_exchange* h, int* v, int n);      /* in place, 1 <= n <= 8192 */
+int rpe_host_exchange_set_label(rpe_host_exchange* h, const char* label);      /* e.g. the rank's GPU (PCI bus id) */
+int rpe_host_exchange_labels_collide(rpe_host_exchange* h);                    /* after an exchange: do two ranks carry the same label? */
+int rpe_host_exchange_unlink(rpe_host_exchange* h);                            /* drop the name once every rank has opened it */
+void rpe_host_exchange_close(rpe_host_exchange* h);
 /* Whole refinement loop on one GPU: up to 3 residual kinds summed with scales; stops when |delta| < tol.
  * iters_out = iterations run; returns RPE_ERR_DEGENERATE if a solve failed. */
 int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,

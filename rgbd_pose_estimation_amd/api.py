@@ -274,6 +274,14 @@ class Context:
     def comm_destroy(self):
         L.check(L.lib().rpe_comm_destroy(self._h))
 
+    def hostex_init(self, world: int, rank: int, name: str, create: bool):
+        """Host-side all-reduce between the node's rank processes (POSIX shared memory, sums in rank order); after this
+        gn_step_dist / gn_steps_dist / gn_refine / score are sharded calls."""
+        L.check(L.lib().rpe_hostex_init(self._h, world, rank, name.encode(), 1 if create else 0))
+
+    def hostex_destroy(self):
+        L.check(L.lib().rpe_hostex_destroy(self._h))
+
     def timing_enable(self, max_records: int, stride: int = 1):
         L.check(L.lib().rpe_timing_enable(self._h, max_records, stride))
 
@@ -424,3 +432,37 @@ def run_replay(method, poses7, first, dtype=L.F32, xw=None, xc=None, bv=None, nw
     L.check(L.lib().rpe_run_replay(method, C.byref(prob), _p(poses7), _p(first), len(first) - 1, thre_3d, thre_2d, thre_nl, C.byref(it), confidence, ls,
                                    score_mode, _p(R), _p(t), C.byref(mv), _p(mo)))
     return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mo)
+
+
+class HostExchange:
+    """The host-side exchange by itself (no GPU): all-reduce of up to 64 doubles / 8192 int32 between the rank processes of one node
+    through a POSIX shared-memory segment; every rank gets bitwise the same sums (rank order)."""
+
+    def __init__(self, name: str, world: int, rank: int, create: bool, timeout_s: float = 10.0):
+        self._h = C.c_void_p()
+        L.check(L.lib().rpe_host_exchange_open(name.encode(), world, rank, 1 if create else 0, float(timeout_s), C.byref(self._h)))
+        self.world, self.rank = world, rank
+
+    def allreduce_f64(self, v) -> np.ndarray:
+        a = np.ascontiguousarray(v, np.float64).copy()
+        L.check(L.lib().rpe_host_exchange_allreduce_f64(self._h, _p(a), a.size))
+        return a
+
+    def allreduce_i32(self, v) -> np.ndarray:
+        a = np.ascontiguousarray(v, np.int32).copy()
+        L.check(L.lib().rpe_host_exchange_allreduce_i32(self._h, _p(a), a.size))
+        return a
+
+    def set_label(self, label: str):
+        L.check(L.lib().rpe_host_exchange_set_label(self._h, label.encode()))
+
+    def labels_collide(self) -> bool:
+        return bool(L.lib().rpe_host_exchange_labels_collide(self._h))
+
+    def unlink(self):
+        L.check(L.lib().rpe_host_exchange_unlink(self._h))
+
+    def close(self):
+        if self._h:
+            L.lib().rpe_host_exchange_close(self._h)
+            self._h = C.c_void_p()

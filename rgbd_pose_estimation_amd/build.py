@@ -1,7 +1,8 @@
 """Compile the HIP backend for gfx950 in-tree: rgbd_pose_estimation_amd/lib/librgbdpose_hip.so.
 
 hipcc cross-compiles without a GPU.  Sources: csrc/rpe_kernels.hip (solver kernels), csrc/rpe_frontend.hip (depth-frame front end), csrc/rpe_hypotheses.hip (batched 3-point hypothesis generation), csrc/rpe_prosac.hip (PROSAC order: top-k select + sort), csrc/rpe_capi.hip (C-ABI shim),
-csrc/library.cpp (reference-compatible ao / ao_ransac / py2c and the adapter-level pipelines)."""
+csrc/library.cpp (reference-compatible ao / ao_ransac / py2c and the adapter-level pipelines), csrc/rpe_hostex.cpp (host-side all-reduce between
+the rank processes of one node)."""
 from __future__ import annotations
 
 import os
@@ -13,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librgbdpose_hip.so")
-SOURCES = ["rpe_kernels.hip", "rpe_frontend.hip", "rpe_hypotheses.hip", "rpe_prosac.hip", "rpe_capi.hip", "library.cpp"]
+SOURCES = ["rpe_kernels.hip", "rpe_frontend.hip", "rpe_hypotheses.hip", "rpe_prosac.hip", "rpe_capi.hip", "library.cpp", "rpe_hostex.cpp"]
 ARCH = "gfx950"
 LINK_RT = "--rtlib=libgcc"
 

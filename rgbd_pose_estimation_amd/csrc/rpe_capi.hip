@@ -134,6 +134,9 @@ struct rpe_context {
   double* h_big = nullptr;        // pinned + mapped: tagged 16-byte pairs {value, sequence} -- the run records of collecting launches, added here on the host
   size_t h_big_pairs = 0;
   bool collecting = false;        // the launch in flight publishes run records into h_big (collect_target)
+  rpe_host_exchange* hostex = nullptr;   // host-side all-reduce between the node's rank processes (rpe_hostex_init)
+  int hostex_world = 1;
+  bool hostex_shared_gpu = false; // two ranks on one GPU: no resident kernels (they would wait for each other's hosts without both being resident)
   // PROSAC order on the device (rpe_prosac_order): scratch
   float* ps_w = nullptr; size_t ps_w_cap = 0;
   unsigned int* ps_hist = nullptr;        // 2048 + 8 uints (histogram | control words)
@@ -457,6 +460,7 @@ void rpe_destroy(rpe_context* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ctl) (void)hipFree((void*)c->ctl);
   if (c->h_big) (void)hipHostFree(c->h_big);
+  if (c->hostex) rpe_host_exchange_close(c->hostex);
   if (c->ps_w) (void)hipFree(c->ps_w);
   if (c->ps_hist) (void)hipFree(c->ps_hist);
   if (c->ps_cand) (void)hipFree(c->ps_cand);
@@ -830,7 +834,10 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   int it = 0;
   double step = 0, cost = 0;
   const double sc = scales ? scales[0] : 1.0;
-  if (c->resident && max_iter >= 2 && kinds[0] != RPE_RES_BEARING && !c->comm && c->p2p_world_saved < 1) {
+  // sharded contexts: only with the host-side exchange (every rank's host thread adds the peers' records to its own each iteration);
+  // RCCL / in-kernel peer-to-peer contexts take rpe_gn_steps_dist
+  const bool sharded_ok = c->hostex ? !c->hostex_shared_gpu : (!c->comm && c->p2p_world_saved < 1);
+  if (c->resident && max_iter >= 2 && kinds[0] != RPE_RES_BEARING && sharded_ok) {
     // ONE launch for the whole loop: the grid stays resident, the host hands every new pose to it through the control block in
     // device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration) and solves / updates as before.
     int rc = kind_arrays(c, kinds[0]);
@@ -872,6 +879,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
       double tot[32];
       if ((rc = wait_host_partials(c, runs, nacc, tot))) { status = rc; break; }
       if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; }
+      if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) { status = rc; received++; break; }
       received++;
       if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
       cost = sc * ne[27];
@@ -895,6 +903,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     double ne[32], d[6];
     int rc = rpe_normal_eq(c, kinds[0], flags, pose12, ne);
     if (rc) return rc;
+    if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) return rc;
     cost = sc * ne[27];
     if (!rpe::solve_normal_eq6(ne, d)) {
       if (iters_out) *iters_out = it;
@@ -1018,7 +1027,44 @@ int rpe_p2p_destroy(rpe_context* c) {
 
 // Sharded Gauss-Newton step: local normal equations -> in-place all-reduce(sum) of the 32-double record over RCCL on the
 // context's stream -> publish to pinned host memory -> (every rank, identically) solve + exp-map update.
+// ---- host-side exchange between the rank processes of one node (csrc/rpe_hostex.cpp)
+int rpe_hostex_init(rpe_context* c, int world, int rank, const char* name, int create) {
+  if (!c || !name) return fail(RPE_ERR_ARG, "rpe_hostex_init: bad argument");
+  if (c->hostex) return fail(RPE_ERR_STATE, "rpe_hostex_init: an exchange is already set (rpe_hostex_destroy first)");
+  rpe_host_exchange* h = nullptr;
+  int rc = rpe_host_exchange_open(name, world, rank, create, 10.0, &h);
+  if (rc) return rc;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, c->device) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof bus, "device%d", c->device); }
+  (void)rpe_host_exchange_set_label(h, bus);
+  double probe[1] = {1.0};   // first exchange: every rank is here, and every rank's GPU label is in place
+  rc = rpe_host_exchange_allreduce_f64(h, probe, 1);
+  if (rc == RPE_OK && probe[0] != (double)world) rc = fail(RPE_ERR_STATE, "host exchange: %g of %d ranks answered", probe[0], world);
+  if (rc) { rpe_host_exchange_close(h); return rc; }
+  if (create) (void)rpe_host_exchange_unlink(h);   // everyone has it mapped: the name can go (nothing is left behind in /dev/shm)
+  static const bool allow_shared = getenv("RPE_HOSTEX_ALLOW_SHARED") && atoi(getenv("RPE_HOSTEX_ALLOW_SHARED")) != 0;
+  c->hostex_shared_gpu = rpe_host_exchange_labels_collide(h) != 0 && !allow_shared;
+  c->hostex = h; c->hostex_world = world;
+  return RPE_OK;
+}
+int rpe_hostex_destroy(rpe_context* c) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (c->hostex) { rpe_host_exchange_close(c->hostex); c->hostex = nullptr; c->hostex_world = 1; c->hostex_shared_gpu = false; }
+  return RPE_OK;
+}
+
 int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double* ne32_out, double* step_norm) {
+  if (c && c->hostex) {   // ONE launch with the single-GPU collecting stage; the shards' records meet on the hosts
+    double ne[32], d[6];
+    int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
+    if (rc) return rc;
+    if ((rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) return rc;
+    if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
+    rpe::se3_left_update(d, pose12);
+    if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
+    if (step_norm) *step_norm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    return RPE_OK;
+  }
   if (!c || (!c->comm && c->p2p_world < 1)) return fail(RPE_ERR_STATE, "neither rpe_p2p_init nor rpe_comm_init was called");
   int rc;
   if (c->p2p_world >= 1) {
@@ -1123,23 +1169,24 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
   for (int h0 = 0; h0 < H; h0 += rpe::kMaxScoreH) {
     const int hb = std::min(rpe::kMaxScoreH, H - h0);
     stage_poses(c->dtype, exact, poses7 + (size_t)7 * h0, hb, c->h_poses);
-    if (!c->comm && c->p2p_world < 1 && hb <= rpe::score_small_cap(c->dtype, exact)) {
+    if ((c->hostex || (!c->comm && c->p2p_world < 1)) && hb <= rpe::score_small_cap(c->dtype, exact)) {
       // short list on one GPU: ONE launch -- the hypotheses ride in the kernel argument, the counts come back as run records
       rpe::ReduceTarget rt = collect_target(c);
       if (rt.rows > 0) {
         HIP_TRY(rpe::launch_score_small(c->arrays(), kind, exact, c->h_poses, nullptr, hb, thr, rt, c->stream));
         if ((rc = wait_host(c, rpe::kNeLd))) return rc;
         for (int i = 0; i < hb; i++) votes_out[h0 + i] = (int)c->h_out[i];
+        if (c->hostex && (rc = rpe_host_exchange_allreduce_i32(c->hostex, votes_out + h0, hb))) return rc;   // sharded: the shards' counts meet on the hosts
         continue;
       }
     }
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
-    if (c->comm && c->p2p_world < 1 && (rc = nccl_votes_or_clear(c, rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream), hb))) return rc;  // sharded correspondences
+    if (!c->hostex && c->comm && c->p2p_world < 1 && (rc = nccl_votes_or_clear(c, rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream), hb))) return rc;  // sharded correspondences
     // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counters into pinned host memory, raises
     // a sequence word the host spins on, and clears the counters for the next launch
     const unsigned long long seq = ++c->vote_seq;
-    if (c->p2p_world >= 1) {   // sharded correspondences, one node: the read-out kernel also exchanges and sums the counters
+    if (!c->hostex && c->p2p_world >= 1) {   // sharded correspondences, one node: the read-out kernel also exchanges and sums the counters
       if ((rc = votes_or_clear(c, rpe::launch_publish_votes_p2p(c->d_votes, hb, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream), hb))) return rc;
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
       if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP, "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
@@ -1148,6 +1195,7 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
     }
     std::memcpy(votes_out + h0, c->h_votes, (size_t)hb * sizeof(int));
+    if (c->hostex && (rc = rpe_host_exchange_allreduce_i32(c->hostex, votes_out + h0, hb))) return rc;
   }
   return RPE_OK;
 }
@@ -1162,7 +1210,7 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
   // The generator samples THIS context's arrays: on a sharded context (rpe_comm_init / rpe_p2p_init) iteration i would be a different
   // pose on every rank and the summed votes would mix unrelated hypotheses.  Sharded RANSAC = host hypotheses (every rank the same
   // list) + rpe_score, which all-reduces the votes of IDENTICAL poses.
-  if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1)
+  if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1 || c->hostex)
     return fail(RPE_ERR_STATE, "rpe_ransac33_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
   HIP_TRY(hipSetDevice(c->device));
   const int exact = mode == RPE_SCORE_EXACT;

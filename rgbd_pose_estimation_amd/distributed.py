@@ -144,6 +144,43 @@ def init_p2p(ctx: "api.Context", group=None) -> bool:
     return True
 
 
+def exchange_name(group=None) -> str:
+    """A segment name every rank of the group agrees on (rank 0 draws it, torch.distributed ferries it)."""
+    import os
+    import secrets
+    rank = dist.get_rank(group)
+    box = [f"/rpe_hx_{os.getpid()}_{secrets.token_hex(4)}" if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
+
+
+def init_host_exchange(ctx: "api.Context", group=None) -> bool:
+    """Host-side all-reduce for ONE node: the rank processes exchange their 32-double records (and vote counters) through a POSIX
+    shared-memory segment and add them in rank order, so the sharded step needs no collective kernel at all and rpe_gn_refine keeps
+    its resident kernel on every rank.  Rank 0 creates the segment, a barrier, the others open it; rpe_hostex_init's first exchange
+    is the rendezvous.  All ranks return the same answer; False leaves the context untouched."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world > 8:
+        return False
+    name = exchange_name(group)
+    ok = 1
+    # exactly one creator, and it must come first: rank 0 enters rpe_hostex_init (create) while the others wait for the segment
+    # to appear inside their own call (bounded); the call's first exchange then holds everyone until all ranks have it mapped
+    try:
+        ctx.hostex_init(world, rank, name, rank == 0)
+    except Exception as e:  # noqa: BLE001
+        ok = 0
+        print(f"[rgbd_pose_estimation_amd] rank {rank}: host exchange unavailable ({e})", flush=True)
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        ctx.hostex_destroy()
+        return False
+    return True
+
+
 class HipShard:
     """This rank's shard resident in HBM + the device-side record buffer the collective reduces in place."""
 

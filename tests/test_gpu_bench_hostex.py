@@ -1,0 +1,28 @@
+"""-m gpu: bench.py's N > 1 path with the host-side exchange, from a bare shell, two ranks sharing the one GPU of the test box (gloo
+carries the plumbing; RPE_BENCH_SHARE_GPU=1 maps both ranks to cuda:0, so rpe_gn_refine launches once per iteration instead of keeping
+two resident grids that would wait for each other's hosts).  No kernel waits for another process on this path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_host_exchange_from_a_bare_shell():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_COLLECTIVE="host", RPE_BENCH_PREWARM_STEPS="300", RPE_BENCH_BACKEND="gloo",
+               RPE_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--n-total", "614400",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 20 and j["value"] > 1e9
+    assert j["config"]["global_corr"] == 614400 and j["config"]["corr_rank0"] == 307200
+    assert "configs[4]" in j["config"]["workload"] and "host-side exchange" in j["config"]["collective"]
+    assert j["config"]["collective_step_us"]["host_us"] > 0 and j["config"]["rccl_ranks"] == 0
+    assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2

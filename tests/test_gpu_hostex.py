@@ -1,0 +1,70 @@
+"""-m gpu: sharded Gauss-Newton and scoring whose all-reduce is the host-side exchange (rpe_hostex_init), with 2 / 4 ranks sharing
+the one GPU of the test box (tests/hostex_worker.py).  No kernel ever waits for another process here (the exchange happens between
+the host threads), so these cases are part of the default -m gpu suite."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(world, mode, n, steps, env_extra=None, timeout=240):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPE_QUIET="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "hostex_worker.py"), mode, str(n), str(steps)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("host-exchange workers timed out")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")]
+    assert line, outs[0][-2000:]
+    return json.loads(line[0][7:])
+
+
+def check_poses(res):
+    ranks = res["ranks"]
+    assert all(r["hostex"] and "error" not in r for r in ranks), ranks
+    poses = [np.array(r["pose"]) for r in ranks]
+    for p in poses[1:]:
+        assert np.array_equal(p, poses[0])            # rank-ordered sums: bitwise the same record, hence pose, on every rank
+    assert np.abs(poses[0] - np.array(res["reference"])).max() < 1e-9   # shards add up to the whole (different summation order only)
+    return ranks
+
+
+@pytest.mark.parametrize("world,n", [(2, 20000), (4, 307200)])
+def test_sharded_steps_match_the_single_gpu_run(world, n):
+    check_poses(run_world(world, "steps", n, 6))
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_sharded_refine_resident_and_launch_per_step(resident):
+    """rpe_gn_refine on a sharded context: ranks that share a GPU launch once per iteration; with one GPU per rank (simulated here:
+    RPE_HOSTEX_ALLOW_SHARED=1 on a problem whose grids are all resident at once) every rank keeps its resident kernel."""
+    res = run_world(2, "refine", 20000, 30, {"RPE_HOSTEX_ALLOW_SHARED": "1"} if resident else None)
+    ranks = check_poses(res)
+    assert ranks[0]["iters"] == ranks[1]["iters"] == ranks[0]["ref_iters"] < 30
+
+
+def test_sharded_votes_add_up():
+    res = run_world(2, "score", 50001, 40)
+    ranks = res["ranks"]
+    assert all(r["hostex"] and "error" not in r for r in ranks), ranks
+    for r in ranks:
+        assert r["votes"] == res["reference"]
+        assert r["votes_short"] == res["reference"][:12]
