@@ -78,7 +78,7 @@ def launch_children(argv: list[str], gpus: int) -> int:
     return 0
 
 
-def pin_to_gpu_numa_node(local_rank: int):
+def pin_to_gpu_numa_node(local_rank: int, world_size: int = 1):
     """The host thread that waits for every record and hands every pose over should sit next to the GPU's PCIe root.  Plain
     sched_setaffinity on this process, before any GPU call (no exec, no wrapper).  Best effort: returns what it did."""
     global ORIG_AFFINITY
@@ -107,10 +107,16 @@ def pin_to_gpu_numa_node(local_rank: int):
             lo, _, hi = part.partition("-")
             cpus += list(range(int(lo), int(hi or lo) + 1))
         cand = [c for c in cpus if c in allowed] or allowed
-        # one CPU per rank, away from CPU 0 (interrupts), spread so that ranks do not share a core
-        cpu = cand[(1 + 2 * local_rank) % len(cand)]
-        os.sched_setaffinity(0, {cpu})
-        return {"pinned": True, "cpu": cpu, "numa_node": open(os.path.join(dev, "numa_node")).read().strip(), "gpu_local_cpus": len(cpus)}
+        # away from CPU 0 (interrupts).  One GPU: one CPU for the polling thread.  Several ranks: four CPUs each, disjoint between the
+        # ranks -- threads created later (RCCL's, torch's) inherit the mask and must not share a single core with a thread that spins
+        if world_size > 1:
+            first = (1 + 4 * local_rank) % len(cand)
+            mine = {cand[(first + k) % len(cand)] for k in range(4)}
+        else:
+            mine = {cand[1 % len(cand)]}
+        os.sched_setaffinity(0, mine)
+        return {"pinned": True, "cpu": sorted(mine)[0] if len(mine) == 1 else sorted(mine), "numa_node": open(os.path.join(dev, "numa_node")).read().strip(),
+                "gpu_local_cpus": len(cpus)}
     except Exception as e:  # noqa: BLE001
         return {"pinned": False, "reason": repr(e)}
 
@@ -698,7 +704,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and "WORLD_SIZE" in os.environ:
         args.gpus = world
-    affinity = pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0"))) if os.environ.get("RPE_BENCH_NO_PIN") != "1" else {"pinned": False, "reason": "RPE_BENCH_NO_PIN=1"}
+    affinity = pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))) if os.environ.get("RPE_BENCH_NO_PIN") != "1" else {"pinned": False, "reason": "RPE_BENCH_NO_PIN=1"}
     worker(args, affinity)
 
 
