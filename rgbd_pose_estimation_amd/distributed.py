@@ -34,12 +34,15 @@ class ShardedGaussNewton:
     oracle-backed callable to exercise the sharding + collective + update logic without a GPU.
     """
 
-    def __init__(self, local_normal_eq: Callable[[np.ndarray], torch.Tensor], group=None):
+    def __init__(self, local_normal_eq: Callable[[np.ndarray], torch.Tensor], group=None, exchange: "Optional[api.HostExchange]" = None):
         self.local_normal_eq = local_normal_eq
         self.group = group
+        self.exchange = exchange   # host-side exchange between the node's rank processes instead of a torch.distributed collective
 
     def reduce_record(self, pose12: np.ndarray) -> np.ndarray:
         rec = self.local_normal_eq(pose12)
+        if self.exchange is not None:
+            return self.exchange.allreduce_f64(rec.detach().to("cpu").numpy())
         if dist.is_available() and dist.is_initialized():   # also with one rank: same code path at every N
             dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
         return rec.detach().to("cpu").numpy()
@@ -63,12 +66,15 @@ class ShardedGaussNewton:
 class ShardedScorer:
     """Batched RANSAC hypothesis scoring over sharded correspondences: local int32 votes, all-reduce(sum)."""
 
-    def __init__(self, local_votes: Callable[[np.ndarray], torch.Tensor], group=None):
+    def __init__(self, local_votes: Callable[[np.ndarray], torch.Tensor], group=None, exchange: "Optional[api.HostExchange]" = None):
         self.local_votes = local_votes
         self.group = group
+        self.exchange = exchange
 
     def score(self, poses7: np.ndarray) -> np.ndarray:
         v = self.local_votes(poses7)
+        if self.exchange is not None:
+            return self.exchange.allreduce_i32(v.detach().to("cpu").numpy())
         if _world(self.group) > 1:
             dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
         return v.detach().to("cpu").numpy()
@@ -152,6 +158,18 @@ def exchange_name(group=None) -> str:
     box = [f"/rpe_hx_{os.getpid()}_{secrets.token_hex(4)}" if rank == 0 else None]
     dist.broadcast_object_list(box, src=0, group=group)
     return box[0]
+
+
+def open_host_exchange(group=None, timeout_s: float = 10.0) -> "api.HostExchange":
+    """The exchange by itself (no GPU context): rank 0 creates the segment, everybody opens it, one exchange as the rendezvous, rank 0
+    drops the name.  For ShardedGaussNewton / ShardedScorer (`exchange=`)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    name = exchange_name(group)
+    hx = api.HostExchange(name, world, rank, create=(rank == 0), timeout_s=timeout_s)
+    assert hx.allreduce_f64([1.0])[0] == world
+    if rank == 0:
+        hx.unlink()
+    return hx
 
 
 def init_host_exchange(ctx: "api.Context", group=None) -> bool:

@@ -20,11 +20,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, host_exchange=False):
     import oracle_lib as O
-    from rgbd_pose_estimation_amd.distributed import ShardedGaussNewton, ShardedScorer, shard_range
+    from rgbd_pose_estimation_amd.distributed import ShardedGaussNewton, ShardedScorer, open_host_exchange, shard_range
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    hx = open_host_exchange() if host_exchange else None   # the records then meet between the host processes (shared memory), gloo only ferries the name
     try:
         sc = util.scene33(42, n, np.float32, outliers=0.0)
         lo, hi = shard_range(n, rank, world)
@@ -35,25 +36,28 @@ def _worker(rank, world, port, n, q):
             rec[:29] = O.gn_normal_eq(O.GN_P2P, xw, xc, pose=pose12)
             return torch.from_numpy(rec)
 
-        gn = ShardedGaussNewton(local_ne)
+        gn = ShardedGaussNewton(local_ne, exchange=hx)
         p0 = O.pose12(np.eye(3), np.zeros(3))
         p, its, step = gn.refine(p0, max_iter=30, tol=1e-10)
         prob = O.Problem(False, xw=xw, xc=xc)
         hyps = np.array([O.pose7_from_Rt(*util.perturbed_pose(np.random.default_rng(h), sc.R, sc.t, 0.002 * h, 0.01 * h), False) for h in range(8)])
-        scorer = ShardedScorer(lambda q7: torch.from_numpy(O.votes(prob, O.V_33, q7, thre_3d=0.15).astype(np.int32)))
+        scorer = ShardedScorer(lambda q7: torch.from_numpy(O.votes(prob, O.V_33, q7, thre_3d=0.15).astype(np.int32)), exchange=hx)
         votes = scorer.score(hyps)
         q.put((rank, p, its, votes, (lo, hi)))
     finally:
+        if hx is not None:
+            hx.close()
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("host_exchange", [False, True])
 @pytest.mark.parametrize("n", [1001, 20000])
-def test_sharded_gn_and_scoring_equal_single_process(oracle, n):
+def test_sharded_gn_and_scoring_equal_single_process(oracle, n, host_exchange):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, host_exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
