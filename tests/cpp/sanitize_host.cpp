@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 #include "../../include/rgbd_pose_hip.h"
 
@@ -126,6 +128,37 @@ int main() {
   std::memset(A, 0, sizeof(A));
   rpe_host_svd3(A, U, sv, V);
   CHECK(sv[0] == 0 && U[0] == 1 && V[4] == 1);
+  // the host-side exchange between rank processes (csrc/rpe_hostex.cpp), three "ranks" as threads of this process, each with its own mapping
+  {
+    char name[64];
+    std::snprintf(name, sizeof name, "/rpe_hx_san_%d", (int)getpid());
+    const int world = 3, steps = 300;
+    int bad[3] = {0, 0, 0};
+    auto rank_main = [&](int rank) {
+      rpe_host_exchange* hx = nullptr;
+      if (rpe_host_exchange_open(name, world, rank, rank == 0, 20.0, &hx) != RPE_OK) { bad[rank] = 1000; return; }
+      for (int s = 1; s <= steps; s++) {
+        const int n = 1 + (s * 5) % 64;
+        double v[64];
+        for (int i = 0; i < n; i++) v[i] = (rank + 1) * 0.5 + i + s;
+        if (rpe_host_exchange_allreduce_f64(hx, v, n) != RPE_OK) { bad[rank]++; continue; }
+        for (int i = 0; i < n; i++) bad[rank] += v[i] != ((0.5 + i + s) + (1.0 + i + s)) + (1.5 + i + s);
+        if (s % 4 == 0) {
+          std::vector<int> c(1 + (s * 37) % 8192, rank + 1);
+          if (rpe_host_exchange_allreduce_i32(hx, c.data(), (int)c.size()) != RPE_OK) { bad[rank]++; continue; }
+          for (int x : c) bad[rank] += x != 6;
+        }
+      }
+      if (rank == 0) rpe_host_exchange_unlink(hx);
+      rpe_host_exchange_close(hx);
+    };
+    std::thread t1(rank_main, 1), t2(rank_main, 2);
+    rank_main(0);
+    t1.join(); t2.join();
+    CHECK(bad[0] == 0 && bad[1] == 0 && bad[2] == 0);
+    double one[1] = {1.0};
+    CHECK(rpe_host_exchange_allreduce_f64(nullptr, one, 1) != RPE_OK);
+  }
   std::printf(fails ? "sanitize_host: %d FAILED\n" : "sanitize_host: ok\n", fails);
   return fails ? 1 : 0;
 }

@@ -1,7 +1,7 @@
 """CPU: AddressSanitizer + UndefinedBehaviorSanitizer over the host code (GPU ASan / XNACK are not available on
 this pool).  Two programs are built with g++ -fsanitize=address,undefined -fno-sanitize-recover=all and run:
   * tests/cpp/sanitize_host.cpp + csrc/library.cpp (product host side: drop-in headers, samplers, minimal solvers, RANSAC engine in
-    capture mode, rpe_host_*) + oracle/oracle_capi.cpp (the whole CPU restatement: pipelines, vote loops, replay);
+    capture mode, rpe_host_*) + csrc/rpe_hostex.cpp (the host-side exchange, three ranks as threads) + oracle/oracle_capi.cpp (the whole CPU restatement: pipelines, vote loops, replay);
   * tests/cpp/host_logic.cpp (PROSAC order, lazy index lists, sparse Fisher-Yates).
 librgbdpose_hip.so is linked for the GPU-facing symbols the headers reference; no GPU call is made."""
 import os
@@ -27,6 +27,7 @@ def _build(tmp_path, name, sources):
 def test_host_side_and_oracle_under_asan_ubsan(tmp_path):
     exe = _build(tmp_path, "sanitize_host", [os.path.join(ROOT, "tests", "cpp", "sanitize_host.cpp"),
                                             os.path.join(ROOT, "rgbd_pose_estimation_amd", "csrc", "library.cpp"),
+                                            os.path.join(ROOT, "rgbd_pose_estimation_amd", "csrc", "rpe_hostex.cpp"),
                                             os.path.join(ROOT, "oracle", "oracle_capi.cpp")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=ENV)
     assert r.returncode == 0 and "sanitize_host: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
