@@ -566,8 +566,8 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
 // sequence number} (one sc1 store per lane; no drain, no arrival counter) and are done; the collecting workgroup reads its run's
 // granules (collect_rows), adds the rows in a fixed order and sends the run's NACC sums to pinned host memory as tagged 16-byte pairs
 // (slot 1 + run * NACC + j; slot 0 = a header pair from workgroup 0 that tells the host how many runs of how many sums to expect).
-// The host adds the runs in run order and expands the record (rpe_capi.hip wait_collect).  R = one granule per collecting thread
-// (BLK / NACC rows), lengthened until the runs fit in ~512 pairs.  One hand-off hop of ~1 us replaces the arrival counters + the last
+// The host adds the runs in run order and expands the record (rpe_capi.hip wait_collect).  R = BLK / NACC rows (one granule per
+// collecting thread) times 1..4, aiming at <= 8 runs; longer still if the runs would not fit in ~512 pairs.  One hand-off hop of ~1 us replaces the arrival counters + the last
 // workgroup's re-read of all G records + the drain before the flag (profiles/r02_tail_timeline.jsonl); the sums are a fixed function
 // of G whichever workgroup finishes first.  Placement-independent: only the collecting workgroups ever wait, and only for workgroups
 // that never wait themselves.
@@ -579,7 +579,13 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   __shared__ double c_part[RGN][NACC];
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
   const int G = gridDim.x;
-  int R = RGN * ((G + RGN * kMaxRuns - 1) / (RGN * kMaxRuns));
+  // run length: aim at <= 8 runs with up to 4 granules per collecting thread (one batch of loads in flight: the hop costs the same as
+  // with one), and never more pairs than ~512 whatever the grid
+  int mult = (G + RGN * 8 - 1) / (RGN * 8);
+  if (mult > 4) mult = 4;
+  const int mult_cap = (G + RGN * kMaxRuns - 1) / (RGN * kMaxRuns);
+  if (mult < mult_cap) mult = mult_cap;
+  int R = RGN * mult;
   if (R > fin.rows) R = fin.rows;
   const int run = blockIdx.x / R, leader = run * R;
   if (threadIdx.x < NACC) {
@@ -2070,6 +2076,7 @@ static inline int reduce_grid(int64_t n, int P, int max_blocks, int block) {
   const int64_t groups = (n + P - 1) / P;
   const int64_t one = (groups + block - 1) / block, two = (groups + 2 * (int64_t)block - 1) / (2 * (int64_t)block);
   int64_t g = two < 128 ? one : two;
+  if (block <= 256 && one <= max_blocks) g = one;   // 256-thread workgroups (collecting stage): one group per thread while that is at most 2 workgroups per CU
   static const int force = getenv("RPE_REDUCE_GROUPS") ? atoi(getenv("RPE_REDUCE_GROUPS")) : 0;   // experiments: 1 / 2 groups per thread
   if (force == 1) g = one; else if (force == 2) g = two;
   if (g < 1) g = 1;
@@ -2100,7 +2107,9 @@ static Finish make_finish(const ReduceTarget& rt) {
 // most 2 per CU (512 records), is the measured sweet spot on MI355X from 307 200 correspondences up; rt.block /
 // rt.max_blocks (RPE_BLOCK / RPE_MAX_BLOCKS) override it for experiments.
 static inline int pick_block(const ReduceTarget& rt, bool allow_1024) {
-  int b = rt.block > 0 ? rt.block : 512;
+  // with the collecting stage the cross-workgroup cost no longer grows with the number of workgroups, and 256-thread workgroups (one
+  // wave per SIMD on a frame, two workgroups per CU beyond) win: 5.7 vs 6.3 us at 307 200 points, configs[3] cold 11.8 vs 13.0 us
+  int b = rt.block > 0 ? rt.block : (rt.rows > 0 ? 256 : 512);
   if (b >= 1024 && allow_1024) return 1024;
   if (b >= 512) return 512;
   return 256;
