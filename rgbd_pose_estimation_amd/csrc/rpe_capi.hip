@@ -858,12 +858,12 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     // cross-workgroup stage of the resident kernel: runs of `rows` workgroups are added by the first workgroup of the run (granule
     // hand-off, one hop), the run records come to the host, which adds them in run order.  A handful of small records (grid x sums <=
     // 1024 pairs, i.e. a few thousand correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the
-    // GPU at all; otherwise the largest run a collecting workgroup can take with one granule per thread (30 for point-to-point: 5 run
-    // records at 640 x 480), which keeps the PCIe side to a few hundred bytes.  RPE_RESIDENT_ROWS forces a run length.
-    int grid = 0, nacc = 0, max_rows = 1;
-    rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc, &max_rows);
+    // GPU at all; otherwise runs of one granule per collecting thread (30 workgroups for point-to-point: 5 run records at 640 x 480),
+    // up to four when that keeps the number of runs at <= 8 -- a few hundred bytes over PCIe.  RPE_RESIDENT_ROWS forces a run length.
+    int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
+    rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
-    const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : max_rows);
+    const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
     const int runs = (grid + rows - 1) / rows;
     rt.rows = rows;
     rt.h_out = c->h_big;

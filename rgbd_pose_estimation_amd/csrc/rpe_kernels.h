@@ -70,7 +70,7 @@ hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const do
 // first_tag + i; the run records of iteration i (rt.rows) are published with sequence value rt.seq + i.  Needs host-writable device
 // memory (large BAR).
 constexpr unsigned long long kResidentStopBit = 1ull << 63;
-void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows);
+void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // test hook: one application of the device-resident loop's 6x6 LDL^T solve + SE(3) exp-map update (d_step_ok: |delta|, ok flag)

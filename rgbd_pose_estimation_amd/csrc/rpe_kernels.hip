@@ -507,9 +507,6 @@ __device__ __forceinline__ void sum_records(const double* __restrict__ partials,
 // the collecting workgroup's read: thread (r, j) = (tid / NACC, tid % NACC) takes rows r, r + RGN, r + 2 RGN ... of the run (row 0 is the
 // workgroup's own record, already in part[0]), up to CH granules in flight at once (buffer loads with the sc1 bit, aux 16, re-issued
 // until every tag is this launch's), added in increasing row order into part[r][j].  Returns true if a granule never arrived (2 s).
-#ifndef RPE_RESIDENT_CH
-#define RPE_RESIDENT_CH 1
-#endif
 template <int NACC, int BLK, int CH = 4>
 __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gran, int G, int leader, int rows, unsigned long long tag,
                                              double (*part)[NACC]) {
@@ -1099,8 +1096,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #endif
     // ---- cross-workgroup stage: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the first of a run
     // collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no drain, no arrival
-    // counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls ONE granule (sc1 load until the
-    // tag is this iteration's), the rows are added in row order, and the run's NACC sums go to the host as tagged 16-byte pairs.  The
+    // counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls its granule(s) (collect_rows:
+    // sc1 loads until the tag is this iteration's), the rows are added in a fixed order, and the run's NACC sums go to the host as tagged 16-byte pairs.  The
     // host thread that owns the 6x6 solve adds the ceil(G / R) run records in run order.  So one hand-off hop on the GPU (about 1 us: a
     // collecting wave reads a few hundred bytes, MI355X_MICROARCH.md "handoff-1to1"), a few hundred bytes over PCIe, and sums that are
     // a fixed function of (G, R) whichever workgroup finishes first.  R = 1: every workgroup sends its own record (tiny problems).
@@ -1129,7 +1126,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #endif
       if ((int)blockIdx.x == leader) {
         const int rows = min(R, (int)gridDim.x - leader);
-        const bool lost = collect_rows<NACC, BLK, RPE_RESIDENT_CH>(gran, (int)gridDim.x, leader, rows, tag, g_part);
+        const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part);
 #ifdef RPE_STAMPS
         if (stamp_it) RPE_STAMP(3);
 #endif
@@ -1139,7 +1136,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #endif
         if (threadIdx.x < NACC) {
           double t = 0.0;
-          for (int k = 0; k < rows; k++) t += g_part[k][threadIdx.x];
+          const int nr = rows < RGN ? rows : RGN;
+          for (int k = 0; k < nr; k++) t += g_part[k][threadIdx.x];
           store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, t, fin.seq + (unsigned long long)it);
         }
 #ifdef RPE_STAMPS
@@ -2162,6 +2160,11 @@ hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const do
   return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s, ev0, ev1);
 }
 
+// workgroup size of the resident kernel and the largest grid that is resident at once (one workgroup per CU).  256-thread workgroups
+// (two per CU) were measured and lose here -- 6.95-7.3 vs 6.0-6.7 us per step at 307 200 points, 46 vs 39 us at 10 M -- although
+// they win for the one-launch kernels: twice the workgroups poll the control block and twice the granules cross the hop every iteration
+static inline int resident_block() { return 512; }
+static inline int resident_cap(int) { return 256; }
 // resident form: ONE launch for up to max_iters iterations; ctl = the control block in fine-grained device memory, first_tag + i =
 // tag of pose i (i = 1 ...), rt.seq + i = sequence value published with record i
 template <class T, int KIND, int BLK>
@@ -2173,11 +2176,12 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   const int mod = KIND == KIND_BEARING ? 0 : 1;
   const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
-  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < 256 ? rt.max_blocks : 256, BLK);   // at most one workgroup per CU: all co-resident
+  const int cap = resident_cap(BLK);
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);   // every workgroup resident at once: 8 waves per CU
   const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
   const bool in_regs = (int64_t)G * BLK >= groups;
   Finish fin = make_finish(rt);
-  constexpr int kMaxRows = BLK / (KIND == KIND_P2P ? 17 : 29);
+  constexpr int kMaxRows = 4 * (BLK / (KIND == KIND_P2P ? 17 : 29));   // up to 4 granules per collecting thread
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
   if (fin.rows < 1) fin.rows = 1;
 #define RPE_RES_LAUNCH2(M, W, R)                                                                                                             \
@@ -2203,12 +2207,19 @@ static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const u
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
-// grid the resident kernel runs with, the number of sums per record, and the largest run of workgroups one collecting workgroup can take
-void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows) {
+// grid the resident kernel runs with, the number of sums per record, the longest run of workgroups one collecting workgroup can take,
+// and the run length used unless the caller forces one: BLK / sums rows (one granule per collecting thread) times 1..4, aiming at <= 8 runs
+void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto) {
   const int P = A.dtype ? 2 : 4;
-  *grid = reduce_grid(A.n, P, max_blocks < 256 ? max_blocks : 256, 512);
+  const int blk = resident_block(), cap = resident_cap(blk);
+  *grid = reduce_grid(A.n, P, max_blocks < cap ? max_blocks : cap, blk);
   *nacc = kind == KIND_P2P ? 17 : 29;
-  *max_rows = 512 / *nacc;
+  const int rgn = blk / *nacc;
+  *max_rows = 4 * rgn;
+  int mult = (*grid + rgn * 8 - 1) / (rgn * 8);
+  if (mult > 4) mult = 4;
+  if (mult < 1) mult = 1;
+  *rows_auto = rgn * mult;
 }
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
