@@ -624,15 +624,22 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
         fctx.model_from_frame(pose12(Ra, ta))
         fctx.frame_set_depth(S.render_depth(Rb, tb, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
         K, reps = 20, 25
-        fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
-        t0i = time.perf_counter()
-        for _ in range(reps):
-            pi, iti, _, _, pairs = fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=True, fused=True)
-        dti = (time.perf_counter() - t0i) / reps
-        out["icp_frame_loop"] = {"value": pairs * K / dti, "unit": "pixel-residuals/s", "us_per_round": dti / K * 1e6, "rounds": K,
-                                 "pairs": pairs, "pixels": 307200, "rot_err_rad_vs_truth": rot_err(pi[:9].reshape(3, 3), Rb),
-                                 "trans_err_m_vs_truth": float(np.linalg.norm(pi[9:] - tb)),
-                                 "note": "rpe_icp fused + device-resident: projective association + point-to-plane normal equations in one kernel per round"}
+        modes = {}
+        for name, dev_res in (("host_update_resident_kernel", False), ("device_resident_one_launch_per_round", True)):
+            fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=dev_res, fused=True)
+            t0i = time.perf_counter()
+            for _ in range(reps):
+                pi, iti, _, _, pairs = fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=dev_res, fused=True)
+            dti = (time.perf_counter() - t0i) / reps
+            modes[name] = {"us_per_round": dti / K * 1e6, "pixel_residuals_per_s": pairs * K / dti, "rot_err_rad_vs_truth": rot_err(pi[:9].reshape(3, 3), Rb),
+                           "trans_err_m_vs_truth": float(np.linalg.norm(pi[9:] - tb))}
+        best = modes["host_update_resident_kernel"]
+        out["icp_frame_loop"] = {"value": best["pixel_residuals_per_s"], "unit": "pixel-residuals/s", "us_per_round": best["us_per_round"], "rounds": K,
+                                 "pairs": pairs, "pixels": 307200, "rot_err_rad_vs_truth": best["rot_err_rad_vs_truth"],
+                                 "trans_err_m_vs_truth": best["trans_err_m_vs_truth"], "modes": modes,
+                                 "note": "rpe_icp, fused projective association + point-to-plane normal equations; value = host-update form (ONE resident launch "
+                                         "per call: the frame's pixels stay in registers, the host hands over a pose per round); per call incl. the launch and "
+                                         "the closing association pass"}
         fctx.close()
     except Exception as e:  # noqa: BLE001
         out["icp_frame_loop"] = {"error": repr(e)}

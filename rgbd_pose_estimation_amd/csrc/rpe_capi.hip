@@ -375,6 +375,66 @@ int check_flags(rpe_context* c, int kind, int flags) {
 
 }  // namespace
 
+// Host side of a RESIDENT loop (rpe_gn_refine, rpe_icp): ONE launch (`launch(rt, base)`) whose grid stays resident; the host hands every
+// pose to it through the control block in device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration),
+// receives the run records of every iteration, adds them, solves the 6x6 system and applies the SE(3) update, as the one-launch-per-
+// iteration loop does.  Pose i carries tag base + i, the records of iteration i carry sequence base + i.
+// Cross-workgroup stage: runs of `rows` workgroups are added by the first workgroup of the run (granule hand-off, one hop), the run
+// records come to the host, which adds them in run order.  A handful of small records (grid x sums <= 1024 pairs, i.e. a few thousand
+// correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the GPU at all; otherwise runs of one
+// granule per collecting thread (30 workgroups for point-to-point: 5 run records at 640 x 480), up to four when that keeps the number
+// of runs at <= 8 -- a few hundred bytes over PCIe.  RPE_RESIDENT_ROWS forces a run length.
+template <class Launch>
+static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale, double* pose12, int max_iter,
+                       double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what) {
+  const unsigned long long base = c->seq;
+  auto hand_over = [&](const double* p, unsigned long long tag) {
+    if (p) for (int k = 0; k < 12; k++) { unsigned long long w; std::memcpy(&w, &p[k], 8); c->ctl[1 + k] = w; }   // words 1..7 | 8..12
+    store_fence();
+    c->ctl[0] = tag; c->ctl[15] = tag;
+    store_fence();
+  };
+  hand_over(pose12, base + 1);
+  rpe::ReduceTarget rt = host_target(c);
+  rt.seq = base;
+  rt.tagged = 1;
+  static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
+  const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
+  const int runs = (grid + rows - 1) / rows;
+  rt.rows = rows;
+  rt.h_out = c->h_big;
+  c->seq = base;
+  {
+    const hipError_t e = launch(rt, base);
+    if (e != hipSuccess) return fail(RPE_ERR_HIP, "resident launch: %s", hipGetErrorString(e));
+  }
+  int status = RPE_OK, received = 0, it = 0, rc;   // records received so far = poses the grid has consumed
+  double step = 0, cost = 0, weight = 0;
+  double tp = c->loop_prof ? clock_us() : 0;
+  for (;;) {
+    c->seq = base + (unsigned long long)received + 1;
+    double ne[32], d[6];
+    double tot[32];
+    if ((rc = wait_host_partials(c, runs, nacc, tot))) { status = rc; break; }
+    if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; }
+    if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) { status = rc; received++; break; }
+    received++;
+    if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
+    cost = cost_scale * ne[27]; weight = ne[28];
+    if (!rpe::solve_normal_eq6(ne, d)) { status = fail(RPE_ERR_DEGENERATE, "%s are not positive definite at iteration %d (weight sum %g)", what, it, ne[28]); break; }
+    rpe::se3_left_update(d, pose12);
+    step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    it = received;
+    if (step < tol || received == max_iter) break;
+    hand_over(pose12, base + (unsigned long long)received + 1);
+    if (c->loop_prof) { const double t = clock_us(); c->prof_host_us += t - tp; tp = t; }
+  }
+  if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);   // the grid is still waiting: release it
+  c->seq = base + (unsigned long long)max_iter + 1;   // stays ahead of every tag / sequence value this launch could use
+  *it_out = it; *step_out = step; *cost_out = cost; *weight_out = weight;
+  return status;
+}
+
 extern "C" {
 
 int rpe_abi_version(void) { return 1; }
@@ -844,57 +904,18 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     if (rc) return rc;
     if ((rc = check_flags(c, kinds[0], flags))) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    const unsigned long long base = c->seq;   // record i carries sequence base + i; pose i carries tag base + i
-    auto hand_over = [&](const double* p, unsigned long long tag) {
-      if (p) for (int k = 0; k < 12; k++) { unsigned long long w; std::memcpy(&w, &p[k], 8); c->ctl[1 + k] = w; }   // words 1..7 | 8..12
-      store_fence();
-      c->ctl[0] = tag; c->ctl[15] = tag;
-      store_fence();
-    };
-    hand_over(pose12, base + 1);
-    rpe::ReduceTarget rt = host_target(c);
-    rt.seq = base;
-    rt.tagged = 1;
-    // cross-workgroup stage of the resident kernel: runs of `rows` workgroups are added by the first workgroup of the run (granule
-    // hand-off, one hop), the run records come to the host, which adds them in run order.  A handful of small records (grid x sums <=
-    // 1024 pairs, i.e. a few thousand correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the
-    // GPU at all; otherwise runs of one granule per collecting thread (30 workgroups for point-to-point: 5 run records at 640 x 480),
-    // up to four when that keeps the number of runs at <= 8 -- a few hundred bytes over PCIe.  RPE_RESIDENT_ROWS forces a run length.
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
-    static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
-    const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
-    const int runs = (grid + rows - 1) / rows;
-    rt.rows = rows;
-    rt.h_out = c->h_big;
-    c->seq = base;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
-    HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), kinds[0], flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream, e0, e1));
-    int status = RPE_OK, received = 0;   // records received so far = poses the grid has consumed
-    double tp = c->loop_prof ? clock_us() : 0;
-    for (;;) {
-      c->seq = base + (unsigned long long)received + 1;
-      double ne[32], d[6];
-      double tot[32];
-      if ((rc = wait_host_partials(c, runs, nacc, tot))) { status = rc; break; }
-      if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; }
-      if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) { status = rc; received++; break; }
-      received++;
-      if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
-      cost = sc * ne[27];
-      if (!rpe::solve_normal_eq6(ne, d)) { status = fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, ne[28]); break; }
-      rpe::se3_left_update(d, pose12);
-      step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
-      it = received;
-      if (step < tol || received == max_iter) break;
-      hand_over(pose12, base + (unsigned long long)received + 1);
-      if (c->loop_prof) { const double t = clock_us(); c->prof_host_us += t - tp; tp = t; }
-    }
-    if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);   // the grid is still waiting: release it
-    c->seq = base + (unsigned long long)max_iter + 1;   // stays ahead of every tag / sequence value this launch could use
+    const int kind = kinds[0];
+    double weight = 0;
+    auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+      return rpe::launch_normal_eq_resident(c->arrays(), kind, flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream, e0, e1);
+    };
+    rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations");
     if (iters_out) *iters_out = it;
-    if (status != RPE_OK) return status;
+    if (rc != RPE_OK) return rc;
     if (last_step) *last_step = step;
     if (final_cost) *final_cost = cost;
     return RPE_OK;
@@ -1492,6 +1513,17 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
     step = c->h_out[12]; cost = c->h_out[13]; it = (int)c->h_out[14]; pairs = c->h_out[16];
     if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
+  } else if (o->fused && c->resident && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
+    // host-driven ICP in ONE launch: the frame's pixels stay in registers, every iteration the host hands the pose over, the grid pairs
+    // its pixels with the model under that pose and sends the run records back (rpe_kernels.hip icp_resident_kernel)
+    int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
+    rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
+    auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
+      return rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr, o->use_normals,
+                                      o->kind, (const unsigned long long*)c->ctl, base, o->max_iter, rt, c->stream);
+    };
+    rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs, "ICP: normal equations");
+    if (rc != RPE_OK) { if (iters_out) *iters_out = it; return rc; }
   } else {
     for (; it < o->max_iter; it++) {
       if ((rc = round(pose12, collect_target(c), false))) return rc;

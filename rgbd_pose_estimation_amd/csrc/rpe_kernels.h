@@ -138,4 +138,10 @@ hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, con
                             const PoseF& M, float dist_sq, float cos_thr, int use_normals, int kind, const double* pose12, const ReduceTarget& rt,
                             hipStream_t s);
 
+// resident ICP loop (one launch; poses through the control block, run records to the host -- as launch_normal_eq_resident)
+void icp_resident_geometry(int64_t n, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
+hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam, const PoseF& M,
+                               float dist_sq, float cos_thr, int use_normals, int kind, const unsigned long long* ctl, unsigned long long first_tag,
+                               int max_iters, const ReduceTarget& rt, hipStream_t s);
+
 }  // namespace rpe

@@ -1026,6 +1026,90 @@ __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T
   }
 }
 
+// ---- the two halves of a RESIDENT iteration that do not depend on what is being summed (shared by the normal-equation and the ICP
+// resident kernels).
+// Wait for pose number `want` in the control block (16 words in fine-grained device memory that the host writes through the PCIe BAR:
+// word 0 = tag, words 1..12 = pose, word 15 = tag again, so the two 64-byte halves may arrive in any order).  The first 16 lanes of
+// wave 0 read one 8-byte word each until both tags match.  Returns 1 = go (pose in s_pose), 2 = stop requested, 3 = the host went
+// away (2 s); the value is uniform over the workgroup.
+template <int BLK>
+__device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want, double* __restrict__ s_pose,
+                                                  int* __restrict__ s_go) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    int go = 0;
+    unsigned long long w = 0;
+    for (;;) {
+      if (lane < 16) w = __hip_atomic_load(ctl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long ta = __shfl(w, 0, 64), tb = __shfl(w, 15, 64);
+      if (ta == tb && (ta & ~kResidentStop) == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
+      if (wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // the host went away: give up (2 s)
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane >= 1 && lane <= 12) s_pose[lane - 1] = __longlong_as_double((long long)w);
+    if (lane == 0) *s_go = go;
+  }
+  __syncthreads();
+  return *s_go;
+}
+// Cross-workgroup stage of one resident iteration: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the
+// first of a run collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no
+// drain, no arrival counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls its granule(s)
+// (collect_rows: sc1 loads until the tag is this iteration's), the rows are added in a fixed order, and the run's NACC sums go to the
+// host as tagged 16-byte pairs.  The host thread that owns the 6x6 solve adds the ceil(G / R) run records in run order.  So one
+// hand-off hop on the GPU (about 1 us: a collecting wave reads a few hundred bytes, MI355X_MICROARCH.md "handoff-1to1"), a few hundred
+// bytes over PCIe, and sums that are a fixed function of (G, R) whichever workgroup finishes first.  R = 1: every workgroup sends its
+// own record (tiny problems).  A workgroup overwrites its granules only in the next iteration, which the host starts after it has
+// received every run record, i.e. after the granules have been read.  Returns false if a granule never arrived (the kernel ends without
+// publishing; the host reports that).
+template <int NACC, int BLK>
+__device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, unsigned long long seq,
+                                                     bool stamp_it) {
+  constexpr int NW = BLK / 64;
+  constexpr int RGN = BLK / NACC;                       // rows a collecting workgroup takes with one granule per thread
+  __shared__ double g_red[NW][NACC];
+  __shared__ double g_part[RGN][NACC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
+  const int R = fin.rows, run = blockIdx.x / R, leader = run * R;
+  wave_reduce_to<NACC>(acc, g_red[wave], lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double own = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
+    if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+    else g_part[0][threadIdx.x] = own;
+  }
+#ifdef RPE_STAMPS
+  if (stamp_it) RPE_STAMP(2);
+#endif
+  bool ok = true;
+  if ((int)blockIdx.x == leader) {
+    const int rows = min(R, (int)gridDim.x - leader);
+    const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part);
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(3);
+#endif
+    if (__syncthreads_or(lost)) ok = false;
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(4);
+#endif
+    if (ok && threadIdx.x < NACC) {
+      double t = 0.0;
+      const int nr = rows < RGN ? rows : RGN;
+      for (int k = 0; k < nr; k++) t += g_part[k][threadIdx.x];
+      store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, t, seq);
+    }
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(5);
+#endif
+  }
+  __syncthreads();   // g_red / g_part are reused by the next iteration
+  return ok;
+}
+
 // IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
 // loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
 template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS>
@@ -1049,25 +1133,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     rpresent = g0 < full ? P : (int)(n - full * P);
   }
   for (int it = 1; it <= max_iters; it++) {
-    // ---- wait for pose number `it`: the first 16 lanes read the control block (one 8-byte word each), until both tags match
-    if (threadIdx.x < 64) {
-      const unsigned long long want = first_tag + (unsigned long long)it;
-      const int lane = threadIdx.x;
-      const unsigned long long t0 = wall_clock64();
-      int go = 0;
-      unsigned long long w = 0;
-      for (;;) {
-        if (lane < 16) w = __hip_atomic_load(ctl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long ta = __shfl(w, 0, 64), tb = __shfl(w, 15, 64);
-        if (ta == tb && (ta & ~kResidentStop) == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
-        if (wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // the host went away: give up (2 s)
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (lane >= 1 && lane <= 12) s_pose[lane - 1] = __longlong_as_double((long long)w);
-      if (lane == 0) s_go = go;
-    }
-    __syncthreads();
-    if (s_go != 1) return;   // stop requested (2) or no host (3): uniform for the workgroup
+    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;   // stop requested or no host: uniform for the workgroup
 #ifdef RPE_STAMPS
     const bool stamp_it = it == 1000;
     if (stamp_it) RPE_STAMP(0);
@@ -1094,58 +1160,10 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(1);
 #endif
-    // ---- cross-workgroup stage: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the first of a run
-    // collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no drain, no arrival
-    // counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls its granule(s) (collect_rows:
-    // sc1 loads until the tag is this iteration's), the rows are added in a fixed order, and the run's NACC sums go to the host as tagged 16-byte pairs.  The
-    // host thread that owns the 6x6 solve adds the ceil(G / R) run records in run order.  So one hand-off hop on the GPU (about 1 us: a
-    // collecting wave reads a few hundred bytes, MI355X_MICROARCH.md "handoff-1to1"), a few hundred bytes over PCIe, and sums that are
-    // a fixed function of (G, R) whichever workgroup finishes first.  R = 1: every workgroup sends its own record (tiny problems).
-    // A workgroup overwrites its granules only in the next iteration, which the host starts after it has received every run record,
-    // i.e. after the granules have been read.
-    {
-      constexpr int NW = BLK / 64;
-      constexpr int RGN = BLK / NACC;                       // rows a collecting workgroup can take, one granule per thread
-      __shared__ double g_red[NW][NACC];
-      __shared__ double g_part[RGN][NACC];
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      const unsigned long long tag = first_tag + (unsigned long long)it;
-      unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
-      const int R = fin.rows, run = blockIdx.x / R, leader = run * R;
-      wave_reduce_to<NACC>(acc, g_red[wave], lane);
-      __syncthreads();
-      if (threadIdx.x < NACC) {
-        double own = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
-        if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
-        else g_part[0][threadIdx.x] = own;
-      }
-#ifdef RPE_STAMPS
-      if (stamp_it) RPE_STAMP(2);
+#ifndef RPE_STAMPS
+    const bool stamp_it = false;
 #endif
-      if ((int)blockIdx.x == leader) {
-        const int rows = min(R, (int)gridDim.x - leader);
-        const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part);
-#ifdef RPE_STAMPS
-        if (stamp_it) RPE_STAMP(3);
-#endif
-        if (__syncthreads_or(lost)) return;   // no record: the host reports the kernel as having ended without publishing
-#ifdef RPE_STAMPS
-        if (stamp_it) RPE_STAMP(4);
-#endif
-        if (threadIdx.x < NACC) {
-          double t = 0.0;
-          const int nr = rows < RGN ? rows : RGN;
-          for (int k = 0; k < nr; k++) t += g_part[k][threadIdx.x];
-          store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, t, fin.seq + (unsigned long long)it);
-        }
-#ifdef RPE_STAMPS
-        if (stamp_it) RPE_STAMP(5);
-#endif
-      }
-      __syncthreads();
-    }
+    if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, stamp_it)) return;
   }
 }
 
@@ -1214,6 +1232,86 @@ __global__ __launch_bounds__(BLK) void icp_fused_kernel(const float* __restrict_
     normal_eq_group<float, KIND, false, false, NACC>(pose, vw, vb, vc, m_none, w_none, left, acc);
   }
   reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
+}
+
+// RESIDENT form of the fused ICP round (host-driven ICP: rpe_icp with fused = 1, device_resident = 0): ONE launch for the whole loop.
+// The frame's vertices and normals (one group of 4 pixels per thread at 640 x 480) are read once and stay in registers; every
+// iteration the workgroups wait for the host's pose (resident_wait_pose), pair their pixels with the model under that pose
+// (associate_pixel: the model vertex / normal gathers are the only memory traffic of an iteration) and accumulate the normal equations,
+// and the sums reach the host through the collecting stage (resident_cross_stage).  Pairing function and per-pixel arithmetic are
+// the fused kernel's; only the order of the cross-workgroup sums differs.
+template <int KIND, int BLK, bool IN_REGS>
+__global__ __launch_bounds__(BLK) void icp_resident_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n,
+                                                           const float* __restrict__ mv, const float* __restrict__ mn, AssocParams P,
+                                                           const unsigned long long* __restrict__ ctl, unsigned long long first_tag,
+                                                           int max_iters, Finish fin) {
+  constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
+  __shared__ double s_pose[12];
+  __shared__ int s_go;
+  const short m_none[4] = {1, 1, 1, 1};
+  const float w_none[4] = {1.f, 1.f, 1.f, 1.f};
+  const float nan = __int_as_float(0x7fc00000);
+  const int64_t full = n / 4, groups = (n + 3) / 4;
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  const int64_t g0 = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  // one group of frame pixels: 16-byte loads for whole groups, bounds-checked scalars for the ragged last one
+  auto load_pixels = [&](int64_t g, float (&V)[12], float (&N)[12]) {
+    if (g < full) {
+      const float4* v4 = reinterpret_cast<const float4*>(vmap);
+      const float4* n4 = reinterpret_cast<const float4*>(nmap);
+      unpack3(v4[3 * g], v4[3 * g + 1], v4[3 * g + 2], V);
+      unpack3(n4[3 * g], n4[3 * g + 1], n4[3 * g + 2], N);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        const int64_t q = 12 * g + i;
+        const bool in = q < 3 * n;
+        V[i] = in ? vmap[q] : nan;
+        N[i] = in ? nmap[q] : nan;
+      }
+    }
+  };
+  float rV[12], rN[12];
+  const bool mine = IN_REGS && g0 < groups;
+  if (mine) load_pixels(g0, rV, rN);
+  for (int it = 1; it <= max_iters; it++) {
+    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;
+    PoseK<double> pose;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose.t[k] = s_pose[9 + k];
+    PoseF T;
+#pragma unroll
+    for (int k = 0; k < 9; k++) T.R[k] = (float)pose.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) T.t[k] = (float)pose.t[k];
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+    auto pair_and_add = [&](const float (&V)[12], const float (&N)[12], int present) {
+      float vw[12], vb[12], vc[12];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float gx, gy, gz;
+        const bool ok = associate_pixel(T, P, mv, mn, V[3 * i], V[3 * i + 1], V[3 * i + 2], N[3 * i], N[3 * i + 1], N[3 * i + 2], vw[3 * i],
+                                        vw[3 * i + 1], vw[3 * i + 2], gx, gy, gz);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { vb[3 * i + k] = ok ? V[3 * i + k] : nan; vc[3 * i + k] = ok ? N[3 * i + k] : nan; }
+      }
+      normal_eq_group<float, KIND, false, false, NACC>(pose, vw, vb, vc, m_none, w_none, present, acc);
+    };
+    if (IN_REGS) {
+      if (mine) pair_and_add(rV, rN, g0 < full ? 4 : (int)(n - full * 4));
+    } else {
+      for (int64_t g = g0; g < groups; g += stride) {
+        float V[12], N[12];
+        load_pixels(g, V, N);
+        pair_and_add(V, N, g < full ? 4 : (int)(n - full * 4));
+      }
+    }
+    if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, false)) return;
+  }
 }
 
 // ================================================================================================
@@ -2251,6 +2349,34 @@ hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, con
     if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
     else hipLaunchKernelGGL((icp_fused_kernel<KIND_P2PLANE, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
   }
+  return hipGetLastError();
+}
+
+// resident ICP loop: grid / record geometry exactly as the resident normal-equation kernel's (pixels in groups of 4)
+void icp_resident_geometry(int64_t n, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto) {
+  DeviceArrays A{};
+  A.n = n; A.dtype = 0;
+  resident_geometry(A, kind, max_blocks, grid, nacc, max_rows, rows_auto);
+}
+hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam, const PoseF& M,
+                               float dist_sq, float cos_thr, int use_normals, int kind, const unsigned long long* ctl, unsigned long long first_tag,
+                               int max_iters, const ReduceTarget& rt, hipStream_t s) {
+  if (kind != KIND_P2P && kind != KIND_P2PLANE) return hipErrorInvalidValue;
+  AssocParams P;
+  P.mcam = mcam; P.M = M; P.dist_sq = dist_sq; P.cos_thr = cos_thr; P.use_normals = use_normals;
+  constexpr int BLK = 512;
+  const int cap = resident_cap(BLK);
+  const int G = reduce_grid(n, 4, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);
+  const int64_t groups = (n + 3) / 4;
+  const bool in_regs = (int64_t)G * BLK >= groups;
+  Finish fin = make_finish(rt);
+  const int max_rows = 4 * (BLK / (kind == KIND_P2P ? 17 : 29));
+  if (fin.rows > max_rows) fin.rows = max_rows;
+  if (fin.rows < 1) fin.rows = 1;
+#define RPE_ICP_RES(K, R) hipLaunchKernelGGL((icp_resident_kernel<K, BLK, R>), dim3(G), dim3(BLK), 0, s, vmap, nmap, n, mv, mn, P, ctl, first_tag, max_iters, fin)
+  if (kind == KIND_P2P) { if (in_regs) RPE_ICP_RES(KIND_P2P, true); else RPE_ICP_RES(KIND_P2P, false); }
+  else { if (in_regs) RPE_ICP_RES(KIND_P2PLANE, true); else RPE_ICP_RES(KIND_P2PLANE, false); }
+#undef RPE_ICP_RES
   return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 """GPU parity of the front end (csrc/rpe_frontend.hip through Part 3 of the C ABI) against oracle/frontend_oracle.py.
 The bar is BIT-EXACT maps, pairs and counts (same fp32 operations in the same order, no FMA contraction); the ICP loop,
 whose normal equations are summed in a different order than the fp64 oracle's, agrees to 1e-6 rad."""
+import os
 import numpy as np
 import pytest
 
@@ -208,3 +209,35 @@ def test_fused_icp_matches_the_two_kernel_icp(gpu_ctx_factory, cam, kind, device
     # the slots hold the pairs under the returned pose
     XW, XC, BV, NW, NC, cnt = FO.associate(V, N, B, MV, MN, cam, one[0], pA, 0.15, 0.8, True)
     assert same(ctx.download(L.XC), XC) and same(ctx.download(L.XW), XW) and same(ctx.download(L.NC), NC)
+
+
+def test_resident_icp_streaming_form_and_early_stop(tmp_path):
+    """The host-driven fused ICP runs in ONE resident launch.  (a) With a grid too small to keep a group per thread (RPE_MAX_BLOCKS=16)
+    the kernel re-reads the frame every iteration: same poses as the two-kernel ICP.  (b) A tolerance that stops the loop early must
+    release the waiting grid (STOP hand-over) and leave the context usable."""
+    import subprocess
+    import sys
+    script = tmp_path / "icp_small_grid.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+sys.path.insert(0, {repr(os.path.dirname(os.path.abspath(__file__)))})
+import numpy as np
+from rgbd_pose_estimation_amd import _lib as L, api
+from test_gpu_frontend import load_pair, FULL_CAM, rot_err
+ctx = api.Context(0)
+(V, N, B, MV, MN), pA, pB = load_pair(ctx, FULL_CAM, noise=0.002)
+two = ctx.icp(pA, L.RES_P2PLANE, 8, 0.0, 0.15, 0.8, device_resident=False, fused=False)
+one = ctx.icp(pA, L.RES_P2PLANE, 8, 0.0, 0.15, 0.8, device_resident=False, fused=True)
+assert rot_err(one[0][:9].reshape(3, 3), two[0][:9].reshape(3, 3)) < 1e-9 and np.linalg.norm(one[0][9:] - two[0][9:]) < 1e-9, (one, two)
+assert one[1] == two[1] == 8 and abs(one[4] - two[4]) <= 2
+early2 = ctx.icp(pA, L.RES_P2PLANE, 50, 1e-5, 0.15, 0.8, device_resident=False, fused=False)
+early1 = ctx.icp(pA, L.RES_P2PLANE, 50, 1e-5, 0.15, 0.8, device_resident=False, fused=True)
+assert early1[1] == early2[1] < 50 and early1[2] < 1e-5
+again = ctx.icp(pA, L.RES_P2PLANE, 8, 0.0, 0.15, 0.8, device_resident=False, fused=True)   # the context still works after the early stop
+assert np.array_equal(again[0], one[0])
+print("ok")
+""")
+    for env_extra in ({"RPE_MAX_BLOCKS": "16"}, {}):
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
