@@ -11,6 +11,9 @@ import numpy as np
 import pytest
 
 pytestmark = [pytest.mark.gpu]
+# the cases in which kernels of different processes must run on the one GPU AT THE SAME TIME (two resident grids that wait for each
+# other's hosts), and the 4-rank frame-sized case, run on request like the other multi-process-on-one-GPU tests
+multiproc = pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1", reason="the larger multi-process-on-one-GPU cases run with RPE_TEST_MULTIPROC=1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -47,12 +50,12 @@ def check_poses(res):
     return ranks
 
 
-@pytest.mark.parametrize("world,n", [(2, 20000), (4, 307200)])
+@pytest.mark.parametrize("world,n", [(2, 20000), pytest.param(4, 307200, marks=multiproc)])
 def test_sharded_steps_match_the_single_gpu_run(world, n):
     check_poses(run_world(world, "steps", n, 6))
 
 
-@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("resident", [False, pytest.param(True, marks=multiproc)])
 def test_sharded_refine_resident_and_launch_per_step(resident):
     """rpe_gn_refine on a sharded context: ranks that share a GPU launch once per iteration; with one GPU per rank (simulated here:
     RPE_HOSTEX_ALLOW_SHARED=1 on a problem whose grids are all resident at once) every rank keeps its resident kernel."""
