@@ -12,6 +12,8 @@
 #include <ctime>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -374,6 +376,20 @@ int check_flags(rpe_context* c, int kind, int flags) {
 }
 
 }  // namespace
+
+// The exact 3D test is  sqrt(s) < thre_3d  in the array dtype (Eigen norm(), AbsoluteOrientation.hpp:137-138).  The correctly rounded
+// square root is monotonic, so the set of s that pass is { s < cut } with cut = the smallest value whose square root reaches the
+// threshold; the kernels compare s with `cut` and never take the root.  Found by stepping from thr^2 with the host's own sqrt.
+template <class T> static T sqrt_cut(T thr) {
+  if (thr != thr) return thr;                                   // NaN: nothing passes, either way
+  if (!(thr > T(0))) return T(0);                               // sqrt(s) < thr <= 0 never holds; s < 0 never holds
+  if (std::isinf(thr)) return thr;                              // every finite s passes
+  T x = thr * thr;
+  if (std::isinf(x)) x = std::numeric_limits<T>::max();
+  while (x > T(0) && std::sqrt(x) >= thr) x = std::nextafter(x, T(0));
+  while (std::sqrt(x) < thr) x = std::nextafter(x, std::numeric_limits<T>::infinity());
+  return x;
+}
 
 // Host side of a RESIDENT loop (rpe_gn_refine, rpe_icp): ONE launch (`launch(rt, base)`) whose grid stays resident; the host hands every
 // pose to it through the control block in device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration),
@@ -1159,7 +1175,7 @@ static void stage_poses(int dtype, int exact, const double* poses7, int H, void*
   }
 }
 static void stage_thresholds(int dtype, int exact, double thre_3d, double cos_thr, double cos_nl, double thr[3]) {
-  if (exact) thr[0] = thre_3d;
+  if (exact) thr[0] = dtype == RPE_F64 ? sqrt_cut<double>(thre_3d) : (double)sqrt_cut<float>((float)thre_3d);
   else thr[0] = dtype == RPE_F64 ? thre_3d * thre_3d : (double)((float)thre_3d * (float)thre_3d);
   thr[1] = cos_thr; thr[2] = cos_nl;
 }

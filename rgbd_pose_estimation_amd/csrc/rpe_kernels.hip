@@ -1606,7 +1606,7 @@ template <class T> struct Hyp<T, false> {
 };
 // exact form: the reference's own operation sequence in Tp, no FMA contraction.
 //   R*x     = Eigen _transformVector (sophus/so3.hpp:238-240): uv = 2 (u x v); v + w uv + u x uv
-//   3D test = |Xc - (R Xw + t)| < thre_3d with norm = sqrt(x^2 + y^2 + z^2)      (AbsoluteOrientation.hpp:137-138)
+//   3D test = |Xc - (R Xw + t)| < thre_3d with norm = sqrt(x^2 + y^2 + z^2)      (AbsoluteOrientation.hpp:137-138), evaluated as x^2 + y^2 + z^2 < cut
 //   2D test = normalize(R Xw + t) . bv > cos_thr, normalisation by division        (:413-418)
 //   N-N     = Nc . (R Nw) > cos_nl                                                  (AbsoluteOrientationNormal.hpp:248-249)
 template <class T> struct Hyp<T, true> {
@@ -1631,12 +1631,15 @@ template <class T> struct Hyp<T, true> {
     const T cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
     ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
   }
-  __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T thr) const {
+  // `cut` = the smallest value whose correctly rounded square root reaches thre_3d (computed on the host, rpe_capi.hip sqrt_cut):
+  // sqrt is monotonic, so  sqrt(s) < thre_3d  <=>  s < cut  for every s -- the reference's test, bit for bit, without the square root
+  // (a third of the instructions of this predicate).  s is formed exactly as Eigen's squaredNorm() forms it.
+  __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T cut) const {
 #pragma clang fp contract(off)
     T rx, ry, rz;
     rot(x, y, z, rx, ry, rz);
     const T ex = cx - (rx + t[0]), ey = cy - (ry + t[1]), ez = cz - (rz + t[2]);
-    return sqrt(ex * ex + ey * ey + ez * ez) < thr;
+    return (ex * ex + ey * ey + ez * ez) < cut;
   }
   __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool use_matrix) const {
 #pragma clang fp contract(off)
