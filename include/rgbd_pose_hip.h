@@ -177,6 +177,9 @@ int rpe_p2p_init(rpe_context* ctx, int world, int rank, const void* handles);
 /* pause = 1 keeps the mailboxes but routes rpe_gn_step_dist / rpe_score through the RCCL communicator (stand-by); 0 resumes. */
 int rpe_p2p_pause(rpe_context* ctx, int pause);
 int rpe_p2p_destroy(rpe_context* ctx);
+/* What the exact scoring kernels compare the SQUARED 3D residual with (dtype RPE_F32: evaluated in float): the smallest value whose
+ * correctly rounded square root reaches thre_3d, so that  sqrt(s) < thre_3d  <=>  s < cut  for every s (test hook; no GPU involved). */
+double rpe_host_sqrt_cut(int dtype, double thre_3d);
 /* Host-side exchange for ONE node (the third way to all-reduce; csrc/rpe_hostex.cpp): on one GPU a reduction's final sum already
  * happens on the host (a few run records per launch, added by the calling thread), so with sharded correspondences every rank's host
  * thread holds its shard's record microseconds after its kernel -- and the rank processes share the node's memory.  The records are

@@ -1194,6 +1194,9 @@ static int nccl_votes_or_clear(rpe_context* c, ncclResult_t r, int count) {
   return fail(RPE_ERR_HIP, "all-reduce of the vote counters: %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
 }
 
+// test hook: the value the exact kernels compare the squared 3D residual with (dtype 0: evaluated in float, 1: in double)
+double rpe_host_sqrt_cut(int dtype, double thre_3d) { return dtype == RPE_F64 ? sqrt_cut<double>(thre_3d) : (double)sqrt_cut<float>((float)thre_3d); }
+
 int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
   int rc = vote_arrays(c, kind);
   if (rc) return rc;

@@ -31,7 +31,7 @@ def _p(a):
 def test_header_symbols_all_exported():
     hdr = open(os.path.join(ROOT, "include", "rgbd_pose_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(?:int|void|const char\*)\s+(\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|void|double|const char\*)\s+(\w+)\s*\(", hdr))
     declared.discard("rpe_status")
     assert {"ao", "ao_ransac", "py2c", "rpe_create", "rpe_normal_eq", "rpe_score", "rpe_run"} <= declared
     out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
@@ -231,3 +231,27 @@ def test_pose7_helper_matches_oracle(oracle):
             assert np.array_equal(api.pose7_from_Rt(R, t, dt), oracle.pose7_from_Rt(R, t, f64))
     R = np.diag([-1.0, -1.0, 1.0])  # trace <= 0 branch
     assert np.array_equal(api.pose7_from_Rt(R, np.zeros(3), L.F64), oracle.pose7_from_Rt(R, np.zeros(3), True))
+
+
+def test_sqrt_cut_is_the_exact_threshold_of_the_rooted_test():
+    """The exact 3D vote is sqrt(s) < thr (Eigen norm(), reference AbsoluteOrientation.hpp:137-138); the kernels evaluate s < cut.
+    numpy's sqrt is the correctly rounded one: the two predicates must agree for every s, in particular in the ulps around the cut."""
+    lib = L.lib()
+    rng = np.random.default_rng(0)
+    for dt, code in ((np.float32, L.F32), (np.float64, L.F64)):
+        thrs = np.concatenate([np.array([0.2, 0.1, 1.0, 3.0, 1e-3, 1e-20, 1e18, 0.05, 2.0 ** -10], dt), rng.uniform(1e-4, 50.0, 300).astype(dt)])
+        for thr in thrs:
+            cut = dt(lib.rpe_host_sqrt_cut(code, float(thr)))
+            s = cut
+            near = [s]
+            for _ in range(40):
+                s = np.nextafter(s, dt(0)); near.append(s)
+            s = cut
+            for _ in range(40):
+                s = np.nextafter(s, dt(np.inf)); near.append(s)
+            near = np.array(near + list(rng.uniform(0, 4 * float(thr) ** 2, 200).astype(dt)) + [dt(0), dt(np.inf), dt(np.nan)], dt)
+            with np.errstate(invalid="ignore"):
+                assert np.array_equal(np.sqrt(near) < thr, near < cut), (dt, thr, cut)
+    # degenerate thresholds: nothing passes for thr <= 0 or NaN; every finite s passes for thr = inf
+    assert lib.rpe_host_sqrt_cut(L.F32, 0.0) == 0.0 and lib.rpe_host_sqrt_cut(L.F32, -1.0) == 0.0
+    assert np.isnan(lib.rpe_host_sqrt_cut(L.F64, float("nan"))) and lib.rpe_host_sqrt_cut(L.F64, float("inf")) == float("inf")
