@@ -1641,6 +1641,43 @@ template <class T> struct Hyp<T, true> {
     const T ex = cx - (rx + t[0]), ey = cy - (ry + t[1]), ez = cz - (rz + t[2]);
     return (ex * ex + ey * ey + ez * ez) < cut;
   }
+  // two correspondences at once as 2-vectors (element-wise IEEE operations in the same order as above: the same bits), so that the
+  // fp32 forms issue as packed v_pk_mul_f32 / v_pk_add_f32 -- half the instructions of the scalar sequence
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ void rot2(V2 x, V2 y, V2 z, V2& ox, V2& oy, V2& oz) const {
+#pragma clang fp contract(off)
+    V2 ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const V2 cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
+  }
+  __device__ __forceinline__ void rotm2(V2 x, V2 y, V2 z, V2& ox, V2& oy, V2& oz) const {   // so3().matrix() * x (kneip_ransac, P3P.hpp:365)
+#pragma clang fp contract(off)
+    ox = M[0] * x + M[1] * y + M[2] * z; oy = M[3] * x + M[4] * y + M[5] * z; oz = M[6] * x + M[7] * y + M[8] * z;
+  }
+  // the 3D and 2D tests of a pair, given the pair's rotated points (one rotation serves both tests, as in the scalar code after CSE)
+  __device__ __forceinline__ void in33_rot_x2(V2 rx, V2 ry, V2 rz, V2 cx, V2 cy, V2 cz, T cut, bool& a, bool& b) const {
+#pragma clang fp contract(off)
+    const V2 ex = cx - (rx + t[0]), ey = cy - (ry + t[1]), ez = cz - (rz + t[2]);
+    const V2 ss = ex * ex + ey * ey + ez * ez;
+    a = ss.x < cut; b = ss.y < cut;
+  }
+  __device__ __forceinline__ void in23_rot_x2(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b) const {
+#pragma clang fp contract(off)
+    V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+    const V2 n2 = px * px + py * py + pz * pz;
+    const V2 len = {sqrt(n2.x), sqrt(n2.y)};
+    px = px / len; py = py / len; pz = pz / len;
+    const V2 d = px * bx + py * by + pz * bz;
+    a = d.x > c; b = d.y > c;
+  }
+  __device__ __forceinline__ void innnx2(V2 nwx, V2 nwy, V2 nwz, V2 ncx, V2 ncy, V2 ncz, T cnl, bool& a, bool& b) const {
+#pragma clang fp contract(off)
+    V2 rx, ry, rz;
+    rot2(nwx, nwy, nwz, rx, ry, rz);
+    const V2 d = ncx * rx + ncy * ry + ncz * rz;
+    a = d.x > cnl; b = d.y > cnl;
+  }
   __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool use_matrix) const {
 #pragma clang fp contract(off)
     T rx, ry, rz;
@@ -1661,6 +1698,66 @@ template <class T> struct Hyp<T, true> {
     return (ncx * rx + ncy * ry + ncz * rz) > cnl;
   }
 };
+
+// votes of ONE hypothesis over one group of P correspondences, summed over the wave (every lane gets the wave's count).  Predicates are
+// evaluated unconditionally and masked with '&': no divergent branches; the compare IS the ballot.  EXACT: the 3D and normal tests run
+// on pairs of correspondences as 2-vectors (packed fp32 instructions), the 2D test (a square root and three divisions) stays scalar.
+template <class T, int KIND, bool EXACT>
+__device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
+                                                 const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
+                                                 const bool (&present)[Pk<T>::P], const bool (&valid)[Pk<T>::P], T thr33, T cthr, T cnl) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  int cnt = 0;
+  if constexpr (EXACT) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    static_assert(P % 2 == 0, "pairs");
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+      const int a = 2 * j, b = 2 * j + 1;
+      const V2 x = {vw[3 * a], vw[3 * b]}, y = {vw[3 * a + 1], vw[3 * b + 1]}, z = {vw[3 * a + 2], vw[3 * b + 2]};
+      if (MD::mnn) {
+        const V2 nwx = {vnw[3 * a], vnw[3 * b]}, nwy = {vnw[3 * a + 1], vnw[3 * b + 1]}, nwz = {vnw[3 * a + 2], vnw[3 * b + 2]};
+        const V2 ncx = {vnc[3 * a], vnc[3 * b]}, ncy = {vnc[3 * a + 1], vnc[3 * b + 1]}, ncz = {vnc[3 * a + 2], vnc[3 * b + 2]};
+        bool va, vb2;
+        hyp.innnx2(nwx, nwy, nwz, ncx, ncy, ncz, cnl, va, vb2);
+        cnt += __popcll(__ballot(valid[a] & va)) + __popcll(__ballot(valid[b] & vb2));
+      }
+      V2 rx, ry, rz;
+      if (KIND == VOTE_23_MATRIX) hyp.rotm2(x, y, z, rx, ry, rz); else hyp.rot2(x, y, z, rx, ry, rz);
+      if (MD::m33) {
+        const V2 cx = {vc[3 * a], vc[3 * b]}, cy = {vc[3 * a + 1], vc[3 * b + 1]}, cz = {vc[3 * a + 2], vc[3 * b + 2]};
+        bool va, vb2;
+        hyp.in33_rot_x2(rx, ry, rz, cx, cy, cz, thr33, va, vb2);
+        cnt += __popcll(__ballot(valid[a] & va)) + __popcll(__ballot(valid[b] & vb2));
+      }
+      if (MD::m23) {
+        const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
+        bool va, vb2;
+        hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, va, vb2);
+        cnt += __popcll(__ballot(present[a] & va)) + __popcll(__ballot(present[b] & vb2));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      if (MD::mnn) {
+        const bool v = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
+        cnt += __popcll(__ballot(v));
+      }
+      if (MD::m33) {
+        const bool v = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
+        cnt += __popcll(__ballot(v));
+      }
+      if (MD::m23) {
+        const bool v = present[i] & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
+        cnt += __popcll(__ballot(v));
+      }
+    }
+  }
+  return cnt;
+}
 
 // grid = (x: correspondence tiles, grid-stride) x (y: chunks of `hchunk` hypotheses).  Small problems (640x480 frames)
 // cannot fill 256 CUs with one tile sweep, so the hypothesis list is split across blockIdx.y and the (L2-resident)
@@ -1700,23 +1797,7 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
       for (int hl = 0; hl < hmax; hl++) {
         Hyp<T, EXACT> hyp;
         hyp.load(poses + (size_t)(hbeg + h0 + hl) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < P; i++) {  // predicates are evaluated unconditionally and masked with '&': no divergent branches
-          const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-          if (MD::mnn) {
-            const bool v = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
-            cnt += __popcll(__ballot(v));
-          }
-          if (MD::m33) {
-            const bool v = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
-            cnt += __popcll(__ballot(v));
-          }
-          if (MD::m23) {
-            const bool v = present[i] & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
-            cnt += __popcll(__ballot(v));
-          }
-        }
+        const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
         mine += (lane == hl) ? cnt : 0;
       }
       if (lane < hmax && mine != 0) atomicAdd(&lds_votes[h0 + lane], mine);
@@ -1768,23 +1849,7 @@ __global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict
       Hyp<T, EXACT> hyp;
       if (dposes) hyp.load(dposes + (size_t)hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);   // a list generated on the device
       else hyp.load(sp.v + hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
-      int cnt = 0;
-#pragma unroll
-      for (int i = 0; i < P; i++) {
-        const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-        if (MD::mnn) {
-          const bool v = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
-          cnt += __popcll(__ballot(v));
-        }
-        if (MD::m33) {
-          const bool v = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
-          cnt += __popcll(__ballot(v));
-        }
-        if (MD::m23) {
-          const bool v = present[i] & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
-          cnt += __popcll(__ballot(v));
-        }
-      }
+      const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
       mine += (lane == hl) ? cnt : 0;
     }
   }
