@@ -32,3 +32,7 @@ def test_committed_bench_line_matches_the_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and "sample" in c
     e = j["pose_error_vs_cpu"]
     assert e["rot_rad"] <= e["tolerance"]["rot_rad"] == 1e-5 and e["trans_rel"] <= e["tolerance"]["trans_rel"] == 1e-4
+    cv = j["convergence"]                                      # iterations to |delta| < 1e-9
+    for name in ("all_points", "inliers_only"):
+        assert 1 <= cv[name]["iterations"] < 50 and cv[name]["last_step"] < 1e-9
+        assert cv[name]["rot_rad_vs_cpu_closed_form"] <= 1e-5 and cv[name]["trans_rel_vs_cpu_closed_form"] <= 1e-4
