@@ -1486,9 +1486,10 @@ int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double 
   HIP_TRY(hipSetDevice(c->device));
   if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
   if ((rc = associate_launch(c, pose12, dist_thr, cos_thr, use_normals, false, matched != nullptr))) return rc;
-  if (matched) {
-    HIP_TRY(hipMemcpyAsync(c->h_votes, c->fe.d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+  if (matched) {   // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counter into pinned host memory and raises a sequence word
+    const unsigned long long seq = ++c->vote_seq;
+    HIP_TRY(rpe::launch_publish_i32(c->fe.d_count, 1, c->h_votes, c->h_flag2, seq, c->stream));
+    if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
     *matched = c->h_votes[0];
   }
   return RPE_OK;
