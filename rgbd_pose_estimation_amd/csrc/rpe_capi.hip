@@ -183,11 +183,8 @@ int ensure_mask(rpe_context* c, int mod, bool fill_ones) {
     c->mask_cap[mod] = need;
   }
   c->mask[mod] = c->mask_store[mod];
-  if (fill_ones && c->n) {  // adapters start with all-ones masks (e.g. AOPoseAdapter.hpp:103-106)
-    std::vector<short> ones((size_t)c->n, 1);
-    HIP_TRY(hipMemcpyAsync(c->mask[mod], ones.data(), need, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  }
+  if (fill_ones && c->n)   // adapters start with all-ones masks (e.g. AOPoseAdapter.hpp:103-106): filled on the device, in stream order
+    HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)c->mask[mod], (unsigned short)1, (size_t)c->n, c->stream));
   return RPE_OK;
 }
 
