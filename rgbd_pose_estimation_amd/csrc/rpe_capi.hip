@@ -1274,6 +1274,36 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
   return RPE_OK;
 }
 
+// Device-side generation + scoring of one batch of iterations of the P3P solvers, FAST scoring mode (tolerance parity with the host's
+// hypotheses, not bit parity): solver 0 = kneip_ransac (1 slot per iteration), 1 = shinji_kneip_ransac (2 slots: 3-point fit, P3P)
+int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr, int* votes_out,
+                         double* q7_out, unsigned char* valid_out) {
+  if (solver != 0 && solver != 1) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: solver must be 0 (kneip) or 1 (shinji + kneip)");
+  int rc = solver == 1 ? need_arrays(c, {RPE_XW, RPE_XC, RPE_BV}) : need_arrays(c, {RPE_XW, RPE_BV});
+  if (rc) return rc;
+  const int per = solver == 1 ? 2 : 1;
+  if (!votes_out || !q7_out || !valid_out || iters < 1 || (int64_t)iters * per > rpe::kMaxScoreH)
+    return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: bad argument (1 <= iters x slots <= %d)", rpe::kMaxScoreH);
+  if (c->n < 4) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: fewer than 4 correspondences");
+  if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1 || c->hostex)   // as rpe_ransac33_batch: the generator samples the local shard
+    return fail(RPE_ERR_STATE, "rpe_ransac_p3p_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
+  HIP_TRY(hipSetDevice(c->device));
+  const int slots = iters * per, kind = solver == 1 ? RPE_VOTE_33_23 : RPE_VOTE_23;
+  double thr[3];
+  stage_thresholds(c->dtype, /*exact=*/0, thre_3d, cos_thr, 2.0, thr);
+  HIP_TRY(rpe::launch_gen_p3p(c->arrays(), solver, rng_state, rng_inc, iters, c->d_poses, c->h_poses, c->stream));
+  HIP_TRY(rpe::launch_score(c->arrays(), kind, 0, c->d_poses, slots, thr, c->d_votes, c->score_blocks, c->stream));
+  const unsigned long long seq = ++c->vote_seq;
+  if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, slots, c->h_votes, c->h_flag2, seq, c->stream), slots))) return rc;
+  if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
+  std::memcpy(votes_out, c->h_votes, (size_t)slots * sizeof(int));
+  for (int i = 0; i < slots; i++) {
+    if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }
+    else { const float* h = (const float*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0f; }
+  }
+  return RPE_OK;
+}
+
 int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
   int rc = vote_arrays(c, kind);
   if (rc) return rc;

@@ -112,6 +112,12 @@ hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned 
 hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
                              void* h_q7, hipStream_t s);
 
+// FAST-mode generator of the P3P solvers (tolerance parity): solver 0 = kneip_ransac (1 slot per iteration), 1 = shinji_kneip_ransac
+// (2 slots per iteration: 3-point fit, then P3P); same sample stream as the host (4 draws per iteration); d_poses in the FAST scoring
+// layout (12 values per slot), h_q7 pinned, 8 values per slot (qw qx qy qz tx ty tz valid)
+hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters, void* d_poses, void* h_q7,
+                          hipStream_t s);
+
 // ---- PROSAC order (rpe_prosac.hip): the first top_k (<= kProsacMaxTopK) positions of "indices by weight descending, ties to the lower
 // index" for n float weights in HBM.  d_hist: 2048 uints, zero on entry and on exit; d_ctl: 8 uints; d_cand: kProsacSortCap keys;
 // d_status: 0 ok, 1 = more candidates than the LDS sort holds (heavy ties around the cut): use the host order.

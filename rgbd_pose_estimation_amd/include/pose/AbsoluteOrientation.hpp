@@ -169,7 +169,11 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
     { PnPPoseAdapter<Tp>* p23 = &adapter; p23->forgetInlierIdx(); adapter.forgetInlierIdx(); }  // both are requested again below
     adapter.setInlierFromDevice(cols, device_cols);
   };
-  ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+  const Settings& cfg = Settings::get();
+  if (!prosac && cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/1, gen, commit, Iter, confidence, /*mask_cols=*/2);   // FAST mode: later batches generated on the device
+  else
+    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   PnPPoseAdapter<Tp>* pAdapter = &adapter;
   pAdapter->cvtInlier();
   adapter.cvtInlier();

@@ -202,7 +202,13 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
     if (arg >= 0) out.push_back(sols[arg]);
   };
   auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
-  ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/1);
+  // plain RANSAC in FAST scoring mode: batches beyond the first few are generated on the device too (4 draws per iteration: every
+  // iteration's position in the random stream is known up front)
+  const Settings& cfg = Settings::get();
+  if (!prosac && cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K && !cfg.capture && !cfg.replay)
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/0, gen, commit, Iter, confidence, /*mask_cols=*/1);
+  else
+    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/1);
   adapter.cvtInlier();
 }
 }  // namespace rpe

@@ -204,6 +204,57 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
   ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
 }
 
+// The P3P solvers in FAST scoring mode (kneip_ransac: solver 0, shinji_kneip_ransac: solver 1): batches beyond the first few are
+// generated AND scored on the device (rpe_ransac_p3p_batch; one slot per hypothesis an iteration can yield, invalid slots skipped in the
+// replay).  The device P3P agrees with the host's to rounding only, which is why the vote-exact default never takes this path.
+template <class Tp, class Adapter, class Gen, class Commit>
+void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int solver, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+  constexpr int kHostBatch = 32;
+  Settings& cfg = Settings::get();
+  rpe_context* ctx = adapter.device().ctx();
+  const int per = solver == 1 ? 2 : 1;
+  std::vector<double> q7;
+  std::vector<unsigned char> valid;
+  std::vector<int> all_votes;
+  auto produce = [&](int iters, std::vector<SE3<Tp> >& hyps, std::vector<int>& first, std::vector<int>& votes) {
+    first.assign(1, 0);
+    if (iters <= kHostBatch) {
+      const double t0 = cfg.profile ? now_us() : 0;
+      for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
+      if (cfg.profile) { const double t1 = now_us(); cfg.prof.generate += t1 - t0; cfg.prof.score -= t1 - t0; }
+      if (hyps.empty()) return;
+      q7.resize(hyps.size() * 7);
+      for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
+      votes.resize(hyps.size());
+      check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+                      (double)spec.cos_nl, votes.data()), "rpe_score");
+      return;
+    }
+    Rand31& g = global_rng();
+    const size_t slots = (size_t)iters * per;
+    q7.resize(slots * 7); valid.resize(slots); all_votes.resize(slots);
+    for (int done = 0; done < iters;) {
+      const int chunk = std::min(iters - done, 8192 / per);
+      check(rpe_ransac_p3p_batch(ctx, solver, g.state(), g.inc(), chunk, (double)spec.thre_3d, (double)spec.cos_thr, all_votes.data() + (size_t)done * per,
+                                 q7.data() + 7 * (size_t)done * per, valid.data() + (size_t)done * per), "rpe_ransac_p3p_batch");
+      g.advance(4ull * (uint64_t)chunk);   // the host sampler draws 4 per iteration
+      done += chunk;
+    }
+    for (int i = 0; i < iters; i++) {
+      for (int k = 0; k < per; k++) {
+        const size_t sl = (size_t)i * per + k;
+        if (valid[sl]) {
+          const double* q = &q7[7 * sl];
+          hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]), Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
+          votes.push_back(all_votes[sl]);
+        }
+      }
+      first.push_back((int)hyps.size());
+    }
+  };
+  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
+}
+
 }  // namespace rpe
 
 #endif
