@@ -253,13 +253,14 @@ int rpe_score(rpe_context* ctx, int kind, int mode, const double* poses7, int H,
  * sample hit an invalid (all-NaN) camera point and the reference skips the iteration.  The caller advances its stream by 3*iters. */
 int rpe_ransac33_batch(rpe_context* ctx, uint64_t rng_state, uint64_t rng_inc, int iters, int mode, double thre_3d, int* votes_out,
                        double* q7_out, unsigned char* valid_out);
-/* The same for the P3P solvers, FAST scoring mode only (the device P3P agrees with the host's to rounding, not bit
- * for bit -- the vote-exact default keeps the host generators): solver 0 = kneip_ransac (one slot per iteration: the P3P branch that
- * best reprojects the 4th sample), 1 = shinji_kneip_ransac (two slots per iteration: 3-point fit, then P3P).  The sample of iteration
- * i is the host sampler's (4 draws per iteration from (rng_state, rng_inc)).  votes_out / valid_out: iters x slots, q7_out: x 7.
- * cos_thr = cos(atan(thre_2d / f)). */
+/* The same for the plain-RANSAC solvers with a 4-point sample, FAST scoring mode only (the device solvers agree with
+ * the host's to rounding, not bit for bit -- the vote-exact default keeps the host generators).  solver: 0 = kneip_ransac (one slot
+ * per iteration: the P3P branch that best reprojects the 4th sample), 1 = shinji_kneip_ransac (3-point fit, P3P), 2 = nl_kneip_ransac
+ * (P3P), 3 = nl_shinji_ransac (3-point fit, nl_2p), 4 = nl_shinji_kneip_ransac (3-point fit, P3P, nl_2p).  The sample of iteration i is
+ * the host sampler's (4 draws per iteration from (rng_state, rng_inc)).  votes_out / valid_out: iters x slots, q7_out: x 7.
+ * cos_thr = cos(atan(thre_2d / f)), cos_nl = cos(nl_thre). */
 int rpe_ransac_p3p_batch(rpe_context* ctx, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr,
-                         int* votes_out, double* q7_out, unsigned char* valid_out);
+                         double cos_nl, int* votes_out, double* q7_out, unsigned char* valid_out);
 /* K4b: write the winner's inlier masks into the context's device masks (all modalities of `kind`; others
  * untouched) -- what setInlier() stores; returns the vote total. */
 int rpe_inlier_mask(rpe_context* ctx, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,

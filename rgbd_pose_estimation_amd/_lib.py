@@ -141,7 +141,7 @@ def lib():
         L.rpe_timing_calibrate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rpe_score.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.rpe_ransac33_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rpe_ransac_p3p_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpe_ransac_p3p_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_inlier_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.rpe_prosac_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.rpe_nl_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

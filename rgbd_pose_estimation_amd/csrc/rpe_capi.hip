@@ -1274,23 +1274,27 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
   return RPE_OK;
 }
 
-// Device-side generation + scoring of one batch of iterations of the P3P solvers, FAST scoring mode (tolerance parity with the host's
-// hypotheses, not bit parity): solver 0 = kneip_ransac (1 slot per iteration), 1 = shinji_kneip_ransac (2 slots: 3-point fit, P3P)
-int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr, int* votes_out,
-                         double* q7_out, unsigned char* valid_out) {
-  if (solver != 0 && solver != 1) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: solver must be 0 (kneip) or 1 (shinji + kneip)");
-  int rc = solver == 1 ? need_arrays(c, {RPE_XW, RPE_XC, RPE_BV}) : need_arrays(c, {RPE_XW, RPE_BV});
+// Device-side generation + scoring of one batch of iterations of a plain-RANSAC solver with a 4-point sample, FAST scoring mode
+// (tolerance parity with the host's hypotheses, not bit parity): solver 0 = kneip_ransac, 1 = shinji_kneip_ransac, 2 = nl_kneip_ransac,
+// 3 = nl_shinji_ransac, 4 = nl_shinji_kneip_ransac (slots per iteration: 1, 2, 1, 2, 3)
+int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr, double cos_nl,
+                         int* votes_out, double* q7_out, unsigned char* valid_out) {
+  const int per = rpe::gen_p3p_slots(solver);
+  if (per == 0) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: solver must be 0 .. 4");
+  static const int kinds[5] = {RPE_VOTE_23, RPE_VOTE_33_23, RPE_VOTE_NN_23, RPE_VOTE_NN_33, RPE_VOTE_NN_33_23};
+  const int kind = kinds[solver];
+  int rc = vote_arrays(c, kind);
   if (rc) return rc;
-  const int per = solver == 1 ? 2 : 1;
+  if (solver == 3 && (rc = need_arrays(c, {RPE_XW, RPE_XC, RPE_NW, RPE_NC}))) return rc;
   if (!votes_out || !q7_out || !valid_out || iters < 1 || (int64_t)iters * per > rpe::kMaxScoreH)
     return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: bad argument (1 <= iters x slots <= %d)", rpe::kMaxScoreH);
   if (c->n < 4) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: fewer than 4 correspondences");
   if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1 || c->hostex)   // as rpe_ransac33_batch: the generator samples the local shard
     return fail(RPE_ERR_STATE, "rpe_ransac_p3p_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
   HIP_TRY(hipSetDevice(c->device));
-  const int slots = iters * per, kind = solver == 1 ? RPE_VOTE_33_23 : RPE_VOTE_23;
+  const int slots = iters * per;
   double thr[3];
-  stage_thresholds(c->dtype, /*exact=*/0, thre_3d, cos_thr, 2.0, thr);
+  stage_thresholds(c->dtype, /*exact=*/0, thre_3d, cos_thr, cos_nl, thr);
   HIP_TRY(rpe::launch_gen_p3p(c->arrays(), solver, rng_state, rng_inc, iters, c->d_poses, c->h_poses, c->stream));
   HIP_TRY(rpe::launch_score(c->arrays(), kind, 0, c->d_poses, slots, thr, c->d_votes, c->score_blocks, c->stream));
   const unsigned long long seq = ++c->vote_seq;

@@ -216,13 +216,47 @@ __device__ inline int kneip_dev(const V3d Pw[3], const V3d bv[3], double rot_eps
   return count;
 }
 
-// One thread per RANSAC iteration of kneip_ransac (solver 0: one slot per iteration) or shinji_kneip_ransac (solver 1: two slots per
-// iteration, the 3-point fit first, then P3P -- the order in which the reference scores them, AbsoluteOrientation.hpp:397).  The
-// sample is the host sampler's (4 draws per iteration from the same PCG32 stream); the P3P branch is the one that best reprojects the
-// 4th correspondence (P3P.hpp:250-294 / :341-360).  Poses go to HBM in the FAST scoring layout and, as quaternion + translation +
-// valid flag, to pinned host memory for the replay.
+// rotation by `angle` about the unit `axis` (Rodrigues), row-major
+__device__ inline void angle_axis(double angle, V3d k, double R[9]) {
+  const double c = cos(angle), s = sin(angle), v = 1.0 - c;
+  R[0] = c + k.x * k.x * v;       R[1] = k.x * k.y * v - k.z * s; R[2] = k.x * k.z * v + k.y * s;
+  R[3] = k.y * k.x * v + k.z * s; R[4] = c + k.y * k.y * v;       R[5] = k.y * k.z * v - k.x * s;
+  R[6] = k.z * k.x * v - k.y * s; R[7] = k.z * k.y * v + k.x * s; R[8] = c + k.z * k.z * v;
+}
+// the 2-point + normal solver (pose/AbsoluteOrientationNormal.hpp:77-142): align the normals with the x axis in both frames, then the
+// in-plane directions of the second point (the unsigned angle the reference takes, acos of their dot product)
+__device__ inline void nl_2p_dev(V3d pt1_c, V3d nl1_c, V3d pt2_c, V3d pt1_w, V3d nl1_w, V3d pt2_w, double R[9], double t[3]) {
+  auto to_x_axis = [](V3d nv, double Rx[9]) {
+    V3d axis{0.0, nv.z, -nv.y};
+    axis = (1.0 / norm(axis)) * axis;
+    angle_axis(acos(nv.x), axis, Rx);
+  };
+  double Rw[9], Rc[9], Rp[9];
+  to_x_axis(nl1_w, Rw);
+  to_x_axis(nl1_c, Rc);
+  auto apply = [](const double M[9], V3d v) { return V3d{M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z}; };
+  V3d a = apply(Rw, pt2_w - pt1_w); a.x = 0.0; a = (1.0 / norm(a)) * a;
+  V3d b = apply(Rc, pt2_c - pt1_c); b.x = 0.0; b = (1.0 / norm(b)) * b;
+  angle_axis(acos(dot(a, b)), V3d{1.0, 0.0, 0.0}, Rp);
+  const double RcT[9] = {Rc[0], Rc[3], Rc[6], Rc[1], Rc[4], Rc[7], Rc[2], Rc[5], Rc[8]};
+  double PW[9];
+  mat3_mul(Rp, Rw, PW);
+  mat3_mul(RcT, PW, R);
+  const V3d rp = apply(R, pt1_w);
+  t[0] = pt1_c.x - rp.x; t[1] = pt1_c.y - rp.y; t[2] = pt1_c.z - rp.z;
+}
+
+// One thread per RANSAC iteration of a plain-RANSAC solver with a 4-point sample.  Slots per iteration, in the order in which the
+// reference scores an iteration's hypotheses:
+//   solver 0 kneip_ransac: P3P | 1 shinji_kneip_ransac: 3-point fit, P3P | 2 nl_kneip_ransac: P3P | 3 nl_shinji_ransac: 3-point fit,
+//   nl_2p | 4 nl_shinji_kneip_ransac: 3-point fit, P3P, nl_2p.
+// The sample is the host sampler's (4 draws per iteration from the same PCG32 stream); the P3P branch is the one that best reprojects
+// the 4th correspondence (P3P.hpp:250-294 / :341-360); nl_2p runs on whatever the first two sampled columns hold, valid or not, and
+// always yields a hypothesis (as the reference, AbsoluteOrientationNormal.hpp:315,389).  Poses go to HBM in the FAST scoring layout
+// and, as quaternion + translation + valid flag, to pinned host memory for the replay.
 template <class T>
-__global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bvp, int n, int solver,
+__global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bvp,
+                                                     const T* __restrict__ nwp, const T* __restrict__ ncp, int n, int solver,
                                                      unsigned long long state, unsigned long long inc, int iters, T* __restrict__ out_pose,
                                                      T* __restrict__ h_q7) {
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -240,7 +274,9 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
     set(top, vp);
     sel[s] = vp;
   }
-  const int slots = solver == 1 ? 2 : 1;
+  const bool has_fit = solver == 1 || solver == 3 || solver == 4, has_p3p = solver != 3, has_nl = solver == 3 || solver == 4;
+  const int slots = (has_fit ? 1 : 0) + (has_p3p ? 1 : 0) + (has_nl ? 1 : 0);
+  int slot_next = 0;
   auto put = [&](int slot, const double R[9], const double t[3], bool valid) {
     const size_t o = (size_t)slots * i + slot;
     T* op = out_pose + 12 * o;
@@ -253,7 +289,7 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
     hq[0] = q.w; hq[1] = q.x; hq[2] = q.y; hq[3] = q.z; hq[4] = (T)t[0]; hq[5] = (T)t[1]; hq[6] = (T)t[2]; hq[7] = valid ? T(1) : T(0);
   };
   const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
-  if (solver == 1) {   // the 3-point closed form on the first three correspondences (needs valid camera points)
+  if (has_fit) {   // the 3-point closed form on the first three correspondences (needs valid camera points)
     T X_w[9], X_c[9];
     bool valid = true;
     for (int s = 0; s < 3; s++) {
@@ -268,13 +304,13 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
     const Quat<double> qd{(double)q[0], (double)q[1], (double)q[2], (double)q[3]};
     quat_to_R<double>(qd, Rd);
     const double td[3] = {(double)t[0], (double)t[1], (double)t[2]};
-    put(0, Rd, td, valid);
+    put(slot_next++, Rd, td, valid);
   }
-  V3d Pw[4], bv[4];
-  for (int s = 0; s < 4; s++) {
-    Pw[s] = V3d{(double)xw[3 * (size_t)sel[s]], (double)xw[3 * (size_t)sel[s] + 1], (double)xw[3 * (size_t)sel[s] + 2]};
-    bv[s] = V3d{(double)bvp[3 * (size_t)sel[s]], (double)bvp[3 * (size_t)sel[s] + 1], (double)bvp[3 * (size_t)sel[s] + 2]};
-  }
+  V3d Pw[4];
+  for (int s = 0; s < 4; s++) Pw[s] = V3d{(double)xw[3 * (size_t)sel[s]], (double)xw[3 * (size_t)sel[s] + 1], (double)xw[3 * (size_t)sel[s] + 2]};
+  if (has_p3p) {
+  V3d bv[4];
+  for (int s = 0; s < 4; s++) bv[s] = V3d{(double)bvp[3 * (size_t)sel[s]], (double)bvp[3 * (size_t)sel[s] + 1], (double)bvp[3 * (size_t)sel[s] + 2]};
   double Rs[4][9], ts[4][3];
   const int found = kneip_dev(Pw, bv, (double)Eps<T>::value(), Rs, ts);
   double best = 1e300;
@@ -286,20 +322,30 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
     const double score = 1.0 - dot(pc, bv[3]);
     if (score < best) { best = score; arg = k; }
   }
-  if (arg >= 0) put(slots - 1, Rs[arg], ts[arg], true);
-  else put(slots - 1, I9, z3, false);
+  if (arg >= 0) put(slot_next++, Rs[arg], ts[arg], true);
+  else put(slot_next++, I9, z3, false);
+  }
+  if (has_nl) {
+    auto col = [&](const T* a, int s) { return V3d{(double)a[3 * (size_t)sel[s]], (double)a[3 * (size_t)sel[s] + 1], (double)a[3 * (size_t)sel[s] + 2]}; };
+    double R[9], t[3];
+    nl_2p_dev(col(xc, 0), col(ncp, 0), col(xc, 1), Pw[0], col(nwp, 0), Pw[1], R, t);
+    put(slot_next++, R, t, true);   // a degenerate sample gives a NaN pose, which scores no votes -- it still counts as a hypothesis
+  }
 }
 
 }  // namespace
 
-// solver 0 = kneip_ransac (1 slot per iteration), 1 = shinji_kneip_ransac (2 slots per iteration: 3-point fit, P3P).  FAST scoring layout.
+// slots per iteration of a solver (0 kneip, 1 shinji + kneip, 2 nl_kneip, 3 nl_shinji, 4 nl_shinji_kneip); 0 for an unknown solver
+int gen_p3p_slots(int solver) {
+  switch (solver) { case 0: case 2: return 1; case 1: case 3: return 2; case 4: return 3; default: return 0; }
+}
 hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters, void* d_poses, void* h_q7,
                           hipStream_t s) {
   if (iters < 1) return hipSuccess;
-  if (solver != 0 && solver != 1) return hipErrorInvalidValue;
+  if (gen_p3p_slots(solver) == 0) return hipErrorInvalidValue;
   const int G = (iters + 63) / 64;
-  if (A.dtype) hipLaunchKernelGGL(gen_p3p_kernel<double>, dim3(G), dim3(64), 0, s, (const double*)A.a[0], (const double*)A.a[1], (const double*)A.a[2], (int)A.n, solver, state, inc, iters, (double*)d_poses, (double*)h_q7);
-  else hipLaunchKernelGGL(gen_p3p_kernel<float>, dim3(G), dim3(64), 0, s, (const float*)A.a[0], (const float*)A.a[1], (const float*)A.a[2], (int)A.n, solver, state, inc, iters, (float*)d_poses, (float*)h_q7);
+  if (A.dtype) hipLaunchKernelGGL(gen_p3p_kernel<double>, dim3(G), dim3(64), 0, s, (const double*)A.a[0], (const double*)A.a[1], (const double*)A.a[2], (const double*)A.a[3], (const double*)A.a[4], (int)A.n, solver, state, inc, iters, (double*)d_poses, (double*)h_q7);
+  else hipLaunchKernelGGL(gen_p3p_kernel<float>, dim3(G), dim3(64), 0, s, (const float*)A.a[0], (const float*)A.a[1], (const float*)A.a[2], (const float*)A.a[3], (const float*)A.a[4], (int)A.n, solver, state, inc, iters, (float*)d_poses, (float*)h_q7);
   return hipGetLastError();
 }
 

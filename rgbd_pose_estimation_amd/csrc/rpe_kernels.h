@@ -112,9 +112,11 @@ hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned 
 hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
                              void* h_q7, hipStream_t s);
 
-// FAST-mode generator of the P3P solvers (tolerance parity): solver 0 = kneip_ransac (1 slot per iteration), 1 = shinji_kneip_ransac
-// (2 slots per iteration: 3-point fit, then P3P); same sample stream as the host (4 draws per iteration); d_poses in the FAST scoring
-// layout (12 values per slot), h_q7 pinned, 8 values per slot (qw qx qy qz tx ty tz valid)
+// FAST-mode generator of the plain-RANSAC solvers with a 4-point sample (tolerance parity): solver 0 = kneip_ransac (P3P), 1 =
+// shinji_kneip_ransac (3-point fit, P3P), 2 = nl_kneip_ransac (P3P), 3 = nl_shinji_ransac (3-point fit, nl_2p), 4 =
+// nl_shinji_kneip_ransac (3-point fit, P3P, nl_2p): gen_p3p_slots(solver) slots per iteration; same sample stream as the host (4 draws
+// per iteration); d_poses in the FAST scoring layout (12 values per slot), h_q7 pinned, 8 values per slot (qw qx qy qz tx ty tz valid)
+int gen_p3p_slots(int solver);
 hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters, void* d_poses, void* h_q7,
                           hipStream_t s);
 

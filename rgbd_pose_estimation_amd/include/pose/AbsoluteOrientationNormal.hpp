@@ -145,7 +145,11 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
     adapter.forgetInlierIdx();
     adapter.setInlierFromDevice(cols, device_cols);
   };
-  ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/3);
+  const Settings& cfg = Settings::get();
+  if (cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/2 + which, gen, commit, Iter, confidence, /*mask_cols=*/3);   // FAST mode: later batches generated on the device
+  else
+    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/3);
   if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->cvtInlier(); }
   if (which != 0) { AOPoseAdapter<Tp>* p = &adapter; p->cvtInlier(); }
   adapter.cvtInlier();

@@ -204,15 +204,16 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
   ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
 }
 
-// The P3P solvers in FAST scoring mode (kneip_ransac: solver 0, shinji_kneip_ransac: solver 1): batches beyond the first few are
-// generated AND scored on the device (rpe_ransac_p3p_batch; one slot per hypothesis an iteration can yield, invalid slots skipped in the
-// replay).  The device P3P agrees with the host's to rounding only, which is why the vote-exact default never takes this path.
+// The plain-RANSAC solvers with a 4-point sample in FAST scoring mode (solver 0 kneip_ransac, 1 shinji_kneip_ransac, 2 nl_kneip_ransac,
+// 3 nl_shinji_ransac, 4 nl_shinji_kneip_ransac): batches beyond the first few are generated AND scored on the device
+// (rpe_ransac_p3p_batch; one slot per hypothesis an iteration can yield, invalid slots skipped in the replay).  The device P3P agrees with the host's to rounding only, which is why the vote-exact default never takes this path.
 template <class Tp, class Adapter, class Gen, class Commit>
 void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int solver, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
   constexpr int kHostBatch = 32;
   Settings& cfg = Settings::get();
   rpe_context* ctx = adapter.device().ctx();
-  const int per = solver == 1 ? 2 : 1;
+  static const int kSlots[5] = {1, 2, 1, 2, 3};
+  const int per = kSlots[solver];
   std::vector<double> q7;
   std::vector<unsigned char> valid;
   std::vector<int> all_votes;
@@ -235,7 +236,7 @@ void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int so
     q7.resize(slots * 7); valid.resize(slots); all_votes.resize(slots);
     for (int done = 0; done < iters;) {
       const int chunk = std::min(iters - done, 8192 / per);
-      check(rpe_ransac_p3p_batch(ctx, solver, g.state(), g.inc(), chunk, (double)spec.thre_3d, (double)spec.cos_thr, all_votes.data() + (size_t)done * per,
+      check(rpe_ransac_p3p_batch(ctx, solver, g.state(), g.inc(), chunk, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, all_votes.data() + (size_t)done * per,
                                  q7.data() + 7 * (size_t)done * per, valid.data() + (size_t)done * per), "rpe_ransac_p3p_batch");
       g.advance(4ull * (uint64_t)chunk);   // the host sampler draws 4 per iteration
       done += chunk;

@@ -34,19 +34,24 @@ def rot_from_q(q):
 
 
 @pytest.mark.parametrize("f64", [False, True])
-@pytest.mark.parametrize("solver,method", [(0, api.M_KNEIP_RANSAC), (1, api.M_SK_RANSAC)])
+@pytest.mark.parametrize("solver,method", [(0, api.M_KNEIP_RANSAC), (1, api.M_SK_RANSAC), (2, api.M_NL_KNEIP_RANSAC), (3, api.M_NL_SHINJI_RANSAC),
+                                           (4, api.M_NL_SK_RANSAC)])
 def test_device_p3p_hypotheses_follow_the_host_stream(gpu_ctx_factory, solver, method, f64):
     n, iters, seed = 5000, 400, 7
     dt = np.float64 if f64 else np.float32
-    sc = util.scene_full(31, n, dt, n2d=2.0, n3d=0.01, outliers=0.2, nan_frac=0.05)
-    keys = dict(xw=sc.Q, xc=sc.P, bv=sc.U) if solver == 1 else dict(xw=sc.Q, bv=sc.U)
+    # (no invalid camera points here: on a sample that hits one the reference's nl_2p reuses whatever the previous iteration left in its
+    # sample matrices, AbsoluteOrientationNormal.hpp:315,389 -- a junk hypothesis either way, but not the same junk)
+    sc = util.scene_full(31, n, dt, n2d=2.0, n3d=0.01, nnl_deg=0.5, outliers=0.2, nan_frac=0.05 if solver < 2 else 0.0)
+    full = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    keys = {0: dict(xw=sc.Q, bv=sc.U), 1: dict(xw=sc.Q, xc=sc.P, bv=sc.U), 2: full, 3: full, 4: full}[solver]
     hq7, hfirst = api.host_hypotheses(method, L.F64 if f64 else L.F32, iters=iters, seed=seed, **keys)
     ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, **keys)
-    per = 2 if solver == 1 else 1
+    per = (1, 2, 1, 2, 3)[solver]
     votes = np.zeros(iters * per, np.int32); q7 = np.zeros((iters * per, 7)); valid = np.zeros(iters * per, np.uint8)
     state, inc = rand31_state(seed)
     cos_thr = float(np.cos(np.arctan(8.0 / 585.0)))
-    L.check(L.lib().rpe_ransac_p3p_batch(ctx._h, solver, C.c_uint64(state), C.c_uint64(inc), iters, 0.2, cos_thr, votes.ctypes.data_as(C.c_void_p),
+    cos_nl = float(np.cos(0.1))
+    L.check(L.lib().rpe_ransac_p3p_batch(ctx._h, solver, C.c_uint64(state), C.c_uint64(inc), iters, 0.2, cos_thr, cos_nl, votes.ctypes.data_as(C.c_void_p),
                                          q7.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p)))
     # the same iterations yield the same NUMBER of hypotheses (validity decisions agree away from degenerate samples) ...
     dev_counts = valid.reshape(iters, per).sum(axis=1)
@@ -67,8 +72,8 @@ def test_device_p3p_hypotheses_follow_the_host_stream(gpu_ctx_factory, solver, m
     assert len(errs) > 0.9 * iters and np.median(errs) < med_tol and np.mean(errs < rot_tol) > 0.97, (np.median(errs), np.sort(errs)[-10:])
     # the votes are those rpe_score gives the same device poses in FAST mode
     sel = np.nonzero(valid)[0][:64]
-    kind = L.VOTE_33_23 if solver == 1 else L.VOTE_23
-    again = ctx.score(kind, q7[sel], 0.2, cos_thr, 2.0, mode=L.SCORE_FAST)
+    kind = (L.VOTE_23, L.VOTE_33_23, L.VOTE_NN_23, L.VOTE_NN_33, L.VOTE_NN_33_23)[solver]
+    again = ctx.score(kind, q7[sel], 0.2, cos_thr, cos_nl, mode=L.SCORE_FAST)
     assert np.mean(np.abs(again - votes[sel]) <= 2) > 0.95   # the pose went through quaternion form and back: a vote may flip at a threshold
 
 
@@ -85,9 +90,11 @@ from rgbd_pose_estimation_amd import _lib as L, api
 out = {{}}
 for f64 in (False, True):
     sc = util.scene_full(5, 40000, np.float64 if f64 else np.float32, n2d=2.0, n3d=0.02, outliers=0.55, nan_frac=0.0)
-    for name, m, keys in (("kneip", api.M_KNEIP_RANSAC, ("xw", "bv")), ("sk", api.M_SK_RANSAC, ("xw", "xc", "bv"))):
-        data = dict(xw=sc.Q, xc=sc.P, bv=sc.U)
-        r = api.run(m, L.F64 if f64 else L.F32, thre_3d=0.1, thre_2d=6.0, iters=2000, confidence=0.9999, seed=3, score_mode=L.SCORE_FAST, **{{k: data[k] for k in keys}})
+    all5 = ("xw", "xc", "bv", "nw", "nc")
+    for name, m, keys in (("kneip", api.M_KNEIP_RANSAC, ("xw", "bv")), ("sk", api.M_SK_RANSAC, ("xw", "xc", "bv")), ("nlk", api.M_NL_KNEIP_RANSAC, all5),
+                          ("nls", api.M_NL_SHINJI_RANSAC, all5), ("nlsk", api.M_NL_SK_RANSAC, all5)):
+        data = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+        r = api.run(m, L.F64 if f64 else L.F32, thre_3d=0.1, thre_2d=6.0, thre_nl=0.1, iters=2000, confidence=0.9999, seed=3, score_mode=L.SCORE_FAST, **{{k: data[k] for k in keys}})
         out[name + ("64" if f64 else "32")] = dict(votes=int(r["max_votes"]), iters=int(r["iters"]), rot=float(util.rot_err(r["R"], sc.R)),
                                                     trans=float(np.linalg.norm(r["t"] - sc.t)))
 print("RESULT " + json.dumps(out))
