@@ -256,33 +256,6 @@ int wait_host(rpe_context* c, int ld) {
   }
 }
 
-// Tagged form (resident loop): the record arrives as `ld` pairs {value, seq}, each written by ONE 16-byte store; it is complete
-// when every pair carries the wanted sequence value.  A pair's value is read after its tag (acquire): both came in one write.
-[[maybe_unused]] int wait_host_tagged(rpe_context* c, int ld, double* out) {
-  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_out);
-  const unsigned long long want = c->seq;
-  for (unsigned long long spins = 0;; spins++) {
-    int have = 0;
-    for (int i = ld - 1; i >= 0; i--) {
-      if (__atomic_load_n(pairs + 2 * i + 1, __ATOMIC_ACQUIRE) != want) break;
-      have++;
-    }
-    if (have == ld) {
-      for (int i = 0; i < ld; i++) { const unsigned long long w = __atomic_load_n(pairs + 2 * i, __ATOMIC_RELAXED); std::memcpy(out + i, &w, 8); }
-      return RPE_OK;
-    }
-    if ((spins & 0xFFFFF) == 0xFFFFF) {
-      hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
-      if (q == hipSuccess) {   // the resident kernel is gone (it gives up after ~2 s without a new pose): did the record still arrive?
-        int all = 1;
-        for (int i = 0; i < ld; i++) all = all && __atomic_load_n(pairs + 2 * i + 1, __ATOMIC_ACQUIRE) == want;
-        if (!all) return fail(RPE_ERR_HIP, "the resident kernel ended without publishing record %llu", want);
-      }
-    }
-  }
-}
-
 // Host-side final sum (resident loop): `grid` collecting workgroups each sent `nacc` pairs {value, seq}; add them in run order as they
 // arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps the arrival of the
 // later ones.
@@ -410,7 +383,6 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   hand_over(pose12, base + 1);
   rpe::ReduceTarget rt = host_target(c);
   rt.seq = base;
-  rt.tagged = 1;
   static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
   const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
   const int runs = (grid + rows - 1) / rows;

@@ -56,7 +56,6 @@ struct ReduceTarget {
   GnState* gn = nullptr;       // its state (null = ordinary launch: pose from the kernel argument, record published)
   const P2PDesc* p2p = nullptr;   // multi-GPU: exchange + sum the record with the peers before publishing (h_out path only)
   unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
-  int tagged = 0;              // h_out receives LD pairs {value, seq} (16 bytes, one store each) instead of the record + a sequence word
   int tail = -1;               // cross-workgroup stage of the ordinary kernels: -1 = default / RPE_TAIL
   int rows = 0;                // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out must hold

@@ -258,7 +258,6 @@ struct Finish {
   const P2PDesc* p2p;          // multi-GPU peer-to-peer all-reduce of the record (null = single GPU / collective done elsewhere)
   unsigned long long p2p_step;
   int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
-  int tagged;                  // 1: publish to out_host as LD pairs {value, seq} of 16 bytes, one store each, no drain and no separate sequence word
   int rows;                    // > 0: collecting workgroups + host-side final sum (collect_and_send / the resident kernel): cap on the run length
 };
 
@@ -718,10 +717,6 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     int failed = 0;
     val = p2p_allreduce32(val, fin, &failed);
     if (failed && threadIdx.x == 31) val = 1e300;   // error marker in the last (padding) entry of the record: the host checks it
-  }
-  if (fin.tagged) {   // resident loop: tagged pairs, no drain, no flag
-    if (threadIdx.x < LD) store_tagged_pair(fin.out_host, threadIdx.x, val, fin.seq);
-    return;
   }
   if (threadIdx.x < LD) {
     if (fin.gn == nullptr) {
@@ -2262,7 +2257,6 @@ static Finish make_finish(const ReduceTarget& rt) {
   // first, profiles/r02_tail_timeline.jsonl: 7.9 / 8.1 / 8.7 us per launch at 307 200 points); RPE_TAIL overrides for experiments
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
-  f.tagged = rt.tagged;
   f.rows = rt.rows > 0 ? rt.rows : 0;
   return f;
 }
