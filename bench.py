@@ -478,6 +478,46 @@ def worker(args, affinity):
         except Exception as e:  # noqa: BLE001
             sharded_loop = {"error": repr(e)}
 
+    # weak-scaling figure beside the strong-scaling headline (every rank takes part): a frame-sized shard (configs[1]: 307 200) on every
+    # rank, the same way of adding the records as the headline
+    weak = None
+    if world > 1 and not args.no_extras and (hostex or (rccl_ok and not p2p)):
+        try:
+            wn = 307200
+            wsc = make_shard(1000 + rank, wn)
+            wctx = api.Context(local_rank)
+            wctx.load(L.F32, xw=wsc.Q, xc=wsc.P)
+            Rw0, tw0 = initial_pose(wsc)
+            winl = int(wctx.inlier_mask(L.VOTE_33, pose7_from_Rt(Rw0, tw0, L.F32), thre_3d=THRE_3D))
+            ok = init_host_exchange(wctx) if hostex else init_native_comm(wctx)
+            if ok:
+                Kw = 400
+                def wrun(k):
+                    q = pose12(Rw0, tw0)
+                    if hostex:
+                        wctx.gn_refine([L.RES_P2P], q, None, L.USE_MASK, k, 0.0)
+                    else:
+                        wctx.gn_steps_dist(L.RES_P2P, q, k, L.USE_MASK)
+                wrun(200)
+                dist.barrier()
+                t0w = time.perf_counter()
+                wrun(Kw)
+                tw = torch.tensor([time.perf_counter() - t0w], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+                tiw = torch.tensor([winl], dtype=torch.int64, device=cdev)
+                dist.all_reduce(tiw)
+                weak = {"corr_per_rank": wn, "global_corr": wn * world, "valid_corr_per_step": int(tiw.item()), "us_per_step": float(tw.item()) / Kw * 1e6,
+                        "value": float(tiw.item()) * Kw / float(tw.item()), "unit": "correspondence-residuals/s",
+                        "note": "weak scaling: a configs[1]-sized shard (307 200) on every rank, records added as in the headline; beside, not instead of, it"}
+                dist.barrier()
+                if hostex:
+                    wctx.hostex_destroy()
+                else:
+                    wctx.comm_destroy()
+            wctx.close()
+        except Exception as e:  # noqa: BLE001
+            weak = {"error": repr(e)}
+
     # global inlier count (valid correspondences) for the headline value
     inl_total = inl
     if world > 1:
@@ -574,6 +614,7 @@ def worker(args, affinity):
             out["pose_error_vs_truth"] = {"rot_rad": rot_err(pose[:9].reshape(3, 3), sc.R), "trans_abs_m": float(np.linalg.norm(pose[9:] - sc.t))}
             out["cpu_baseline"] = None
             # the weak-scaling figure beside the strong-scaling headline: every rank's own frame-sized shard at the same step rate
+            out["weak_scaling"] = weak
             out["weak_scaling_note"] = "strong scaling (fixed 10 M total) is the headline for N > 1; per-GPU work at N = 1 is configs[1] (307 200)"
     # tear everything down first: RCCL prints its version banner on stdout around communicator life-cycle events, and
     # the JSON line must be the LAST line rank 0 prints

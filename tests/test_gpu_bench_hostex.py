@@ -18,7 +18,7 @@ def test_bench_two_ranks_host_exchange_from_a_bare_shell():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--n-total", "614400",
-                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 20 and j["value"] > 1e9
@@ -26,3 +26,5 @@ def test_bench_two_ranks_host_exchange_from_a_bare_shell():
     assert "configs[4]" in j["config"]["workload"] and "host-side exchange" in j["config"]["collective"]
     assert j["config"]["collective_step_us"]["host_us"] > 0 and j["config"]["rccl_ranks"] == 0
     assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2
+    w = j["weak_scaling"]                                    # a frame-sized shard per rank, same exchange
+    assert w["corr_per_rank"] == 307200 and w["global_corr"] == 614400 and w["value"] > 1e9 and 0.8 * 614400 < w["valid_corr_per_step"] <= 614400
