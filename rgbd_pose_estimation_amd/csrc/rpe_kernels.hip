@@ -820,6 +820,38 @@ __device__ __forceinline__ void p2plane_point(const PoseK<double>& T, C x, C y, 
   add_row(J, r, w, s);
   s[28] += w;
 }
+// Two correspondences at once: the 35 products of a Jacobian row's outer product as 2-vectors (packed fp32 instructions for fp32
+// arrays), each lane of the pair keeping its own partial sums; the pair's sums are added at the end of the group.
+template <class V> __device__ __forceinline__ void add_row2(const V (&J)[6], V r, V w, V (&s)[29]) {
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const V wa = w * J[a];
+#pragma unroll
+    for (int b = a; b < 6; b++) { s[k] = __builtin_elementwise_fma(wa, J[b], s[k]); k++; }
+    s[21 + a] = __builtin_elementwise_fma(wa, r, s[21 + a]);
+  }
+  s[27] = __builtin_elementwise_fma(w * r, r, s[27]);
+}
+template <class C>
+__device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&cx)[2], const C (&cy)[2],
+                                             const C (&cz)[2], const C (&nx)[2], const C (&ny)[2], const C (&nz)[2], const C (&w)[2],
+                                             C __attribute__((ext_vector_type(2))) (&s)[29]) {
+  typedef C V __attribute__((ext_vector_type(2)));
+  C px[2], py[2], pz[2], r[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {   // the fp64 part stays per point: transform and the (cancelling) residual
+    double pxd, pyd, pzd;
+    transform<C>(T, x[e], y[e], z[e], pxd, pyd, pzd);
+    px[e] = (C)pxd; py[e] = (C)pyd; pz[e] = (C)pzd;
+    r[e] = (C)((double)nx[e] * (pxd - (double)cx[e]) + (double)ny[e] * (pyd - (double)cy[e]) + (double)nz[e] * (pzd - (double)cz[e]));
+  }
+  const V PX = {px[0], px[1]}, PY = {py[0], py[1]}, PZ = {pz[0], pz[1]}, NX = {nx[0], nx[1]}, NY = {ny[0], ny[1]}, NZ = {nz[0], nz[1]};
+  const V J[6] = {NX, NY, NZ, PY * NZ - PZ * NY, PZ * NX - PX * NZ, PX * NY - PY * NX};  // [n ; p x n]
+  const V R = {r[0], r[1]}, W = {w[0], w[1]};
+  add_row2<V>(J, R, W, s);
+  s[28] += W;
+}
 // 1 / sqrt(x) in fp64 without the ~45-instruction IEEE sqrt + divide sequences: the fp32 hardware estimate (v_rsq_f32, 1e-7)
 // refined by two Newton steps y <- y (3/2 - x/2 y^2), each squaring the error: ~1 ulp of fp64 in ~10 instructions.  x is a
 // squared point norm in metres^2 (fits fp32 comfortably).
@@ -863,6 +895,35 @@ __device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const
                                                 const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P], const T (&wv)[Pk<T>::P],
                                                 int npresent, double (&acc)[NACC]) {
   constexpr int P = Pk<T>::P;
+  if constexpr (KIND == KIND_P2PLANE) {   // pairs of correspondences (the accumulation is 35 of the ~50 operations per point)
+    typedef T V __attribute__((ext_vector_type(2)));
+    V s2[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) s2[k] = V{T(0), T(0)};
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+      T x[2], y[2], z[2], bx[2], by[2], bz[2], nx[2], ny[2], nz[2], wi[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int i = 2 * j + e;
+        x[e] = vw[3 * i]; y[e] = vw[3 * i + 1]; z[e] = vw[3 * i + 2];
+        bx[e] = vb[3 * i]; by[e] = vb[3 * i + 1]; bz[e] = vb[3 * i + 2];
+        T w = WEIGHT ? wv[i] : T(1);
+        if (MASK) w = m[i] == 1 ? w : T(0);
+        w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
+        const bool off = w == T(0);
+        // keeps NaN / inf of skipped columns out of the sums (selects, not branches)
+        x[e] = off ? T(0) : x[e]; y[e] = off ? T(0) : y[e]; z[e] = off ? T(0) : z[e];
+        bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
+        nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1]; nz[e] = off ? T(0) : vc[3 * i + 2];
+        wi[e] = w;
+      }
+      p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
+    }
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] += (double)(s2[k].x + s2[k].y);
+    return;
+  }
   T s[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) s[k] = T(0);
