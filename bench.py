@@ -116,7 +116,7 @@ def pin_to_gpu_numa_node(local_rank: int, world_size: int = 1):
             mine = {cand[1 % len(cand)]}
         os.sched_setaffinity(0, mine)
         return {"pinned": True, "cpu": sorted(mine)[0] if len(mine) == 1 else sorted(mine), "numa_node": open(os.path.join(dev, "numa_node")).read().strip(),
-                "gpu_local_cpus": len(cpus)}
+                "gpu_local_cpus": len(cpus), "gpu_local_cpu_ids": cpus}
     except Exception as e:  # noqa: BLE001
         return {"pinned": False, "reason": repr(e)}
 
@@ -419,6 +419,34 @@ def worker(args, affinity):
             t_pre = time.perf_counter()
             while time.perf_counter() - t_pre < float(os.environ.get("RPE_BENCH_PREWARM_S", "1.5")):
                 pose = run_steps(pose, 500)
+        # which host CPU polls fastest differs from box to box (GPU-local cores usually, the other socket's on some boxes, by 5-10 %):
+        # try a few of both kinds with a short refinement each and keep the best one (one GPU, resident loop, pinned runs only)
+        if not dist_path and resident and affinity.get("pinned") and os.environ.get("RPE_BENCH_NO_CALIBRATE") != "1":
+            try:
+                allowed = sorted(ORIG_AFFINITY) if ORIG_AFFINITY else sorted(os.sched_getaffinity(0))
+                mine = affinity["cpu"] if isinstance(affinity["cpu"], int) else affinity["cpu"][0]
+                local = set(affinity.get("gpu_local_cpu_ids", []))
+                near = [c for c in allowed if c in local and c != mine]
+                far = [c for c in allowed if c not in local]
+                cands = [mine] + [near[len(near) // 2]] * bool(near) + ([far[1 % len(far)], far[len(far) // 2]] if far else [])
+                trial = {}
+                reps_c = max(3, min(12, 6000 // args.steps))
+                for cpu in dict.fromkeys(cands):   # each trial has the shape of the timed region: synchronize, K steps, synchronize
+                    os.sched_setaffinity(0, {cpu})
+                    run_steps(pose12(R0, t0), args.steps)
+                    ts_c = []
+                    for _ in range(reps_c):
+                        torch.cuda.synchronize()
+                        t_c = time.perf_counter()
+                        run_steps(pose12(R0, t0), args.steps)
+                        torch.cuda.synchronize()
+                        ts_c.append((time.perf_counter() - t_c) / args.steps)
+                    trial[cpu] = percentile(ts_c, 0.5) * 1e6
+                pick = min(trial, key=trial.get)
+                os.sched_setaffinity(0, {pick})
+                affinity = dict(affinity, cpu=pick, calibration_us_per_step={str(k): round(v, 3) for k, v in trial.items()})
+            except Exception as e:  # noqa: BLE001
+                affinity = dict(affinity, calibration_error=repr(e))
         run_steps(pose12(R0, t0), args.warmup)
 
         # ---- timed: `repeats` repetitions of EXACTLY `steps` steps, each bracketed by barrier + synchronize, MAX over ranks
@@ -573,7 +601,7 @@ def worker(args, affinity):
                                      "rpe_gn_steps_dist: one launch + one collective per step" if dist_path else "rpe_gn_refine: one launch per step")},
             "timing": {"repeats": args.repeats, "statistic": "median over repetitions of the whole K-step region (MAX over ranks each)",
                        "ms_per_step_p10": percentile(samples, 0.1) / args.steps * 1e3, "ms_per_step_p90": percentile(samples, 0.9) / args.steps * 1e3,
-                       "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": affinity, "loop_profile": loop_prof},
+                       "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": {k: v for k, v in affinity.items() if k != "gpu_local_cpu_ids"}, "loop_profile": loop_prof},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_launch, "steps_per_launch": steps_per_launch,
