@@ -421,7 +421,7 @@ def worker(args, affinity):
                 pose = run_steps(pose, 500)
         # which host CPU polls fastest differs from box to box (GPU-local cores usually, the other socket's on some boxes, by 5-10 %):
         # try a few of both kinds with a short refinement each and keep the best one (one GPU, resident loop, pinned runs only)
-        if not dist_path and resident and affinity.get("pinned") and os.environ.get("RPE_BENCH_NO_CALIBRATE") != "1":
+        if not dist_path and resident and affinity.get("pinned") and not args.no_extras and os.environ.get("RPE_BENCH_NO_CALIBRATE") != "1":   # (--no-extras: profiled runs hold the timed launches only)
             try:
                 allowed = sorted(ORIG_AFFINITY) if ORIG_AFFINITY else sorted(os.sched_getaffinity(0))
                 mine = affinity["cpu"] if isinstance(affinity["cpu"], int) else affinity["cpu"][0]
