@@ -110,3 +110,21 @@ print("RESULT " + json.dumps(out))
         assert d["rot"] < 0.05 and d["trans"] < 0.25 and h["rot"] < 0.05 and h["trans"] < 0.25, (k, d, h)
         assert abs(d["votes"] - h["votes"]) <= 0.02 * h["votes"], (k, d, h)
         assert d["iters"] > 56 and h["iters"] > 56, (k, d, h)   # 8 + 16 + 32 host-generated iterations, then device batches
+
+
+def test_p3p_batch_argument_and_state_errors(gpu_ctx_factory):
+    sc = util.scene_full(3, 500, np.float32)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, bv=sc.U)
+    votes = np.zeros(64, np.int32); q7 = np.zeros((64, 7)); valid = np.zeros(64, np.uint8)
+    args = lambda solver, iters: (ctx._h, solver, C.c_uint64(1), C.c_uint64(109), iters, 0.2, 0.9999, 0.99, votes.ctypes.data_as(C.c_void_p),
+                                  q7.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+    lib = L.lib()
+    assert lib.rpe_ransac_p3p_batch(*args(5, 8)) == L.RPE_ERR_ARG            # unknown solver
+    assert lib.rpe_ransac_p3p_batch(*args(0, 0)) == L.RPE_ERR_ARG            # no iterations
+    assert lib.rpe_ransac_p3p_batch(*args(0, 8193)) == L.RPE_ERR_ARG         # more slots than one scoring launch takes
+    assert lib.rpe_ransac_p3p_batch(*args(1, 8)) == L.RPE_ERR_STATE          # shinji + kneip needs the camera points
+    assert lib.rpe_ransac_p3p_batch(*args(4, 8)) == L.RPE_ERR_STATE          # the normal-aware solvers need all five arrays
+    assert lib.rpe_ransac_p3p_batch(*args(0, 8)) == L.RPE_OK
+    tiny = gpu_ctx_factory().load(L.F32, xw=sc.Q[:3], bv=sc.U[:3])
+    a = list(args(0, 8)); a[0] = tiny._h
+    assert lib.rpe_ransac_p3p_batch(*a) == L.RPE_ERR_ARG                     # fewer than 4 correspondences

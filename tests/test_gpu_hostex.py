@@ -71,3 +71,35 @@ def test_sharded_votes_add_up():
     for r in ranks:
         assert r["votes"] == res["reference"]
         assert r["votes_short"] == res["reference"][:12]
+
+
+def test_hostex_single_rank_and_misuse(gpu_ctx_factory):
+    """world = 1: the exchange is the identity, every sharded entry point still works; a second init is refused; sharded contexts refuse
+    the device generators (they sample the local shard)."""
+    import ctypes as C
+    import util
+    from rgbd_pose_estimation_amd import _lib as L, api
+    sc = util.scene33(4, 20000, np.float32, noise=0.02, outliers=0.0)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P)
+    ref = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P)
+    name = f"/rpe_hx_test_solo_{os.getpid()}"
+    ctx.hostex_init(1, 0, name, True)
+    assert not os.path.exists("/dev/shm" + name)          # the name is dropped as soon as every rank has the segment mapped
+    with pytest.raises(L.RpeError) as e:
+        ctx.hostex_init(1, 0, name + "b", True)
+    assert e.value.code == L.RPE_ERR_STATE
+    p0 = api.pose12(np.eye(3), np.zeros(3))
+    a = ctx.gn_refine([L.RES_P2P], p0, max_iter=20, tol=1e-10)
+    b = ref.gn_refine([L.RES_P2P], p0, max_iter=20, tol=1e-10)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    pa, pb = p0.copy(), p0.copy()
+    ctx.gn_steps_dist(L.RES_P2P, pa, 3)
+    for _ in range(3):
+        ref.gn_step(L.RES_P2P, pb)
+    assert np.abs(pa - pb).max() < 1e-12
+    votes = np.zeros(8, np.int32); q7 = np.zeros((8, 7)); valid = np.zeros(8, np.uint8)
+    rc = L.lib().rpe_ransac33_batch(ctx._h, C.c_uint64(1), C.c_uint64(109), 8, L.SCORE_EXACT, 0.2, votes.ctypes.data_as(C.c_void_p),
+                                    q7.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+    assert rc == L.RPE_ERR_STATE
+    ctx.hostex_destroy()
+    ctx.hostex_destroy()                                   # idempotent
