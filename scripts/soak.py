@@ -1,0 +1,30 @@
+"""Soak of the two cross-workgroup protocols (development aid, run on the GPU box): the resident loop and the collecting launches must
+give BITWISE the same result every time (fixed summation order whichever workgroup finishes first) and never lose a granule.
+  python scripts/soak.py [seconds]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import numpy as np
+from rgbd_pose_estimation_amd import _lib as L, api
+from tail_timeline import scene
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+out = {}
+for n, kind in ((307200, 0), (1000000, 1), (20000, 0)):
+    R, t, arrs = scene(n)
+    ctx = api.Context(0).load(L.F32, **arrs)
+    p = api.pose12(R, t)
+    first_pose = ctx.gn_refine([kind], p, max_iter=500, tol=0.0)[0]
+    first_rec = np.asarray(ctx.normal_eq(kind, p)[0] if isinstance(ctx.normal_eq(kind, p), tuple) else ctx.normal_eq(kind, p))
+    t0, calls, iters, bad = time.perf_counter(), 0, 0, 0
+    while time.perf_counter() - t0 < seconds / 6:
+        q = ctx.gn_refine([kind], p, max_iter=500, tol=0.0)[0]
+        bad += int(not np.array_equal(q, first_pose)); calls += 1; iters += 500
+    t1, ncalls, nbad = time.perf_counter(), 0, 0
+    while time.perf_counter() - t1 < seconds / 6:
+        r = ctx.normal_eq(kind, p)
+        r = np.asarray(r[0] if isinstance(r, tuple) else r)
+        nbad += int(not np.array_equal(r, first_rec)); ncalls += 1
+    out[f"{n}_{kind}"] = dict(resident_calls=calls, resident_iterations=iters, resident_pose_changed=bad, collect_calls=ncalls, collect_record_changed=nbad)
+    ctx.close()
+print(json.dumps(out))
