@@ -368,7 +368,39 @@ def worker(args, affinity):
                     ctx.hostex_destroy()
                     hostex = False
             if hostex:
-                coll_times["host_us"] = timed(400, refine=True) * 1e6   # rpe_gn_refine: resident kernel per rank + exchange between the hosts
+                # rpe_gn_refine: resident kernel per rank + exchange between the hosts.  Every wait in it is bounded, so a rank that fails
+                # takes the others out with it after the exchange's timeout: all ranks arrive at the flag below and fall back together.
+                def all_ok(ok):
+                    f = torch.tensor([int(ok)], dtype=torch.int32, device=cdev)
+                    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                    return int(f.item()) == 1
+                def refine_ok(k):
+                    if os.environ.get("RPE_BENCH_INJECT_HOSTEX_FAIL") == str(rank):   # tests: this rank drops out, the peers run into the exchange's timeout
+                        print(f"[bench] rank {rank}: injected host-exchange failure", file=sys.stderr, flush=True)
+                        return False
+                    try:
+                        ctx.gn_refine([L.RES_P2P], pose12(R0, t0), None, L.USE_MASK, k, 0.0)
+                        return True
+                    except (L.RpeError, AssertionError) as e:
+                        print(f"[bench] rank {rank}: refinement over the host-side exchange failed: {e}", file=sys.stderr, flush=True)
+                        return False
+                good = all_ok(refine_ok(200))   # the ranks agree after every phase, so they always enter the same torch collective next
+                if good:
+                    dist.barrier()
+                    t0_ = time.perf_counter()
+                    ran = refine_ok(400)
+                    tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    host_us = float(tt.item()) / 400 * 1e6
+                    good = all_ok(ran)
+                if not good:
+                    if rank == 0:
+                        print("[bench] host-side exchange dropped: falling back to RCCL", file=sys.stderr, flush=True)
+                    ctx.hostex_destroy()
+                    hostex = False
+                else:
+                    coll_times["host_us"] = host_us
+            if hostex:
                 if want == "auto" and rccl_ok and coll_times["rccl_us"] < coll_times["host_us"]:
                     dist.barrier()
                     ctx.hostex_destroy()

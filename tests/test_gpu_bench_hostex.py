@@ -28,3 +28,19 @@ def test_bench_two_ranks_host_exchange_from_a_bare_shell():
     assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2
     w = j["weak_scaling"]                                    # a frame-sized shard per rank, same exchange
     assert w["corr_per_rank"] == 307200 and w["global_corr"] == 614400 and w["value"] > 1e9 and 0.8 * 614400 < w["valid_corr_per_step"] <= 614400
+
+
+def test_bench_falls_back_together_when_one_rank_loses_the_exchange():
+    """auto mode: rank 1 drops out of the exchange's trial refinement; rank 0 runs into the exchange's bounded wait, both agree on the
+    failure and the run finishes on the other collective (torch.distributed here: two ranks on one GPU cannot form an RCCL communicator)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_COLLECTIVE="auto", RPE_BENCH_PREWARM_STEPS="100", RPE_BENCH_BACKEND="gloo",
+               RPE_BENCH_SHARE_GPU="1", RPE_BENCH_INJECT_HOSTEX_FAIL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "5", "--n-total", "614400",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
+    assert "host-side exchange dropped" in r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["value"] > 1e8 and "host-side exchange" not in j["config"]["collective"]
+    assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2
