@@ -319,7 +319,7 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
     double dj = A[j][j];
 #pragma unroll
     for (int m = 0; m < j; m++) dj -= Lm[j][m] * Lm[j][m] * D[m];
-    ok = ok && (dj > 0) && (dj < 1e300);
+    ok = ok && (dj > 1e-12 * A[j][j]) && (dj < 1e300);   // relative pivot floor, as rpe/linalg.hpp solve_normal_eq6
     D[j] = dj;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {

@@ -312,7 +312,9 @@ RPE_HD inline bool solve_normal_eq6(const double* ne, double d[6]) {
   for (int j = 0; j < 6; j++) {
     double dj = A[j][j];
     for (int m = 0; m < j; m++) dj -= L[j][m] * L[j][m] * D[m];
-    if (!(dj > 0) || !(dj < 1e300)) return false;
+    // a pivot that cancelled to rounding noise (rank-deficient sets: one repeated point, points on a line, a single plane for
+    // point-to-plane) is "not positive definite" too: dividing by it would hand back a finite but meaningless update
+    if (!(dj > 1e-12 * A[j][j]) || !(dj < 1e300)) return false;
     D[j] = dj;
     L[j][j] = 1.0;
     for (int i = j + 1; i < 6; i++) {
