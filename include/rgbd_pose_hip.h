@@ -50,7 +50,7 @@ typedef enum {
   RPE_ERR_HIP = -2,
   RPE_ERR_ARG = -3,
   RPE_ERR_STATE = -4,         /* a required array was never uploaded / bound */
-  RPE_ERR_DEGENERATE = -5,    /* normal equations not positive definite, or NaN result */
+  RPE_ERR_DEGENERATE = -5,    /* normal equations not positive definite (a pivot <= 1e-12 of its diagonal counts: rank-deficient sets), or NaN result */
   RPE_ERR_ALIGN = -6          /* bound device pointer not 16-byte aligned */
 } rpe_status;
 
