@@ -602,7 +602,7 @@ def worker(args, affinity):
         bytes_per_launch = BYTES_PER_CORR * n * steps_per_launch
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else None
         traffic, traffic_src, rocprof_avg_us, rocprof_src = None, None, None, None
-        kernel_name = "rpe::normal_eq_resident_kernel<float, 0, 512, true, false, true>" if resident else "rpe::normal_eq_kernel<float, 0, 512, true, false>"
+        kernel_name = "rpe::normal_eq_resident_kernel<float, 0, 512, true, false, true, false>" if resident else "rpe::normal_eq_kernel<float, 0, 512, true, false>"
         if world == 1 and resident:
             try:   # the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), for side-by-side reading
                 import csv

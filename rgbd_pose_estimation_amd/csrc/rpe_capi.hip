@@ -807,6 +807,31 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   // records on every rank give identical poses and identical stop decisions, so the loop stays one launch per iteration at any
   // number of GPUs.  Launches after convergence skip the exchange on every rank alike; the step counter advances per launch.
   const bool sharded = c->p2p_world >= 1;
+  // One GPU, one of the two 3D-3D kinds: ONE launch for the whole loop.  The grid stays resident and iterates by itself -- granule
+  // hand-off to the collecting workgroups, run records read back by every workgroup, solve + exp-map in every workgroup alike
+  // (rpe_kernels.hip resident_auto_stage); the host hears from it once, when the loop has finished.  RPE_DEVICE_LOOP_RESIDENT=0: one
+  // launch per iteration, as the other residual kinds and the sharded loop keep.
+  static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
+  if (auto_on && single && !sharded && !c->comm && !c->hostex && max_iter >= 2 && (terms[0].kind == RPE_RES_P2P || terms[0].kind == RPE_RES_P2PLANE)) {
+    int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
+    rpe::resident_geometry(c->arrays(), terms[0].kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
+    const unsigned long long base = c->seq;          // granule / run-record tags base + 1 ... base + max_iter
+    rt.rows = grid * nacc <= 1024 ? 1 : rows_auto;   // as the host-driven loop: the run records are the ones its host would add
+    c->seq = base + (unsigned long long)max_iter + 1;
+    rt.seq = c->seq;                                  // published with the result
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+    HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0, e1));
+    int rc = wait_host(c, rpe::kNeLd);
+    if (rc) return rc;
+    for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
+    if (last_step) *last_step = c->h_out[12];
+    if (final_cost) *final_cost = c->h_out[13];
+    if (iters_out) *iters_out = (int)c->h_out[14];
+    if (c->h_out[15] == 2.0) return fail(RPE_ERR_HIP, "device loop: a workgroup's sums never arrived at iteration %d", (int)c->h_out[14]);
+    if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
+    return RPE_OK;
+  }
   for (int it = 0; it < max_iter; it++) {
     if (sharded) { rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++; }
     if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose12, rt, c->stream));

@@ -1088,6 +1088,7 @@ __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T
 // word 0 = tag, words 1..12 = pose, word 15 = tag again, so the two 64-byte halves may arrive in any order).  The first 16 lanes of
 // wave 0 read one 8-byte word each until both tags match.  Returns 1 = go (pose in s_pose), 2 = stop requested, 3 = the host went
 // away (2 s); the value is uniform over the workgroup.
+constexpr int kAutoMaxRunSums = 1024;   // run records x sums an autonomous iteration reads per workgroup (resident_auto_stage)
 template <int BLK>
 __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want, double* __restrict__ s_pose,
                                                   int* __restrict__ s_go) {
@@ -1166,9 +1167,99 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
   return ok;
 }
 
+// Cross-workgroup stage of one AUTONOMOUS resident iteration (rpe_gn_refine_device: solve and exp-map on the GPU, no host in the loop).
+// First hop as above -- runs of R workgroups, the first of a run collects its rows' granules -- but the run's NACC sums go to a RUN
+// RECORD in device memory (granules again: {value, iteration tag}, one sc1 store per lane) instead of to the host.  Second hop: EVERY
+// workgroup reads all ceil(G / R) run records, adds them in run order (the order the host uses: bitwise the host-driven loop's
+// record), expands the record, and its first lane solves the 6x6 system and applies the update to the workgroup's own copy of the
+// pose in LDS.  All workgroups compute the same bits, so they agree on the next pose and on when to stop without another hop.
+// Run records are double-buffered by iteration parity: a collecting workgroup can publish iteration i + 1 while a late workgroup of
+// another run still reads iteration i; it cannot reach i + 2 before that workgroup has delivered its granules of i + 1, i.e. after
+// it has finished reading i.  Granules need no second buffer: a workgroup writes iteration i + 1's after it has read run records
+// that its collector published after reading iteration i's.  Returns 0 = next iteration, 1 = finished (workgroup 0 published pose |
+// step | cost | iterations | status | weight sum to the host), 2 = a granule never arrived (2 s).
+template <int NACC, int BLK>
+__device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it, int max_iters,
+                                                   double tol, double* __restrict__ s_pose) {
+  constexpr int NW = BLK / 64;
+  constexpr int RGN = BLK / NACC;
+  constexpr int MODE = NACC == 17 ? 1 : 0;
+  __shared__ double a_red[NW][NACC];
+  __shared__ double a_part[RGN][NACC];
+  __shared__ double a_runs[kAutoMaxRunSums];
+  __shared__ double a_tot[32], a_rec[32];
+  __shared__ double a_step;
+  __shared__ int a_ok;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = (int)gridDim.x, R = fin.rows, run = blockIdx.x / R, leader = run * R, runs = (G + R - 1) / R;
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);          // [workgroup][NACC] granules of 2 words
+  unsigned long long* rrec = gran + 2 * ((size_t)G * NACC + (size_t)(it & 1) * runs * NACC);   // [parity][run][NACC]
+  wave_reduce_to<NACC>(acc, a_red[wave], lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double own = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) own += a_red[w][threadIdx.x];
+    if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+    else a_part[0][threadIdx.x] = own;
+  }
+  bool lost = false;
+  if ((int)blockIdx.x == leader) {
+    const int rows = min(R, G - leader);
+    lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part));
+    if (!lost && threadIdx.x < NACC) {
+      double t = 0.0;
+      const int nr = rows < RGN ? rows : RGN;
+      for (int k = 0; k < nr; k++) t += a_part[k][threadIdx.x];
+      store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
+    }
+  }
+  if (!lost) {
+    const int total = runs * NACC;
+    for (int i = threadIdx.x; i < total; i += BLK) {
+      const unsigned long long t0 = wall_clock64();
+      granule_t q;
+      for (unsigned int spins = 1;; spins++) {
+        q = load_granule16(rrec + 2 * (size_t)i);
+        if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
+        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a run record never came
+      }
+      a_runs[i] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
+    }
+  }
+  lost = __syncthreads_or(lost);
+  if (!lost && threadIdx.x < 32) {
+    double t = 0.0;
+    if (threadIdx.x < NACC) for (int r = 0; r < runs; r++) t += a_runs[r * NACC + threadIdx.x];
+    a_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (!lost && threadIdx.x < 32) a_rec[threadIdx.x] = record_entry<MODE>(a_tot, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double step = 0.0;
+    a_ok = !lost && gn_solve_update(a_rec, s_pose, &step) ? 1 : 0;
+    a_step = step;
+  }
+  __syncthreads();
+  const bool ok = a_ok != 0;
+  const bool done = !ok || a_step < tol || it >= max_iters;
+  if (done && blockIdx.x == 0 && threadIdx.x == 0 && fin.out_host) {
+    for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, s_pose[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 12, a_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 13, lost ? 0.0 : a_rec[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 14, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (lost ? 2.0 : 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : a_rec[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return lost ? 2 : (done ? 1 : 0);
+}
+
 // IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
 // loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS>
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, bool AUTO>
 __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                                                                  const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                                                                  const unsigned long long* __restrict__ ctl, unsigned long long first_tag,
@@ -1188,8 +1279,16 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     load_any_group<T, KIND, MASK, WEIGHT>(xw, b, c, mask, weight, g0, full, n, rw, rb, rc, rm, rwv);
     rpresent = g0 < full ? P : (int)(n - full * P);
   }
+  // autonomous form (fin.gn set): the first pose comes from HBM, every later one from this workgroup's own solve (resident_auto_stage)
+  constexpr bool autonomous = AUTO;   // a template parameter: the host-driven instances carry no call to the solve (registers, scratch)
+  double tol = 0.0;
+  if (autonomous) {
+    if (threadIdx.x < 12) s_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
+    tol = fin.gn->tol;
+    __syncthreads();
+  }
   for (int it = 1; it <= max_iters; it++) {
-    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;   // stop requested or no host: uniform for the workgroup
+    if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;   // stop requested or no host: uniform for the workgroup
 #ifdef RPE_STAMPS
     const bool stamp_it = it == 1000;
     if (stamp_it) RPE_STAMP(0);
@@ -1219,6 +1318,10 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #ifndef RPE_STAMPS
     const bool stamp_it = false;
 #endif
+    if (autonomous) {
+      if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose) != 0) return;
+      continue;
+    }
     if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, stamp_it)) return;
   }
 }
@@ -2405,11 +2508,12 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   constexpr int kMaxRows = 4 * (BLK / (KIND == KIND_P2P ? 17 : 29));   // up to 4 granules per collecting thread
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
   if (fin.rows < 1) fin.rows = 1;
-#define RPE_RES_LAUNCH2(M, W, R)                                                                                                             \
+#define RPE_RES_LAUNCH3(M, W, R, AU)                                                                                                         \
   do {                                                                                                                                       \
-    if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
-    else hipLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R>), dim3(G), dim3(BLK), 0, s, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin);     \
+    if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
+    else hipLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU>), dim3(G), dim3(BLK), 0, s, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin);     \
   } while (0)
+#define RPE_RES_LAUNCH2(M, W, R) do { if (fin.gn != nullptr) RPE_RES_LAUNCH3(M, W, R, true); else RPE_RES_LAUNCH3(M, W, R, false); } while (0)
 #define RPE_RES_LAUNCH(M, W) do { if (in_regs) RPE_RES_LAUNCH2(M, W, true); else RPE_RES_LAUNCH2(M, W, false); } while (0)
   if (mask && weight) RPE_RES_LAUNCH(true, true);
   else if (mask) RPE_RES_LAUNCH(true, false);
@@ -2417,6 +2521,7 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   else RPE_RES_LAUNCH(false, false);
 #undef RPE_RES_LAUNCH
 #undef RPE_RES_LAUNCH2
+#undef RPE_RES_LAUNCH3
 }
 template <class T>
 static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
