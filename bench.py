@@ -735,7 +735,7 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
         dtd = time.perf_counter() - t0d
         out["device_resident_loop"] = {"value": out["config"]["valid_corr_per_step"] * K / dtd, "unit": "correspondence-residuals/s", "us_per_iteration": dtd / K * 1e6,
                                        "iterations": itd, "rot_rad_vs_host_loop": rot_err(pd[:9].reshape(3, 3), pose[:9].reshape(3, 3)),
-                                       "note": "rpe_gn_refine_device: solve + exp-map on the GPU, one launch per iteration; reported beside, not instead of, the host-update headline"}
+                                       "note": "rpe_gn_refine_device: solve + exp-map on the GPU, one launch for the whole loop (the resident grid iterates by itself); reported beside, not instead of, the host-update headline"}
     except Exception as e:  # noqa: BLE001
         out["device_resident_loop"] = {"error": repr(e)}
     # (3) the step BEFORE the path: dense projective ICP on two rendered 640x480 depth frames

@@ -136,9 +136,11 @@ int rpe_normal_eq_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int
 int rpe_gn_refine_joint(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
                         int* iters_out, double* last_step, double* final_cost);
 
-/* Device-resident variant of rpe_gn_refine_joint: pose and loop state stay in HBM, every iteration is one kernel launch whose
- * last workgroup solves the 6x6 system (LDL^T) and applies the SE(3) exp-map update on the GPU; the host enqueues max_iter
- * launches and waits once.  Launches after convergence return immediately.  Same arithmetic as the host loop.
+/* Device-resident variant of rpe_gn_refine_joint: pose and loop state stay on the GPU, which solves the 6x6 system (LDL^T) and
+ * applies the SE(3) exp-map update itself; the host waits once.  One GPU and a single plain point-to-point or point-to-plane term
+ * (scale 1, no robust weight): ONE launch whose resident grid iterates by itself until |delta| < tol or max_iter.  Otherwise one
+ * launch per iteration whose last workgroup solves (the host enqueues max_iter launches; those after convergence return
+ * immediately).  Same arithmetic as the host loop.  RPE_DEVICE_LOOP_RESIDENT=0 selects the per-iteration form everywhere.
  * After rpe_p2p_init the loop is SHARDED: every launch's last workgroup first exchanges and sums the record with its peers, so
  * the refinement stays one launch per iteration on any number of GPUs of a node (collective: all ranks call it alike). */
 int rpe_gn_refine_device(rpe_context* ctx, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
