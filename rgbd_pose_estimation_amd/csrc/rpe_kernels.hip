@@ -301,10 +301,11 @@ __device__ __forceinline__ double p2p_allreduce32(double val, const Finish& fin,
 // ---- device-resident Gauss-Newton: solve H d = -g (LDL^T) and T <- exp(d) T by ONE lane of the last workgroup.
 // Fully unrolled so that every matrix entry is a register (a rolled version over LDS arrays took ~10 us per call: one
 // lane, ~500 dependent LDS round trips); the streaming body's occupancy is unaffected as long as the kernel stays within
-// 256 VGPRs (one 512-thread workgroup per CU = 2 waves per SIMD).  Arithmetic mirrors rpe/linalg.hpp operation for operation.
+// 256 VGPRs (one 512-thread workgroup per CU = 2 waves per SIMD).  Arithmetic follows rpe/linalg.hpp except for two latency savers
+// (one reciprocal per pivot, one sincos of the half angle): last-bit differences, checked against the golden (1e-13).
 __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* LDS */, double* __restrict__ pose /* LDS, 12, in/out */,
                                              double* step_out) {
-  double A[6][6], Lm[6][6], D[6], y[6], d[6];
+  double A[6][6], Lm[6][6], D[6], Dinv[6], y[6], d[6];
   {
     int k = 0;
 #pragma unroll
@@ -321,12 +322,14 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
     for (int m = 0; m < j; m++) dj -= Lm[j][m] * Lm[j][m] * D[m];
     ok = ok && (dj > 1e-12 * A[j][j]) && (dj < 1e300);   // relative pivot floor, as rpe/linalg.hpp solve_normal_eq6
     D[j] = dj;
+    const double inv = 1.0 / dj;   // ONE division per column (the host divides every entry; the results differ in the last bit at most)
+    Dinv[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double sacc = A[i][j];
 #pragma unroll
       for (int m = 0; m < j; m++) sacc -= Lm[i][m] * Lm[j][m] * D[m];
-      Lm[i][j] = sacc / dj;
+      Lm[i][j] = sacc * inv;
     }
   }
   if (!ok) return false;
@@ -338,7 +341,7 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
     y[i] = sacc;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     double sacc = y[i];
@@ -354,9 +357,11 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
   // exp(d): rotation from the quaternion (cos(th/2), sin(th/2) w / th), V = I + c1 W + c2 W^2  (sophus/se3.hpp:321-342)
   const double wx = d[3], wy = d[4], wz = d[5];
   const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-  double imag, real;
+  // ONE sincos of the half angle serves the quaternion and, through sin th = 2 s c and 1 - cos th = 2 s^2, the V matrix (a single lane
+  // runs this: four separate fp64 sin / cos calls were a quarter of the solve's time)
+  double imag, real, sh = 0.0, ch = 1.0;
   if (th < 1e-10) { imag = 0.5 - th2 / 48.0 + th2 * th2 / 3840.0; real = 1.0 - th2 / 8.0 + th2 * th2 / 384.0; }
-  else { imag = sin(0.5 * th) / th; real = cos(0.5 * th); }
+  else { sincos(0.5 * th, &sh, &ch); imag = sh / th; real = ch; }
   double Rd[9], V[9];
   {
     const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
@@ -371,7 +376,7 @@ __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* L
 #pragma unroll
     for (int k = 0; k < 9; k++) V[k] = Rd[k];
   } else {
-    const double c1 = (1.0 - cos(th)) / th2, c2 = (th - sin(th)) / (th2 * th);
+    const double c1 = (2.0 * sh * sh) / th2, c2 = (th - 2.0 * sh * ch) / (th2 * th);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
 #pragma unroll
