@@ -1,5 +1,5 @@
-"""Soak of the two cross-workgroup protocols (development aid, run on the GPU box): the resident loop and the collecting launches must
-give BITWISE the same result every time (fixed summation order whichever workgroup finishes first) and never lose a granule.
+"""Soak of the cross-workgroup protocols (development aid, run on the GPU box): the host-driven resident loop, the collecting launches and
+the one-launch device loop (granules + double-buffered run records, no host in the loop) must give BITWISE the same result every time (fixed summation order whichever workgroup finishes first) and never lose a granule.
   python scripts/soak.py [seconds]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,14 +17,20 @@ for n, kind in ((307200, 0), (1000000, 1), (20000, 0)):
     first_pose = ctx.gn_refine([kind], p, max_iter=500, tol=0.0)[0]
     first_rec = np.asarray(ctx.normal_eq(kind, p)[0] if isinstance(ctx.normal_eq(kind, p), tuple) else ctx.normal_eq(kind, p))
     t0, calls, iters, bad = time.perf_counter(), 0, 0, 0
-    while time.perf_counter() - t0 < seconds / 6:
+    while time.perf_counter() - t0 < seconds / 9:
         q = ctx.gn_refine([kind], p, max_iter=500, tol=0.0)[0]
         bad += int(not np.array_equal(q, first_pose)); calls += 1; iters += 500
     t1, ncalls, nbad = time.perf_counter(), 0, 0
-    while time.perf_counter() - t1 < seconds / 6:
+    while time.perf_counter() - t1 < seconds / 9:
         r = ctx.normal_eq(kind, p)
         r = np.asarray(r[0] if isinstance(r, tuple) else r)
         nbad += int(not np.array_equal(r, first_rec)); ncalls += 1
-    out[f"{n}_{kind}"] = dict(resident_calls=calls, resident_iterations=iters, resident_pose_changed=bad, collect_calls=ncalls, collect_record_changed=nbad)
+    first_dev = ctx.gn_refine_device([(kind, 1.0)], p, 0, 500, 0.0)[0]
+    t2, dcalls, dbad = time.perf_counter(), 0, 0
+    while time.perf_counter() - t2 < seconds / 9:
+        q = ctx.gn_refine_device([(kind, 1.0)], p, 0, 500, 0.0)[0]
+        dbad += int(not np.array_equal(q, first_dev)); dcalls += 1
+    out[f"{n}_{kind}"] = dict(resident_calls=calls, resident_iterations=iters, resident_pose_changed=bad, collect_calls=ncalls, collect_record_changed=nbad,
+                              device_loop_calls=dcalls, device_loop_iterations=500 * dcalls, device_loop_pose_changed=dbad)
     ctx.close()
 print(json.dumps(out))
