@@ -750,7 +750,7 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
         fctx.frame_set_depth(S.render_depth(Rb, tb, as_u16=True), S.DEFAULT_CAMERA, 0.001, 0.1, 10.0, 0.1)
         K, reps = 20, 25
         modes = {}
-        for name, dev_res in (("host_update_resident_kernel", False), ("device_resident_one_launch_per_round", True)):
+        for name, dev_res in (("host_update_resident_kernel", False), ("device_resident_one_launch", True)):
             fctx.icp(pose12(Ra, ta), L.RES_P2PLANE, K, 0.0, 0.15, 0.8, device_resident=dev_res, fused=True)
             t0i = time.perf_counter()
             for _ in range(reps):

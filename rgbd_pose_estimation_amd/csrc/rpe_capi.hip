@@ -1556,10 +1556,24 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     rpe::ReduceTarget rt = host_target(c);
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
-    for (int k = 0; k < o->max_iter; k++) if ((rc = round(pose12, rt, true))) return rc;
+    static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
+    if (auto_on && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world < 1) {
+      // ONE launch: the resident grid pairs, sums, solves and updates by itself (icp_resident_kernel with resident_auto_stage)
+      int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
+      rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
+      const unsigned long long base = c->seq;
+      rt.rows = grid * nacc <= 1024 ? 1 : rows_auto;
+      c->seq = base + (unsigned long long)o->max_iter + 1;
+      rt.seq = c->seq;
+      HIP_TRY(rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr, o->use_normals,
+                                       o->kind, nullptr, base, o->max_iter, rt, c->stream));
+    } else {
+      for (int k = 0; k < o->max_iter; k++) if ((rc = round(pose12, rt, true))) return rc;
+    }
     if ((rc = wait_host(c, rpe::kNeLd))) return rc;
     for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
     step = c->h_out[12]; cost = c->h_out[13]; it = (int)c->h_out[14]; pairs = c->h_out[16];
+    if (c->h_out[15] == 2.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_HIP, "ICP device loop: a workgroup's sums never arrived at iteration %d", it); }
     if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
   } else if (o->fused && c->resident && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
     // host-driven ICP in ONE launch: the frame's pixels stay in registers, every iteration the host hands the pose over, the grid pairs

@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(BLK) void icp_fused_kernel(const float* __restrict_
 // (associate_pixel: the model vertex / normal gathers are the only memory traffic of an iteration) and accumulate the normal equations,
 // and the sums reach the host through the collecting stage (resident_cross_stage).  Pairing function and per-pixel arithmetic are
 // the fused kernel's; only the order of the cross-workgroup sums differs.
-template <int KIND, int BLK, bool IN_REGS>
+template <int KIND, int BLK, bool IN_REGS, bool AUTO>
 __global__ __launch_bounds__(BLK) void icp_resident_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n,
                                                            const float* __restrict__ mv, const float* __restrict__ mn, AssocParams P,
                                                            const unsigned long long* __restrict__ ctl, unsigned long long first_tag,
@@ -1438,8 +1438,15 @@ __global__ __launch_bounds__(BLK) void icp_resident_kernel(const float* __restri
   float rV[12], rN[12];
   const bool mine = IN_REGS && g0 < groups;
   if (mine) load_pixels(g0, rV, rN);
+  // AUTO (rpe_icp with device_resident): no host in the loop -- first pose from HBM, every later one from the workgroup's own solve
+  double tol = 0.0;
+  if (AUTO) {
+    if (threadIdx.x < 12) s_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
+    tol = fin.gn->tol;
+    __syncthreads();
+  }
   for (int it = 1; it <= max_iters; it++) {
-    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;
+    if (!AUTO && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
@@ -1473,6 +1480,10 @@ __global__ __launch_bounds__(BLK) void icp_resident_kernel(const float* __restri
         load_pixels(g, V, N);
         pair_and_add(V, N, g < full ? 4 : (int)(n - full * 4));
       }
+    }
+    if (AUTO) {
+      if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose) != 0) return;
+      continue;
     }
     if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, false)) return;
   }
@@ -2606,10 +2617,12 @@ hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, 
   const int max_rows = 4 * (BLK / (kind == KIND_P2P ? 17 : 29));
   if (fin.rows > max_rows) fin.rows = max_rows;
   if (fin.rows < 1) fin.rows = 1;
-#define RPE_ICP_RES(K, R) hipLaunchKernelGGL((icp_resident_kernel<K, BLK, R>), dim3(G), dim3(BLK), 0, s, vmap, nmap, n, mv, mn, P, ctl, first_tag, max_iters, fin)
+#define RPE_ICP_RES2(K, R, AU) hipLaunchKernelGGL((icp_resident_kernel<K, BLK, R, AU>), dim3(G), dim3(BLK), 0, s, vmap, nmap, n, mv, mn, P, ctl, first_tag, max_iters, fin)
+#define RPE_ICP_RES(K, R) do { if (fin.gn != nullptr) RPE_ICP_RES2(K, R, true); else RPE_ICP_RES2(K, R, false); } while (0)
   if (kind == KIND_P2P) { if (in_regs) RPE_ICP_RES(KIND_P2P, true); else RPE_ICP_RES(KIND_P2P, false); }
   else { if (in_regs) RPE_ICP_RES(KIND_P2PLANE, true); else RPE_ICP_RES(KIND_P2PLANE, false); }
 #undef RPE_ICP_RES
+#undef RPE_ICP_RES2
   return hipGetLastError();
 }
 
