@@ -351,7 +351,8 @@ int rpe_model_upload(rpe_context* ctx, const float* vertex_w, const float* norma
 int rpe_associate(rpe_context* ctx, const double* pose12, double dist_thr, double cos_thr, int use_normals, int64_t* matched);
 /* ICP: max_iter rounds of { rpe_associate under the current pose ; one Gauss-Newton step of residual `kind`
  * (RPE_RES_P2PLANE uses the FRAME's normals, RPE_RES_P2P none) }.
- * device_resident = 1 keeps pose, solve and exp-map on the GPU (one host wait at the end), 0 solves on the host each round
+ * device_resident = 1 keeps pose, solve and exp-map on the GPU (one host wait at the end; with fused = 1 ONE launch whose resident grid
+ * iterates by itself), 0 solves on the host each round
  * (with fused = 1 that is ONE resident launch for the whole loop: the frame's pixels stay in registers and the host hands a pose to
  * the waiting grid every round, as rpe_gn_refine does -- the fastest form, needs a large-BAR device).
  * fused = 1 pairs and accumulates in ONE kernel per round (the pairs never exist in HBM: 48 B/pixel instead of 156); same

@@ -33,7 +33,7 @@ struct IcpOptions {
   int max_iter = 10;
   double tol = 1e-6, dist_thr = 0.1, cos_thr = 0.9;
   // fused + host update = ONE resident launch for the whole loop (the fastest form: 11 us per round at 640 x 480); device_resident = true
-  // keeps solve and update in the kernel instead (one launch per round, 15 us; no busy host thread)
+  // keeps solve and update on the GPU instead (also one launch, the grid iterates by itself: 12 us per round; no busy host thread)
   bool use_normals = true, device_resident = false, fused = true;
 };
 struct IcpResult { int iterations = 0; double last_step = 0, cost = 0; long long pairs = 0; };
