@@ -1208,8 +1208,8 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
     if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
     else a_part[0][threadIdx.x] = own;
   }
-  bool lost = false;
-  if ((int)blockIdx.x == leader) {
+  bool lost = runs * NACC > kAutoMaxRunSums;   // a geometry the launcher never chooses: reported like a lost granule, not overrun
+  if (!lost && (int)blockIdx.x == leader) {
     const int rows = min(R, G - leader);
     lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part));
     if (!lost && threadIdx.x < NACC) {

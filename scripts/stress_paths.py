@@ -1,5 +1,5 @@
 """Randomised cross-check of the collecting / resident paths against the arrival-counter / launch-per-step paths (RPE_COLLECT=0,
-RPE_RESIDENT=0): sizes around every geometry boundary, fp32 / fp64, all three residual kinds, with and without masks -- records to
+RPE_RESIDENT=0, RPE_DEVICE_LOOP_RESIDENT=0): sizes around every geometry boundary, fp32 / fp64, all three residual kinds, with and without masks -- records to
 rounding, votes exactly, refined poses to 1e-7.  Development aid (run on the GPU box)."""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,8 +40,15 @@ def worker(seed0, count):
                 ref = ctx.gn_refine([kind], p, None, flags, 12, 0.0)[0]
             except L.RpeError as e:
                 ref = "ERR " + str(e)[:60]
+        dev = None   # the device loop: one launch (new) against one launch per iteration (old, RPE_DEVICE_LOOP_RESIDENT=0)
+        if n >= 6 and kind != 2:
+            try:
+                dev = ctx.gn_refine_device([(kind, 1.0)], p, flags, 12, 0.0)[0]
+            except L.RpeError as e:
+                dev = "ERR " + str(e)[:60]
         out.append(dict(n=n, f64=f64, kind=kind, flags=flags, rec=np.asarray(rec).tolist(), mom=np.asarray(mom).tolist(), votes=votes.tolist(),
-                        ref=ref if isinstance(ref, str) or ref is None else np.asarray(ref).tolist()))
+                        ref=ref if isinstance(ref, str) or ref is None else np.asarray(ref).tolist(),
+                        dev=dev if isinstance(dev, str) or dev is None else np.asarray(dev).tolist()))
         ctx.close()
     print("RESULT " + json.dumps(out))
 
@@ -53,7 +60,7 @@ if __name__ == "__main__":
         total = 0
         for seed in range(8):
             res = {}
-            for tag, env in (("new", {}), ("old", {"RPE_COLLECT": "0", "RPE_RESIDENT": "0"})):
+            for tag, env in (("new", {}), ("old", {"RPE_COLLECT": "0", "RPE_RESIDENT": "0", "RPE_DEVICE_LOOP_RESIDENT": "0"})):
                 r = subprocess.run([sys.executable, __file__, str(seed), "25"], env=dict(os.environ, RPE_QUIET="1", **env), capture_output=True, text=True, timeout=900)
                 if r.returncode != 0:
                     print("worker failed", tag, seed, r.stderr[-1500:]); bad += 1; continue
@@ -71,6 +78,12 @@ if __name__ == "__main__":
                     ok &= np.allclose(np.array(a["ref"]), np.array(b["ref"]), rtol=0, atol=1e-7)
                 else:
                     ok &= (type(a["ref"]) == type(b["ref"]))
+                if isinstance(a["dev"], list) and isinstance(b["dev"], list):
+                    ok &= np.allclose(np.array(a["dev"]), np.array(b["dev"]), rtol=0, atol=1e-7)
+                    if isinstance(a["ref"], list):
+                        ok &= np.allclose(np.array(a["dev"]), np.array(a["ref"]), rtol=0, atol=1e-7)   # and against the host-driven loop of the same run
+                else:
+                    ok &= (type(a["dev"]) == type(b["dev"]))
                 if not ok:
                     bad += 1
                     drec = float(np.max(np.abs(ra - rb) / (1e-300 + np.abs(rb).max())))
