@@ -109,11 +109,13 @@ def pin_to_gpu_numa_node(local_rank: int, world_size: int = 1):
         cand = [c for c in cpus if c in allowed] or allowed
         # away from CPU 0 (interrupts).  One GPU: one CPU for the polling thread.  Several ranks: four CPUs each, disjoint between the
         # ranks -- threads created later (RCCL's, torch's) inherit the mask and must not share a single core with a thread that spins
+        # (the first cores of a socket take the interrupts and poll 3-4 % slower: start at the 17th, scripts/core_sweep.py)
+        skip = 16 if len(cand) >= 64 else 1
         if world_size > 1:
-            first = (1 + 4 * local_rank) % len(cand)
+            first = (skip + 4 * local_rank) % len(cand)
             mine = {cand[(first + k) % len(cand)] for k in range(4)}
         else:
-            mine = {cand[1 % len(cand)]}
+            mine = {cand[skip % len(cand)]}
         os.sched_setaffinity(0, mine)
         return {"pinned": True, "cpu": sorted(mine)[0] if len(mine) == 1 else sorted(mine), "numa_node": open(os.path.join(dev, "numa_node")).read().strip(),
                 "gpu_local_cpus": len(cpus), "gpu_local_cpu_ids": cpus}
@@ -460,7 +462,14 @@ def worker(args, affinity):
                 local = set(affinity.get("gpu_local_cpu_ids", []))
                 near = [c for c in allowed if c in local and c != mine]
                 far = [c for c in allowed if c not in local]
-                cands = [mine] + [near[len(near) // 2]] * bool(near) + ([far[1 % len(far)], far[len(far) // 2]] if far else [])
+                # measured (scripts/core_sweep.py): the cores of one socket are alike to 1 %, except its first ones (CPU 0 / 1 take the
+                # interrupts: 3-4 % slower), and the sockets differ by 10 % -- in either direction, whatever sysfs calls GPU-local.
+                # So: the default core, three cores spread over the local socket, two over the other one and one SMT sibling there.
+                half = (os.cpu_count() or 2) // 2
+                near_phys = [c for c in near if c < half] or near
+                far_phys = [c for c in far if c < half] or far
+                spread = lambda v, fr: [v[min(len(v) - 1, int(len(v) * f))] for f in fr] if v else []
+                cands = [mine] + spread(near_phys, (0.5, 0.75, 0.9)) + spread(far_phys, (0.02, 0.5)) + ([far[len(far) // 2]] if far else [])
                 trial = {}
                 reps_c = max(3, min(12, 6000 // args.steps))
                 for cpu in dict.fromkeys(cands):   # each trial has the shape of the timed region: synchronize, K steps, synchronize
