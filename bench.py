@@ -495,10 +495,13 @@ def worker(args, affinity):
         time_every = 1 if (resident or args.steps < 256) else 16
         per_rep_records = (launches_per_rep + time_every - 1) // time_every
         budget = 4096
-        timed_reps = max(1, min(args.repeats, budget // max(per_rep_records, 1)))
+        # HIP events on a launch are instrumentation with a cost of their own (about 8 us per launch: 0.4 us per step of a 20-step
+        # region): --event-reps of the repetitions carry them (for roofline.avg_launch_us), interleaved with the plain ones
+        timed_reps = max(1, min(args.repeats, args.event_reps, budget // max(per_rep_records, 1)))
+        event_every = max(1, args.repeats // timed_reps)
         samples, k_cnt, k_total_ms, k_min_ms = [], 0, 0.0, 1e30
         for rep in range(args.repeats):
-            timing = rep < timed_reps
+            timing = rep % event_every == 0 and rep // event_every < timed_reps
             if timing:
                 ctx.timing_enable(per_rep_records + 1, time_every)
             p_start = pose12(R0, t0)
@@ -641,6 +644,7 @@ def worker(args, affinity):
                                     ("rpe_gn_refine on every rank: one launch per step + exchange between the host threads (ranks share a GPU)" if hostex else
                                      "rpe_gn_steps_dist: one launch + one collective per step" if dist_path else "rpe_gn_refine: one launch per step")},
             "timing": {"repeats": args.repeats, "statistic": "median over repetitions of the whole K-step region (MAX over ranks each)",
+                       "event_timed_repetitions": timed_reps, "event_timed_note": "every %d-th repetition also carries HIP events on its launches (instrumentation for roofline.avg_launch_us, about 8 us per launch); all repetitions enter the median" % event_every,
                        "ms_per_step_p10": percentile(samples, 0.1) / args.steps * 1e3, "ms_per_step_p90": percentile(samples, 0.9) / args.steps * 1e3,
                        "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": {k: v for k, v in affinity.items() if k != "gpu_local_cpu_ids"}, "loop_profile": loop_prof},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -832,6 +836,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=50, help="repetitions of the timed K-step region; the median is reported")
+    ap.add_argument("--event-reps", type=int, default=16, help="how many of the repetitions also time their launches with HIP events (roofline.avg_launch_us)")
     ap.add_argument("--n-per-gpu", type=int, default=N_FRAME, help="correspondences at N = 1 (configs[1])")
     ap.add_argument("--n-total", type=int, default=0, help="total correspondences at N > 1 (default configs[4]: 10 000 000)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
