@@ -25,7 +25,7 @@ def test_committed_bench_line_matches_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
-    assert r["launches_timed"] >= 20 and r["steps_per_launch"] >= 1
+    assert r["launches_timed"] >= 16 and r["steps_per_launch"] >= 1   # bench.py --event-reps
     assert (r["traffic"] is None) == (r["traffic_source"] is None)       # a counter figure always names the profiles/ file it was read from
     assert (r["rocprofv3_avg_launch_us"] is None) == (r["rocprofv3_source"] is None)
     c = j["cpu_baseline"]
