@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -370,6 +371,14 @@ template <class T> static T sqrt_cut(T thr) {
 // correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the GPU at all; otherwise runs of one
 // granule per collecting thread (30 workgroups for point-to-point: 5 run records at 640 x 480), up to four when that keeps the number
 // of runs at <= 8 -- a few hundred bytes over PCIe.  RPE_RESIDENT_ROWS forces a run length.
+// One resident loop per GPU at a time within this process: two resident grids launched together (two contexts, two threads) could each
+// get only part of their workgroups onto the CUs and then wait for workgroups that cannot start (the bounded waits would end both with
+// an error).  Other PROCESSES on the same GPU are the caller's to serialise.
+static std::mutex& resident_mutex(int device) {
+  static std::mutex m[64];
+  return m[device >= 0 && device < 64 ? device : 0];
+}
+
 template <class Launch>
 static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale, double* pose12, int max_iter,
                        double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what) {
@@ -821,6 +830,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     rt.seq = c->seq;                                  // published with the result
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+    std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
     HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0, e1));
     int rc = wait_host(c, rpe::kNeLd);
     if (rc) return rc;
@@ -923,7 +933,8 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
       if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
       return rpe::launch_normal_eq_resident(c->arrays(), kind, flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream, e0, e1);
     };
-    rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations");
+    { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations"); }
     if (iters_out) *iters_out = it;
     if (rc != RPE_OK) return rc;
     if (last_step) *last_step = step;
@@ -1557,8 +1568,10 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     rpe::ReduceTarget rt = host_target(c);
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
     static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
+    std::unique_lock<std::mutex> one_resident_grid(resident_mutex(c->device), std::defer_lock);
     if (auto_on && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world < 1) {
       // ONE launch: the resident grid pairs, sums, solves and updates by itself (icp_resident_kernel with resident_auto_stage)
+      one_resident_grid.lock();   // until the result has arrived (end of this block's scope)
       int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
       rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
       const unsigned long long base = c->seq;
@@ -1584,7 +1597,8 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       return rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr, o->use_normals,
                                       o->kind, (const unsigned long long*)c->ctl, base, o->max_iter, rt, c->stream);
     };
-    rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs, "ICP: normal equations");
+    { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs, "ICP: normal equations"); }
     if (rc != RPE_OK) { if (iters_out) *iters_out = it; return rc; }
   } else {
     for (; it < o->max_iter; it++) {

@@ -102,3 +102,37 @@ def test_one_launch_form_equals_one_launch_per_iteration_form():
         assert a["it"] == b["it"] and 0 < a["it"] < 25
         assert np.max(np.abs(np.array(a["pose"]) - np.array(b["pose"]))) < 1e-7    # different summation trees over the workgroups, stopped at |delta| < 1e-6
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(b["cost"])
+
+
+def test_two_threads_two_contexts_one_gpu(gpu_ctx_factory):
+    """resident loops of one process are serialised per GPU inside the library: two threads with a context each (ctypes releases the GIL
+    during the calls) refine concurrently -- host-driven and one-launch device loops mixed -- and every result equals the single-threaded one"""
+    import threading
+    n = 307200
+    sc, mask, w, p0 = _scene(n, np.float32)
+    ctxs = [gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, nc=sc.N, nw=sc.M) for _ in range(2)]
+    ref_h = ctxs[0].gn_refine([L.RES_P2P], p0, None, 0, 12, 0.0)[0]
+    ref_d = ctxs[0].gn_refine_device([(L.RES_P2P, 1.0)], p0, 0, 12, 0.0)[0]
+    errors = []
+
+    def work(ctx, first_device):
+        try:
+            for k in range(150):
+                if (k + first_device) % 2:
+                    out = ctx.gn_refine_device([(L.RES_P2P, 1.0)], p0, 0, 12, 0.0)[0]
+                    if not np.array_equal(out, ref_d):
+                        errors.append(("device", k))
+                else:
+                    out = ctx.gn_refine([L.RES_P2P], p0, None, 0, 12, 0.0)[0]
+                    if not np.array_equal(out, ref_h):
+                        errors.append(("host", k))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(ctxs[i], i)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts)
+    assert not errors, errors[:5]
