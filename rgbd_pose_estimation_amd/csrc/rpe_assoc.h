@@ -1,5 +1,5 @@
 // Per-pixel projective data association, shared by the stand-alone association kernel (rpe_frontend.hip) and by the
-// fused ICP kernel (rpe_kernels.hip) so that both pair pixels IDENTICALLY: fp32, fixed operation order, no FMA
+// fused ICP kernel (rpe_icp.hip) so that both pair pixels IDENTICALLY: fp32, fixed operation order, no FMA
 // contraction (the contract flag is per instruction and survives inlining).
 #pragma once
 #include "rpe_kernels.h"

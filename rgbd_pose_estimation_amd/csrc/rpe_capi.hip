@@ -130,7 +130,7 @@ struct rpe_context {
   unsigned long long p2p_step = 0;
   unsigned long long p2p_vote_step = 0;   // the same for the vote counters of sharded scoring
   // resident Gauss-Newton loop (rpe_gn_refine on one GPU): control block in fine-grained device memory that the HOST writes through
-  // the PCIe BAR and every workgroup of the resident kernel polls (layout: rpe_kernels.hip).  Null when the device memory is not
+  // the PCIe BAR and every workgroup of the resident kernel polls (layout: rpe_residuals.hpp).  Null when the device memory is not
   // host-accessible (no large BAR): the loop then launches one kernel per iteration.
   volatile unsigned long long* ctl = nullptr;
   bool resident = false;
@@ -225,7 +225,7 @@ rpe::ReduceTarget host_target(rpe_context* c) {
   c->collecting = false;
   return rt;
 }
-// host-consumed result of ONE launch on a single GPU: collecting workgroups + host-side final sum (rpe_kernels.hip collect_and_send);
+// host-consumed result of ONE launch on a single GPU: collecting workgroups + host-side final sum (rpe_reduce.hpp collect_and_send);
 // wait_host then assembles the record in c->h_out.  RPE_COLLECT=0: the arrival-counter tail (as the device / collective targets use)
 rpe::ReduceTarget collect_target(rpe_context* c) {
   rpe::ReduceTarget rt = host_target(c);
@@ -281,7 +281,7 @@ int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int f
   }
   return RPE_OK;
 }
-// the 17 structured point-to-point sums -> the packed record (same map as record_entry<1> in rpe_kernels.hip)
+// the 17 structured point-to-point sums -> the packed record (same map as record_entry<1> in rpe_reduce.hpp)
 void expand_p2p17(const double* t, double* ne) {
   for (int i = 0; i < 32; i++) ne[i] = 0.0;
   const double nn = t[0], Sx = t[1], Sy = t[2], Sz = t[3], xx = t[4], xy = t[5], xz = t[6], yy = t[7], yz = t[8], zz = t[9];
@@ -818,7 +818,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   const bool sharded = c->p2p_world >= 1;
   // One GPU, one of the two 3D-3D kinds: ONE launch for the whole loop.  The grid stays resident and iterates by itself -- granule
   // hand-off to the collecting workgroups, run records read back by every workgroup, solve + exp-map in every workgroup alike
-  // (rpe_kernels.hip resident_auto_stage); the host hears from it once, when the loop has finished.  RPE_DEVICE_LOOP_RESIDENT=0: one
+  // (rpe_residuals.hpp resident_auto_stage); the host hears from it once, when the loop has finished.  RPE_DEVICE_LOOP_RESIDENT=0: one
   // launch per iteration, as the other residual kinds and the sharded loop keep.
   static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
   if (auto_on && single && !sharded && !c->comm && !c->hostex && max_iter >= 2 && (terms[0].kind == RPE_RES_P2P || terms[0].kind == RPE_RES_P2PLANE)) {
@@ -1590,7 +1590,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
   } else if (o->fused && c->resident && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
     // host-driven ICP in ONE launch: the frame's pixels stay in registers, every iteration the host hands the pose over, the grid pairs
-    // its pixels with the model under that pose and sends the run records back (rpe_kernels.hip icp_resident_kernel)
+    // its pixels with the model under that pose and sends the run records back (rpe_icp.hip icp_resident_kernel)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {

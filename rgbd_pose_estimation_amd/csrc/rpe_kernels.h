@@ -1,4 +1,5 @@
-// Internal launcher interface between the C-ABI shim (rpe_capi.hip) and the gfx950 kernels (rpe_kernels.hip).
+// Internal launcher interface between the C-ABI shim (rpe_capi.hip) and the gfx950 kernel units (rpe_normal_eq.hip,
+// rpe_icp.hip, rpe_joint.hip, rpe_score.hip, rpe_nl.hip; shared device code: rpe_reduce.hpp, rpe_residuals.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,7 +66,7 @@ struct ReduceTarget {
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // RESIDENT form of the same kernels: one launch serves up to max_iters Gauss-Newton iterations; between iterations every workgroup
-// waits for the next pose in `ctl` (16 words in fine-grained device memory written by the host: layout in rpe_kernels.hip), tagged
+// waits for the next pose in `ctl` (16 words in fine-grained device memory written by the host: layout in rpe_residuals.hpp), tagged
 // first_tag + i; the run records of iteration i (rt.rows) are published with sequence value rt.seq + i.  Needs host-writable device
 // memory (large BAR).
 constexpr unsigned long long kResidentStopBit = 1ull << 63;

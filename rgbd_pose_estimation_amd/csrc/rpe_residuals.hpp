@@ -1,0 +1,411 @@
+// Residual / Jacobian arithmetic of the Gauss-Newton normal equations (K1 point-to-point, K2 point-to-plane, K3 bearing) and the
+// resident-loop stages shared by the normal-equation and the ICP kernels.
+#pragma once
+#include "rpe_reduce.hpp"
+
+namespace rpe {
+
+// ================================================================================================
+// K1 / K2 / K3 : Gauss-Newton normal equations
+// ================================================================================================
+// p2p keeps 17 structured sums: w | w p (3) | w p p^T (6) | w r (3) | w p x r (3) | w r^2
+// The pose stays fp64 and p = R x + t, r = p - Xc are formed in fp64: the subtraction cancels ~3 digits
+// (|p| ~ 10 m, |r| ~ 5 cm), so doing it in fp32 would dominate the error budget.  p and r are then rounded
+// to the compute type C for the products (fp32 for fp32 arrays), and the sums are widened to fp64 per group.
+template <class C>
+__device__ __forceinline__ void p2p_point(const PoseK<double>& T, C x, C y, C z, C cx, C cy, C cz, C w, C (&s)[17]) {
+  double pxd, pyd, pzd;
+  transform<C>(T, x, y, z, pxd, pyd, pzd);
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
+  const C rx = (C)(pxd - (double)cx), ry = (C)(pyd - (double)cy), rz = (C)(pzd - (double)cz);
+  const C wpx = w * px, wpy = w * py, wpz = w * pz;
+  const C wrx = w * rx, wry = w * ry, wrz = w * rz;
+  s[0] += w;
+  s[1] += wpx; s[2] += wpy; s[3] += wpz;
+  s[4] = fma(wpx, px, s[4]); s[5] = fma(wpx, py, s[5]); s[6] = fma(wpx, pz, s[6]);
+  s[7] = fma(wpy, py, s[7]); s[8] = fma(wpy, pz, s[8]); s[9] = fma(wpz, pz, s[9]);
+  s[10] += wrx; s[11] += wry; s[12] += wrz;
+  s[13] += py * wrz - pz * wry;
+  s[14] += pz * wrx - px * wrz;
+  s[15] += px * wry - py * wrx;
+  s[16] = fma(wrx, rx, fma(wry, ry, fma(wrz, rz, s[16])));
+}
+// general packed record: H upper triangle (21) | g (6) | w r^2 | w
+template <class C> __device__ __forceinline__ void add_row(const C (&J)[6], C r, C w, C (&s)[29]) {
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const C wa = w * J[a];
+#pragma unroll
+    for (int b = a; b < 6; b++) { s[k] = fma(wa, J[b], s[k]); k++; }
+    s[21 + a] = fma(wa, r, s[21 + a]);
+  }
+  s[27] = fma(w * r, r, s[27]);
+}
+template <class C>
+__device__ __forceinline__ void p2plane_point(const PoseK<double>& T, C x, C y, C z, C cx, C cy, C cz, C nx, C ny, C nz, C w, C (&s)[29]) {
+  double pxd, pyd, pzd;
+  transform<C>(T, x, y, z, pxd, pyd, pzd);
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
+  const C r = (C)((double)nx * (pxd - (double)cx) + (double)ny * (pyd - (double)cy) + (double)nz * (pzd - (double)cz));
+  const C J[6] = {nx, ny, nz, py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx};  // [n ; p x n]
+  add_row(J, r, w, s);
+  s[28] += w;
+}
+// Two correspondences at once: the 35 products of a Jacobian row's outer product as 2-vectors (packed fp32 instructions for fp32
+// arrays), each lane of the pair keeping its own partial sums; the pair's sums are added at the end of the group.
+template <class V> __device__ __forceinline__ void add_row2(const V (&J)[6], V r, V w, V (&s)[29]) {
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const V wa = w * J[a];
+#pragma unroll
+    for (int b = a; b < 6; b++) { s[k] = __builtin_elementwise_fma(wa, J[b], s[k]); k++; }
+    s[21 + a] = __builtin_elementwise_fma(wa, r, s[21 + a]);
+  }
+  s[27] = __builtin_elementwise_fma(w * r, r, s[27]);
+}
+template <class C>
+__device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&cx)[2], const C (&cy)[2],
+                                             const C (&cz)[2], const C (&nx)[2], const C (&ny)[2], const C (&nz)[2], const C (&w)[2],
+                                             C __attribute__((ext_vector_type(2))) (&s)[29]) {
+  typedef C V __attribute__((ext_vector_type(2)));
+  C px[2], py[2], pz[2], r[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {   // the fp64 part stays per point: transform and the (cancelling) residual
+    double pxd, pyd, pzd;
+    transform<C>(T, x[e], y[e], z[e], pxd, pyd, pzd);
+    px[e] = (C)pxd; py[e] = (C)pyd; pz[e] = (C)pzd;
+    r[e] = (C)((double)nx[e] * (pxd - (double)cx[e]) + (double)ny[e] * (pyd - (double)cy[e]) + (double)nz[e] * (pzd - (double)cz[e]));
+  }
+  const V PX = {px[0], px[1]}, PY = {py[0], py[1]}, PZ = {pz[0], pz[1]}, NX = {nx[0], nx[1]}, NY = {ny[0], ny[1]}, NZ = {nz[0], nz[1]};
+  const V J[6] = {NX, NY, NZ, PY * NZ - PZ * NY, PZ * NX - PX * NZ, PX * NY - PY * NX};  // [n ; p x n]
+  const V R = {r[0], r[1]}, W = {w[0], w[1]};
+  add_row2<V>(J, R, W, s);
+  s[28] += W;
+}
+// 1 / sqrt(x) in fp64 without the ~45-instruction IEEE sqrt + divide sequences: the fp32 hardware estimate (v_rsq_f32, 1e-7)
+// refined by two Newton steps y <- y (3/2 - x/2 y^2), each squaring the error: ~1 ulp of fp64 in ~10 instructions.  x is a
+// squared point norm in metres^2 (fits fp32 comfortably).
+__device__ __forceinline__ double rsqrt64(double x) {
+  double y = (double)rsqrtf((float)x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
+template <class C>
+__device__ __forceinline__ void bearing_point(const PoseK<double>& T, C x, C y, C z, C bx, C by, C bz, C w, C (&s)[29]) {
+  double pxd, pyd, pzd;
+  transform<C>(T, x, y, z, pxd, pyd, pzd);
+  const double invd = rsqrt64(pxd * pxd + pyd * pyd + pzd * pzd);
+  const double hxd = pxd * invd, hyd = pyd * invd, hzd = pzd * invd;
+  // sine residual p^ x bv: near the optimum p^ ~ bv, so this too is a cancelling difference -> fp64
+  const C r[3] = {(C)(hyd * (double)bz - hzd * (double)by), (C)(hzd * (double)bx - hxd * (double)bz), (C)(hxd * (double)by - hyd * (double)bx)};
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd, inv = (C)invd;
+  const C hx = (C)hxd, hy = (C)hyd, hz = (C)hzd;
+  // A = -[bv]x (I - h h^T) * inv ; row u of A = -(e_u^T [bv]x) (I - h h^T) inv
+  const C Bx[3][3] = {{C(0), -bz, by}, {bz, C(0), -bx}, {-by, bx, C(0)}};
+  const C h[3] = {hx, hy, hz};
+#pragma unroll
+  for (int u = 0; u < 3; u++) {
+    const C bh = Bx[u][0] * h[0] + Bx[u][1] * h[1] + Bx[u][2] * h[2];
+    const C a0 = -(Bx[u][0] - bh * h[0]) * inv, a1 = -(Bx[u][1] - bh * h[1]) * inv, a2 = -(Bx[u][2] - bh * h[2]) * inv;
+    // J = a^T [I | -[p]x] : translation part a, rotation part (p x a)
+    const C J[6] = {a0, a1, a2, py * a2 - pz * a1, pz * a0 - px * a2, px * a1 - py * a0};
+    add_row(J, r[u], w, s);
+  }
+  s[28] += w;
+}
+
+// The main loop runs over FULL groups only and is branch-free (mask / weight presence are template flags), so the
+// compiler issues all 16-byte loads of an iteration up front behind one wait; the <= P-1 leftover correspondences
+// are handled once, by thread 0 of workgroup 0, through the bounds-checked loaders.
+template <class T, int KIND, bool MASK, bool WEIGHT, int NACC>
+__device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const T (&vw)[3 * Pk<T>::P], const T (&vb)[3 * Pk<T>::P],
+                                                const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P], const T (&wv)[Pk<T>::P],
+                                                int npresent, double (&acc)[NACC]) {
+  constexpr int P = Pk<T>::P;
+  if constexpr (KIND == KIND_P2PLANE) {   // pairs of correspondences (the accumulation is 35 of the ~50 operations per point)
+    typedef T V __attribute__((ext_vector_type(2)));
+    V s2[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) s2[k] = V{T(0), T(0)};
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+      T x[2], y[2], z[2], bx[2], by[2], bz[2], nx[2], ny[2], nz[2], wi[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int i = 2 * j + e;
+        x[e] = vw[3 * i]; y[e] = vw[3 * i + 1]; z[e] = vw[3 * i + 2];
+        bx[e] = vb[3 * i]; by[e] = vb[3 * i + 1]; bz[e] = vb[3 * i + 2];
+        T w = WEIGHT ? wv[i] : T(1);
+        if (MASK) w = m[i] == 1 ? w : T(0);
+        w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
+        const bool off = w == T(0);
+        // keeps NaN / inf of skipped columns out of the sums (selects, not branches)
+        x[e] = off ? T(0) : x[e]; y[e] = off ? T(0) : y[e]; z[e] = off ? T(0) : z[e];
+        bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
+        nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1]; nz[e] = off ? T(0) : vc[3 * i + 2];
+        wi[e] = w;
+      }
+      p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
+    }
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] += (double)(s2[k].x + s2[k].y);
+    return;
+  }
+  T s[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) s[k] = T(0);
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+    T bx = vb[3 * i], by = vb[3 * i + 1], bz = vb[3 * i + 2];
+    T wi = WEIGHT ? wv[i] : T(1);
+    if (MASK) wi = m[i] == 1 ? wi : T(0);
+    wi = (i < npresent && !all_nan(bx, by, bz)) ? wi : T(0);
+    const bool off = wi == T(0);
+    // keeps NaN / inf of skipped columns out of the sums (selects, not branches)
+    x = off ? T(0) : x; y = off ? T(0) : y; bx = off ? T(0) : bx; by = off ? T(0) : by; bz = off ? T(1) : bz;
+    if (KIND == KIND_P2P) {
+      z = off ? T(0) : z;
+      p2p_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[17]>(s));
+    } else if (KIND == KIND_P2PLANE) {
+      z = off ? T(0) : z;
+      const T nx = off ? T(0) : vc[3 * i], ny = off ? T(0) : vc[3 * i + 1], nz = off ? T(0) : vc[3 * i + 2];
+      p2plane_point<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, reinterpret_cast<T(&)[29]>(s));
+    } else {
+      z = off ? T(1) : z;  // p != 0 so that the normalisation stays finite
+      bearing_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[29]>(s));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] += (double)s[k];
+}
+
+// ================================================================================================
+// K1 / K2 / K3, RESIDENT form: the host-driven Gauss-Newton loop in ONE launch.
+// The north-star loop keeps the 6x6 solve and the SE(3) exp-map on the host, so every iteration needs a host round trip; with one
+// launch per iteration that round trip also pays a kernel launch, the dispatch ramp of the grid (1.3 - 2.3 us for 150 workgroups,
+// profiles/r02_tail_timeline.jsonl) and a re-read of the arrays.  Here the grid stays resident between iterations: every workgroup
+// waits for the next pose in a control block that lives in fine-grained DEVICE memory and that the host writes through the PCIe BAR
+// (MI355X: 1.9 us host -> 256 polling workgroups -> host, scripts/ubench/hostmailbox.hip; polling pinned HOST memory from 150
+// workgroups costs 13 us), evaluates its slice, and the last workgroup publishes the record exactly as normal_eq_kernel does.
+// Frame-sized problems (one group per thread) keep their correspondences IN REGISTERS across the iterations -- the arrays are read
+// from memory once per refinement, not once per iteration.
+// Control block: 16 words of 8 bytes = two 64-byte halves, each carrying its own copy of the tag so that no ordering between the
+// host's stores to the two halves is assumed:   [0] tag | [1..7] pose[0..6]   ||   [8..12] pose[7..11] | [13,14] - | [15] tag.
+// The host writes the pose, then both tags (= first_tag + iteration; bit 63 set = stop).  Co-residency: the grid has at most one
+// workgroup per CU (reduce_grid, max_blocks <= 256) and no workgroup waits for another one -- only for the host, and only for a
+// bounded time (~2 s of the 100 MHz clock, then the kernel exits without publishing and the host reports an error).
+// ================================================================================================
+constexpr unsigned long long kResidentStop = 1ull << 63;
+// one group of P correspondences through the bounds-checked loaders when it is the ragged last one (g == full), plain 16-byte loads otherwise
+template <class T, int KIND, bool MASK, bool WEIGHT>
+__device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c, const short* __restrict__ mask,
+                                               const T* __restrict__ weight, int64_t g, int64_t full, int64_t n, T (&vw)[3 * Pk<T>::P],
+                                               T (&vb)[3 * Pk<T>::P], T (&vc)[3 * Pk<T>::P], short (&m)[Pk<T>::P], T (&wv)[Pk<T>::P]) {
+  typedef typename Pk<T>::V V;
+  if (g < full) {
+    const V* xw4 = reinterpret_cast<const V*>(xw);
+    const V* b4 = reinterpret_cast<const V*>(b);
+    const V x0 = xw4[3 * g], x1 = xw4[3 * g + 1], x2 = xw4[3 * g + 2];
+    const V y0 = b4[3 * g], y1 = b4[3 * g + 1], y2 = b4[3 * g + 2];
+    unpack3(x0, x1, x2, vw);
+    unpack3(y0, y1, y2, vb);
+    if (KIND == KIND_P2PLANE) { const V* c4 = reinterpret_cast<const V*>(c); const V z0 = c4[3 * g], z1 = c4[3 * g + 1], z2 = c4[3 * g + 2]; unpack3(z0, z1, z2, vc); }
+    if (MASK) load_mask_full(mask, g, m);
+    if (WEIGHT) load_weight_full(weight, g, wv);
+  } else {
+    load_group<T>(xw, g, n, vw);
+    load_group<T>(b, g, n, vb);
+    if (KIND == KIND_P2PLANE) load_group<T>(c, g, n, vc);
+    if (MASK) load_scalars<T, short>(mask, g, n, m, (short)0);
+    if (WEIGHT) load_scalars<T, T>(weight, g, n, wv, T(0));
+  }
+}
+
+// ---- the two halves of a RESIDENT iteration that do not depend on what is being summed (shared by the normal-equation and the ICP
+// resident kernels).
+// Wait for pose number `want` in the control block (16 words in fine-grained device memory that the host writes through the PCIe BAR:
+// word 0 = tag, words 1..12 = pose, word 15 = tag again, so the two 64-byte halves may arrive in any order).  The first 16 lanes of
+// wave 0 read one 8-byte word each until both tags match.  Returns 1 = go (pose in s_pose), 2 = stop requested, 3 = the host went
+// away (2 s); the value is uniform over the workgroup.
+constexpr int kAutoMaxRunSums = 1024;   // run records x sums an autonomous iteration reads per workgroup (resident_auto_stage)
+template <int BLK>
+__device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want, double* __restrict__ s_pose,
+                                                  int* __restrict__ s_go) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    int go = 0;
+    unsigned long long w = 0;
+    for (;;) {
+      if (lane < 16) w = __hip_atomic_load(ctl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long ta = __shfl(w, 0, 64), tb = __shfl(w, 15, 64);
+      if (ta == tb && (ta & ~kResidentStop) == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
+      if (wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // the host went away: give up (2 s)
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane >= 1 && lane <= 12) s_pose[lane - 1] = __longlong_as_double((long long)w);
+    if (lane == 0) *s_go = go;
+  }
+  __syncthreads();
+  return *s_go;
+}
+// Cross-workgroup stage of one resident iteration: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the
+// first of a run collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no
+// drain, no arrival counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls its granule(s)
+// (collect_rows: sc1 loads until the tag is this iteration's), the rows are added in a fixed order, and the run's NACC sums go to the
+// host as tagged 16-byte pairs.  The host thread that owns the 6x6 solve adds the ceil(G / R) run records in run order.  So one
+// hand-off hop on the GPU (about 1 us: a collecting wave reads a few hundred bytes, MI355X_MICROARCH.md "handoff-1to1"), a few hundred
+// bytes over PCIe, and sums that are a fixed function of (G, R) whichever workgroup finishes first.  R = 1: every workgroup sends its
+// own record (tiny problems).  A workgroup overwrites its granules only in the next iteration, which the host starts after it has
+// received every run record, i.e. after the granules have been read.  Returns false if a granule never arrived (the kernel ends without
+// publishing; the host reports that).
+template <int NACC, int BLK>
+__device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, unsigned long long seq,
+                                                     bool stamp_it) {
+  constexpr int NW = BLK / 64;
+  constexpr int RGN = BLK / NACC;                       // rows a collecting workgroup takes with one granule per thread
+  __shared__ double g_red[NW][NACC];
+  __shared__ double g_part[RGN][NACC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
+  const int R = fin.rows, run = blockIdx.x / R, leader = run * R;
+  wave_reduce_to<NACC>(acc, g_red[wave], lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double own = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
+    if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+    else g_part[0][threadIdx.x] = own;
+  }
+#ifdef RPE_STAMPS
+  if (stamp_it) RPE_STAMP(2);
+#endif
+  bool ok = true;
+  if ((int)blockIdx.x == leader) {
+    const int rows = min(R, (int)gridDim.x - leader);
+    const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part);
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(3);
+#endif
+    if (__syncthreads_or(lost)) ok = false;
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(4);
+#endif
+    if (ok && threadIdx.x < NACC) {
+      double t = 0.0;
+      const int nr = rows < RGN ? rows : RGN;
+      for (int k = 0; k < nr; k++) t += g_part[k][threadIdx.x];
+      store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, t, seq);
+    }
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(5);
+#endif
+  }
+  __syncthreads();   // g_red / g_part are reused by the next iteration
+  return ok;
+}
+
+// Cross-workgroup stage of one AUTONOMOUS resident iteration (rpe_gn_refine_device: solve and exp-map on the GPU, no host in the loop).
+// First hop as above -- runs of R workgroups, the first of a run collects its rows' granules -- but the run's NACC sums go to a RUN
+// RECORD in device memory (granules again: {value, iteration tag}, one sc1 store per lane) instead of to the host.  Second hop: EVERY
+// workgroup reads all ceil(G / R) run records, adds them in run order (the order the host uses: bitwise the host-driven loop's
+// record), expands the record, and its first lane solves the 6x6 system and applies the update to the workgroup's own copy of the
+// pose in LDS.  All workgroups compute the same bits, so they agree on the next pose and on when to stop without another hop.
+// Run records are double-buffered by iteration parity: a collecting workgroup can publish iteration i + 1 while a late workgroup of
+// another run still reads iteration i; it cannot reach i + 2 before that workgroup has delivered its granules of i + 1, i.e. after
+// it has finished reading i.  Granules need no second buffer: a workgroup writes iteration i + 1's after it has read run records
+// that its collector published after reading iteration i's.  Returns 0 = next iteration, 1 = finished (workgroup 0 published pose |
+// step | cost | iterations | status | weight sum to the host), 2 = a granule never arrived (2 s).
+template <int NACC, int BLK>
+__device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it, int max_iters,
+                                                   double tol, double* __restrict__ s_pose) {
+  constexpr int NW = BLK / 64;
+  constexpr int RGN = BLK / NACC;
+  constexpr int MODE = NACC == 17 ? 1 : 0;
+  __shared__ double a_red[NW][NACC];
+  __shared__ double a_part[RGN][NACC];
+  __shared__ double a_runs[kAutoMaxRunSums];
+  __shared__ double a_tot[32], a_rec[32];
+  __shared__ double a_step;
+  __shared__ int a_ok;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = (int)gridDim.x, R = fin.rows, run = blockIdx.x / R, leader = run * R, runs = (G + R - 1) / R;
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);          // [workgroup][NACC] granules of 2 words
+  unsigned long long* rrec = gran + 2 * ((size_t)G * NACC + (size_t)(it & 1) * runs * NACC);   // [parity][run][NACC]
+  wave_reduce_to<NACC>(acc, a_red[wave], lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double own = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) own += a_red[w][threadIdx.x];
+    if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+    else a_part[0][threadIdx.x] = own;
+  }
+  bool lost = runs * NACC > kAutoMaxRunSums;   // a geometry the launcher never chooses: reported like a lost granule, not overrun
+  if (!lost && (int)blockIdx.x == leader) {
+    const int rows = min(R, G - leader);
+    lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part));
+    if (!lost && threadIdx.x < NACC) {
+      double t = 0.0;
+      const int nr = rows < RGN ? rows : RGN;
+      for (int k = 0; k < nr; k++) t += a_part[k][threadIdx.x];
+      store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
+    }
+  }
+  if (!lost) {
+    const int total = runs * NACC;
+    for (int i = threadIdx.x; i < total; i += BLK) {
+      const unsigned long long t0 = wall_clock64();
+      granule_t q;
+      for (unsigned int spins = 1;; spins++) {
+        q = load_granule16(rrec + 2 * (size_t)i);
+        if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
+        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a run record never came
+      }
+      a_runs[i] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
+    }
+  }
+  lost = __syncthreads_or(lost);
+  if (!lost && threadIdx.x < 32) {
+    double t = 0.0;
+    if (threadIdx.x < NACC) for (int r = 0; r < runs; r++) t += a_runs[r * NACC + threadIdx.x];
+    a_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (!lost && threadIdx.x < 32) a_rec[threadIdx.x] = record_entry<MODE>(a_tot, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double step = 0.0;
+    a_ok = !lost && gn_solve_update(a_rec, s_pose, &step) ? 1 : 0;
+    a_step = step;
+  }
+  __syncthreads();
+  const bool ok = a_ok != 0;
+  const bool done = !ok || a_step < tol || it >= max_iters;
+  if (done && blockIdx.x == 0 && threadIdx.x == 0 && fin.out_host) {
+    for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, s_pose[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 12, a_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 13, lost ? 0.0 : a_rec[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 14, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (lost ? 2.0 : 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : a_rec[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return lost ? 2 : (done ? 1 : 0);
+}
+
+// workgroup size of the resident kernel and the largest grid that is resident at once (one workgroup per CU).  256-thread workgroups
+// (two per CU) were measured and lose here -- 6.95-7.3 vs 6.0-6.7 us per step at 307 200 points, 46 vs 39 us at 10 M -- although
+// they win for the one-launch kernels: twice the workgroups poll the control block and twice the granules cross the hop every iteration
+static inline int resident_block() { return 512; }
+static inline int resident_cap(int) { return 256; }
+
+}  // namespace rpe

@@ -1,0 +1,479 @@
+// K4: batched RANSAC hypothesis scoring (the eight vote loops) and K4b: the winner's inlier masks.
+#include "rpe_reduce.hpp"
+
+namespace rpe {
+
+// ================================================================================================
+// K4 : batched hypothesis scoring (vote loops V1..V8) and K4b : winner mask
+// ================================================================================================
+enum { VOTE_33 = 0, VOTE_23 = 1, VOTE_33_23 = 2, VOTE_NN_23 = 3, VOTE_NN_33 = 4, VOTE_NN_33_23 = 5, VOTE_23_MATRIX = 6 };
+template <int KIND> struct VoteMods {
+  static constexpr bool m33 = KIND == VOTE_33 || KIND == VOTE_33_23 || KIND == VOTE_NN_33 || KIND == VOTE_NN_33_23;
+  static constexpr bool m23 = KIND == VOTE_23 || KIND == VOTE_33_23 || KIND == VOTE_NN_23 || KIND == VOTE_NN_33_23 || KIND == VOTE_23_MATRIX;
+  static constexpr bool mnn = KIND == VOTE_NN_23 || KIND == VOTE_NN_33 || KIND == VOTE_NN_33_23;
+  static constexpr bool need_xc = m33 || mnn;  // isValid() gates the N-N vote too
+};
+
+// one hypothesis in registers (wave-uniform -> SGPRs)
+template <class T, bool EXACT> struct Hyp;
+template <class T> struct Hyp<T, false> {
+  T R[9], t[3];
+  enum { STRIDE = 12 };
+  __device__ __forceinline__ void load(const T* __restrict__ p, bool) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = p[k];
+    t[0] = p[9]; t[1] = p[10]; t[2] = p[11];
+  }
+  __device__ __forceinline__ void rot(T x, T y, T z, T& ox, T& oy, T& oz) const {
+    ox = fma(R[0], x, fma(R[1], y, R[2] * z));
+    oy = fma(R[3], x, fma(R[4], y, R[5] * z));
+    oz = fma(R[6], x, fma(R[7], y, R[8] * z));
+  }
+  // fast forms: squared distance / squared cosine compares (no sqrt, no divide)
+  __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T thr_sq) const {
+    const T ex = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0] - cx)));
+    const T ey = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1] - cy)));
+    const T ez = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2] - cz)));
+    return fma(ex, ex, fma(ey, ey, ez * ez)) < thr_sq;
+  }
+  __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool) const {
+    const T px = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0])));
+    const T py = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1])));
+    const T pz = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2])));
+    const T d = fma(px, bx, fma(py, by, pz * bz));
+    const T n2 = fma(px, px, fma(py, py, pz * pz));
+    // d > c |p|  <=>  d|d| > c|c| |p|^2  (u -> u|u| is strictly increasing): one branch-free form for either sign of c
+    return d * fabs(d) > (c * fabs(c)) * n2;
+  }
+  __device__ __forceinline__ bool innn(T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T cnl) const {
+    T rx, ry, rz;
+    rot(nwx, nwy, nwz, rx, ry, rz);
+    return fma(ncx, rx, fma(ncy, ry, ncz * rz)) > cnl;
+  }
+};
+// exact form: the reference's own operation sequence in Tp, no FMA contraction.
+//   R*x     = Eigen _transformVector (sophus/so3.hpp:238-240): uv = 2 (u x v); v + w uv + u x uv
+//   3D test = |Xc - (R Xw + t)| < thre_3d with norm = sqrt(x^2 + y^2 + z^2)      (AbsoluteOrientation.hpp:137-138), evaluated as x^2 + y^2 + z^2 < cut
+//   2D test = normalize(R Xw + t) . bv > cos_thr, normalisation by division        (:413-418)
+//   N-N     = Nc . (R Nw) > cos_nl                                                  (AbsoluteOrientationNormal.hpp:248-249)
+template <class T> struct Hyp<T, true> {
+  T qw, qx, qy, qz, t[3];
+  T M[9];  // toRotationMatrix(), only for the kneip_ransac variant that multiplies by so3().matrix() (P3P.hpp:365)
+  enum { STRIDE = 8 };
+  __device__ __forceinline__ void load(const T* __restrict__ p, bool need_matrix) {
+#pragma clang fp contract(off)
+    qw = p[0]; qx = p[1]; qy = p[2]; qz = p[3]; t[0] = p[4]; t[1] = p[5]; t[2] = p[6];
+    if (!need_matrix) return;
+    const T tx = T(2) * qx, ty = T(2) * qy, tz = T(2) * qz;
+    const T twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const T tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    M[0] = T(1) - (tyy + tzz); M[1] = txy - twz; M[2] = txz + twy;
+    M[3] = txy + twz; M[4] = T(1) - (txx + tzz); M[5] = tyz - twx;
+    M[6] = txz - twy; M[7] = tyz + twx; M[8] = T(1) - (txx + tyy);
+  }
+  __device__ __forceinline__ void rot(T x, T y, T z, T& ox, T& oy, T& oz) const {
+#pragma clang fp contract(off)
+    T ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const T cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
+  }
+  // `cut` = the smallest value whose correctly rounded square root reaches thre_3d (computed on the host, rpe_capi.hip sqrt_cut):
+  // sqrt is monotonic, so  sqrt(s) < thre_3d  <=>  s < cut  for every s -- the reference's test, bit for bit, without the square root
+  // (a third of the instructions of this predicate).  s is formed exactly as Eigen's squaredNorm() forms it.
+  __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T cut) const {
+#pragma clang fp contract(off)
+    T rx, ry, rz;
+    rot(x, y, z, rx, ry, rz);
+    const T ex = cx - (rx + t[0]), ey = cy - (ry + t[1]), ez = cz - (rz + t[2]);
+    return (ex * ex + ey * ey + ez * ez) < cut;
+  }
+  // two correspondences at once as 2-vectors (element-wise IEEE operations in the same order as above: the same bits), so that the
+  // fp32 forms issue as packed v_pk_mul_f32 / v_pk_add_f32 -- half the instructions of the scalar sequence
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ void rot2(V2 x, V2 y, V2 z, V2& ox, V2& oy, V2& oz) const {
+#pragma clang fp contract(off)
+    V2 ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+    ux = ux + ux; uy = uy + uy; uz = uz + uz;
+    const V2 cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+    ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
+  }
+  __device__ __forceinline__ void rotm2(V2 x, V2 y, V2 z, V2& ox, V2& oy, V2& oz) const {   // so3().matrix() * x (kneip_ransac, P3P.hpp:365)
+#pragma clang fp contract(off)
+    ox = M[0] * x + M[1] * y + M[2] * z; oy = M[3] * x + M[4] * y + M[5] * z; oz = M[6] * x + M[7] * y + M[8] * z;
+  }
+  // the 3D and 2D tests of a pair, given the pair's rotated points (one rotation serves both tests, as in the scalar code after CSE)
+  __device__ __forceinline__ void in33_rot_x2(V2 rx, V2 ry, V2 rz, V2 cx, V2 cy, V2 cz, T cut, bool& a, bool& b) const {
+#pragma clang fp contract(off)
+    const V2 ex = cx - (rx + t[0]), ey = cy - (ry + t[1]), ez = cz - (rz + t[2]);
+    const V2 ss = ex * ex + ey * ey + ez * ez;
+    a = ss.x < cut; b = ss.y < cut;
+  }
+  __device__ __forceinline__ void in23_rot_x2(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b) const {
+#pragma clang fp contract(off)
+    V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+    const V2 n2 = px * px + py * py + pz * pz;
+    const V2 len = {sqrt(n2.x), sqrt(n2.y)};
+    px = px / len; py = py / len; pz = pz / len;
+    const V2 d = px * bx + py * by + pz * bz;
+    a = d.x > c; b = d.y > c;
+  }
+  __device__ __forceinline__ void innnx2(V2 nwx, V2 nwy, V2 nwz, V2 ncx, V2 ncy, V2 ncz, T cnl, bool& a, bool& b) const {
+#pragma clang fp contract(off)
+    V2 rx, ry, rz;
+    rot2(nwx, nwy, nwz, rx, ry, rz);
+    const V2 d = ncx * rx + ncy * ry + ncz * rz;
+    a = d.x > cnl; b = d.y > cnl;
+  }
+  __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool use_matrix) const {
+#pragma clang fp contract(off)
+    T rx, ry, rz;
+    if (use_matrix) {
+      rx = M[0] * x + M[1] * y + M[2] * z; ry = M[3] * x + M[4] * y + M[5] * z; rz = M[6] * x + M[7] * y + M[8] * z;
+    } else {
+      rot(x, y, z, rx, ry, rz);
+    }
+    T px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+    const T len = sqrt(px * px + py * py + pz * pz);
+    px = px / len; py = py / len; pz = pz / len;
+    return (px * bx + py * by + pz * bz) > c;
+  }
+  __device__ __forceinline__ bool innn(T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T cnl) const {
+#pragma clang fp contract(off)
+    T rx, ry, rz;
+    rot(nwx, nwy, nwz, rx, ry, rz);
+    return (ncx * rx + ncy * ry + ncz * rz) > cnl;
+  }
+};
+
+// votes of ONE hypothesis over one group of P correspondences, summed over the wave (every lane gets the wave's count).  Predicates are
+// evaluated unconditionally and masked with '&': no divergent branches; the compare IS the ballot.  EXACT: the 3D and normal tests run
+// on pairs of correspondences as 2-vectors (packed fp32 instructions), the 2D test (a square root and three divisions) stays scalar.
+template <class T, int KIND, bool EXACT>
+__device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
+                                                 const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
+                                                 const bool (&present)[Pk<T>::P], const bool (&valid)[Pk<T>::P], T thr33, T cthr, T cnl) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  int cnt = 0;
+  if constexpr (EXACT) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    static_assert(P % 2 == 0, "pairs");
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+      const int a = 2 * j, b = 2 * j + 1;
+      const V2 x = {vw[3 * a], vw[3 * b]}, y = {vw[3 * a + 1], vw[3 * b + 1]}, z = {vw[3 * a + 2], vw[3 * b + 2]};
+      if (MD::mnn) {
+        const V2 nwx = {vnw[3 * a], vnw[3 * b]}, nwy = {vnw[3 * a + 1], vnw[3 * b + 1]}, nwz = {vnw[3 * a + 2], vnw[3 * b + 2]};
+        const V2 ncx = {vnc[3 * a], vnc[3 * b]}, ncy = {vnc[3 * a + 1], vnc[3 * b + 1]}, ncz = {vnc[3 * a + 2], vnc[3 * b + 2]};
+        bool va, vb2;
+        hyp.innnx2(nwx, nwy, nwz, ncx, ncy, ncz, cnl, va, vb2);
+        cnt += __popcll(__ballot(valid[a] & va)) + __popcll(__ballot(valid[b] & vb2));
+      }
+      V2 rx, ry, rz;
+      if (KIND == VOTE_23_MATRIX) hyp.rotm2(x, y, z, rx, ry, rz); else hyp.rot2(x, y, z, rx, ry, rz);
+      if (MD::m33) {
+        const V2 cx = {vc[3 * a], vc[3 * b]}, cy = {vc[3 * a + 1], vc[3 * b + 1]}, cz = {vc[3 * a + 2], vc[3 * b + 2]};
+        bool va, vb2;
+        hyp.in33_rot_x2(rx, ry, rz, cx, cy, cz, thr33, va, vb2);
+        cnt += __popcll(__ballot(valid[a] & va)) + __popcll(__ballot(valid[b] & vb2));
+      }
+      if (MD::m23) {
+        const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
+        bool va, vb2;
+        hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, va, vb2);
+        cnt += __popcll(__ballot(present[a] & va)) + __popcll(__ballot(present[b] & vb2));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      if (MD::mnn) {
+        const bool v = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
+        cnt += __popcll(__ballot(v));
+      }
+      if (MD::m33) {
+        const bool v = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
+        cnt += __popcll(__ballot(v));
+      }
+      if (MD::m23) {
+        const bool v = present[i] & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
+        cnt += __popcll(__ballot(v));
+      }
+    }
+  }
+  return cnt;
+}
+
+// grid = (x: correspondence tiles, grid-stride) x (y: chunks of `hchunk` hypotheses).  Small problems (640x480 frames)
+// cannot fill 256 CUs with one tile sweep, so the hypothesis list is split across blockIdx.y and the (L2-resident)
+// arrays are swept once per chunk; large problems use one chunk so the arrays stream from HBM once per launch.
+template <class T, int KIND, bool EXACT>
+__global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                       const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                       const T* __restrict__ poses, int H, int hchunk, T thr33, T cthr, T cnl,
+                                                       int* __restrict__ votes) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  extern __shared__ int lds_votes[];
+  const int hbeg = blockIdx.y * hchunk;
+  const int hcnt = min(hchunk, H - hbeg);
+  for (int i = threadIdx.x; i < hcnt; i += kBlock) lds_votes[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  // loop bound is workgroup-uniform so that every lane of a wave takes part in the per-hypothesis ballots
+  for (int64_t gb = (int64_t)blockIdx.x * kBlock; gb < groups; gb += stride) {
+    const int64_t g = gb + threadIdx.x;
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    bool present[P], valid[P];
+    load_group<T>(xw, g, n, vw);
+    if (MD::need_xc) load_group<T>(xc, g, n, vc);
+    if (MD::m23) load_group<T>(bv, g, n, vb);
+    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      present[i] = (g * P + i) < n;
+      valid[i] = present[i] & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+    }
+    for (int h0 = 0; h0 < hcnt; h0 += 64) {
+      const int hmax = min(64, hcnt - h0);
+      int mine = 0;
+      for (int hl = 0; hl < hmax; hl++) {
+        Hyp<T, EXACT> hyp;
+        hyp.load(poses + (size_t)(hbeg + h0 + hl) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
+        const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
+        mine += (lane == hl) ? cnt : 0;
+      }
+      if (lane < hmax && mine != 0) atomicAdd(&lds_votes[h0 + lane], mine);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < hcnt; i += kBlock) {
+    const int v = lds_votes[i];
+    if (v != 0) atomicAdd(&votes[hbeg + i], v);
+  }
+}
+
+// Small batches (the first RANSAC batches: 8 .. 32 hypotheses): ONE launch and no device-side staging at all -- the hypotheses arrive as
+// a kernel argument (no H2D copy), every wave counts as above (lane h holds hypothesis h's count), the per-wave counts go straight into
+// the collecting stage (collect_and_send: integers < 2^53 as doubles, exact), and the host adds the run records.  Replaces copy +
+// scoring kernel + read-out kernel + flag (42 us per batch of 16 at 640 x 480) for lists of up to HB hypotheses.
+template <class T, int HB, int STRIDE> struct SmallPoses { T v[HB * STRIDE]; };
+template <class T, int KIND, bool EXACT, int HB>
+__global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                             const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                             SmallPoses<T, HB, Hyp<T, EXACT>::STRIDE> sp, const T* __restrict__ dposes, int H, int hs,
+                                                             T thr33, T cthr, T cnl, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // hs (1, 2 or 4) waves share a tile of correspondences and split the list between them (wave copy c takes hypotheses c, c + hs, ...):
+  // a frame-sized problem then runs as 4 x as many, 4 x shorter waves -- the pass is a long serial chain per wave (every predicate of
+  // every hypothesis on the wave's points), so with one group per thread it is bound by that chain, not by memory or issue rate
+  const int per_copy = (kBlock / 64) / hs, copy = wave / per_copy;
+  const int tile = kBlock / hs;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * tile;
+  int mine = 0;
+  // loop bound is workgroup-uniform so that every lane of a wave takes part in the per-hypothesis ballots
+  for (int64_t gb = (int64_t)blockIdx.x * tile; gb < groups; gb += stride) {
+    const int64_t g = gb + (wave % per_copy) * 64 + lane;
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    bool present[P], valid[P];
+    load_group<T>(xw, g, n, vw);
+    if (MD::need_xc) load_group<T>(xc, g, n, vc);
+    if (MD::m23) load_group<T>(bv, g, n, vb);
+    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      present[i] = (g * P + i) < n;
+      valid[i] = present[i] & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+    }
+    for (int hl = copy; hl < H; hl += hs) {
+      Hyp<T, EXACT> hyp;
+      if (dposes) hyp.load(dposes + (size_t)hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);   // a list generated on the device
+      else hyp.load(sp.v + hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
+      const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
+      mine += (lane == hl) ? cnt : 0;
+    }
+  }
+  __shared__ double red[kBlock / 64][HB];
+  if (lane < HB) red[wave][lane] = (double)mine;
+  __syncthreads();
+  collect_and_send<HB, 0, kBlock>(red, fin);
+}
+
+// P flags of one group as ONE store (8 bytes for fp32 / P = 4, 4 bytes for fp64 / P = 2): a thread owns P consecutive
+// correspondences, so its shorts are contiguous; 2-byte scattered stores cost an order of magnitude more per byte.
+__device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[4]) {
+  uint2 u;
+  u.x = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+  u.y = (unsigned int)v[2] | ((unsigned int)v[3] << 16);
+  *reinterpret_cast<uint2*>(m + 4 * g) = u;
+}
+__device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[2]) {
+  *reinterpret_cast<unsigned int*>(m + 2 * g) = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+}
+
+template <class T> struct PoseArg { T v[12]; };  // one hypothesis by value (kernel argument): no H2D copy for a single pose
+
+template <class T, int KIND, bool EXACT>
+__global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                      const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                      PoseArg<T> pose, T thr33, T cthr, T cnl, short* __restrict__ m23,
+                                                      short* __restrict__ m33, short* __restrict__ mnn, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  typedef VoteMods<KIND> MD;
+  Hyp<T, EXACT> hyp;
+  hyp.load(pose.v, KIND == VOTE_23_MATRIX);
+  int cnt = 0;
+  const int64_t groups = (n + P - 1) / P, full = n / P;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    load_group<T>(xw, g, n, vw);
+    if (MD::need_xc) load_group<T>(xc, g, n, vc);
+    if (MD::m23) load_group<T>(bv, g, n, vb);
+    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+    bool f23[P], f33[P], fnn[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const bool present = (g * P + i) < n;
+      const bool valid = present & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      fnn[i] = MD::mnn ? (valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl)) : false;
+      f33[i] = MD::m33 ? (valid & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33)) : false;
+      f23[i] = MD::m23 ? (present & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX)) : false;
+      cnt += (int)fnn[i] + (int)f33[i] + (int)f23[i];
+    }
+    if (g < full) {
+      if (MD::mnn) store_mask_full(mnn, g, fnn);
+      if (MD::m33) store_mask_full(m33, g, f33);
+      if (MD::m23) store_mask_full(m23, g, f23);
+    } else {
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        const int64_t idx = g * P + i;
+        if (idx < n) {
+          if (MD::mnn) mnn[idx] = fnn[i];
+          if (MD::m33) m33[idx] = f33[i];
+          if (MD::m23) m23[idx] = f23[i];
+        }
+      }
+    }
+  }
+  // the vote total rides the same in-launch reduction + pinned-host publish as the normal equations (exact: integers < 2^53)
+  double acc[1] = {(double)cnt};
+  reduce_and_finish<1, kNeLd, 0, kBlock>(acc, fin);
+}
+
+template <class T, int KIND, bool EXACT>
+static void score_launch(const DeviceArrays& A, const void* d_poses, int H, const double* thr, int* d_votes, int G, hipStream_t s) {
+  // enough workgroups for ~8 per CU: split the hypothesis list (in multiples of 64) over blockIdx.y when one sweep is too few
+  int gy = 1, hchunk = H;
+  if (G < 2048 && H > 64) {
+    const int chunks64 = (H + 63) / 64;
+    gy = (2048 + G - 1) / G;
+    if (gy > chunks64) gy = chunks64;
+    hchunk = ((chunks64 + gy - 1) / gy) * 64;
+    gy = (H + hchunk - 1) / hchunk;
+  }
+  hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G, gy), dim3(kBlock), (size_t)hchunk * sizeof(int), s, (const T*)A.a[0], (const T*)A.a[1],
+                     (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, hchunk, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
+}
+template <class T, int KIND, bool EXACT>
+static void mask_launch(const DeviceArrays& A, const double* pose12, const double* thr, const ReduceTarget& rt, int G, hipStream_t s) {
+  PoseArg<T> pa;
+  for (int i = 0; i < 12; i++) pa.v[i] = (T)pose12[i];
+  hipLaunchKernelGGL((mask_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
+                     (const T*)A.a[3], (const T*)A.a[4], A.n, pa, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2],
+                     make_finish(rt));
+}
+#define RPE_KIND_SWITCH(FN, T, EX, ...)                                    \
+  switch (kind) {                                                          \
+    case VOTE_33: FN<T, VOTE_33, EX>(__VA_ARGS__); break;                  \
+    case VOTE_23: FN<T, VOTE_23, EX>(__VA_ARGS__); break;                  \
+    case VOTE_33_23: FN<T, VOTE_33_23, EX>(__VA_ARGS__); break;            \
+    case VOTE_NN_23: FN<T, VOTE_NN_23, EX>(__VA_ARGS__); break;            \
+    case VOTE_NN_33: FN<T, VOTE_NN_33, EX>(__VA_ARGS__); break;            \
+    case VOTE_NN_33_23: FN<T, VOTE_NN_33_23, EX>(__VA_ARGS__); break;      \
+    case VOTE_23_MATRIX: FN<T, VOTE_23_MATRIX, EX>(__VA_ARGS__); break;    \
+    default: return hipErrorInvalidValue;                                  \
+  }
+
+hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
+                        int max_blocks, hipStream_t s) {
+  if (H < 1 || H > kMaxScoreH) return hipErrorInvalidValue;
+  // d_votes must be zero on entry: allocated zeroed, and re-zeroed by launch_publish_votes after every read-out
+  if (A.dtype) {
+    const int G = grid_for(A.n, 2, max_blocks);
+    if (exact) { RPE_KIND_SWITCH(score_launch, double, true, A, d_poses, H, thr3, d_votes, G, s) }
+    else { RPE_KIND_SWITCH(score_launch, double, false, A, d_poses, H, thr3, d_votes, G, s) }
+  } else {
+    const int G = grid_for(A.n, 4, max_blocks);
+    if (exact) { RPE_KIND_SWITCH(score_launch, float, true, A, d_poses, H, thr3, d_votes, G, s) }
+    else { RPE_KIND_SWITCH(score_launch, float, false, A, d_poses, H, thr3, d_votes, G, s) }
+  }
+  return hipGetLastError();
+}
+template <class T, int KIND, bool EXACT>
+static void score_small_launch(const DeviceArrays& A, const void* h_poses, const void* d_poses, int H, const double* thr, const ReduceTarget& rt, int cap,
+                               hipStream_t s) {
+  constexpr int STRIDE = Hyp<T, EXACT>::STRIDE;
+  const Finish fin = make_finish(rt);
+  // up to a million correspondences the list is split over the 4 waves of a workgroup (RPE_SCORE_SPLIT = 1 | 2 | 4 overrides)
+  static const int env_hs = getenv("RPE_SCORE_SPLIT") ? atoi(getenv("RPE_SCORE_SPLIT")) : 0;
+  const int hs = (env_hs == 1 || env_hs == 2 || env_hs == 4) ? env_hs : (A.n <= (int64_t)1 << 20 ? 4 : 1);
+  const int64_t tiles = ((A.n + Pk<T>::P - 1) / Pk<T>::P + kBlock / hs - 1) / (kBlock / hs);
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cap));
+#define RPE_SMALL(HB)                                                                                                                        \
+  do {                                                                                                                                       \
+    SmallPoses<T, HB, STRIDE> sp;                                                                                                            \
+    std::memset(&sp, 0, sizeof(sp));                                                                                                         \
+    if (h_poses) std::memcpy(sp.v, h_poses, (size_t)H * STRIDE * sizeof(T));                                                                 \
+    hipLaunchKernelGGL((score_small_kernel<T, KIND, EXACT, HB>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], \
+                       (const T*)A.a[3], (const T*)A.a[4], A.n, sp, (const T*)d_poses, H, hs, (T)thr[0], (T)thr[1], (T)thr[2], fin);                                 \
+  } while (0)
+  if (H <= 16) RPE_SMALL(16); else RPE_SMALL(32);
+#undef RPE_SMALL
+}
+// largest list the single-launch form takes for this dtype / mode (the hypotheses travel as a kernel argument of at most 2 KB)
+int score_small_cap(int dtype, int exact) {
+  const int bytes = (exact ? 8 : 12) * (dtype ? 8 : 4);
+  return 32 * bytes <= 2048 ? 32 : 16;
+}
+// h_poses: H hypotheses staged in HOST memory in the scoring layout of `exact`, values of the array dtype (they travel in the kernel
+// argument) -- or null and d_poses: the same list in HBM (a device-generated batch).  The vote counts arrive through rt (a collecting
+// target): record[h] = votes of hypothesis h.
+hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H, const double* thr3,
+                              const ReduceTarget& rt, hipStream_t s) {
+  if (H < 1 || H > score_small_cap(A.dtype, exact) || rt.rows < 1 || (!h_poses == !d_poses)) return hipErrorInvalidValue;
+  const int cap = 2048;   // workgroups (grid-stride beyond)
+  if (A.dtype) {
+    if (exact) { RPE_KIND_SWITCH(score_small_launch, double, true, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+    else { RPE_KIND_SWITCH(score_small_launch, double, false, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+  } else {
+    if (exact) { RPE_KIND_SWITCH(score_small_launch, float, true, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+    else { RPE_KIND_SWITCH(score_small_launch, float, false, A, h_poses, d_poses, H, thr3, rt, cap, s) }
+  }
+  return hipGetLastError();
+}
+hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
+                       hipStream_t s) {
+  const int cap = rt.max_blocks < 1024 ? 1024 : rt.max_blocks;  // streaming + stores: 4 workgroups of 256 per CU
+  if (A.dtype) {
+    const int G = grid_for(A.n, 2, cap);
+    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, pose12, thr3, rt, G, s) }
+    else { RPE_KIND_SWITCH(mask_launch, double, false, A, pose12, thr3, rt, G, s) }
+  } else {
+    const int G = grid_for(A.n, 4, cap);
+    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, pose12, thr3, rt, G, s) }
+    else { RPE_KIND_SWITCH(mask_launch, float, false, A, pose12, thr3, rt, G, s) }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rpe

@@ -1,5 +1,5 @@
 """-m gpu: rpe_gn_refine_device in its one-launch form (the grid iterates by itself: granule hand-off, run records, solve + exp-map in every
-workgroup; rpe_kernels.hip resident_auto_stage) against the host-driven loop (rpe_gn_refine: same kernels' sums added in the same order,
+workgroup; rpe_residuals.hpp resident_auto_stage) against the host-driven loop (rpe_gn_refine: same kernels' sums added in the same order,
 solve on the host) and against its own one-launch-per-iteration form (RPE_DEVICE_LOOP_RESIDENT=0, a subprocess: the switch is read once)."""
 import json
 import os
