@@ -38,8 +38,7 @@ N_SHARDED = 10_000_000       # configs[4]
 BYTES_PER_CORR = 24 + 2      # Xw 12 + Xc 12 + short inlier mask 2 (p2p fp32 + mask)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 THRE_3D = 0.2                # Parameters.yml thre_3d
-PMC_FILE = "profiles/r02_pmc_traffic.json"
-ROCPROF_FILE = "profiles/r02_bench_rocprofv3_kernel_stats.csv"
+PROFILE_INDEX = "profiles/r03_bench_profiles.json"   # rocprofv3 / PMC summaries of THIS command, one entry per steps-per-launch
 
 
 # ------------------------------------------------------------------------------------------------ launcher (no GPU, no torch)
@@ -152,35 +151,69 @@ def rot_err(Ra, Rb):
 ORIG_AFFINITY = None
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sc, seconds: float):
-    """Oracle (CPU restatement of the reference) timed on this host: shinji_ls2<float> through AOOnlyPoseAdapter's
-    virtual getters, exactly what Library.cpp ao() runs; 1 thread because the reference is single-threaded."""
+    """Oracle (CPU restatement of the reference; the reference itself needs Eigen + OpenCV and cannot be built here) timed on this
+    host, SURVEY.md 8(d): shinji_ls2<float> through AOOnlyPoseAdapter's virtual getters -- exactly what Library.cpp ao() runs -- and
+    the shinji_ransac2 vote loop; 1 thread because the reference is single-threaded, and an all-core variant of the SAME restatement
+    beside it; every figure is the MEDIAN of >= 20 timed runs after a warm-up run.  Bounded: about `seconds` of CPU work in all."""
     import numpy as np
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes as C
         import oracle_lib as O
         lib = O.lib()
+        for fn in ("orc_time_ao", "orc_time_ao_threads", "orc_time_gn_p2p", "orc_time_gn_p2p_threads", "orc_time_votes33", "orc_time_votes33_threads"):
+            getattr(lib, fn).restype = C.c_double
         xw, xc = np.ascontiguousarray(sc.Q, np.float32), np.ascontiguousarray(sc.P, np.float32)
         R, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
         n = len(xw)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        lib.orc_time_ao(p(xw), p(xc), n, 1, p(R), p(t))
-        reps, spent = 0, 0.0
-        while spent < seconds:
-            spent += lib.orc_time_ao(p(xw), p(xc), n, 20, p(R), p(t)); reps += 20
+
+        def median_runs(f, budget_s, min_runs=20, max_runs=400):
+            f()   # warm-up
+            ts, spent = [], 0.0
+            while len(ts) < min_runs or (spent < budget_s and len(ts) < max_runs):
+                dt = f(); ts.append(dt); spent += dt
+            return percentile(ts, 0.5), len(ts), spent
+
+        # the bench's host thread is pinned to one CPU; the worker threads of the all-core legs get the process's original CPU set back
+        pinned = os.sched_getaffinity(0)
+        wide = ORIG_AFFINITY or pinned
+        threads = max(1, min(64, len(wide)))
+
+        def all_cores(f):
+            os.sched_setaffinity(0, wide)
+            try:
+                return f()
+            finally:
+                os.sched_setaffinity(0, pinned)
+
+        share = seconds / 4.0
+        ao1, ao1_runs, ao1_spent = median_runs(lambda: lib.orc_time_ao(p(xw), p(xc), n, 1, p(R), p(t)), share * 1.6)
+        aoN, aoN_runs, _ = all_cores(lambda: median_runs(lambda: lib.orc_time_ao_threads(p(xw), p(xc), n, 1, threads, p(R), p(t)), share * 0.4))
         pose = np.concatenate([np.eye(3).reshape(9), np.zeros(3)])
         out = np.zeros(29)
-        g = lib.orc_time_gn_p2p(p(xw), p(xc), C.c_long(n), 20, p(pose), p(out)) / 20
-        # all-core variant of the same pass (SURVEY 8d): the reference itself is single-threaded, so this is beside, not instead.
-        # The bench's host thread is pinned to one CPU; the worker threads of this leg get the process's original CPU set back.
-        pinned = os.sched_getaffinity(0)
-        if ORIG_AFFINITY:
-            os.sched_setaffinity(0, ORIG_AFFINITY)
-        threads = max(1, min(64, len(os.sched_getaffinity(0))))
-        lib.orc_time_gn_p2p_threads.restype = C.c_double
-        ga = lib.orc_time_gn_p2p_threads(p(xw), p(xc), C.c_long(n), 200, p(pose), p(out), threads) / 200
-        os.sched_setaffinity(0, pinned)
+        g1, g1_runs, _ = median_runs(lambda: lib.orc_time_gn_p2p(p(xw), p(xc), C.c_long(n), 1, p(pose), p(out)), share * 0.6)
+        gN, gN_runs, _ = all_cores(lambda: median_runs(lambda: lib.orc_time_gn_p2p_threads(p(xw), p(xc), C.c_long(n), 10, p(pose), p(out), threads) / 10, share * 0.2))
+        # vote loop (V2, 3D-3D): one hypothesis per run, at the scene's true pose
+        from rgbd_pose_estimation_amd.api import pose7_from_Rt
+        q7 = np.ascontiguousarray(pose7_from_Rt(sc.R, sc.t, 0), np.float64).reshape(1, 7)
+        v = np.zeros(1, np.int32)
+        v1, v1_runs, _ = median_runs(lambda: lib.orc_time_votes33(p(xw), p(xc), n, p(q7), 1, C.c_float(THRE_3D), p(v)), share * 0.6)
+        votes_1 = int(v[0])
+        q8 = np.ascontiguousarray(np.tile(q7, (8, 1)))
+        v8 = np.zeros(8, np.int32)
+        vN, vN_runs, _ = all_cores(lambda: median_runs(lambda: lib.orc_time_votes33_threads(p(xw), p(xc), n, p(q8), 8, C.c_float(THRE_3D), p(v8), threads) / 8, share * 0.2))
         # the reference's own default build has no optimisation flag at all (CMakeLists.txt:13-15): the same port compiled that way
         o0 = None
         try:
@@ -188,24 +221,154 @@ def cpu_baseline(sc, seconds: float):
             if os.path.exists(o0_path):
                 lib0 = C.CDLL(o0_path)
                 lib0.orc_time_ao.restype = C.c_double
-                lib0.orc_time_ao(p(xw), p(xc), n, 1, p(R), p(t))
-                r0, s0 = 0, 0.0
-                while s0 < min(2.0, seconds):
-                    s0 += lib0.orc_time_ao(p(xw), p(xc), n, 5, p(R), p(t)); r0 += 5
-                o0 = n * r0 / s0
+                o0m, _, _ = median_runs(lambda: lib0.orc_time_ao(p(xw), p(xc), n, 1, p(R), p(t)), min(1.5, share * 0.4), min_runs=5)
+                o0 = n / o0m
         except Exception:
             o0 = None
-        return {"value": n * reps / spent, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "no_O_flag_value": o0,
-                "sample": f"{reps} calls of the oracle's shinji_ls2<float> (AOOnlyPoseAdapter virtual getters, gather + centroid + covariance "
-                          f"passes + 3x3 SVD = Library.cpp ao()) on the same {n}-correspondence scene, g++ -O2, 1 thread, {spent:.1f} s",
-                "gn_pass_fp64_value": n / g, "gn_pass_fp64_all_cores": {"value": n / ga, "threads": threads}, "host_cpus": os.cpu_count()}
+        return {"value": n / ao1, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "statistic": "median of the timed runs (one warm-up run before)",
+                "runs": ao1_runs, "no_O_flag_value": o0,
+                "sample": f"{ao1_runs} calls of the oracle's shinji_ls2<float> (AOOnlyPoseAdapter virtual getters, gather + centroid + covariance "
+                          f"passes + 3x3 SVD = Library.cpp ao()) on the same {n}-correspondence scene, g++ -O2, 1 thread, {ao1_spent:.1f} s",
+                "all_cores": {"value": n / aoN, "threads": threads, "runs": aoN_runs,
+                              "what": "the same shinji_ls2<float> restatement, its O(N) loops over contiguous index ranges on std::threads"},
+                "vote_loop": {"value": n / v1, "unit": "corr*hyp/s", "cores": 1, "runs": v1_runs, "votes": votes_1,
+                              "what": "shinji_ransac2 vote loop (AbsoluteOrientation.hpp:190-200), one hypothesis per run",
+                              "all_cores": {"value": n / vN, "threads": threads, "runs": vN_runs, "votes_equal": bool(np.all(v8 == votes_1))}},
+                "gn_pass_fp64_value": n / g1, "gn_pass_fp64_runs": g1_runs,
+                "gn_pass_fp64_all_cores": {"value": n / gN, "threads": threads, "runs": gN_runs},
+                "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
     except Exception as e:  # the baseline is a reported number, never a dependency of the GPU path
-        return {"value": None, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e!r}"}
+        return {"value": None, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e!r}", "cpu_model": cpu_model()}
 
 
 def percentile(xs, q):
     xs = sorted(xs)
     return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
+
+
+def collective_plan(world: int, want: str, share_gpu: bool) -> dict:
+    """What `bench.py --gpus N` does about the per-iteration all-reduce, decided BEFORE any GPU is touched (the dry-run launcher test
+    prints it).  The north star's collective -- one RCCL all-reduce of the normal-equation scalars per Gauss-Newton iteration over xGMI,
+    here on a communicator the library owns -- is the headline whenever RCCL can be set up; other ways of adding the 32-double records
+    are timed beside it.  RPE_BENCH_COLLECTIVE = auto (default: RCCL headline, host-side exchange beside) | rccl | host |
+    p2p (the in-kernel mailboxes as headline) | auto_p2p (RCCL headline, mailboxes beside)."""
+    if want not in ("auto", "rccl", "host", "p2p", "auto_p2p"):
+        sys.exit(f"bench.py: unknown RPE_BENCH_COLLECTIVE={want}")
+    if world <= 1:
+        return {"headline": "none", "timed_beside": [], "rccl_init": False, "rccl_ranks_expected": 0, "distinct_gpu_check": False,
+                "scaling": "weak", "weak_scaling_extra": False}
+    headline = {"auto": "rccl", "rccl": "rccl", "host": "host", "p2p": "p2p", "auto_p2p": "rccl"}[want]
+    beside = {"auto": ["host"], "rccl": [], "host": [], "p2p": [], "auto_p2p": ["p2p"]}[want]
+    rccl_init = want != "host" and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1")
+    return {"headline": headline, "timed_beside": beside, "rccl_init": rccl_init, "rccl_ranks_expected": world if rccl_init else 0,
+            "fallback": "host-side exchange, then torch.distributed, if RCCL cannot be set up", "distinct_gpu_check": not share_gpu,
+            "scaling": "strong", "weak_scaling_extra": True,
+            "json_fields": ["config.collective", "config.rccl_ranks", "config.rccl_verified", "config.collective_step_us", "config.pci_bus_ids", "weak_scaling"]}
+
+
+def profile_entries():
+    """profiles/r03_bench_profiles.json: what rocprofv3 --kernel-trace --stats and the two --pmc passes recorded for bench.py's own
+    command, keyed by the steps one launch of the resident kernel served.  File-derived numbers enter the JSON line only next to the
+    steps_per_launch they were recorded with."""
+    try:
+        return json.load(open(os.path.join(ROOT, PROFILE_INDEX)))
+    except Exception:
+        return {}
+
+
+def cheap_scene(n, seed=4):
+    """n correspondences with normals for bandwidth runs: a 250 000-point simulated scene tiled (the bytes streamed are what matters)."""
+    import numpy as np
+    from rgbd_pose_estimation_amd import simulator as S
+    rng = np.random.default_rng(seed)
+    R, t = S.random_pose(rng)
+    base = S.simulate_3d_3d_correspondences(rng, R, t, min(n, 250000), 0.02, 0.0).astype(np.float32)
+    nrm = rng.standard_normal((len(base.Q), 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    reps = (n + len(base.Q) - 1) // len(base.Q)
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (reps, 1))[:n])
+    return R, t, tile(base.Q), tile(base.P), tile(nrm)
+
+
+def hbm_roofline(local_rank):
+    """LIVE bandwidth-bound figures, event-timed in this run (SURVEY 8d 'Config 4', 'Roofline'): configs[3] -- 1 M correspondences with
+    normals, point-to-plane, 36 B each -- steady (the 36 MB set stays in the 256 MiB Infinity Cache between launches) and cold (a
+    480 MB stream evicts it before every launch), and the point-to-point kernel on 10 M and 20 M correspondences (240 / 480 MB: at and
+    past the Infinity Cache).  One launch per call (normal_eq_kernel), HIP events = the dispatch's begin / end timestamps."""
+    from rgbd_pose_estimation_amd import _lib as L, api
+    out = {"peak_GBs": HBM_PEAK_GBS, "timing": "HIP events on the kernel's stream (hipExtLaunchKernelGGL begin / end), mean over the launches"}
+    R, t, Q20, P20, _ = cheap_scene(20_000_000)
+    pose = api.pose12(R, t)
+    big = api.Context(local_rank).load(L.F32, xw=Q20, xc=P20)
+    ten = api.Context(local_rank).load(L.F32, xw=Q20[:10_000_000], xc=P20[:10_000_000])
+    del Q20, P20
+
+    def timed(ctx, kind, launches, before=None):
+        for _ in range(5):
+            ctx.normal_eq(kind, pose)
+        ctx.timing_enable(launches, 1)
+        for _ in range(launches):
+            if before:
+                before()
+            ctx.normal_eq(kind, pose)
+        cnt, tot_ms, mn_ms = ctx.timing_collect()
+        ctx.timing_enable(0, 1)
+        return tot_ms / max(cnt, 1) * 1e-3, mn_ms * 1e-3, cnt
+
+    def row(n, bpc, avg, mn, cnt, **kw):
+        return dict(n=n, bytes_per_corr=bpc, working_set_MB=bpc * n / 1e6, launches=cnt, avg_launch_us=avg * 1e6, min_launch_us=mn * 1e6,
+                    achieved_GBs=bpc * n / avg / 1e9, frac_of_peak=bpc * n / avg / 1e9 / HBM_PEAK_GBS, **kw)
+
+    _, _, Q1, P1, N1 = cheap_scene(1_000_000)
+    c3 = api.Context(local_rank).load(L.F32, xw=Q1, xc=P1, nc=N1)
+    avg, mn, cnt = timed(c3, L.RES_P2PLANE, 60)
+    out["config3_p2plane_1M_steady"] = row(1_000_000, 36, avg, mn, cnt, kernel="rpe::normal_eq_kernel<float, 1, 256, false, false>")
+    avg, mn, cnt = timed(c3, L.RES_P2PLANE, 40, before=lambda: big.p2p_moments())
+    out["config3_p2plane_1M_cold"] = row(1_000_000, 36, avg, mn, cnt, evicted_by="a 480 MB moments pass of another context before every launch")
+    c3.close()
+    avg, mn, cnt = timed(big, L.RES_P2P, 30)
+    out["p2p_20M"] = row(20_000_000, 24, avg, mn, cnt, note="480 MB > 256 MiB Infinity Cache: HBM streaming")
+    avg, mn, cnt = timed(ten, L.RES_P2P, 30)
+    out["p2p_10M"] = row(10_000_000, 24, avg, mn, cnt, note="240 MB <= Infinity Cache: the steady state is served on-die, above the HBM read ceiling")
+    big.close(); ten.close()
+    return out
+
+
+def fp64_lines(local_rank):
+    """Tp = double (what TestMain.cpp:52-326 instantiates): event-timed K1 / K2 launches (48 / 72 B per correspondence) and the exact
+    3D-3D scoring rate at 307 200 and 1 M correspondences."""
+    import numpy as np
+    from rgbd_pose_estimation_amd import _lib as L, api
+    out = {}
+    for n in (307200, 1_000_000):
+        R, t, Q, P, Nn = cheap_scene(n, seed=5)
+        ctx = api.Context(local_rank).load(L.F64, xw=Q.astype(np.float64), xc=P.astype(np.float64), nc=Nn.astype(np.float64))
+        pose = api.pose12(R, t)
+        rows = {}
+        for name, kind, bpc in (("K1_p2p", L.RES_P2P, 48), ("K2_p2plane", L.RES_P2PLANE, 72)):
+            for _ in range(5):
+                ctx.normal_eq(kind, pose)
+            ctx.timing_enable(50, 1)
+            for _ in range(50):
+                ctx.normal_eq(kind, pose)
+            cnt, tot_ms, mn_ms = ctx.timing_collect()
+            ctx.timing_enable(0, 1)
+            avg = tot_ms / max(cnt, 1) * 1e-3
+            rows[name] = {"bytes_per_corr": bpc, "avg_launch_us": avg * 1e6, "achieved_GBs": bpc * n / avg / 1e9, "frac_of_peak": bpc * n / avg / 1e9 / HBM_PEAK_GBS,
+                          "corr_res_per_s": n / avg}
+        H = 512
+        q7 = api.pose7_from_Rt(R, t, L.F64)
+        poses = np.tile(q7, (H, 1)); poses[:, 4:] += 0.01 * np.random.default_rng(1).standard_normal((H, 3))
+        for _ in range(2):
+            ctx.score(L.VOTE_33, poses, THRE_3D, mode=L.SCORE_EXACT)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.score(L.VOTE_33, poses, THRE_3D, mode=L.SCORE_EXACT)
+        dt = (time.perf_counter() - t0) / 5
+        rows["K4_score_33_exact"] = {"hypotheses": H, "us_per_pass": dt * 1e6, "corr_hyp_per_s": n * H / dt}
+        out[str(n)] = rows
+        ctx.close()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -217,7 +380,9 @@ def worker(args, affinity):
         # launcher test on a CPU box: the rank reports the environment it was started with and leaves BEFORE anything touches a GPU
         if rank == 0:
             print(json.dumps({"dry_run": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus, "steps": args.steps,
-                              "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+                              "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", ""),
+                              "collective_plan": collective_plan(world, os.environ.get("RPE_BENCH_COLLECTIVE", "auto"),
+                                                                 os.environ.get("RPE_BENCH_SHARE_GPU") == "1")}), flush=True)
         sys.exit(int(os.environ.get("RPE_BENCH_DRY_EXIT", "0")) if rank == int(os.environ.get("RPE_BENCH_DRY_EXIT_RANK", "-1")) else 0)
     import ctypes as C
     import numpy as np
@@ -282,51 +447,45 @@ def worker(args, affinity):
         gn = ShardedGaussNewton(shard.normal_eq)
         pose = pose12(R0, t0)
 
-        # ---- N > 1: how the shards' 32-double records meet every iteration.  RPE_BENCH_COLLECTIVE =
-        #   auto (default): RCCL all-reduce on a library-owned communicator AND the host-side exchange (the rank processes' host threads
-        #                   add the records through shared memory; every rank keeps its resident kernel) are both set up, the
-        #                   exchange is verified against the all-reduced record, both are timed in this run, the faster one carries
-        #                   the measurement and both times go into the JSON line;
-        #   rccl | host   : that one only;
-        #   p2p | auto_p2p: the in-kernel peer-to-peer exchange over xGMI (only on request: it has never run on real xGMI), alone or
-        #                   timed against RCCL.
+        # ---- N > 1: how the shards' 32-double records meet every iteration (collective_plan above).  The north star's collective --
+        # ONE RCCL all-reduce per Gauss-Newton iteration, on a communicator the library owns -- carries the measurement whenever RCCL
+        # can be set up; the host-side exchange (and, on request, the in-kernel peer-to-peer mailboxes) are timed in the same run and
+        # reported beside it in config.collective_step_us.
         want = os.environ.get("RPE_BENCH_COLLECTIVE", "auto")
-        if want not in ("auto", "rccl", "host", "p2p", "auto_p2p"):
-            sys.exit(f"bench.py: unknown RPE_BENCH_COLLECTIVE={want}")
-        want_p2p = want in ("p2p", "auto_p2p")
+        plan = collective_plan(world if world > 1 else (2 if force_dist else 1), want, os.environ.get("RPE_BENCH_SHARE_GPU") == "1")
+        if world == 1 and force_dist:   # the collective path exercised with one rank (tests)
+            plan.update(rccl_ranks_expected=1 if plan["rccl_init"] else 0, distinct_gpu_check=False)
         p2p = native = rccl_ok = hostex = False
+        rccl_ranks, rccl_verified, bus_ids = 0, False, []
         coll_times = {}
         if dist_path:
             for _ in range(200):   # first launches of a process on a cold box can take seconds: ranks enter the first collective together
                 ctx.normal_eq(L.RES_P2P, pose12(R0, t0), L.USE_MASK)
             dist.barrier()
-        if dist_path and want_p2p:
-            p2p = init_p2p(ctx)
-            if p2p:
-                chk = pose12(R0, t0)
-                rec = np.zeros(32)
-                dist.barrier()
-                try:
-                    L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
-                    delivered = 1
-                except L.RpeError as e:
-                    delivered = 0
-                    print(f"[bench] rank {rank}: peer-to-peer step failed: {e}", file=sys.stderr, flush=True)
-                ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
-                dist.all_reduce(ref)
-                ref = ref.cpu().numpy()
-                good = int(delivered and np.all(np.abs(rec[:29] - ref[:29]) <= 1e-9 * (1.0 + np.abs(ref[:29]))))
-                flag = torch.tensor([good], dtype=torch.int32, device=cdev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    if rank == 0:
-                        print("[bench] peer-to-peer record differs from the all-reduced one: falling back to RCCL", file=sys.stderr, flush=True)
-                    ctx.p2p_destroy()
-                    p2p = False
-        if dist_path and not p2p and want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1":
-            sys.exit("bench.py: the peer-to-peer collective was requested strictly and is not available")
-        if dist_path and want != "host" and not (want == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1"):
-            rccl_ok = init_native_comm(ctx)   # with a peer-to-peer path in place rpe_gn_step_dist prefers it; the communicator is its stand-by
+            # one process per GPU: every rank must sit on a GPU of its own (the test rig with several ranks on one GPU says so explicitly)
+            bus_ids = [None] * world
+            dist.all_gather_object(bus_ids, ctx.bus_id())
+            if plan["distinct_gpu_check"] and len(set(bus_ids)) != world:
+                sys.exit(f"bench.py: rank {rank}: the {world} ranks do not sit on {world} different GPUs (PCI bus ids {bus_ids}); "
+                         "one process per GPU is required (RPE_BENCH_SHARE_GPU=1 is the test rig's override)")
+
+        def verify_step(label):
+            """one sharded step's record against the all-reduced local records (every rank takes part; all ranks get the same answer)"""
+            chk, rec = pose12(R0, t0), np.zeros(32)
+            try:
+                L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
+                delivered = 1
+            except L.RpeError as e:
+                delivered = 0
+                print(f"[bench] rank {rank}: {label} step failed: {e}", file=sys.stderr, flush=True)
+            ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
+            dist.all_reduce(ref)
+            ref = ref.cpu().numpy()
+            good = int(delivered and np.all(np.abs(rec[:29] - ref[:29]) <= 1e-9 * (1.0 + np.abs(ref[:29]))))
+            flag = torch.tensor([good], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
         def timed(k, refine=False):
             q = pose12(R0, t0)
             run = (lambda kk: ctx.gn_refine([L.RES_P2P], q, None, L.USE_MASK, kk, 0.0)) if refine else (lambda kk: ctx.gn_steps_dist(L.RES_P2P, q, kk, L.USE_MASK))
@@ -337,45 +496,54 @@ def worker(args, affinity):
             tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()) / k
-        if dist_path and p2p and rccl_ok:
-            coll_times["p2p_us"] = timed(400) * 1e6
-            L.check(L.lib().rpe_p2p_pause(ctx._h, 1))      # stand-by: the same call now takes the RCCL path
-            coll_times["rccl_us"] = timed(400) * 1e6
-            L.check(L.lib().rpe_p2p_pause(ctx._h, 0))
-            if coll_times["rccl_us"] < coll_times["p2p_us"]:
-                dist.barrier()
-                ctx.p2p_destroy()
-                p2p = False
-        if dist_path and want in ("auto", "host"):
+
+        def all_ok(ok):
+            f = torch.tensor([int(ok)], dtype=torch.int32, device=cdev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return int(f.item()) == 1
+
+        # (1) RCCL on the library's communicator
+        if dist_path and plan["rccl_init"]:
+            rccl_ok = init_native_comm(ctx)
             if rccl_ok:
-                coll_times["rccl_us"] = timed(400) * 1e6   # before the exchange exists: rpe_gn_steps_dist = kernel + ncclAllReduce + publish
-            hostex = init_host_exchange(ctx)
-            if hostex:   # verify: one sharded step's record against the all-reduced local records
-                chk, rec = pose12(R0, t0), np.zeros(32)
-                try:
-                    L.check(L.lib().rpe_gn_step_dist(ctx._h, L.RES_P2P, L.USE_MASK, chk.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p), None))
-                    delivered = 1
-                except L.RpeError as e:
-                    delivered = 0
-                    print(f"[bench] rank {rank}: host-exchange step failed: {e}", file=sys.stderr, flush=True)
-                ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
-                dist.all_reduce(ref)
-                ref = ref.cpu().numpy()
-                good = int(delivered and np.all(np.abs(rec[:29] - ref[:29]) <= 1e-9 * (1.0 + np.abs(ref[:29]))))
-                flag = torch.tensor([good], dtype=torch.int32, device=cdev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
+                rccl_verified = verify_step("RCCL")
+                rccl_ranks = ctx.comm_count() if rccl_verified else 0   # from the communicator (ncclCommCount), not from which path wins
+                if not rccl_verified:
                     if rank == 0:
-                        print("[bench] host-exchange record differs from the all-reduced one: falling back to RCCL", file=sys.stderr, flush=True)
-                    ctx.hostex_destroy()
-                    hostex = False
+                        print("[bench] the RCCL step's record differs from the all-reduced local records: communicator dropped", file=sys.stderr, flush=True)
+                    ctx.comm_destroy()
+                    rccl_ok = False
+            if rccl_ok:
+                coll_times["rccl_us"] = timed(400) * 1e6   # rpe_gn_steps_dist = kernel + ncclAllReduce + publish kernel per step
+        # (2) the in-kernel peer-to-peer exchange (only on request: it has never run on real xGMI)
+        if dist_path and ("p2p" in plan["timed_beside"] or plan["headline"] == "p2p"):
+            p2p = init_p2p(ctx)
+            if p2p:
+                dist.barrier()
+                if not verify_step("peer-to-peer"):
+                    if rank == 0:
+                        print("[bench] peer-to-peer record differs from the all-reduced one: dropped", file=sys.stderr, flush=True)
+                    ctx.p2p_destroy()
+                    p2p = False
+            if p2p:
+                coll_times["p2p_us"] = timed(400) * 1e6
+                if plan["headline"] != "p2p":
+                    dist.barrier()
+                    ctx.p2p_destroy()   # timed beside; the headline runs on RCCL
+                    p2p = False
+            if not p2p and plan["headline"] == "p2p" and os.environ.get("RPE_BENCH_STRICT_COLLECTIVE") == "1":
+                sys.exit("bench.py: the peer-to-peer collective was requested strictly and is not available")
+        # (3) the host-side exchange (every rank keeps its resident kernel; the hosts add the records through shared memory)
+        if dist_path and ("host" in plan["timed_beside"] or plan["headline"] == "host" or not (rccl_ok or p2p)):
+            hostex = init_host_exchange(ctx)
+            if hostex and not verify_step("host-exchange"):
+                if rank == 0:
+                    print("[bench] host-exchange record differs from the all-reduced one: dropped", file=sys.stderr, flush=True)
+                ctx.hostex_destroy()
+                hostex = False
             if hostex:
                 # rpe_gn_refine: resident kernel per rank + exchange between the hosts.  Every wait in it is bounded, so a rank that fails
                 # takes the others out with it after the exchange's timeout: all ranks arrive at the flag below and fall back together.
-                def all_ok(ok):
-                    f = torch.tensor([int(ok)], dtype=torch.int32, device=cdev)
-                    dist.all_reduce(f, op=dist.ReduceOp.MIN)
-                    return int(f.item()) == 1
                 def refine_ok(k):
                     if os.environ.get("RPE_BENCH_INJECT_HOSTEX_FAIL") == str(rank):   # tests: this rank drops out, the peers run into the exchange's timeout
                         print(f"[bench] rank {rank}: injected host-exchange failure", file=sys.stderr, flush=True)
@@ -397,23 +565,22 @@ def worker(args, affinity):
                     good = all_ok(ran)
                 if not good:
                     if rank == 0:
-                        print("[bench] host-side exchange dropped: falling back to RCCL", file=sys.stderr, flush=True)
+                        print("[bench] host-side exchange dropped", file=sys.stderr, flush=True)
                     ctx.hostex_destroy()
                     hostex = False
                 else:
                     coll_times["host_us"] = host_us
-            if hostex:
-                if want == "auto" and rccl_ok and coll_times["rccl_us"] < coll_times["host_us"]:
-                    dist.barrier()
-                    ctx.hostex_destroy()
-                    hostex = False
-            if not hostex and want == "host":
-                sys.exit("bench.py: the host-side exchange was requested and is not available")
+            if hostex and (rccl_ok or p2p) and plan["headline"] != "host":
+                dist.barrier()
+                ctx.hostex_destroy()   # timed beside; the headline runs on the RCCL communicator (north star)
+                hostex = False
+            if not hostex and plan["headline"] == "host" and not (rccl_ok or p2p):
+                sys.exit("bench.py: the host-side exchange was requested and neither it nor RCCL is available")
         native = rccl_ok or p2p
         collective = "none" if not dist_path else (
             "host-side exchange: every rank's host thread adds the peers' 32 fp64 records (shared memory, rank order) each iteration" if hostex else
             "peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
-            "all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
+            "rccl: all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
 
         # The host side of the loop (wait for the record, 6x6 solve, SE(3) exp-map update, next pose out) is C++ inside the library:
         # rpe_gn_refine / rpe_gn_steps_dist with tol = 0 run exactly k iterations, so the timed region contains no Python per step.
@@ -450,9 +617,11 @@ def worker(args, affinity):
         if dist_path:
             pose = run_steps(pose, int(os.environ.get("RPE_BENCH_PREWARM_STEPS", "20000")))   # a FIXED count: every rank issues the same number of collective steps
         else:
+            # launches of the TIMED length, so that every launch of the resident kernel in this process serves args.steps iterations
+            # and a rocprofv3 --kernel-trace --stats average over the run is the average timed launch (only the --warmup launch differs)
             t_pre = time.perf_counter()
             while time.perf_counter() - t_pre < float(os.environ.get("RPE_BENCH_PREWARM_S", "1.5")):
-                pose = run_steps(pose, 500)
+                pose = run_steps(pose12(R0, t0), args.steps)
         # which host CPU polls fastest differs from box to box (GPU-local cores usually, the other socket's on some boxes, by 5-10 %):
         # try a few of both kinds with a short refinement each and keep the best one (one GPU, resident loop, pinned runs only)
         if not dist_path and resident and affinity.get("pinned") and not args.no_extras and os.environ.get("RPE_BENCH_NO_CALIBRATE") != "1":   # (--no-extras: profiled runs hold the timed launches only)
@@ -613,24 +782,19 @@ def worker(args, affinity):
         k_avg_s = (k_total_ms / max(k_cnt, 1)) * 1e-3
         bytes_per_launch = BYTES_PER_CORR * n * steps_per_launch
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else None
-        traffic, traffic_src, rocprof_avg_us, rocprof_src = None, None, None, None
         kernel_name = "rpe::normal_eq_resident_kernel<float, 0, 512, true, false, true, false>" if resident else "rpe::normal_eq_kernel<float, 0, 512, true, false>"
+        # profiles/ evidence of this command (rocprofv3 --kernel-trace --stats; two --pmc passes), recorded per steps-per-launch.  A
+        # per-launch value from a file stands in the line ONLY if the file's launches served the same number of steps as this run's;
+        # otherwise the line carries the file's per-step values with the file's own steps_per_launch beside them.
+        traffic, profile_same, profile_other = None, None, []
         if world == 1 and resident:
-            try:   # the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), for side-by-side reading
-                import csv
-                with open(os.path.join(ROOT, ROCPROF_FILE)) as fh:
-                    for row in csv.DictReader(fh):
-                        if "normal_eq_resident_kernel<float, 0" in row["Name"]:
-                            rocprof_avg_us = float(row["AverageNs"]) * 1e-3
-                            rocprof_src = ROCPROF_FILE
-            except Exception:
-                pass
-            try:
-                j = json.load(open(os.path.join(ROOT, PMC_FILE)))
-                traffic = j.get("normal_eq_resident_p2p_f32_bytes_per_launch")
-                traffic_src = PMC_FILE
-            except Exception:
-                pass
+            for e in profile_entries().get("normal_eq_resident_p2p_f32", []):
+                if e.get("steps_per_launch") == steps_per_launch and profile_same is None:
+                    profile_same = e
+                else:
+                    profile_other.append({k: e.get(k) for k in ("steps_per_launch", "rocprofv3_us_per_step", "traffic_bytes_per_step", "source")})
+            if profile_same:
+                traffic = profile_same.get("traffic_bytes_per_launch")
         ms_med = elapsed / args.steps * 1e3
         out = {
             "metric": "correspondence-residuals/sec", "value": float(inl_total) * args.steps / elapsed, "unit": "correspondence-residuals/s",
@@ -639,7 +803,10 @@ def worker(args, affinity):
             "config": {"workload": workload, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
                        "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
                        "streamed_corr_per_s": float(total_n) * args.steps / elapsed, "accumulate": "fp64", "collective": collective,
-                       "collective_step_us": coll_times or None, "rccl_ranks": world if (dist_path and rccl_ok and not p2p and not hostex) else 0,
+                       "collective_step_us": ({"rccl_us": coll_times.get("rccl_us"), "host_us": coll_times.get("host_us"), "p2p_us": coll_times.get("p2p_us")} if dist_path else None),
+                       "collective_step_us_note": "same run, same shards, 400 steps each: rccl = kernel + ncclAllReduce + publish kernel per step; host = resident kernel per rank + records added by the host threads; p2p = in-kernel mailboxes (timed on request only: RPE_BENCH_COLLECTIVE=auto_p2p)" if dist_path else None,
+                       "rccl_ranks": rccl_ranks, "rccl_ranks_source": "ncclCommCount on the library's communicator after one verified all-reduce" if rccl_ranks else None,
+                       "rccl_verified": rccl_verified, "pci_bus_ids": bus_ids or None, "collective_plan": plan if dist_path else None,
                        "host_loop": "rpe_gn_refine: ONE resident launch per refinement, poses handed over through device memory" if resident else
                                     ("rpe_gn_refine on every rank: one launch per step + exchange between the host threads (ranks share a GPU)" if hostex else
                                      "rpe_gn_steps_dist: one launch + one collective per step" if dist_path else "rpe_gn_refine: one launch per step")},
@@ -648,19 +815,24 @@ def worker(args, affinity):
                        "ms_per_step_p10": percentile(samples, 0.1) / args.steps * 1e3, "ms_per_step_p90": percentile(samples, 0.9) / args.steps * 1e3,
                        "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": {k: v for k, v in affinity.items() if k != "gpu_local_cpu_ids"}, "loop_profile": loop_prof},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_launch, "steps_per_launch": steps_per_launch,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_per_step": (traffic / steps_per_launch) if traffic else None,
+                         "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_step": BYTES_PER_CORR * n,
+                         "steps_per_launch": steps_per_launch,
                          "avg_launch_us": k_avg_s * 1e6, "avg_launch_us_per_step": k_avg_s * 1e6 / steps_per_launch, "min_launch_us": (k_min_ms * 1e3) if k_cnt else None,
-                         "launches_timed": k_cnt, "empty_event_pair_us": ev_avg_ms * 1e3, "rocprofv3_avg_launch_us": rocprof_avg_us,
-                         "rocprofv3_source": rocprof_src,
+                         "launches_timed": k_cnt, "empty_event_pair_us": ev_avg_ms * 1e3,
+                         "profile_same_steps_per_launch": profile_same, "profiles_other_steps_per_launch": profile_other or None,
                          "note": "HIP events on the kernel's own stream (hipExtLaunchKernelGGL start / stop = the dispatch's begin / end timestamps, what "
                                  "rocprofv3 reports); one launch per step, 26 B x correspondences of this rank per launch" if not resident else
                                  "HIP events on the kernel's own stream (hipExtLaunchKernelGGL start / stop = the dispatch's begin / end timestamps, what "
                                  "rocprofv3 reports).  One launch of the resident kernel serves steps_per_launch iterations; its duration INCLUDES the host's "
                                  "turn of every iteration (record over PCIe, 6x6 solve, exp-map, next pose over PCIe): algorithmic bytes = 26 B x "
                                  "correspondences x iterations.  The correspondences of a frame-sized problem stay in registers between iterations, so "
-                                 "this is not an HBM-streaming figure (DESIGN.md section 5); traffic / rocprofv3_* are read from the named profiles/ files "
-                                 "(collected with the same command on another box), not measured in this run"},
+                                 "this is not an HBM-streaming figure (DESIGN.md section 5; the bandwidth-bound figures are in roofline_hbm).  traffic = PMC "
+                                 "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate passes) from profile_same_steps_per_launch, i.e. from a "
+                                 "profile of this command whose launches served the same number of steps as this run's; null when no such profile is "
+                                 "committed (the per-step values of the other profiles are listed with their own steps_per_launch)"},
         }
         if world == 1:
             try:   # pose parity: converged GN pose vs the CPU oracle's closed form (shinji, fp64, same fp32 inputs, same inlier set)
@@ -689,8 +861,17 @@ def worker(args, affinity):
             except Exception as e:  # noqa: BLE001
                 out["convergence"] = {"error": repr(e)}
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(sc, args.cpu_seconds)
+            if not args.no_hbm:
+                try:
+                    out["roofline_hbm"] = hbm_roofline(local_rank)
+                except Exception as e:  # noqa: BLE001
+                    out["roofline_hbm"] = {"error": repr(e)}
             if not args.no_extras:
                 extras(out, args, ctx, sc, n, R0, t0, pose, local_rank)
+                try:
+                    out["fp64"] = fp64_lines(local_rank)
+                except Exception as e:  # noqa: BLE001
+                    out["fp64"] = {"error": repr(e)}
         else:
             if sharded_loop is not None:
                 out["device_resident_loop"] = sharded_loop
@@ -842,6 +1023,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs reported beside the headline (profiling runs: only the headline's launches)")
+    ap.add_argument("--no-hbm", action="store_true", help="skip the live bandwidth-bound block (roofline_hbm: 1 M point-to-plane steady / cold, 10 M / 20 M point-to-point)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
         sys.exit("bench.py: --gpus, --steps and --repeats must be positive")

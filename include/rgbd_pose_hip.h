@@ -163,6 +163,10 @@ int rpe_gn_step(rpe_context* ctx, int kind, int flags, double* pose12, double* n
 int rpe_comm_unique_id(void* id128);
 int rpe_comm_init(rpe_context* ctx, int world, int rank, const void* id128);
 int rpe_comm_destroy(rpe_context* ctx);
+/* ranks of the context's RCCL communicator as the communicator reports them (ncclCommCount; 0 = none), and the PCI bus id of the
+ * context's GPU (one process per GPU: every rank of a node reports a different one) */
+int rpe_comm_count(rpe_context* ctx, int* ranks);
+int rpe_device_bus_id(rpe_context* ctx, char* buf, int len);
 int rpe_gn_step_dist(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
 /* `steps` such steps in one call (every rank passes the same count). */
 int rpe_gn_steps_dist(rpe_context* ctx, int kind, int flags, double* pose12, int steps, double* last_step_norm);
@@ -213,6 +217,14 @@ int rpe_gn_refine(rpe_context* ctx, int nterms, const int* kinds, const double* 
  * microseconds over `steps` steady-state iterations, of the host's WAIT for a record (pose hand-over in flight + one iteration of the
  * resident kernel + record in flight) and of the host's own turn (6x6 solve + SE(3) update + hand-over stores). */
 int rpe_debug_loop_profile(rpe_context* ctx, int enable, double* wait_us, double* host_us, long long* steps);
+
+/* State of a context's RESIDENT loops (rpe_gn_refine, rpe_gn_refine_joint, rpe_icp, rpe_gn_refine_device run as ONE launch whose grid
+ * must be on the compute units all at once).  enabled: large-BAR device, at least one workgroup of the resident kernels per compute
+ * unit, and fewer than two lost grids so far; lost: refinements whose grid lost a workgroup's sums (another process on the GPU, a
+ * partition smaller than the occupancy query promised) and that were FINISHED with one launch per iteration -- such a call still
+ * succeeds, a context that sees it twice stops using resident loops; cap: workgroups of a resident kernel the device holds at once
+ * (occupancy x compute units, at most 256; RPE_RESIDENT_CAP lowers it). */
+int rpe_debug_resident_state(rpe_context* ctx, int* enabled, int* lost, int* cap);
 
 /* HIP-event timing of the normal-equation kernel, on the context's stream: after enable(max_records, stride)
  * every stride-th rpe_normal_eq* call launches its kernel with an event pair that receives the dispatch's own begin / end

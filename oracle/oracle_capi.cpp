@@ -5,6 +5,7 @@
 #include "orc_gn.hpp"
 #include <cstdio>
 #include <chrono>
+#include <atomic>
 #include <thread>
 
 using namespace orc;
@@ -436,6 +437,131 @@ double orc_time_gn_p2p_threads(const float* x_w, const float* x_c, long n, int r
   for (const NormalEq& ne : part) { for (int a = 0; a < 6; a++) { tot.g[a] += ne.g[a]; for (int b = a; b < 6; b++) tot.H[a][b] += ne.H[a][b]; } tot.cost += ne.cost; tot.wsum += ne.wsum; }
   tot.pack(out29);
   return dt;
+}
+// ---- all-core variants of the SAME restatement ("an OpenMP all-core variant of the same restatement for fairness").
+// The reference is single-threaded; these spread its O(N) loops over `threads` host threads by contiguous index ranges, every thread
+// running the reference's per-index body (virtual getters, by-value 3-vectors) on its range, per-thread partial sums added in thread
+// order.  One pool per call, phases separated by a spinning barrier (a thread spawn per phase would cost more than the phase).
+namespace {
+struct SpinBarrier {
+  std::atomic<int> count{0}, sense{0};
+  int n;
+  explicit SpinBarrier(int n_) : n(n_) {}
+  void wait() {
+    const int s = sense.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) { count.store(0, std::memory_order_relaxed); sense.store(s ^ 1, std::memory_order_release); }
+    else {   // spin briefly, then let the scheduler run whoever is late (a busy box would otherwise burn a time slice per barrier)
+      for (unsigned spins = 0; sense.load(std::memory_order_acquire) == s; spins++) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if (spins > 2000) std::this_thread::yield();
+      }
+    }
+  }
+};
+}  // namespace
+// shinji_ls2<float> (= Library.cpp ao()): copy-in, gather through the getters, centroid pass, covariance pass -- each over index ranges;
+// the O(1) tail (M / cols, SVD, det test, t) on thread 0.  Returns the wall time of `reps` repetitions.
+double orc_time_ao_threads(float* x_w, float* x_c, int n, int reps, int threads, float* R_cw, float* t) {
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n > 0 ? n : 1;
+  typedef float T;
+  MatX<T> Xw0(3, n), Xc0(3, n), Xw(3, n), Xc(3, n);
+  AOOnlyPoseAdapter<T> adapter(Xc0, Xw0);
+  adapter.setFocal(555.f, 555.f);
+  std::vector<V3<T>> pCw((size_t)threads), pCc((size_t)threads);
+  std::vector<M3<T>> pM((size_t)threads);
+  V3<T> Cw, Cc;
+  SpinBarrier bar(threads);
+  auto body = [&](int k) {
+    const int lo = (int)((long)n * k / threads), hi = (int)((long)n * (k + 1) / threads);
+    for (int r = 0; r < reps; r++) {
+      for (int i = lo; i < hi; i++) {   // Library.cpp:20-22: the arrays copied into the matrices the adapter refers to
+        Xw0.set_col3(i, V3<T>(x_w[3 * i], x_w[3 * i + 1], x_w[3 * i + 2]));
+        Xc0.set_col3(i, V3<T>(x_c[3 * i], x_c[3 * i + 1], x_c[3 * i + 2]));
+      }
+      for (int i = lo; i < hi; i++) { Xw.set_col3(i, adapter.getPointGlob(i)); Xc.set_col3(i, adapter.getPointCurr(i)); }   // shinji_ls2 :331-336
+      V3<T> cw, cc;
+      for (int i = lo; i < hi; i++) { cw = cw + Xw.col3(i); cc = cc + Xc.col3(i); }   // shinji :57-62
+      pCw[(size_t)k] = cw; pCc[(size_t)k] = cc;
+      bar.wait();
+      if (k == 0) {
+        V3<T> a, b;
+        for (int j = 0; j < threads; j++) { a = a + pCw[(size_t)j]; b = b + pCc[(size_t)j]; }
+        Cw = a / (T)n; Cc = b / (T)n;
+      }
+      bar.wait();
+      M3<T> M;
+      T sigma_w = 0, sigma_c = 0;
+      for (int i = lo; i < hi; i++) {   // :66-74
+        V3<T> Aw = Xw.col3(i) - Cw; sigma_w += norm(Aw);
+        V3<T> Ac = Xc.col3(i) - Cc; sigma_c += norm(Ac);
+        M = M + outer(Ac, Aw);
+      }
+      (void)sigma_w; (void)sigma_c;
+      pM[(size_t)k] = M;
+      bar.wait();
+      if (k == 0) {
+        M3<T> Mt;
+        for (int j = 0; j < threads; j++) Mt = Mt + pM[(size_t)j];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Mt(i, j) = Mt(i, j) / (T)n;
+        SVD3<T> d = svd3(Mt);
+        M3<T> Tmp = d.U * transpose(d.V);
+        SO3<T> R;
+        if (det(Tmp) < T(0)) { M3<T> I = M3<T>::identity(); I(2, 2) = -1; R = SO3<T>(d.U * I * transpose(d.V)); }
+        else R = SO3<T>(Tmp);
+        V3<T> tt = Cc - R * Cw;
+        adapter.setRcw(R); adapter.sett(tt);
+      }
+      bar.wait();
+    }
+  };
+  std::vector<std::thread> pool;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int k = 1; k < threads; k++) pool.emplace_back(body, k);
+  body(0);
+  for (std::thread& th : pool) th.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  M3<T> R = adapter.getRcw().matrix();
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R_cw[3 * i + j] = R(i, j);
+  V3<T> tw = adapter.gettw();
+  t[0] = tw.x; t[1] = tw.y; t[2] = tw.z;
+  return dt;
+}
+// the 3D-3D vote loop (V1/V2, vote_33's body) over index ranges: every thread writes its range of the mask and counts its votes
+double orc_time_votes33_threads(const float* x_w, const float* x_c, int n, const double* poses7, int H, float thre_3d, int* votes, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n > 0 ? n : 1;
+  MatX<float> Xw = load3<float>(x_w, n), Xc = load3<float>(x_c, n);
+  AOOnlyPoseAdapter<float> ad(Xc, Xw);
+  MaskX m(n, 2);
+  std::vector<int> part((size_t)threads);
+  SpinBarrier bar(threads);
+  auto body = [&](int k) {
+    const int lo = (int)((long)n * k / threads), hi = (int)((long)n * (k + 1) / threads);
+    for (int h = 0; h < H; h++) {
+      const SE3<float> s = pose7<float>(poses7 + 7 * h);
+      int v = 0;
+      for (int c = lo; c < hi; c++) {   // AbsoluteOrientation.hpp:190-200
+        m(c, 1) = 0;
+        if (ad.isValid(c)) {
+          V3<float> e = ad.getPointCurr(c) - (s.R * ad.getPointGlob(c) + s.t);
+          if (norm(e) < thre_3d) { m(c, 1) = 1; v++; }
+        }
+      }
+      part[(size_t)k] = v;
+      bar.wait();
+      if (k == 0) { int tot = 0; for (int j = 0; j < threads; j++) tot += part[(size_t)j]; votes[h] = tot; }
+      bar.wait();
+    }
+  };
+  std::vector<std::thread> pool;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int k = 1; k < threads; k++) pool.emplace_back(body, k);
+  body(0);
+  for (std::thread& th : pool) th.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 // vote loop of shinji_ransac2 (V2) for H hypotheses, float
 double orc_time_votes33(const float* x_w, const float* x_c, int n, const double* poses7, int H, float thre_3d, int* votes) {

@@ -271,6 +271,17 @@ class Context:
     def p2p_destroy(self):
         L.check(L.lib().rpe_p2p_destroy(self._h))
 
+    def comm_count(self) -> int:
+        """ranks of this context's RCCL communicator, from the communicator (ncclCommCount); 0 = none"""
+        n = C.c_int(0)
+        L.check(L.lib().rpe_comm_count(self._h, C.byref(n)))
+        return n.value
+
+    def bus_id(self) -> str:
+        buf = C.create_string_buffer(64)
+        L.check(L.lib().rpe_device_bus_id(self._h, buf, 64))
+        return buf.value.decode()
+
     def comm_destroy(self):
         L.check(L.lib().rpe_comm_destroy(self._h))
 
@@ -295,6 +306,12 @@ class Context:
         cnt, tot, mn = C.c_int(0), C.c_double(0), C.c_double(0)
         L.check(L.lib().rpe_timing_collect(self._h, C.byref(cnt), C.byref(tot), C.byref(mn)))
         return cnt.value, tot.value, mn.value
+
+    def resident_state(self) -> dict:
+        """enabled / lost grids / co-residency cap of this context's resident loops (rpe_debug_resident_state)."""
+        en, lost, cap = C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(L.lib().rpe_debug_resident_state(self._h, C.byref(en), C.byref(lost), C.byref(cap)))
+        return {"enabled": bool(en.value), "lost": lost.value, "cap": cap.value}
 
     def gn_refine(self, kinds, pose, scales=None, flags: int = 0, max_iter: int = 20, tol: float = 1e-9):
         kinds = np.ascontiguousarray(kinds, np.int32)

@@ -51,6 +51,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -65,6 +66,7 @@ Rccl& rccl() {
       r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
       r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
       r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+      r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
       r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
     }
   }
@@ -134,6 +136,8 @@ struct rpe_context {
   // host-accessible (no large BAR): the loop then launches one kernel per iteration.
   volatile unsigned long long* ctl = nullptr;
   bool resident = false;
+  int resident_lost = 0;          // resident loops that lost a granule / ended early and were finished with one launch per iteration
+  int resident_cap = 0;           // workgroups of a resident kernel this device holds at once (rpe::resident_cap_device)
   double* h_big = nullptr;        // pinned + mapped: tagged 16-byte pairs {value, sequence} -- the run records of collecting launches, added here on the host
   size_t h_big_pairs = 0;
   bool collecting = false;        // the launch in flight publishes run records into h_big (collect_target)
@@ -260,11 +264,13 @@ int wait_host(rpe_context* c, int ld) {
 // Host-side final sum (resident loop): `grid` collecting workgroups each sent `nacc` pairs {value, seq}; add them in run order as they
 // arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps the arrival of the
 // later ones.
-int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int first_slot = 0) {
+constexpr int kResidentLost = -1000;   // internal (never returned through the C ABI): the resident grid lost a granule or ended early
+int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int first_slot = 0, bool resident = false) {
   unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big) + 2 * (size_t)first_slot;
   const unsigned long long want = c->seq;
   for (int k = 0; k < nacc; k++) totals[k] = 0.0;
   unsigned long long spins = 0;
+  bool lost = false;
   for (int g = 0; g < grid; g++) {
     unsigned long long* rec = pairs + 2 * (size_t)g * nacc;
     for (int k = nacc - 1; k >= 0; k--) {
@@ -272,12 +278,24 @@ int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int f
         if ((++spins & 0xFFFFF) == 0) {
           hipError_t q = hipStreamQuery(c->stream);
           if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
-          if (q == hipSuccess && __atomic_load_n(rec + 2 * k + 1, __ATOMIC_ACQUIRE) != want)
-            return fail(RPE_ERR_HIP, "the resident kernel ended without publishing record %llu (workgroup %d)", want, g);
+          if (q == hipSuccess && __atomic_load_n(rec + 2 * k + 1, __ATOMIC_ACQUIRE) != want) {
+            (void)fail(RPE_ERR_HIP, "the kernel ended without publishing record %llu (run %d)", want, g);
+            return resident ? kResidentLost : RPE_ERR_HIP;
+          }
         }
       }
     }
-    for (int k = 0; k < nacc; k++) { double v; const unsigned long long w = __atomic_load_n(rec + 2 * k, __ATOMIC_RELAXED); std::memcpy(&v, &w, 8); totals[k] += v; }
+    for (int k = 0; k < nacc; k++) {
+      double v;
+      const unsigned long long w = __atomic_load_n(rec + 2 * k, __ATOMIC_RELAXED);
+      if (w == rpe::kResidentLostMarker) lost = true;   // this run's collecting workgroup never got one of its granules
+      std::memcpy(&v, &w, 8);
+      totals[k] += v;
+    }
+  }
+  if (lost) {
+    (void)fail(RPE_ERR_HIP, "a workgroup's sums never reached its collecting workgroup (record %llu)", want);
+    return resident ? kResidentLost : RPE_ERR_HIP;
   }
   return RPE_OK;
 }
@@ -392,6 +410,9 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   hand_over(pose12, base + 1);
   rpe::ReduceTarget rt = host_target(c);
   rt.seq = base;
+  // a rank that waits for a slow peer inside the host-side exchange (up to its 10 s) must not lose its own grid meanwhile
+  if (c->hostex) rt.pose_wait_ticks = 1200000000ull;
+  if (const char* f = getenv("RPE_TEST_RESIDENT_FAULT")) { const int k = atoi(f); if (k >= 1 && k <= max_iter) rt.fault_tag = base + (unsigned long long)k; }
   static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
   const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
   const int runs = (grid + rows - 1) / rows;
@@ -409,7 +430,7 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     c->seq = base + (unsigned long long)received + 1;
     double ne[32], d[6];
     double tot[32];
-    if ((rc = wait_host_partials(c, runs, nacc, tot))) { status = rc; break; }
+    if ((rc = wait_host_partials(c, runs, nacc, tot, 0, true))) { status = rc; break; }
     if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; }
     if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) { status = rc; received++; break; }
     received++;
@@ -426,6 +447,12 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);   // the grid is still waiting: release it
   c->seq = base + (unsigned long long)max_iter + 1;   // stays ahead of every tag / sequence value this launch could use
   *it_out = it; *step_out = step; *cost_out = cost; *weight_out = weight;
+  if (status == kResidentLost) {
+    // Not all of the grid was on the compute units at once (another process on the GPU, a smaller partition than the occupancy query
+    // promised) or a workgroup was held up for more than its bounded wait.  pose12 holds the pose after `it` whole iterations: the
+    // caller finishes with one launch per iteration.  A context that sees this twice stops using resident loops.
+    if (++c->resident_lost >= 2) c->resident = false;
+  }
   return status;
 }
 
@@ -455,8 +482,11 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, (size_t)(4096 + 8) * rpe::kNlLd * sizeof(double));   // + 8 shard records
-  if (e == hipSuccess) e = hipMemset(c->d_partials, 0, (size_t)(4096 + 8) * rpe::kNlLd * sizeof(double));   // granule tags start below every sequence value
+  // scratch of the cross-workgroup stages, whichever layout a launch uses: (4096 + 8 shard) records of kNlLd doubles, or 16-byte
+  // granules [workgroup <= 4096][sums <= 44] followed by the autonomous loop's run records [2 parities][<= kAutoMaxRunSums = 1024]
+  const size_t partial_doubles = std::max<size_t>((size_t)(4096 + 8) * rpe::kNlLd, (size_t)2 * 4096 * 44 + (size_t)2 * 2 * 1024);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, partial_doubles * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(c->d_partials, 0, partial_doubles * sizeof(double));   // granule tags start below every sequence value
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
   c->h_big_pairs = 8192 + 64;
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_big, c->h_big_pairs * 16, hipHostMallocMapped | hipHostMallocCoherent);
@@ -484,7 +514,9 @@ int rpe_create(rpe_context** out, int device, void* stream) {
     const char* env = getenv("RPE_RESIDENT");
     if (!(env && env[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
       void* p = nullptr;
-      if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+      c->resident_cap = rpe::resident_cap_device();   // 0: not even one workgroup of the resident kernels per compute unit
+      if (c->resident_cap >= 1 && hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess &&
+          hipDeviceSynchronize() == hipSuccess) {
         c->ctl = (volatile unsigned long long*)p;
         c->resident = true;
       } else { (void)hipGetLastError(); if (p) (void)hipFree(p); }
@@ -735,10 +767,12 @@ int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, dou
   return RPE_OK;
 }
 
-static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12) {
+struct JointSpec { int bits = 0, robust[4] = {0, 0, 0, 0}; double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1}; };
+static int joint_spec(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, JointSpec* out) {
   if (!c || !terms || nterms < 1 || nterms > 4 || !pose12) return fail(RPE_ERR_ARG, "rpe_normal_eq_joint: bad argument");
-  int bits = 0, robust[4] = {0, 0, 0, 0};
-  double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1};
+  int& bits = out->bits;
+  int (&robust)[4] = out->robust;
+  double (&scale)[4] = out->scale, (&rk)[4] = out->rk;
   for (int t = 0; t < nterms; t++) {
     const int k = terms[t].kind;
     if (k < 0 || k > 3) return fail(RPE_ERR_ARG, "unknown residual kind %d", k);
@@ -750,8 +784,14 @@ static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* term
     bits |= 1 << k; scale[k] = terms[t].scale; robust[k] = terms[t].robust; rk[k] = terms[t].robust_k > 0 ? terms[t].robust_k : 1.0;
   }
   if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
+  return RPE_OK;
+}
+static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12) {
+  JointSpec sp;
+  int rc = joint_spec(c, nterms, terms, flags, pose12, &sp);
+  if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, collect_target(c), c->stream));
+  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), sp.bits, flags, pose12, sp.scale, sp.robust, sp.rk, collect_target(c), c->stream));
   return RPE_OK;
 }
 
@@ -768,6 +808,31 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
                         double* last_step, double* final_cost) {
   int it = 0;
   double step = 0, cost = 0;
+  if (c && c->resident && max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
+    // ONE launch for the whole refinement, as rpe_gn_refine: the grid of the joint kernel stays resident, the host hands every pose
+    // over through the control block, adds the run records, solves and updates
+    JointSpec sp;
+    int rc = joint_spec(c, nterms, terms, flags, pose12, &sp);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
+    rpe::resident_geometry(c->arrays(), RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);   // the 29-sum geometry
+    double weight = 0;
+    auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
+      return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk, (const unsigned long long*)c->ctl, base,
+                                                  max_iter, rt, c->stream);
+    };
+    { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations"); }
+    if (rc != kResidentLost) {
+      if (iters_out) *iters_out = it;
+      if (rc != RPE_OK) return rc;
+      if (last_step) *last_step = step;
+      if (final_cost) *final_cost = cost;
+      return RPE_OK;
+    }
+    // the resident grid was lost after `it` whole iterations: carry on below, one launch per iteration
+  }
   for (; it < max_iter; it++) {
     double ne[32], d[6];
     int rc = rpe_normal_eq_joint(c, nterms, terms, flags, pose12, ne);
@@ -821,7 +886,9 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   // (rpe_residuals.hpp resident_auto_stage); the host hears from it once, when the loop has finished.  RPE_DEVICE_LOOP_RESIDENT=0: one
   // launch per iteration, as the other residual kinds and the sharded loop keep.
   static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
-  if (auto_on && single && !sharded && !c->comm && !c->hostex && max_iter >= 2 && (terms[0].kind == RPE_RES_P2P || terms[0].kind == RPE_RES_P2PLANE)) {
+  double pose_in[12];
+  std::memcpy(pose_in, pose12, sizeof(pose_in));
+  if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && single && !sharded && !c->comm && !c->hostex && max_iter >= 2) {
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), terms[0].kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     const unsigned long long base = c->seq;          // granule / run-record tags base + 1 ... base + max_iter
@@ -834,18 +901,26 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0, e1));
     int rc = wait_host(c, rpe::kNeLd);
     if (rc) return rc;
-    for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
-    if (last_step) *last_step = c->h_out[12];
-    if (final_cost) *final_cost = c->h_out[13];
-    if (iters_out) *iters_out = (int)c->h_out[14];
-    if (c->h_out[15] == 2.0) return fail(RPE_ERR_HIP, "device loop: a workgroup's sums never arrived at iteration %d", (int)c->h_out[14]);
-    if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
-    return RPE_OK;
+    if (c->h_out[15] != 2.0) {
+      for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
+      if (last_step) *last_step = c->h_out[12];
+      if (final_cost) *final_cost = c->h_out[13];
+      if (iters_out) *iters_out = (int)c->h_out[14];
+      if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
+      return RPE_OK;
+    }
+    // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per iteration
+    ++c->resident_lost;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose_in, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    rt = host_target(c);
+    rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
   }
   for (int it = 0; it < max_iter; it++) {
     if (sharded) { rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++; }
-    if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose12, rt, c->stream));
-    else HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose12, scale, robust, rk, rt, c->stream));
+    if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose_in, rt, c->stream));
+    else HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose_in, scale, robust, rk, rt, c->stream));
   }
   int rc = wait_host(c, rpe::kNeLd);
   if (rc) return rc;
@@ -875,6 +950,16 @@ int rpe_debug_device_gn_update(rpe_context* c, const double* ne32, double* pose1
   if (buf[45] == 0.0) return fail(RPE_ERR_DEGENERATE, "device solve: normal equations are not positive definite");
   for (int i = 0; i < 12; i++) pose12[i] = buf[32 + i];
   if (step_norm) *step_norm = buf[44];
+  return RPE_OK;
+}
+
+// State of the resident loops of a context: enabled (large BAR, at least one workgroup per compute unit, fewer than two lost grids),
+// how many refinements were finished with one launch per iteration after their grid was lost, and the co-residency cap of the device.
+int rpe_debug_resident_state(rpe_context* c, int* enabled, int* lost, int* cap) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  if (enabled) *enabled = c->resident ? 1 : 0;
+  if (lost) *lost = c->resident_lost;
+  if (cap) *cap = c->resident_cap;
   return RPE_OK;
 }
 
@@ -917,7 +1002,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   // sharded contexts: only with the host-side exchange (every rank's host thread adds the peers' records to its own each iteration);
   // RCCL / in-kernel peer-to-peer contexts take rpe_gn_steps_dist
   const bool sharded_ok = c->hostex ? !c->hostex_shared_gpu : (!c->comm && c->p2p_world_saved < 1);
-  if (c->resident && max_iter >= 2 && kinds[0] != RPE_RES_BEARING && sharded_ok) {
+  if (c->resident && max_iter >= 2 && sharded_ok) {
     // ONE launch for the whole loop: the grid stays resident, the host hands every new pose to it through the control block in
     // device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration) and solves / updates as before.
     int rc = kind_arrays(c, kinds[0]);
@@ -935,11 +1020,14 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     };
     { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
       rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations"); }
-    if (iters_out) *iters_out = it;
-    if (rc != RPE_OK) return rc;
-    if (last_step) *last_step = step;
-    if (final_cost) *final_cost = cost;
-    return RPE_OK;
+    if (rc != kResidentLost) {
+      if (iters_out) *iters_out = it;
+      if (rc != RPE_OK) return rc;
+      if (last_step) *last_step = step;
+      if (final_cost) *final_cost = cost;
+      return RPE_OK;
+    }
+    // the resident grid was lost after `it` whole iterations: carry on from pose12 below, one launch per iteration
   }
   for (; it < max_iter; it++) {
     double ne[32], d[6];
@@ -981,6 +1069,23 @@ int rpe_comm_init(rpe_context* c, int world, int rank, const void* id128) {
   std::memcpy(&id, id128, 128);
   NCCL_TRY(rccl().CommInitRank(&c->comm, world, id, rank));
   c->comm_world = world;
+  return RPE_OK;
+}
+
+// ranks of the context's RCCL communicator as the communicator itself reports them (ncclCommCount); 0 = no communicator
+int rpe_comm_count(rpe_context* c, int* ranks) {
+  if (!c || !ranks) return fail(RPE_ERR_ARG, "rpe_comm_count: bad argument");
+  *ranks = 0;
+  if (!c->comm) return RPE_OK;
+  if (!rccl().CommCount) return fail(RPE_ERR_STATE, "ncclCommCount is not exported by the loaded librccl");
+  NCCL_TRY(rccl().CommCount(c->comm, ranks));
+  return RPE_OK;
+}
+
+// PCI bus id of the context's GPU ("0000:05:00.0"): one process per GPU means every rank of a node reports a different one
+int rpe_device_bus_id(rpe_context* c, char* buf, int len) {
+  if (!c || !buf || len < 16) return fail(RPE_ERR_ARG, "rpe_device_bus_id: bad argument (need a buffer of >= 16 bytes)");
+  HIP_TRY(hipDeviceGetPCIBusId(buf, len, c->device));
   return RPE_OK;
 }
 
@@ -1545,6 +1650,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
   if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
   int it = 0;
   double step = 0, cost = 0, pairs = 0;
+  bool host_rounds = false;
   auto& F = c->fe;
   const int64_t n = (int64_t)F.cam.width * F.cam.height;
   const float dgate = (float)o->dist_thr;
@@ -1569,8 +1675,10 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
     static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
     std::unique_lock<std::mutex> one_resident_grid(resident_mutex(c->device), std::defer_lock);
-    if (auto_on && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world < 1) {
+    bool one_launch = false;
+    if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world < 1) {
       // ONE launch: the resident grid pairs, sums, solves and updates by itself (icp_resident_kernel with resident_auto_stage)
+      one_launch = true;
       one_resident_grid.lock();   // until the result has arrived (end of this block's scope)
       int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
       rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
@@ -1584,6 +1692,17 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       for (int k = 0; k < o->max_iter; k++) if ((rc = round(pose12, rt, true))) return rc;
     }
     if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+    if (one_launch && c->h_out[15] == 2.0) {
+      // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per round
+      ++c->resident_lost;
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+      rt = host_target(c);
+      rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
+      for (int k = 0; k < o->max_iter; k++) if ((rc = round(pose12, rt, true))) return rc;
+      if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+    }
     for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
     step = c->h_out[12]; cost = c->h_out[13]; it = (int)c->h_out[14]; pairs = c->h_out[16];
     if (c->h_out[15] == 2.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_HIP, "ICP device loop: a workgroup's sums never arrived at iteration %d", it); }
@@ -1599,8 +1718,10 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     };
     { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
       rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs, "ICP: normal equations"); }
-    if (rc != RPE_OK) { if (iters_out) *iters_out = it; return rc; }
-  } else {
+    if (rc != RPE_OK && rc != kResidentLost) { if (iters_out) *iters_out = it; return rc; }
+    host_rounds = rc == kResidentLost;   // the grid was lost after `it` whole rounds: the rest one launch per round
+  } else host_rounds = true;
+  if (host_rounds) {
     for (; it < o->max_iter; it++) {
       if ((rc = round(pose12, collect_target(c), false))) return rc;
       if ((rc = wait_host(c, rpe::kNeLd))) return rc;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BLK) void icp_resident_kernel(const float* __restri
     __syncthreads();
   }
   for (int it = 1; it <= max_iters; it++) {
-    if (!AUTO && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;
+    if (!AUTO && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
@@ -202,7 +202,7 @@ hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, 
   AssocParams P;
   P.mcam = mcam; P.M = M; P.dist_sq = dist_sq; P.cos_thr = cos_thr; P.use_normals = use_normals;
   constexpr int BLK = 512;
-  const int cap = resident_cap(BLK);
+  const int cap = std::max(1, resident_cap_device());
   const int G = reduce_grid(n, 4, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);
   const int64_t groups = (n + 3) / 4;
   const bool in_regs = (int64_t)G * BLK >= groups;

@@ -79,25 +79,15 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
     if (TERMS & TERM_BEARING) {
       const T bx0 = vb[3 * i], by0 = vb[3 * i + 1], bz0 = vb[3 * i + 2];
       const bool on = present & (k23[i] == 1) & !all_nan(bx0, by0, bz0);
-      const T bx = on ? bx0 : T(0), by = on ? by0 : T(0), bz = on ? bz0 : T(1);
-      const double sx = on ? pxd : 0.0, sy = on ? pyd : 0.0, sz = on ? pzd : 1.0;  // keeps the normalisation finite when off
-      const double invd = rsqrt64(sx * sx + sy * sy + sz * sz);
-      const double hxd = sx * invd, hyd = sy * invd, hzd = sz * invd;
-      const T r[3] = {(T)(hyd * (double)bz - hzd * (double)by), (T)(hzd * (double)bx - hxd * (double)bz), (T)(hxd * (double)by - hyd * (double)bx)};
-      const T w0 = on ? u23[i] : T(0);
-      const T w = w0 * robust_weight<T>(prm.robust[2], (T)prm.robust_k[2], [&]() { return sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]); });
-      const T ws = (T)prm.scale[2] * w;
-      const T qx = (T)sx, qy = (T)sy, qz = (T)sz, inv = (T)invd;
-      const T h[3] = {(T)hxd, (T)hyd, (T)hzd};
-      const T Bx[3][3] = {{T(0), -bz, by}, {bz, T(0), -bx}, {-by, bx, T(0)}};
-#pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const T bh = Bx[u][0] * h[0] + Bx[u][1] * h[1] + Bx[u][2] * h[2];
-        const T a0 = -(Bx[u][0] - bh * h[0]) * inv, a1 = -(Bx[u][1] - bh * h[1]) * inv, a2 = -(Bx[u][2] - bh * h[2]) * inv;
-        const T J[6] = {a0, a1, a2, qy * a2 - qz * a1, qz * a0 - qx * a2, qx * a1 - qy * a0};
-        add_row(J, r[u], ws, s);
+      // wave-uniform skip: configs[2] has bearings for 2 000 of 307 200 correspondences -- a wave none of whose lanes holds one pays a
+      // ballot instead of the term (inside, everything stays predicated by `on`, so the sums do not depend on the branch)
+      if (__builtin_amdgcn_ballot_w64(on) != 0) {
+        const T bx = on ? bx0 : T(0), by = on ? by0 : T(0), bz = on ? bz0 : T(1);
+        const double sx = on ? pxd : 0.0, sy = on ? pyd : 0.0, sz = on ? pzd : 1.0;  // keeps the normalisation finite when off
+        const T w0 = on ? u23[i] : T(0);
+        const T w = w0 * robust_weight<T>(prm.robust[2], (T)prm.robust_k[2], [&]() { return bearing_residual_norm<T>(sx, sy, sz, bx, by, bz); });
+        bearing_point<T>(sx, sy, sz, bx, by, bz, (T)prm.scale[2] * w, w, s);
       }
-      s[28] += w;
     }
     if (TERMS & TERM_NORMAL) {
       const T mx = vnw[3 * i], my = vnw[3 * i + 1], mz = vnw[3 * i + 2];
@@ -126,16 +116,46 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
   for (int k = 0; k < 29; k++) acc[k] += (double)s[k];
 }
 
+// the arrays, masks and weights of the joint kernels (null = absent) ...
+template <class T> struct JointArrays {
+  const T *xw, *xc, *bv, *nw, *nc;
+  const short *m23, *m33, *mnn;
+  const T *w23, *w33, *wnn;
+};
+// ... and one group of P correspondences of them in registers: only what the term set reads is loaded (absent masks / weights read as 1)
+template <class T> struct JointRegs {
+  enum { P = Pk<T>::P };
+  T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+  short k23[P], k33[P], knn[P];
+  T u23[P], u33[P], unn[P];
+  template <int TERMS> __device__ __forceinline__ void load(const JointArrays<T>& A, int64_t g, int64_t n) {
+    constexpr bool HAS33 = (TERMS & (TERM_P2P | TERM_P2PLANE)) != 0;
+    constexpr bool NEED_NC = (TERMS & (TERM_P2PLANE | TERM_NORMAL)) != 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) { k23[i] = k33[i] = knn[i] = 1; u23[i] = u33[i] = unn[i] = T(1); }
+    load_group<T>(A.xw, g, n, vw);
+    if (HAS33) {
+      load_group<T>(A.xc, g, n, vc);
+      if (A.m33) load_mask_group(A.m33, g, n, k33);
+      if (A.w33) load_weight_group(A.w33, g, n, u33);
+    }
+    if (TERMS & TERM_BEARING) {
+      load_group<T>(A.bv, g, n, vb);
+      if (A.m23) load_mask_group(A.m23, g, n, k23);
+      if (A.w23) load_weight_group(A.w23, g, n, u23);
+    }
+    if (TERMS & TERM_NORMAL) {
+      load_group<T>(A.nw, g, n, vnw);
+      if (A.mnn) load_mask_group(A.mnn, g, n, knn);
+      if (A.wnn) load_weight_group(A.wnn, g, n, unn);
+    }
+    if (NEED_NC) load_group<T>(A.nc, g, n, vnc);
+  }
+};
+
 template <class T, int TERMS, int BLK>
-__global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
-                                                              const T* __restrict__ nw, const T* __restrict__ nc,
-                                                              const short* __restrict__ m23, const short* __restrict__ m33,
-                                                              const short* __restrict__ mnn, const T* __restrict__ w23,
-                                                              const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n,
-                                                              PoseK<double> pose, JointParams prm, Finish fin) {
+__global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(JointArrays<T> A, int64_t n, PoseK<double> pose, JointParams prm, Finish fin) {
   constexpr int P = Pk<T>::P;
-  constexpr bool HAS33 = (TERMS & (TERM_P2P | TERM_P2PLANE)) != 0;
-  constexpr bool NEED_NC = (TERMS & (TERM_P2PLANE | TERM_NORMAL)) != 0;
   if (fin.gn != nullptr) {
     if (fin.gn->done) return;
 #pragma unroll
@@ -149,22 +169,65 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(const T* __restric
   const int64_t groups = (n + P - 1) / P;
   const int64_t stride = (int64_t)gridDim.x * BLK;
   for (int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x; g < groups; g += stride) {
-    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
-    short k23[P], k33[P], knn[P];
-    T u23[P], u33[P], unn[P];
-#pragma unroll
-    for (int i = 0; i < P; i++) { k23[i] = k33[i] = knn[i] = 1; u23[i] = u33[i] = unn[i] = T(1); }
-    load_group<T>(xw, g, n, vw);
-    if (HAS33) { load_group<T>(xc, g, n, vc); if (m33) load_mask_group(m33, g, n, k33); if (w33) load_weight_group(w33, g, n, u33); }
-    if (TERMS & TERM_BEARING) { load_group<T>(bv, g, n, vb); if (m23) load_mask_group(m23, g, n, k23); if (w23) load_weight_group(w23, g, n, u23); }
-    if (TERMS & TERM_NORMAL) { load_group<T>(nw, g, n, vnw); if (mnn) load_mask_group(mnn, g, n, knn); if (wnn) load_weight_group(wnn, g, n, unn); }
-    if (NEED_NC) load_group<T>(nc, g, n, vnc);
+    JointRegs<T> q;
+    q.template load<TERMS>(A, g, n);
     const int64_t left = n - g * P;
-    joint_group<T, TERMS>(pose, prm, vw, vc, vb, vnw, vnc, k23, k33, knn, u23, u33, unn, left < P ? (int)left : P, acc);
+    joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn, left < P ? (int)left : P, acc);
   }
   reduce_and_finish<29, kNeLd, 0, BLK>(acc, fin);
 }
 
+// RESIDENT form (rpe_gn_refine_joint on one GPU): ONE launch for the whole refinement, as normal_eq_resident_kernel -- every iteration
+// the workgroups wait for the host's pose in the control block (resident_wait_pose), evaluate their slice of the joint objective and hand
+// the 29 sums to the collecting stage (resident_cross_stage); the host adds the run records, solves and updates.  Frame-sized problems
+// (IN_REGS: one group per thread) read their arrays once per refinement.
+template <class T, int TERMS, int BLK, bool IN_REGS>
+__global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArrays<T> A, int64_t n, JointParams prm,
+                                                                       const unsigned long long* __restrict__ ctl,
+                                                                       unsigned long long first_tag, int max_iters, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  __shared__ double s_pose[12];
+  __shared__ int s_go;
+  const int64_t groups = (n + P - 1) / P;
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  const int64_t g0 = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  JointRegs<T> mine;
+  const bool have = IN_REGS && g0 < groups;
+  if (have) mine.template load<TERMS>(A, g0, n);
+  for (int it = 1; it <= max_iters; it++) {
+    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;   // stop requested or no host
+    PoseK<double> pose;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pose.t[k] = s_pose[9 + k];
+    double acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] = 0.0;
+    if (IN_REGS) {
+      const int64_t left = n - g0 * P;
+      if (have)
+        joint_group<T, TERMS>(pose, prm, mine.vw, mine.vc, mine.vb, mine.vnw, mine.vnc, mine.k23, mine.k33, mine.knn, mine.u23, mine.u33,
+                              mine.unn, left < P ? (int)left : P, acc);
+    } else {
+      for (int64_t g = g0; g < groups; g += stride) {
+        JointRegs<T> q;
+        q.template load<TERMS>(A, g, n);
+        const int64_t left = n - g * P;
+        joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn, left < P ? (int)left : P, acc);
+      }
+    }
+    if (!resident_cross_stage<29, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, false)) return;
+  }
+}
+
+template <class T> static JointArrays<T> joint_arrays(const DeviceArrays& A, bool um, bool uw) {
+  JointArrays<T> J;
+  J.xw = (const T*)A.a[0]; J.xc = (const T*)A.a[1]; J.bv = (const T*)A.a[2]; J.nw = (const T*)A.a[3]; J.nc = (const T*)A.a[4];
+  J.m23 = um ? (const short*)A.mask[0] : nullptr; J.m33 = um ? (const short*)A.mask[1] : nullptr; J.mnn = um ? (const short*)A.mask[2] : nullptr;
+  J.w23 = uw ? (const T*)A.weight[0] : nullptr; J.w33 = uw ? (const T*)A.weight[1] : nullptr; J.wnn = uw ? (const T*)A.weight[2] : nullptr;
+  return J;
+}
 template <class T, int TERMS, int BLK>
 static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s);
 template <class T, int TERMS>
@@ -181,10 +244,7 @@ template <class T, int TERMS, int BLK>
 static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s) {
   const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
-  hipLaunchKernelGGL((normal_eq_joint_kernel<T, TERMS, BLK>), dim3(G), dim3(BLK), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
-                     (const T*)A.a[3], (const T*)A.a[4], um ? (const short*)A.mask[0] : nullptr, um ? (const short*)A.mask[1] : nullptr,
-                     um ? (const short*)A.mask[2] : nullptr, uw ? (const T*)A.weight[0] : nullptr, uw ? (const T*)A.weight[1] : nullptr,
-                     uw ? (const T*)A.weight[2] : nullptr, A.n, pose, prm, make_finish(rt));
+  hipLaunchKernelGGL((normal_eq_joint_kernel<T, TERMS, BLK>), dim3(G), dim3(BLK), 0, s, joint_arrays<T>(A, um, uw), A.n, pose, prm, make_finish(rt));
 }
 template <class T>
 static hipError_t joint_t(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,
@@ -205,6 +265,50 @@ hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, c
                                   const double* robust_k4, const ReduceTarget& rt, hipStream_t s) {
   return A.dtype ? joint_t<double>(A, terms, flags, pose12, scale4, robust4, robust_k4, rt, s)
                  : joint_t<float>(A, terms, flags, pose12, scale4, robust4, robust_k4, rt, s);
+}
+
+// resident form: grid / record geometry as the resident normal-equation kernel's 29-sum kinds (resident_geometry with a non-p2p kind)
+template <class T, int TERMS>
+static void joint_resident_launch(const DeviceArrays& A, int flags, const JointParams& prm, const unsigned long long* ctl, unsigned long long first_tag,
+                                  int max_iters, const ReduceTarget& rt, hipStream_t s) {
+  constexpr int BLK = 512;
+  const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
+  const int cap = std::max(1, resident_cap_device());
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);
+  const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
+  // one group per thread kept in registers across the iterations -- except the three-array fp32 term sets, whose resident groups would
+  // spill (measured with scripts/kernel_resources.py: 180-316 bytes per lane); those re-read their cache-resident slice every iteration
+  constexpr bool regs_fit = !(sizeof(T) == 4 && (TERMS == 12 || TERMS == 13 || TERMS == 14));
+  const bool in_regs = regs_fit && (int64_t)G * BLK >= groups;
+  Finish fin = make_finish(rt);
+  constexpr int kMaxRows = 4 * (BLK / 29);
+  if (fin.rows > kMaxRows) fin.rows = kMaxRows;
+  if (fin.rows < 1) fin.rows = 1;
+  const JointArrays<T> J = joint_arrays<T>(A, um, uw);
+  if (in_regs)
+    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, true>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag, max_iters, fin);
+  else
+    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, false>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag, max_iters, fin);
+}
+template <class T>
+static hipError_t joint_resident_t(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4, const double* robust_k4,
+                                   const unsigned long long* ctl, unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s) {
+  JointParams prm;
+  for (int k = 0; k < 4; k++) { prm.scale[k] = scale4[k]; prm.robust[k] = robust4[k]; prm.robust_k[k] = robust_k4[k]; }
+  switch (terms) {
+#define RPE_JOINT_CASE(M) case M: joint_resident_launch<T, M>(A, flags, prm, ctl, first_tag, max_iters, rt, s); break;
+    RPE_JOINT_CASE(1) RPE_JOINT_CASE(2) RPE_JOINT_CASE(4) RPE_JOINT_CASE(8) RPE_JOINT_CASE(5) RPE_JOINT_CASE(6) RPE_JOINT_CASE(9)
+    RPE_JOINT_CASE(10) RPE_JOINT_CASE(12) RPE_JOINT_CASE(13) RPE_JOINT_CASE(14)
+#undef RPE_JOINT_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_normal_eq_joint_resident(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4,
+                                           const double* robust_k4, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
+                                           const ReduceTarget& rt, hipStream_t s) {
+  return A.dtype ? joint_resident_t<double>(A, terms, flags, scale4, robust4, robust_k4, ctl, first_tag, max_iters, rt, s)
+                 : joint_resident_t<float>(A, terms, flags, scale4, robust4, robust_k4, ctl, first_tag, max_iters, rt, s);
 }
 
 }  // namespace rpe

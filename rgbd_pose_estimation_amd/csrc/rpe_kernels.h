@@ -58,6 +58,8 @@ struct ReduceTarget {
   const P2PDesc* p2p = nullptr;   // multi-GPU: exchange + sum the record with the peers before publishing (h_out path only)
   unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
   int tail = -1;               // cross-workgroup stage of the ordinary kernels: -1 = default / RPE_TAIL
+  unsigned long long pose_wait_ticks = 200000000ull;   // resident kernels: wait for the host's next pose at most this long (100 MHz ticks; 2 s)
+  unsigned long long fault_tag = 0;                    // test hook: see Finish
   int rows = 0;                // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out must hold
                                // 1 + ceil(grid / run length) x sums pairs), and the host adds them in order.  Host-consumed, single-GPU results only
@@ -70,6 +72,11 @@ hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const do
 // first_tag + i; the run records of iteration i (rt.rows) are published with sequence value rt.seq + i.  Needs host-writable device
 // memory (large BAR).
 constexpr unsigned long long kResidentStopBit = 1ull << 63;
+constexpr unsigned long long kResidentLostMarker = 0x7ff8dead00c0ffeeull;   // = kLostMarker (rpe_reduce.hpp): a run whose granules never arrived
+// How many 512-thread workgroups of the resident kernels the CURRENT device holds at once (occupancy of the heaviest instances x compute
+// units, at most 256; 0 = none fits: no resident loops).  Every resident launcher caps its grid with it: a collecting workgroup waits for
+// workgroups of its own launch, so all of them must be on the compute units together.
+int resident_cap_device();
 void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
@@ -79,6 +86,11 @@ hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& 
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
 hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,
                                   const double* robust_k4, const ReduceTarget& rt, hipStream_t s);
+// RESIDENT form of the joint kernel (one launch per refinement; control block, tags and run records as launch_normal_eq_resident;
+// geometry = resident_geometry of a 29-sum kind)
+hipError_t launch_normal_eq_joint_resident(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4,
+                                           const double* robust_k4, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
+                                           const ReduceTarget& rt, hipStream_t s);
 // d_poses: H x 12 (fast: R row-major, t) or H x 8 (exact: qw qx qy qz tx ty tz pad) values of the array dtype.
 // thr: {thre_3d (fast: squared), cos_thr, cos_nl} as doubles holding values of the array dtype.
 // d_votes[0..H) must be zero on entry (launch_publish_votes leaves them so)

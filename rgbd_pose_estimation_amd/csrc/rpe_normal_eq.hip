@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     __syncthreads();
   }
   for (int it = 1; it <= max_iters; it++) {
-    if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go) != 1) return;   // stop requested or no host: uniform for the workgroup
+    if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;   // stop requested or no host: uniform for the workgroup
 #ifdef RPE_STAMPS
     const bool stamp_it = it == 1000;
     if (stamp_it) RPE_STAMP(0);
@@ -251,7 +251,7 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   const int mod = KIND == KIND_BEARING ? 0 : 1;
   const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
-  const int cap = resident_cap(BLK);
+  const int cap = std::max(1, resident_cap_device());
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);   // every workgroup resident at once: 8 waves per CU
   const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
   const bool in_regs = (int64_t)G * BLK >= groups;
@@ -277,18 +277,46 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
 template <class T>
 static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
                              const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-  // the two 3D-3D kinds only: the bearing residual's register footprint (fp64 normalisation, three Jacobian rows) leaves no room
-  // for a resident group without spilling; it keeps one launch per iteration
   if (kind == KIND_P2P) resident_launch<T, KIND_P2P, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else if (kind == KIND_P2PLANE) resident_launch<T, KIND_P2PLANE, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
+  else if (kind == KIND_BEARING) resident_launch<T, KIND_BEARING, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+// Co-residency of the resident kernels, per device: the occupancy the runtime reports for the heaviest instances (512-thread
+// workgroups, up to 256 VGPRs: one workgroup per compute unit) times the compute units of THIS device -- a CPX / DPX partition or a
+// smaller part has fewer than 256 -- and never more than one workgroup per compute unit, whatever a light instance would allow (the
+// occupancy query is known to come out one block too high at some SGPR counts: MI355X_MICROARCH.md, correctness boundaries).  What
+// cannot be known here is another process on the same GPU; that case is caught at run time (a run whose granules never arrive tells
+// the host, which finishes the refinement with one launch per iteration: rpe_capi.hip resident_host_loop).
+int resident_cap_device() {
+  static int cap[64];
+  static bool known[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+  if (known[dev]) return cap[dev];
+  int cus = 0, c = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+  int per_cu = 1;
+  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, false, false>,
+                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, 512, true, false, true, true>,
+                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, 512, true, true, false, false>};
+  for (const void* k : heavy) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 512, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    if (nb < per_cu) per_cu = nb;
+  }
+  c = per_cu >= 1 ? cus : 0;
+  if (c > 256) c = 256;
+  if (const char* e = getenv("RPE_RESIDENT_CAP")) { const int v = atoi(e); if (v >= 0 && v < c) c = v; }   // experiments / tests: a smaller device
+  cap[dev] = c; known[dev] = true;
+  return c;
 }
 // grid the resident kernel runs with, the number of sums per record, the longest run of workgroups one collecting workgroup can take,
 // and the run length used unless the caller forces one: BLK / sums rows (one granule per collecting thread) times 1..4, aiming at <= 8 runs
 void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto) {
   const int P = A.dtype ? 2 : 4;
-  const int blk = resident_block(), cap = resident_cap(blk);
+  const int blk = resident_block(), cap = std::max(1, resident_cap_device());
   *grid = reduce_grid(A.n, P, max_blocks < cap ? max_blocks : cap, blk);
   *nacc = kind == KIND_P2P ? 17 : 29;
   const int rgn = blk / *nacc;

@@ -264,7 +264,12 @@ struct Finish {
   unsigned long long p2p_step;
   int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
   int rows;                    // > 0: collecting workgroups + host-side final sum (collect_and_send / the resident kernel): cap on the run length
+  unsigned long long pose_wait_ticks;   // resident kernels: how long a workgroup waits for the host's next pose (100 MHz ticks) before it gives up
+  unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
 };
+// what a collecting workgroup sends to the host in place of its run's sums when a granule of the run never arrived: a quiet NaN with a
+// payload no arithmetic produces; the host then releases the grid and finishes the refinement with one launch per iteration
+constexpr unsigned long long kLostMarker = 0x7ff8dead00c0ffeeull;
 
 // ---- all-reduce(sum) of the 32-double record across <= 8 GPUs, by the first wave of the LAST workgroup, without leaving the
 // kernel: lane l owns half l of the record (two 32-bit halves per double); it stores {half, tag} as ONE 8-byte word into slot
@@ -805,6 +810,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.rows = rt.rows > 0 ? rt.rows : 0;
+  f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

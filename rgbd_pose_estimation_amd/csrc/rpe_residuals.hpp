@@ -42,16 +42,6 @@ template <class C> __device__ __forceinline__ void add_row(const C (&J)[6], C r,
   }
   s[27] = fma(w * r, r, s[27]);
 }
-template <class C>
-__device__ __forceinline__ void p2plane_point(const PoseK<double>& T, C x, C y, C z, C cx, C cy, C cz, C nx, C ny, C nz, C w, C (&s)[29]) {
-  double pxd, pyd, pzd;
-  transform<C>(T, x, y, z, pxd, pyd, pzd);
-  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
-  const C r = (C)((double)nx * (pxd - (double)cx) + (double)ny * (pyd - (double)cy) + (double)nz * (pzd - (double)cz));
-  const C J[6] = {nx, ny, nz, py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx};  // [n ; p x n]
-  add_row(J, r, w, s);
-  s[28] += w;
-}
 // Two correspondences at once: the 35 products of a Jacobian row's outer product as 2-vectors (packed fp32 instructions for fp32
 // arrays), each lane of the pair keeping its own partial sums; the pair's sums are added at the end of the group.
 template <class V> __device__ __forceinline__ void add_row2(const V (&J)[6], V r, V w, V (&s)[29]) {
@@ -84,39 +74,112 @@ __device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x
   add_row2<V>(J, R, W, s);
   s[28] += W;
 }
-// 1 / sqrt(x) in fp64 without the ~45-instruction IEEE sqrt + divide sequences: the fp32 hardware estimate (v_rsq_f32, 1e-7)
-// refined by two Newton steps y <- y (3/2 - x/2 y^2), each squaring the error: ~1 ulp of fp64 in ~10 instructions.  x is a
-// squared point norm in metres^2 (fits fp32 comfortably).
-__device__ __forceinline__ double rsqrt64(double x) {
-  double y = (double)rsqrtf((float)x);
-  const double hx = 0.5 * x;
-  y = y * fma(-hx * y, y, 1.5);
-  y = y * fma(-hx * y, y, 1.5);
-  return y;
-}
-
-template <class C>
-__device__ __forceinline__ void bearing_point(const PoseK<double>& T, C x, C y, C z, C bx, C by, C bz, C w, C (&s)[29]) {
-  double pxd, pyd, pzd;
-  transform<C>(T, x, y, z, pxd, pyd, pzd);
-  const double invd = rsqrt64(pxd * pxd + pyd * pyd + pzd * pzd);
-  const double hxd = pxd * invd, hyd = pyd * invd, hzd = pzd * invd;
-  // sine residual p^ x bv: near the optimum p^ ~ bv, so this too is a cancelling difference -> fp64
-  const C r[3] = {(C)(hyd * (double)bz - hzd * (double)by), (C)(hzd * (double)bx - hxd * (double)bz), (C)(hxd * (double)by - hyd * (double)bx)};
-  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd, inv = (C)invd;
-  const C hx = (C)hxd, hy = (C)hyd, hz = (C)hzd;
-  // A = -[bv]x (I - h h^T) * inv ; row u of A = -(e_u^T [bv]x) (I - h h^T) inv
-  const C Bx[3][3] = {{C(0), -bz, by}, {bz, C(0), -bx}, {-by, bx, C(0)}};
-  const C h[3] = {hx, hy, hz};
-#pragma unroll
-  for (int u = 0; u < 3; u++) {
-    const C bh = Bx[u][0] * h[0] + Bx[u][1] * h[1] + Bx[u][2] * h[2];
-    const C a0 = -(Bx[u][0] - bh * h[0]) * inv, a1 = -(Bx[u][1] - bh * h[1]) * inv, a2 = -(Bx[u][2] - bh * h[2]) * inv;
-    // J = a^T [I | -[p]x] : translation part a, rotation part (p x a)
-    const C J[6] = {a0, a1, a2, py * a2 - pz * a1, pz * a0 - px * a2, px * a1 - py * a0};
-    add_row(J, r[u], w, s);
+// ---- K3, bearing (sine) residual  r = p^ x bv  (P3P.hpp:482-485; p^ = p / |p|).
+// Both r = -[bv]x p^ and its Jacobian -[bv]x (I - p^ p^T) / |p| [I | -[p]x] lie in the plane orthogonal to bv, so in an
+// orthonormal basis (e1, e2) of that plane TWO rows carry all of J^T J, J^T r and |r|^2 (the third would be zero):
+//     rho_i = e_i . p^ ,   J_i = a_i^T [I | -[p]x] ,   a_i = (e_i - rho_i p^) / |p| ,   weight  w |bv|^2
+// (with p^ = alpha e1 + beta e2 + gamma bv^:  r = |bv| (beta e1 - alpha e2), i.e. the rows above up to order and sign, which
+// neither J^T J nor J^T r sees) -- 70 accumulation FMAs per correspondence instead of 105, no fp64 cross product and no fp64
+// normalisation.  What stays fp64 is what cancels: p = R x + t and the two dots e_i . p (near the optimum p^ ~ bv is orthogonal
+// to e_i); 1 / |p| only scales rho_i and J_i relatively, so the fp32 hardware rsqrt serves.  The basis is the branch-free
+// construction of Duff et al. ("Building an orthonormal basis, revisited", 2017) from bv itself: it depends on the
+// correspondence only, never on the pose, so its rounding (e_i off the plane by <= 1e-7) acts like a fixed 1e-7 rad bearing
+// offset per correspondence, three orders below the measurement noise.
+// Lane-type helpers: V is a scalar (float, double) or a 2-vector of them (pairs of correspondences: packed fp32 instructions).
+template <class V> struct LaneOps;
+template <> struct LaneOps<float> {
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float sign1(float x) { return x < 0.f ? -1.f : 1.f; }
+};
+template <> struct LaneOps<double> {
+  static __device__ __forceinline__ double rsqrt(double x) {   // fp32 estimate + two Newton steps: ~1 ulp of fp64 without the IEEE sqrt + divide sequences
+    double y = (double)__builtin_amdgcn_rsqf((float)x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
   }
-  s[28] += w;
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double sign1(double x) { return x < 0.0 ? -1.0 : 1.0; }
+};
+template <class C> struct LaneOps<C __attribute__((ext_vector_type(2)))> {
+  typedef C V __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ V rsqrt(V x) { return V{LaneOps<C>::rsqrt(x.x), LaneOps<C>::rsqrt(x.y)}; }
+  static __device__ __forceinline__ V rcp(V x) { return V{LaneOps<C>::rcp(x.x), LaneOps<C>::rcp(x.y)}; }
+  static __device__ __forceinline__ V sign1(V x) { return V{LaneOps<C>::sign1(x.x), LaneOps<C>::sign1(x.y)}; }
+};
+// (e1, e2): orthonormal basis of the plane orthogonal to the unit vector (bx, by, bz)
+template <class V>
+__device__ __forceinline__ void tangent_basis(V bx, V by, V bz, V (&e1)[3], V (&e2)[3]) {
+  const V sg = LaneOps<V>::sign1(bz);
+  const V a = -LaneOps<V>::rcp(sg + bz);
+  const V bxa = bx * a, c = bxa * by;
+  e1[0] = __builtin_elementwise_fma(sg * bx, bxa, V(1)); e1[1] = sg * c; e1[2] = -sg * bx;
+  e2[0] = c; e2[1] = __builtin_elementwise_fma(by * by, a, sg); e2[2] = -by;
+}
+// the two rows of one correspondence (or of a pair) into the packed record.  p: the transformed point rounded to the compute type;
+// d1, d2: e1 . p and e2 . p formed in fp64 by the caller and rounded; w: weight of the rows (0 switches the correspondence off),
+// w_count: what the weight sum s[28] receives (the joint kernel scales w per term, the weight sum stays unscaled).
+template <class V>
+__device__ __forceinline__ void bearing_rows(V px, V py, V pz, const V (&e1)[3], const V (&e2)[3], V d1, V d2, V bx, V by, V bz, V w,
+                                             V w_count, V (&s)[29]) {
+  const V inv = LaneOps<V>::rsqrt(__builtin_elementwise_fma(px, px, __builtin_elementwise_fma(py, py, pz * pz)));
+  const V hx = px * inv, hy = py * inv, hz = pz * inv;
+  const V wb = w * __builtin_elementwise_fma(bx, bx, __builtin_elementwise_fma(by, by, bz * bz));   // |bv|^2 = 1 to rounding
+  const V rho[2] = {d1 * inv, d2 * inv};
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const V (&e)[3] = u == 0 ? e1 : e2;
+    const V a0 = __builtin_elementwise_fma(-rho[u], hx, e[0]) * inv, a1 = __builtin_elementwise_fma(-rho[u], hy, e[1]) * inv,
+            a2 = __builtin_elementwise_fma(-rho[u], hz, e[2]) * inv;
+    // J = a^T [I | -[p]x] : translation part a, rotation part (p x a)
+    const V J[6] = {a0, a1, a2, py * a2 - pz * a1, pz * a0 - px * a2, px * a1 - py * a0};
+    add_row2<V>(J, rho[u], wb, s);
+  }
+  s[28] += w_count;
+}
+// e . p with p in fp64 (the cancelling part of the residual)
+__device__ __forceinline__ double dot_e_p(double ex, double ey, double ez, double px, double py, double pz) {
+  return fma(ex, px, fma(ey, py, ez * pz));
+}
+// one correspondence, scalar lanes (the joint kernel's bearing term)
+template <class C>
+__device__ __forceinline__ void bearing_point(double pxd, double pyd, double pzd, C bx, C by, C bz, C w, C w_count, C (&s)[29]) {
+  C e1[3], e2[3];
+  tangent_basis<C>(bx, by, bz, e1, e2);
+  const C d1 = (C)dot_e_p(e1[0], e1[1], e1[2], pxd, pyd, pzd), d2 = (C)dot_e_p(e2[0], e2[1], e2[2], pxd, pyd, pzd);
+  bearing_rows<C>((C)pxd, (C)pyd, (C)pzd, e1, e2, d1, d2, bx, by, bz, w, w_count, s);
+}
+// |r| = |p^ x bv| of one correspondence (the robust weights' argument), from the same two rows
+template <class C>
+__device__ __forceinline__ C bearing_residual_norm(double pxd, double pyd, double pzd, C bx, C by, C bz) {
+  C e1[3], e2[3];
+  tangent_basis<C>(bx, by, bz, e1, e2);
+  const C d1 = (C)dot_e_p(e1[0], e1[1], e1[2], pxd, pyd, pzd), d2 = (C)dot_e_p(e2[0], e2[1], e2[2], pxd, pyd, pzd);
+  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
+  const C inv = LaneOps<C>::rsqrt(fma(px, px, fma(py, py, pz * pz)));
+  return sqrt((d1 * d1 + d2 * d2) * (bx * bx + by * by + bz * bz)) * inv;
+}
+// a pair of correspondences as 2-vectors
+template <class C>
+__device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&bx)[2], const C (&by)[2],
+                                             const C (&bz)[2], const C (&w)[2], C __attribute__((ext_vector_type(2))) (&s)[29]) {
+  typedef C V __attribute__((ext_vector_type(2)));
+  const V BX = {bx[0], bx[1]}, BY = {by[0], by[1]}, BZ = {bz[0], bz[1]};
+  V e1[3], e2[3];
+  tangent_basis<V>(BX, BY, BZ, e1, e2);
+  C px[2], py[2], pz[2], d1[2], d2[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {   // the fp64 part stays per point: transform and the two (cancelling) dots
+    double pxd, pyd, pzd;
+    transform<C>(T, x[e], y[e], z[e], pxd, pyd, pzd);
+    px[e] = (C)pxd; py[e] = (C)pyd; pz[e] = (C)pzd;
+    d1[e] = (C)dot_e_p(e1[0][e], e1[1][e], e1[2][e], pxd, pyd, pzd);
+    d2[e] = (C)dot_e_p(e2[0][e], e2[1][e], e2[2][e], pxd, pyd, pzd);
+  }
+  bearing_rows<V>(V{px[0], px[1]}, V{py[0], py[1]}, V{pz[0], pz[1]}, e1, e2, V{d1[0], d1[1]}, V{d2[0], d2[1]}, BX, BY, BZ, V{w[0], w[1]},
+                  V{w[0], w[1]}, s);
 }
 
 // The main loop runs over FULL groups only and is branch-free (mask / weight presence are template flags), so the
@@ -156,11 +219,38 @@ __device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const
     for (int k = 0; k < 29; k++) acc[k] += (double)(s2[k].x + s2[k].y);
     return;
   }
+  if constexpr (KIND == KIND_BEARING) {   // pairs too: two rows per correspondence, 70 of the ~100 operations are the accumulation
+    typedef T V __attribute__((ext_vector_type(2)));
+    V s2[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) s2[k] = V{T(0), T(0)};
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+      T x[2], y[2], z[2], bx[2], by[2], bz[2], wi[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int i = 2 * j + e;
+        bx[e] = vb[3 * i]; by[e] = vb[3 * i + 1]; bz[e] = vb[3 * i + 2];
+        T w = WEIGHT ? wv[i] : T(1);
+        if (MASK) w = m[i] == 1 ? w : T(0);
+        w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
+        const bool off = w == T(0);
+        // keeps NaN / inf of skipped columns out of the sums (selects, not branches); p = t + R (0, 0, 1) != 0 keeps 1 / |p| finite
+        x[e] = off ? T(0) : vw[3 * i]; y[e] = off ? T(0) : vw[3 * i + 1]; z[e] = off ? T(1) : vw[3 * i + 2];
+        bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
+        wi[e] = w;
+      }
+      bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
+    }
+#pragma unroll
+    for (int k = 0; k < 29; k++) acc[k] += (double)(s2[k].x + s2[k].y);
+    return;
+  }
   T s[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) s[k] = T(0);
 #pragma unroll
-  for (int i = 0; i < P; i++) {
+  for (int i = 0; i < P; i++) {   // point-to-point: 17 structured sums per correspondence
     T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
     T bx = vb[3 * i], by = vb[3 * i + 1], bz = vb[3 * i + 2];
     T wi = WEIGHT ? wv[i] : T(1);
@@ -168,18 +258,9 @@ __device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const
     wi = (i < npresent && !all_nan(bx, by, bz)) ? wi : T(0);
     const bool off = wi == T(0);
     // keeps NaN / inf of skipped columns out of the sums (selects, not branches)
-    x = off ? T(0) : x; y = off ? T(0) : y; bx = off ? T(0) : bx; by = off ? T(0) : by; bz = off ? T(1) : bz;
-    if (KIND == KIND_P2P) {
-      z = off ? T(0) : z;
-      p2p_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[17]>(s));
-    } else if (KIND == KIND_P2PLANE) {
-      z = off ? T(0) : z;
-      const T nx = off ? T(0) : vc[3 * i], ny = off ? T(0) : vc[3 * i + 1], nz = off ? T(0) : vc[3 * i + 2];
-      p2plane_point<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, reinterpret_cast<T(&)[29]>(s));
-    } else {
-      z = off ? T(1) : z;  // p != 0 so that the normalisation stays finite
-      bearing_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[29]>(s));
-    }
+    x = off ? T(0) : x; y = off ? T(0) : y; z = off ? T(0) : z;
+    bx = off ? T(0) : bx; by = off ? T(0) : by; bz = off ? T(1) : bz;
+    p2p_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[17]>(s));
   }
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] += (double)s[k];
@@ -236,7 +317,7 @@ __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T
 constexpr int kAutoMaxRunSums = 1024;   // run records x sums an autonomous iteration reads per workgroup (resident_auto_stage)
 template <int BLK>
 __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want, double* __restrict__ s_pose,
-                                                  int* __restrict__ s_go) {
+                                                  int* __restrict__ s_go, unsigned long long wait_ticks = 200000000ull) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -245,8 +326,14 @@ __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __re
     for (;;) {
       if (lane < 16) w = __hip_atomic_load(ctl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const unsigned long long ta = __shfl(w, 0, 64), tb = __shfl(w, 15, 64);
-      if (ta == tb && (ta & ~kResidentStop) == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
-      if (wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // the host went away: give up (2 s)
+      if (ta == tb) {
+        const unsigned long long num = ta & ~kResidentStop;
+        if (num == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
+        // Tags only grow within a context, and the host writes tag want + 1 only after it has this workgroup's sums of `want`: a larger
+        // tag can only belong to a LATER call -- this launch was stopped and the stop tag has already been overwritten.  Leave.
+        if (num > want) { go = 2; break; }
+      }
+      if (wall_clock64() - t0 > wait_ticks) { go = 3; break; }   // the host went away: give up
       __builtin_amdgcn_s_sleep(2);
     }
     if (lane >= 1 && lane <= 12) s_pose[lane - 1] = __longlong_as_double((long long)w);
@@ -281,7 +368,8 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
     double own = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
-    if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+    const bool withheld = fin.fault_tag != 0 && tag == fin.fault_tag && blockIdx.x + 1 == gridDim.x;   // test hook: a granule that never comes
+    if ((int)blockIdx.x != leader) { if (!withheld) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag); }
     else g_part[0][threadIdx.x] = own;
   }
 #ifdef RPE_STAMPS
@@ -298,11 +386,12 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(4);
 #endif
-    if (ok && threadIdx.x < NACC) {
+    if (threadIdx.x < NACC) {
       double t = 0.0;
       const int nr = rows < RGN ? rows : RGN;
       for (int k = 0; k < nr; k++) t += g_part[k][threadIdx.x];
-      store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, t, seq);
+      // a run with a missing granule tells the host so (it releases the grid and finishes with one launch per iteration)
+      store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, ok ? t : __longlong_as_double((long long)kLostMarker), seq);
     }
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(5);
@@ -402,10 +491,9 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
   return lost ? 2 : (done ? 1 : 0);
 }
 
-// workgroup size of the resident kernel and the largest grid that is resident at once (one workgroup per CU).  256-thread workgroups
-// (two per CU) were measured and lose here -- 6.95-7.3 vs 6.0-6.7 us per step at 307 200 points, 46 vs 39 us at 10 M -- although
-// they win for the one-launch kernels: twice the workgroups poll the control block and twice the granules cross the hop every iteration
+// workgroup size of the resident kernels.  256-thread workgroups (two per CU) were measured and lose here -- 6.95-7.3 vs 6.0-6.7 us
+// per step at 307 200 points, 46 vs 39 us at 10 M -- although they win for the one-launch kernels: twice the workgroups poll the
+// control block and twice the granules cross the hop every iteration.  The largest grid: resident_cap_device() (rpe_kernels.h).
 static inline int resident_block() { return 512; }
-static inline int resident_cap(int) { return 256; }
 
 }  // namespace rpe
