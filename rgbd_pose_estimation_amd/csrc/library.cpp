@@ -320,6 +320,9 @@ int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const
                    double thre_nl, int* iter_io, double confidence, int ls, int score_mode, double* R9, double* t3, int* max_votes,
                    short* mask_out) {
   if (!poses7 || !first || list_iters < 0) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: bad argument");
+  if (first[0] != 0) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: first[0] must be 0");
+  for (int i = 0; i < list_iters; i++)   // first[i] .. first[i + 1] index the hypothesis array: non-negative and non-decreasing, or the copy below runs wild
+    if (first[i + 1] < first[i]) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: first[] must be non-decreasing");
   rpe::Settings::HypothesisList list;
   list.first.assign(first, first + list_iters + 1);
   list.q7.assign(poses7, poses7 + 7 * (size_t)first[list_iters]);

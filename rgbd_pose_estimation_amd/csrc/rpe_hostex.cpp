@@ -20,6 +20,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <string>
+#include <vector>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -59,6 +60,7 @@ struct rpe_host_exchange {
   double timeout_s = 10.0;
   unsigned long long rec_step = 0, vote_step = 0;
   bool owner = false, unlinked = false;
+  bool broken = false;   // a peer missed a step: this rank's step counters have moved on without it, the handle cannot be used again
 };
 
 extern "C" {
@@ -138,6 +140,7 @@ int rpe_host_exchange_labels_collide(rpe_host_exchange* h) {
 
 int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n) {
   if (!h || !v || n < 1 || n > kMaxF64) return err(RPE_ERR_ARG, "rpe_host_exchange_allreduce_f64: bad argument (1 <= n <= 64)");
+  if (h->broken) return err(RPE_ERR_STATE, "host exchange: an earlier step timed out; close this exchange and open a new one on every rank");
   const unsigned long long step = ++h->rec_step;
   RecSlot* row = h->seg->rec[step & 1];
   RecSlot& mine = row[h->rank];
@@ -156,11 +159,12 @@ int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n) {
         else if (now_s() - t0 > h->timeout_s) {
           char msg[160];
           std::snprintf(msg, sizeof msg, "host exchange: rank %d did not deliver its record of step %llu within %.1f s", r, step, h->timeout_s);
+          h->broken = true;   // the caller's v is untouched (the sums live in a local buffer until every rank has delivered)
           return err(RPE_ERR_STATE, msg);
         }
       }
     }
-    if (s.n != n) return err(RPE_ERR_STATE, "host exchange: ranks disagree on the record length of a step");
+    if (s.n != n) { h->broken = true; return err(RPE_ERR_STATE, "host exchange: ranks disagree on the record length of a step"); }
     for (int i = 0; i < n; i++) sum[i] += s.v[i];
   }
   std::memcpy(v, sum, (size_t)n * sizeof(double));
@@ -169,13 +173,14 @@ int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n) {
 
 int rpe_host_exchange_allreduce_i32(rpe_host_exchange* h, int* v, int n) {
   if (!h || !v || n < 1 || n > kMaxI32) return err(RPE_ERR_ARG, "rpe_host_exchange_allreduce_i32: bad argument (1 <= n <= 8192)");
+  if (h->broken) return err(RPE_ERR_STATE, "host exchange: an earlier step timed out; close this exchange and open a new one on every rank");
   const unsigned long long step = ++h->vote_step;
   VoteSlot* row = h->seg->votes[step & 1];
   VoteSlot& mine = row[h->rank];
   std::memcpy(mine.v, v, (size_t)n * sizeof(int));
   mine.n = n;
   __atomic_store_n(&mine.step, step, __ATOMIC_RELEASE);
-  for (int i = 0; i < n; i++) v[i] = 0;
+  std::vector<int> sum((size_t)n, 0);   // the caller's v changes only once every rank has delivered
   double t0 = 0;
   for (int r = 0; r < h->world; r++) {
     VoteSlot& s = row[r];
@@ -186,13 +191,15 @@ int rpe_host_exchange_allreduce_i32(rpe_host_exchange* h, int* v, int n) {
         else if (now_s() - t0 > h->timeout_s) {
           char msg[160];
           std::snprintf(msg, sizeof msg, "host exchange: rank %d did not deliver its counters of step %llu within %.1f s", r, step, h->timeout_s);
+          h->broken = true;
           return err(RPE_ERR_STATE, msg);
         }
       }
     }
-    if (s.n != n) return err(RPE_ERR_STATE, "host exchange: ranks disagree on the counter count of a step");
-    for (int i = 0; i < n; i++) v[i] += s.v[i];
+    if (s.n != n) { h->broken = true; return err(RPE_ERR_STATE, "host exchange: ranks disagree on the counter count of a step"); }
+    for (int i = 0; i < n; i++) sum[(size_t)i] += s.v[i];
   }
+  std::memcpy(v, sum.data(), (size_t)n * sizeof(int));
   return RPE_OK;
 }
 

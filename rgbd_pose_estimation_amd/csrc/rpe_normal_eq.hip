@@ -74,6 +74,15 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     }
     g = full;
   }
+  // pair kinds: the fp32 pair sums of TWO consecutive groups share one widening into the fp64 accumulators (flush_pairs)
+  constexpr bool PAIRS = KIND != KIND_P2P;
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  V2 carry[PAIRS ? 29 : 1];
+  bool carried = false;
+  if (PAIRS) {
+#pragma unroll
+    for (int k = 0; k < (PAIRS ? 29 : 1); k++) carry[k] = V2{T(0), T(0)};
+  }
   while (g < full) {
     const int64_t gn = g + stride;
     const int64_t gl = gn < full ? gn : g;  // clamp: the last iteration re-reads its own (cached) group instead of branching
@@ -89,13 +98,20 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     unpack3(a0, a1, a2, vw);
     unpack3(b0, b1, b2, vb);
     if (KIND == KIND_P2PLANE) unpack3(c0, c1, c2, vc);
-    normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, P, acc);
+    if constexpr (PAIRS) {
+      pair_group<T, KIND, MASK, WEIGHT>(pose, vw, vb, vc, m, wv, P, reinterpret_cast<V2(&)[29]>(carry));
+      if (carried) flush_pairs<T>(reinterpret_cast<V2(&)[29]>(carry), reinterpret_cast<double(&)[29]>(acc));
+      carried = !carried;
+    } else {
+      normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, P, acc);
+    }
     a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
     if (KIND == KIND_P2PLANE) { c0 = nc0; c1 = nc1; c2 = nc2; }
 #pragma unroll
     for (int i = 0; i < P; i++) { if (MASK) m[i] = nm[i]; if (WEIGHT) wv[i] = nwv[i]; }
     g = gn;
   }
+  if constexpr (PAIRS) { if (carried) flush_pairs<T>(reinterpret_cast<V2(&)[29]>(carry), reinterpret_cast<double(&)[29]>(acc)); }
   if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences
     T vw[3 * P], vb[3 * P], vc[3 * P];
     short m[P];

@@ -182,6 +182,44 @@ __device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x
                   V{w[0], w[1]}, s);
 }
 
+// The two pair kinds (point-to-plane, bearing): one group of P correspondences added into the 2-vector partial sums s2 (NOT widened: the
+// caller decides how many groups share one widening into the fp64 accumulators -- flush_pairs).
+template <class T, int KIND, bool MASK, bool WEIGHT>
+__device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&vw)[3 * Pk<T>::P], const T (&vb)[3 * Pk<T>::P],
+                                           const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P], const T (&wv)[Pk<T>::P], int npresent,
+                                           T __attribute__((ext_vector_type(2))) (&s2)[29]) {
+  constexpr int P = Pk<T>::P;
+  static_assert(KIND == KIND_P2PLANE || KIND == KIND_BEARING, "pair kinds");
+#pragma unroll
+  for (int j = 0; j < P / 2; j++) {
+    T x[2], y[2], z[2], bx[2], by[2], bz[2], nx[2], ny[2], nz[2], wi[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int i = 2 * j + e;
+      bx[e] = vb[3 * i]; by[e] = vb[3 * i + 1]; bz[e] = vb[3 * i + 2];
+      T w = WEIGHT ? wv[i] : T(1);
+      if (MASK) w = m[i] == 1 ? w : T(0);
+      w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
+      const bool off = w == T(0);
+      // keeps NaN / inf of skipped columns out of the sums (selects, not branches); bearing: p = t + R (0, 0, 1) != 0 keeps 1 / |p| finite
+      x[e] = off ? T(0) : vw[3 * i]; y[e] = off ? T(0) : vw[3 * i + 1]; z[e] = off ? (KIND == KIND_BEARING ? T(1) : T(0)) : vw[3 * i + 2];
+      bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
+      if (KIND == KIND_P2PLANE) { nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1]; nz[e] = off ? T(0) : vc[3 * i + 2]; }
+      wi[e] = w;
+    }
+    if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);   // 35 of the ~50 operations per point are the accumulation
+    else bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);                                              // two rows per point: 70 of ~100
+  }
+}
+// widen the pair sums into the fp64 accumulators and clear them.  A widening costs three instructions per sum (add the halves,
+// convert, fp64 add: 87 per call), so the streaming loops let two groups (8 fp32 correspondences) share one.
+template <class T>
+__device__ __forceinline__ void flush_pairs(T __attribute__((ext_vector_type(2))) (&s2)[29], double (&acc)[29]) {
+  typedef T V __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < 29; k++) { acc[k] += (double)(s2[k].x + s2[k].y); s2[k] = V{T(0), T(0)}; }
+}
+
 // The main loop runs over FULL groups only and is branch-free (mask / weight presence are template flags), so the
 // compiler issues all 16-byte loads of an iteration up front behind one wait; the <= P-1 leftover correspondences
 // are handled once, by thread 0 of workgroup 0, through the bounds-checked loaders.
@@ -190,60 +228,13 @@ __device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const
                                                 const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P], const T (&wv)[Pk<T>::P],
                                                 int npresent, double (&acc)[NACC]) {
   constexpr int P = Pk<T>::P;
-  if constexpr (KIND == KIND_P2PLANE) {   // pairs of correspondences (the accumulation is 35 of the ~50 operations per point)
+  if constexpr (KIND == KIND_P2PLANE || KIND == KIND_BEARING) {   // pairs of correspondences as 2-vectors
     typedef T V __attribute__((ext_vector_type(2)));
     V s2[29];
 #pragma unroll
     for (int k = 0; k < 29; k++) s2[k] = V{T(0), T(0)};
-#pragma unroll
-    for (int j = 0; j < P / 2; j++) {
-      T x[2], y[2], z[2], bx[2], by[2], bz[2], nx[2], ny[2], nz[2], wi[2];
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const int i = 2 * j + e;
-        x[e] = vw[3 * i]; y[e] = vw[3 * i + 1]; z[e] = vw[3 * i + 2];
-        bx[e] = vb[3 * i]; by[e] = vb[3 * i + 1]; bz[e] = vb[3 * i + 2];
-        T w = WEIGHT ? wv[i] : T(1);
-        if (MASK) w = m[i] == 1 ? w : T(0);
-        w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
-        const bool off = w == T(0);
-        // keeps NaN / inf of skipped columns out of the sums (selects, not branches)
-        x[e] = off ? T(0) : x[e]; y[e] = off ? T(0) : y[e]; z[e] = off ? T(0) : z[e];
-        bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
-        nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1]; nz[e] = off ? T(0) : vc[3 * i + 2];
-        wi[e] = w;
-      }
-      p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
-    }
-#pragma unroll
-    for (int k = 0; k < 29; k++) acc[k] += (double)(s2[k].x + s2[k].y);
-    return;
-  }
-  if constexpr (KIND == KIND_BEARING) {   // pairs too: two rows per correspondence, 70 of the ~100 operations are the accumulation
-    typedef T V __attribute__((ext_vector_type(2)));
-    V s2[29];
-#pragma unroll
-    for (int k = 0; k < 29; k++) s2[k] = V{T(0), T(0)};
-#pragma unroll
-    for (int j = 0; j < P / 2; j++) {
-      T x[2], y[2], z[2], bx[2], by[2], bz[2], wi[2];
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const int i = 2 * j + e;
-        bx[e] = vb[3 * i]; by[e] = vb[3 * i + 1]; bz[e] = vb[3 * i + 2];
-        T w = WEIGHT ? wv[i] : T(1);
-        if (MASK) w = m[i] == 1 ? w : T(0);
-        w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
-        const bool off = w == T(0);
-        // keeps NaN / inf of skipped columns out of the sums (selects, not branches); p = t + R (0, 0, 1) != 0 keeps 1 / |p| finite
-        x[e] = off ? T(0) : vw[3 * i]; y[e] = off ? T(0) : vw[3 * i + 1]; z[e] = off ? T(1) : vw[3 * i + 2];
-        bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
-        wi[e] = w;
-      }
-      bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
-    }
-#pragma unroll
-    for (int k = 0; k < 29; k++) acc[k] += (double)(s2[k].x + s2[k].y);
+    pair_group<T, KIND, MASK, WEIGHT>(pose, vw, vb, vc, m, wv, npresent, s2);
+    flush_pairs<T>(s2, acc);
     return;
   }
   T s[NACC];

@@ -109,14 +109,43 @@ template <class T> struct Hyp<T, true> {
     const V2 ss = ex * ex + ey * ey + ez * ez;
     a = ss.x < cut; b = ss.y < cut;
   }
+  // The reference's 2D test -- normalise by three IEEE divisions behind a square root, dot, compare (AbsoluteOrientation.hpp:413-418) --
+  // costs five times the 3D test.  Its value cos_ref differs from the exact cosine c* = p.bv / |p| by at most 6.5 u (u = unit
+  // roundoff of Tp: |p|^2 carries 3 roundings, the root and each quotient one more, products and the two sums one each; sum |p^_i bv_i|
+  // <= 1), and a cheap estimate  ct = (p.bv) * rsqrt(|p|^2)  -- same |p|^2, hardware reciprocal square root to 1 ulp (fp64: fp32
+  // estimate + two Newton steps), no division -- differs from c* by at most 7.5 u.  So |ct - cos_ref| <= 14 u: outside a band of 24 u
+  // around the threshold the cheap estimate DECIDES the reference's comparison; inside it (and for |p|^2 outside the normal range,
+  // NaN, infinity) the reference's own operation sequence runs.  The branch is wave-uniform (one ballot): a wave none of whose lanes is
+  // within the band -- almost all of them, the band is 1.4e-6 wide in cosine -- never divides.  Votes stay the reference's, bit for bit
+  // (tests/test_gpu_kernels.py test_score_exact_votes_bit_identical, and the near-threshold case of tests/test_gpu_score_filter.py).
   __device__ __forceinline__ void in23_rot_x2(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b) const {
 #pragma clang fp contract(off)
     V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
     const V2 n2 = px * px + py * py + pz * pz;
+#ifndef RPE_NO_23_FILTER
+    {
+      const V2 dt = px * bx + py * by + pz * bz;
+      const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
+      const T band = T(24) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 24 u
+      const T hi = c + band, lo = c - band;
+      const T tiny = T(1e-30), huge = T(1e30);   // |p|^2 in metres^2; also the range in which the fp32 estimate behind the fp64 form is finite
+      const bool in0 = ct.x > hi, in1 = ct.y > hi;
+      const bool sure0 = (in0 | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge), sure1 = (in1 | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge);
+      if (__builtin_amdgcn_ballot_w64(!(sure0 & sure1)) == 0) { a = in0; b = in1; return; }
+    }
+#endif
     const V2 len = {sqrt(n2.x), sqrt(n2.y)};
     px = px / len; py = py / len; pz = pz / len;
     const V2 d = px * bx + py * by + pz * bz;
     a = d.x > c; b = d.y > c;
+  }
+  static __device__ __forceinline__ float rsqrt_est(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ double rsqrt_est(double x) {
+    double y = (double)__builtin_amdgcn_rsqf((float)x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
   }
   __device__ __forceinline__ void innnx2(V2 nwx, V2 nwy, V2 nwz, V2 ncx, V2 ncy, V2 ncz, T cnl, bool& a, bool& b) const {
 #pragma clang fp contract(off)

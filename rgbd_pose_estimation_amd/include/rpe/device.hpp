@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <cstdint>
 #include <mutex>
 #include <stdexcept>
@@ -27,7 +28,8 @@ template <class Tp> struct DType;
 template <> struct DType<float> { enum { value = RPE_F32 }; };
 template <> struct DType<double> { enum { value = RPE_F64 }; };
 
-// process-wide defaults for the solver templates (the reference's free functions have no room for extra arguments)
+// process-wide defaults for the solver templates (the reference's free functions have no room for extra arguments); the two
+// hypothesis-stream hooks at the end are per thread
 // where a RANSAC / PROSAC run spent its wall time (microseconds), accumulated while Settings::profile is set
 struct EngineProfile { double generate = 0, score = 0, replay = 0, mask = 0, upload = 0, sort = 0; int hypotheses = 0, batches = 0; };
 struct Settings {
@@ -35,7 +37,9 @@ struct Settings {
   bool profile = false;
   EngineProfile prof;
   // RPE_SCORE_EXACT (default): the vote kernels replay the reference's operation sequence in Tp, so consensus sets, adapted Iter and
-  // inlier masks are THE reference's, bit for bit.  RPE_SCORE_FAST (opt-in, RPE_SCORE_FAST=1 in the environment sets the default):
+  // inlier masks are bit-exact to the repository's CPU restatement of the reference, whose one non-trivial third-party algorithm --
+  // Eigen 3.3's JacobiSVD on a 3 x 3 -- is itself a restatement of the published algorithm, unverified against a real Eigen build
+  // (none exists in this image: DESIGN.md section 3, "parity unpinned").  RPE_SCORE_FAST (opt-in, RPE_SCORE_FAST=1 in the environment sets the default):
   // rotation-matrix FMA form, 2.7x the scoring rate; votes can differ for correspondences within rounding of a threshold.
   int score_mode = std::getenv("RPE_SCORE_FAST") && std::getenv("RPE_SCORE_FAST")[0] == '1' ? RPE_SCORE_FAST : RPE_SCORE_EXACT;
   // RANSAC iterations generated + scored per round trip: starts at first_batch and doubles up to max_batch.  The adaptive bound
@@ -52,8 +56,10 @@ struct Settings {
   //   replay  != null: the engines take their hypotheses from *replay instead of sampling (rpe_run_replay); scoring, the
   //                    best-so-far / adaptive-Iter replay and the winner's masks run as usual.
   struct HypothesisList { std::vector<double> q7; std::vector<int> first; };   // first[i] .. first[i+1]: hypotheses of iteration i; 7 doubles each
-  HypothesisList* capture = nullptr;
-  const HypothesisList* replay = nullptr;
+  // Per THREAD (the entry points that set them -- rpe_host_hypotheses, rpe_run_replay -- run the solver on the calling thread): a
+  // solver running concurrently on another thread keeps sampling and scoring its own hypotheses.
+  static inline thread_local HypothesisList* capture = nullptr;
+  static inline thread_local const HypothesisList* replay = nullptr;
   static Settings& get() { static Settings s; return s; }
 };
 
@@ -81,10 +87,31 @@ class ContextPool {
 };
 inline ContextPool& pool() { static ContextPool p; return p; }
 
+// Fingerprint of a host array: length + 32 cache lines sampled at even spacing (first and last among them), hashed word by word.
+// The adapters hold REFERENCES to the caller's matrices and the reference library re-reads them on every call
+// (pose/AOOnlyPoseAdapter.hpp:93-95,147-152); the HBM copy is keyed by the host address, so a caller that refills the same buffer
+// with the next frame must not be served the previous frame's upload.  About a microsecond per array and solver run.  A refill
+// changes (nearly) every line and is always caught; an edit confined to lines that are not sampled is not -- invalidateDevice()
+// remains the explicit way to say "the matrices changed".
+inline unsigned long long host_fingerprint(const void* p, size_t bytes) {
+  unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)bytes;
+  if (!p || bytes == 0) return h;
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  const size_t lines = (bytes + 63) / 64, samples = lines < 32 ? lines : 32;
+  for (size_t k = 0; k < samples; k++) {
+    const size_t line = samples > 1 ? k * (lines - 1) / (samples - 1) : 0;
+    const size_t off = line * 64, len = bytes - off < 64 ? bytes - off : 64;
+    unsigned long long w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::memcpy(w, b + off, len);
+    for (int i = 0; i < 8; i++) { h ^= w[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xFF51AFD7ED558CCDull; }
+  }
+  return h;
+}
+
 class DeviceSet {
  public:
   DeviceSet() : _ctx(nullptr), _device(0), _n(0), _dtype(-1), _borrowed(false) {
-    for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) { _src[i] = nullptr; _fp[i] = 0; _fp_known[i] = false; }
     for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
   }
   ~DeviceSet() { if (_ctx && !_borrowed) pool().release(_ctx, _device); }
@@ -107,7 +134,7 @@ class DeviceSet {
   void adopt(rpe_context* ctx, int device, int64_t n, int dtype, const void* const host[RPE_NUM_ARRAYS]) {
     if (_ctx && !_borrowed) pool().release(_ctx, _device);
     _ctx = ctx; _device = device; _n = n; _dtype = dtype; _borrowed = true;
-    for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = host[i];
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) { _src[i] = host[i]; _fp_known[i] = false; }   // produced on the device: the host side is an address only
     for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
   }
   // make sure array `slot` in HBM is the host array at `host` (3 x n of Tp)
@@ -116,13 +143,18 @@ class DeviceSet {
     if (_n != n || _dtype != (int)DType<Tp>::value) {  // first use of this set (a recycled context still holds its last frame)
       check(rpe_set_problem(ctx(), n, DType<Tp>::value), "rpe_set_problem");
       _n = n; _dtype = DType<Tp>::value;
-      for (int i = 0; i < RPE_NUM_ARRAYS; i++) _src[i] = nullptr;
+      for (int i = 0; i < RPE_NUM_ARRAYS; i++) { _src[i] = nullptr; _fp_known[i] = false; }
       for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
     }
-    if (_src[slot] != (const void*)host) {
+    // same address as the resident copy's source: still the same CONTENT?  (arrays adopted from the device have no host content)
+    const bool check_content = !_borrowed || _fp_known[slot];
+    const unsigned long long fp = check_content ? host_fingerprint(host, (size_t)n * 3 * sizeof(Tp)) : 0;
+    if (_src[slot] != (const void*)host || (check_content && _fp_known[slot] && fp != _fp[slot])) {
       const double t0 = Settings::get().profile ? now_us() : 0;
       check(rpe_upload(ctx(), slot, host), "rpe_upload");
       _src[slot] = host;
+      _fp[slot] = check_content ? fp : host_fingerprint(host, (size_t)n * 3 * sizeof(Tp));
+      _fp_known[slot] = true;
       if (Settings::get().profile) { check(rpe_synchronize(ctx()), "rpe_synchronize"); Settings::get().prof.upload += now_us() - t0; }
     }
   }
@@ -156,6 +188,8 @@ class DeviceSet {
   int64_t _n;
   int _dtype;
   const void* _src[RPE_NUM_ARRAYS];
+  unsigned long long _fp[RPE_NUM_ARRAYS];   // content fingerprint of the host array each resident copy was uploaded from
+  bool _fp_known[RPE_NUM_ARRAYS];
   bool _mask_fresh[3], _weight_fresh[3];
   bool _borrowed;
 };

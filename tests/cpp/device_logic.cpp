@@ -113,6 +113,31 @@ int main() {
     const rpe::Matrix3<T> D = a.getRcw().matrix() * R.matrix().transpose();
     CHECK(D(0, 0) + D(1, 1) + D(2, 2) > 2.99f);          // all points again: close to the true rotation despite 10 % outliers
     (void)R1;
+    // ---- the caller refills the SAME matrices with another frame (the adapters hold references, the reference re-reads them on every
+    // call: AOOnlyPoseAdapter.hpp:93-95): the next solver run must see the new content, not the HBM copy keyed by the old address
+    {
+      rpe::sim_seed(11);
+      const rpe::Point3<T> tA = generate_random_translation_uniform<T>(5.0);
+      const rpe::SO3<T> RA = generate_random_rotation<T>(M_PI / 2, false);
+      rpe::MatrixX<T> QA, PA;
+      simulate_3d_3d_correspondences<T>(RA, tA, N, 0.01f, 0.0f, 0.4f, 8.0f, 585.0f, true, &QA, &PA, nullptr);
+      AOOnlyPoseAdapter<T> b(PA, QA);
+      shinji_ls2<T>(b);
+      const rpe::Matrix3<T> DA = b.getRcw().matrix() * RA.matrix().transpose();
+      CHECK(DA(0, 0) + DA(1, 1) + DA(2, 2) > 2.9999f);
+      rpe::sim_seed(12);
+      const rpe::Point3<T> tB = generate_random_translation_uniform<T>(5.0);
+      const rpe::SO3<T> RB = generate_random_rotation<T>(M_PI / 2, false);
+      rpe::MatrixX<T> QB, PB;
+      simulate_3d_3d_correspondences<T>(RB, tB, N, 0.01f, 0.0f, 0.4f, 8.0f, 585.0f, true, &QB, &PB, nullptr);
+      std::memcpy(QA.data(), QB.data(), sizeof(T) * 3 * N);   // in place: same addresses, new frame
+      std::memcpy(PA.data(), PB.data(), sizeof(T) * 3 * N);
+      shinji_ls2<T>(b);
+      const rpe::Matrix3<T> DB = b.getRcw().matrix() * RB.matrix().transpose();
+      CHECK(DB(0, 0) + DB(1, 1) + DB(2, 2) > 2.9999f);        // the second frame's pose, not the first's
+      const rpe::Point3<T> dt = b.gettw() - tB;
+      CHECK(dt.norm() < 0.01f);
+    }
     std::printf(fails ? "device_logic: %d FAILURES\n" : "device_logic: ok\n", fails);
     return fails ? 1 : 0;
   } catch (const rpe::DeviceError& e) {

@@ -20,6 +20,20 @@ def main():
     try:
         hx = api.HostExchange(name, world, rank, create=(rank == 0), timeout_s=1.0 if mode == "timeout" else 20.0)
         hx.set_label("gpu0" if mode == "collide" else f"gpu{rank}")
+        if mode == "timeout":   # the peer never comes: the call fails after its bounded wait, the caller's buffer is untouched, the handle is spent
+            import ctypes as C
+            import time
+            v = np.arange(1, 9, dtype=np.int32)
+            rc = L.lib().rpe_host_exchange_allreduce_i32(hx._h, v.ctypes.data_as(C.c_void_p), len(v))
+            out["first_rc"], out["untouched"] = rc, bool(np.array_equal(v, np.arange(1, 9)))
+            out["error"] = L.lib().rpe_last_error().decode()
+            t0 = time.perf_counter()
+            d = np.ones(4)
+            rc2 = L.lib().rpe_host_exchange_allreduce_f64(hx._h, d.ctypes.data_as(C.c_void_p), 4)
+            out["second_rc"], out["second_error"], out["second_s"] = rc2, L.lib().rpe_last_error().decode(), time.perf_counter() - t0
+            hx.close()
+            print("RESULT " + json.dumps(out), flush=True)
+            return
         bad = 0
         for s in range(1, steps + 1):
             n = 1 + (s * 7) % 64

@@ -255,3 +255,42 @@ def test_sqrt_cut_is_the_exact_threshold_of_the_rooted_test():
     # degenerate thresholds: nothing passes for thr <= 0 or NaN; every finite s passes for thr = inf
     assert lib.rpe_host_sqrt_cut(L.F32, 0.0) == 0.0 and lib.rpe_host_sqrt_cut(L.F32, -1.0) == 0.0
     assert np.isnan(lib.rpe_host_sqrt_cut(L.F64, float("nan"))) and lib.rpe_host_sqrt_cut(L.F64, float("inf")) == float("inf")
+
+
+def test_run_replay_refuses_a_malformed_index_array():
+    """first[i] .. first[i + 1] index the hypothesis array: a negative or decreasing entry would make the copy run wild; refused before
+    anything else happens (no GPU needed to see it)."""
+    import numpy as np
+    from rgbd_pose_estimation_amd import _lib as L, api
+    xw = np.random.default_rng(0).normal(size=(50, 3)).astype(np.float32)
+    poses = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (4, 1))
+    for first in ([0, 2, 1, 4], [1, 2, 3, 4], [0, -1, 2, 4]):
+        with pytest.raises(L.RpeError) as e:
+            api.run_replay(0, poses, first, xw=xw, xc=xw, thre_3d=0.1, iters=3)
+        assert "first[" in str(e.value), str(e.value)
+
+
+def test_hypothesis_capture_is_per_thread():
+    """rpe_host_hypotheses captures on the calling thread only: two threads capturing different streams at once get their own streams."""
+    import threading
+    import numpy as np
+    from rgbd_pose_estimation_amd import api
+    rng = np.random.default_rng(3)
+    xw = rng.normal(size=(400, 3)).astype(np.float32)
+    xc = (xw + 0.01 * rng.normal(size=xw.shape)).astype(np.float32)
+    want = {seed: api.host_hypotheses(0, xw=xw, xc=xc, iters=40, seed=seed) for seed in (11, 12)}
+    got = {}
+
+    def work(seed):
+        for _ in range(20):
+            q, first = api.host_hypotheses(0, xw=xw, xc=xc, iters=40, seed=seed)
+            if not (np.array_equal(q, want[seed][0]) and np.array_equal(first, want[seed][1])):
+                got[seed] = False
+                return
+        got[seed] = True
+    th = [threading.Thread(target=work, args=(s,)) for s in (11, 12)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == {11: True, 12: True}

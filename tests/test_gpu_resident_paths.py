@@ -28,7 +28,8 @@ def _ctx(env=None):
                 os.environ[k] = v
 
 
-def _pose_close(a, b, rot=1e-9, rel=1e-9):
+def _pose_close(a, b, rot=1e-8, rel=1e-8):
+    """same objective, same iteration count, sums added in a different order (fp32 products): the poses agree to a few 1e-9"""
     assert util.rot_err(a[:9].reshape(3, 3), b[:9].reshape(3, 3)) < rot
     assert util.trans_rel_err(a[9:], b[9:]) < rel
 

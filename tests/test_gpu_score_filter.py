@@ -1,0 +1,59 @@
+"""-m gpu: the exact 2D vote (bearing-cosine test) decides most comparisons from a division-free estimate and runs the reference's own
+operation sequence only within 24 units of roundoff of the threshold.  These cases put correspondences ON the threshold -- cosines
+spread over a few hundred ulps either side of it, plus NaN / zero / huge points -- and require the votes and masks of the oracle, bit
+for bit, for every vote kind with a 2D test, fp32 and fp64."""
+import numpy as np
+import pytest
+
+from rgbd_pose_estimation_amd import _lib as L, api
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _near_threshold_scene(n, dt, seed, cos_thr):
+    """bearings constructed so that normalize(R Xw + t) . bv lands within +-300 ulp of cos_thr for the TRUE pose"""
+    rng = np.random.default_rng(seed)
+    sc = util.scene_full(seed, n, np.float64, n2d=0.0, n3d=0.01, nnl_deg=1.0, outliers=0.0)
+    p = sc.Q @ sc.R.T + sc.t
+    ph = p / np.linalg.norm(p, axis=1, keepdims=True)
+    # a unit vector at angle acos(target) from ph, target = cos_thr + k ulps
+    eps = np.finfo(dt).eps
+    target = np.clip(cos_thr + rng.integers(-300, 301, n) * eps * 0.5, -1.0, 1.0)
+    a = np.cross(ph, rng.standard_normal((n, 3)))
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    ang = np.arccos(target)
+    sc.U = ph * np.cos(ang)[:, None] + a * np.sin(ang)[:, None]
+    # a handful of hostile points: NaN, zero world point at a pose with zero translation, huge coordinates
+    sc.Q[0] = np.nan
+    sc.Q[1] = 1e25
+    sc.U[2] = 0.0
+    return sc.astype(dt)
+
+
+KINDS = [L.VOTE_23, L.VOTE_23_MATRIX, L.VOTE_33_23, L.VOTE_NN_23, L.VOTE_NN_33_23]
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("kind", KINDS)
+def test_votes_on_the_threshold_are_the_oracles(gpu_ctx_factory, oracle, kind, f64):
+    dt = np.float64 if f64 else np.float32
+    n = 20000
+    cos_thr = float(np.cos(np.arctan(8.0 / 585.0)))
+    sc = _near_threshold_scene(n, dt, 77, cos_thr)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    rng = np.random.default_rng(1)
+    q_true = oracle.pose7_from_Rt(sc.R, sc.t, f64)
+    poses = np.tile(q_true, (40, 1))
+    poses[1:, :4] += 1e-7 * rng.standard_normal((39, 4))     # rotations a few ulps apart: the cosines move across the threshold
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    poses[20:, 4:] += 1e-6 * rng.standard_normal((20, 3))
+    poses = np.ascontiguousarray(poses.astype(dt).astype(np.float64))
+    v = ctx.score(kind, poses, 0.05, cos_thr, 0.999, mode=L.SCORE_EXACT)
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    okind = {L.VOTE_23: oracle.V_23, L.VOTE_23_MATRIX: oracle.V_23_MATRIX, L.VOTE_33_23: oracle.V_33_23, L.VOTE_NN_23: oracle.V_NN_23,
+             L.VOTE_NN_33_23: oracle.V_NN_33_23}[kind]
+    vo = oracle.votes(prob, okind, poses, thre_3d=0.05, cos_thr=cos_thr, cos_nl=0.999)
+    assert np.array_equal(v, vo), (v[:8], vo[:8])
+    # the case is what it claims to be: the votes differ between hypotheses a few ulps apart, i.e. points do sit on the threshold
+    assert len(set(v.tolist())) >= 3

@@ -44,6 +44,10 @@ def test_shared_gpu_labels_are_noticed():
 def test_missing_peer_fails_the_call_instead_of_hanging():
     res = run_world(2, 3, "timeout", ranks=[0])   # rank 1 never shows up
     assert "did not deliver" in res[0].get("error", ""), res
+    # the caller's counters are still its own (the sums live in a local buffer until every rank has delivered), and the handle refuses
+    # further use at once instead of running every later step into the same wait
+    assert res[0]["first_rc"] != 0 and res[0]["untouched"]
+    assert res[0]["second_rc"] != 0 and "earlier step timed out" in res[0]["second_error"] and res[0]["second_s"] < 0.5
 
 
 def test_bad_arguments():
