@@ -522,6 +522,16 @@ int rpe_create(rpe_context** out, int device, void* stream) {
       } else { (void)hipGetLastError(); if (p) (void)hipFree(p); }
     } else (void)hipGetLastError();
   }
+  {  // first context on this device: load every kernel unit's code object now, not at the first launch out of each
+    static std::mutex m;
+    static bool loaded[64];
+    std::lock_guard<std::mutex> g(m);
+    if (device < 64 && !loaded[device]) {
+      rpe::preload_normal_eq(); rpe::preload_icp(); rpe::preload_joint(); rpe::preload_score(); rpe::preload_nl();
+      rpe::preload_frontend(); rpe::preload_hypotheses(); rpe::preload_prosac();
+      loaded[device] = true;
+    }
+  }
   *out = c;
   return RPE_OK;
 }

@@ -211,4 +211,9 @@ hipError_t launch_associate(const float* vmap, const float* nmap, const float* b
   return hipGetLastError();
 }
 
+void preload_frontend() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)to_world_kernel) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

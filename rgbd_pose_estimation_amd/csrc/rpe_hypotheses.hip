@@ -358,4 +358,9 @@ hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, un
   return hipGetLastError();
 }
 
+void preload_hypotheses() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)gen_shinji_kernel<float>) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

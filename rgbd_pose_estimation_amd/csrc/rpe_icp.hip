@@ -219,4 +219,9 @@ hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, 
   return hipGetLastError();
 }
 
+void preload_icp() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)icp_fused_kernel<KIND_P2P, 512>) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

@@ -311,4 +311,9 @@ hipError_t launch_normal_eq_joint_resident(const DeviceArrays& A, int terms, int
                  : joint_resident_t<float>(A, terms, flags, scale4, robust4, robust_k4, ctl, first_tag, max_iters, rt, s);
 }
 
+void preload_joint() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)normal_eq_joint_kernel<float, TERM_P2P, 256>) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

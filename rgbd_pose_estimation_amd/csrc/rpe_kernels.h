@@ -77,6 +77,10 @@ constexpr unsigned long long kResidentLostMarker = 0x7ff8dead00c0ffeeull;   // =
 // units, at most 256; 0 = none fits: no resident loops).  Every resident launcher caps its grid with it: a collecting workgroup waits for
 // workgroups of its own launch, so all of them must be on the compute units together.
 int resident_cap_device();
+// Each kernel unit is a code object of its own that the runtime loads on the first launch out of it (a few milliseconds, once per
+// process and device).  rpe_create touches one kernel of every unit so that the first frame does not pay for it in the middle of a run.
+void preload_normal_eq(); void preload_icp(); void preload_joint(); void preload_score(); void preload_nl();
+void preload_frontend(); void preload_hypotheses(); void preload_prosac();
 void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);

@@ -422,4 +422,9 @@ hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const 
   return A.dtype ? nl_round_t<double>(A, params24, rt, s) : nl_round_t<float>(A, params24, rt, s);
 }
 
+void preload_nl() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)publish_votes_kernel) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

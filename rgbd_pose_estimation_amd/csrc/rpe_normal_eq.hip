@@ -14,7 +14,7 @@ __global__ void gn_update_probe_kernel(const double* __restrict__ rec, double* _
   __syncthreads();
   if (threadIdx.x == 0) {
     double step = 0.0;
-    const bool ok = gn_solve_update(s_rec, s_pose, &step);
+    const bool ok = gn_solve_update<0>(s_rec, s_pose, &step);
     step_ok[0] = step; step_ok[1] = ok ? 1.0 : 0.0;
     if (ok) for (int k = 0; k < 12; k++) pose[k] = s_pose[k];
   }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     const bool stamp_it = false;
 #endif
     if (autonomous) {
-      if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose) != 0) return;
+      if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose, stamp_it) != 0) return;
       continue;
     }
     if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, stamp_it)) return;
@@ -346,6 +346,11 @@ hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   return A.dtype ? resident_t<double>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1)
                  : resident_t<float>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
+}
+
+void preload_normal_eq() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)gn_update_probe_kernel) != hipSuccess) (void)hipGetLastError();
 }
 
 }  // namespace rpe

@@ -118,4 +118,9 @@ hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int*
   return hipGetLastError();
 }
 
+void preload_prosac() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)prosac_pick_kernel) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

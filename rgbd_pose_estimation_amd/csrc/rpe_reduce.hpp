@@ -308,109 +308,6 @@ __device__ __forceinline__ double p2p_allreduce32(double val, const Finish& fin,
   return sum;
 }
 
-// ---- device-resident Gauss-Newton: solve H d = -g (LDL^T) and T <- exp(d) T by ONE lane of the last workgroup.
-// Fully unrolled so that every matrix entry is a register (a rolled version over LDS arrays took ~10 us per call: one
-// lane, ~500 dependent LDS round trips); the streaming body's occupancy is unaffected as long as the kernel stays within
-// 256 VGPRs (one 512-thread workgroup per CU = 2 waves per SIMD).  Arithmetic follows rpe/linalg.hpp except for two latency savers
-// (one reciprocal per pivot, one sincos of the half angle): last-bit differences, checked against the golden (1e-13).
-static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ rec /* LDS */, double* __restrict__ pose /* LDS, 12, in/out */,
-                                             double* step_out) {
-  double A[6][6], Lm[6][6], D[6], Dinv[6], y[6], d[6];
-  {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-#pragma unroll
-      for (int j = i; j < 6; j++) { A[i][j] = rec[k]; A[j][i] = rec[k]; k++; }
-    }
-  }
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    double dj = A[j][j];
-#pragma unroll
-    for (int m = 0; m < j; m++) dj -= Lm[j][m] * Lm[j][m] * D[m];
-    ok = ok && (dj > 1e-12 * A[j][j]) && (dj < 1e300);   // relative pivot floor, as rpe/linalg.hpp solve_normal_eq6
-    D[j] = dj;
-    const double inv = 1.0 / dj;   // ONE division per column (the host divides every entry; the results differ in the last bit at most)
-    Dinv[j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < 6; i++) {
-      double sacc = A[i][j];
-#pragma unroll
-      for (int m = 0; m < j; m++) sacc -= Lm[i][m] * Lm[j][m] * D[m];
-      Lm[i][j] = sacc * inv;
-    }
-  }
-  if (!ok) return false;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    double sacc = -rec[21 + i];
-#pragma unroll
-    for (int m = 0; m < i; m++) sacc -= Lm[i][m] * y[m];
-    y[i] = sacc;
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    double sacc = y[i];
-#pragma unroll
-    for (int m = i + 1; m < 6; m++) sacc -= Lm[m][i] * d[m];
-    d[i] = sacc;
-  }
-  double n2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; i++) { ok = ok && (d[i] == d[i]) && (d[i] < 1e300 && d[i] > -1e300); n2 += d[i] * d[i]; }
-  if (!ok) return false;
-  *step_out = sqrt(n2);
-  // exp(d): rotation from the quaternion (cos(th/2), sin(th/2) w / th), V = I + c1 W + c2 W^2  (sophus/se3.hpp:321-342)
-  const double wx = d[3], wy = d[4], wz = d[5];
-  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-  // ONE sincos of the half angle serves the quaternion and, through sin th = 2 s c and 1 - cos th = 2 s^2, the V matrix (a single lane
-  // runs this: four separate fp64 sin / cos calls were a quarter of the solve's time)
-  double imag, real, sh = 0.0, ch = 1.0;
-  if (th < 1e-10) { imag = 0.5 - th2 / 48.0 + th2 * th2 / 3840.0; real = 1.0 - th2 / 8.0 + th2 * th2 / 384.0; }
-  else { sincos(0.5 * th, &sh, &ch); imag = sh / th; real = ch; }
-  double Rd[9], V[9];
-  {
-    const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
-    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
-    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-    Rd[0] = 1 - (tyy + tzz); Rd[1] = txy - twz; Rd[2] = txz + twy;
-    Rd[3] = txy + twz; Rd[4] = 1 - (txx + tzz); Rd[5] = tyz - twx;
-    Rd[6] = txz - twy; Rd[7] = tyz + twx; Rd[8] = 1 - (txx + tyy);
-  }
-  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-  if (th < 1e-10) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) V[k] = Rd[k];
-  } else {
-    const double c1 = (2.0 * sh * sh) / th2, c2 = (th - 2.0 * sh * ch) / (th2 * th);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-#pragma unroll
-      for (int jj = 0; jj < 3; jj++) {
-        const double w2 = W[3 * i] * W[jj] + W[3 * i + 1] * W[3 + jj] + W[3 * i + 2] * W[6 + jj];
-        V[3 * i + jj] = (i == jj ? 1.0 : 0.0) + c1 * W[3 * i + jj] + c2 * w2;
-      }
-    }
-  }
-  double P0[12], Pn[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) P0[k] = pose[k];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const double td = V[3 * i] * d[0] + V[3 * i + 1] * d[1] + V[3 * i + 2] * d[2];
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) Pn[3 * i + jj] = Rd[3 * i] * P0[jj] + Rd[3 * i + 1] * P0[3 + jj] + Rd[3 * i + 2] * P0[6 + jj];
-    Pn[9 + i] = Rd[3 * i] * P0[9] + Rd[3 * i + 1] * P0[10] + Rd[3 * i + 2] * P0[11] + td;
-  }
-#pragma unroll
-  for (int k = 0; k < 12; k++) pose[k] = Pn[k];
-  return true;
-}
-
 // the packed 32-entry record entry `i` from the totals (LDS): MODE 0 = the totals are the record, MODE 1 = the 17 structured
 // point-to-point sums expanded to H upper triangle (21) | g (6) | cost | weight
 template <int MODE> __device__ __forceinline__ double record_entry(const double* __restrict__ tot, int i) {
@@ -430,6 +327,124 @@ template <int MODE> __device__ __forceinline__ double record_entry(const double*
     default: return 0.0;
   }
 }
+// ---- device-resident Gauss-Newton: solve H d = -g and T <- exp(d) T by ONE lane.
+// One lane runs this between two iterations of a loop that otherwise takes ~4 us, so what counts is the length of the DEPENDENT chain,
+// not the operation count (an instruction of one lane costs what an instruction of 64 costs, and the next dependent one waits ~8 cycles):
+//  * right-looking elimination of the upper triangle (the Schur complement of an SPD matrix stays symmetric) with the right-hand side as
+//    a seventh column: per pivot one reciprocal, then 5 - k independent factors and their independent updates -- six short steps
+//    instead of the left-looking column recurrences' chains of dependent multiply-subtracts; same pivots, hence the same pivot test as
+//    rpe/linalg.hpp solve_normal_eq6 (d_k > 1e-12 H_kk);
+//  * the reciprocals from v_rcp_f64 + two Newton steps (4 dependent FMAs) instead of the ~12-instruction IEEE division sequence;
+//  * back substitution column-wise (x_i = b_i / d_i, then every remaining b_r -= U_ri x_i independently);
+//  * exp(d) without any division, square root or sincos for |w| < 0.5 rad (every Gauss-Newton step in practice): sin(h)/h, cos(h) of the
+//    half angle and (theta - sin theta)/theta^3 are even power series in the angle, evaluated by Horner in w.w; larger steps take the
+//    closed forms.
+// Fully unrolled so that every matrix entry is a register.  Results agree with the host's LDL^T + rpe::se3_exp to rounding (checked
+// against the golden to 1e-13: tests/test_gpu_joint.py, rpe_debug_device_gn_update).
+static __device__ __forceinline__ double rcp_newton(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+// MODE: how `tot` (LDS) holds the normal equations -- 0 = the packed record itself, 1 = the 17 structured point-to-point sums (expanded
+// here, in registers: record_entry with compile-time indices costs a few adds, a separate expansion pass costs two barriers).
+template <int MODE>
+static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ tot /* LDS */, double* __restrict__ pose /* LDS, 12, in/out */,
+                                                    double* step_out) {
+  double U[6][6], b[6], inv[6], d[6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = i; j < 6; j++) { U[i][j] = record_entry<MODE>(tot, k); k++; }
+      b[i] = -record_entry<MODE>(tot, 21 + i);
+    }
+  }
+  double diag0[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) diag0[i] = U[i][i];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double piv = U[k][k];
+    ok = ok && (piv > 1e-12 * diag0[k]) && (piv < 1e300);   // relative pivot floor, as rpe/linalg.hpp solve_normal_eq6
+    inv[k] = rcp_newton(piv);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double f = U[k][i] * inv[k];   // = L_ik (symmetry of the Schur complement)
+#pragma unroll
+      for (int j = i; j < 6; j++) U[i][j] = fma(-f, U[k][j], U[i][j]);
+      b[i] = fma(-f, b[k], b[i]);
+    }
+  }
+  if (!ok) return false;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    d[i] = b[i] * inv[i];
+#pragma unroll
+    for (int r = 0; r < i; r++) b[r] = fma(-U[r][i], d[i], b[r]);
+  }
+  double n2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { ok = ok && (d[i] == d[i]) && (d[i] < 1e300 && d[i] > -1e300); n2 += d[i] * d[i]; }
+  if (!ok) return false;
+  *step_out = sqrt(n2);
+  // exp(d): rotation from the quaternion (cos(th/2), sin(th/2) w / th), V = I + c1 W + c2 W^2  (sophus/se3.hpp:321-342)
+  const double wx = d[3], wy = d[4], wz = d[5];
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  double imag, real, c1, c2;   // sin(th/2)/th, cos(th/2), (1 - cos th)/th^2, (th - sin th)/th^3
+  if (th2 < 0.25) {
+    const double x = 0.25 * th2;   // (th/2)^2 <= 1/16: the series below are at rounding level after 8 terms
+    double S = -1.0 / 1307674368000.0, Cc = 1.0 / 87178291200.0, K = -1.0 / 355687428096000.0;
+    S = fma(S, x, 1.0 / 6227020800.0); S = fma(S, x, -1.0 / 39916800.0); S = fma(S, x, 1.0 / 362880.0); S = fma(S, x, -1.0 / 5040.0);
+    S = fma(S, x, 1.0 / 120.0); S = fma(S, x, -1.0 / 6.0); S = fma(S, x, 1.0);                                   // sin(h)/h
+    Cc = fma(Cc, x, -1.0 / 479001600.0); Cc = fma(Cc, x, 1.0 / 3628800.0); Cc = fma(Cc, x, -1.0 / 40320.0); Cc = fma(Cc, x, 1.0 / 720.0);
+    Cc = fma(Cc, x, -1.0 / 24.0); Cc = fma(Cc, x, 0.5); Cc = fma(Cc, -x, 1.0);                                  // cos(h)
+    K = fma(K, th2, 1.0 / 1307674368000.0); K = fma(K, th2, -1.0 / 6227020800.0); K = fma(K, th2, 1.0 / 39916800.0);
+    K = fma(K, th2, -1.0 / 362880.0); K = fma(K, th2, 1.0 / 5040.0); K = fma(K, th2, -1.0 / 120.0); K = fma(K, th2, 1.0 / 6.0);   // (th - sin th)/th^3
+    imag = 0.5 * S; real = Cc; c1 = 0.5 * S * S; c2 = K;
+  } else {
+    const double th = sqrt(th2);
+    double sh, ch;
+    sincos(0.5 * th, &sh, &ch);
+    imag = sh / th; real = ch;
+    c1 = (2.0 * sh * sh) / th2; c2 = (th - 2.0 * sh * ch) / (th2 * th);
+  }
+  double Rd[9], V[9];
+  {
+    const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    Rd[0] = 1 - (tyy + tzz); Rd[1] = txy - twz; Rd[2] = txz + twy;
+    Rd[3] = txy + twz; Rd[4] = 1 - (txx + tzz); Rd[5] = tyz - twx;
+    Rd[6] = txz - twy; Rd[7] = tyz + twx; Rd[8] = 1 - (txx + tyy);
+  }
+  {
+    // V = I + c1 W + c2 W^2,  W^2 = w w^T - |w|^2 I
+    const double dxx = c2 * wx * wx, dyy = c2 * wy * wy, dzz = c2 * wz * wz, dxy = c2 * wx * wy, dxz = c2 * wx * wz, dyz = c2 * wy * wz;
+    const double diag = 1.0 - c2 * th2;
+    V[0] = diag + dxx; V[1] = fma(-c1, wz, dxy); V[2] = fma(c1, wy, dxz);
+    V[3] = fma(c1, wz, dxy); V[4] = diag + dyy; V[5] = fma(-c1, wx, dyz);
+    V[6] = fma(-c1, wy, dxz); V[7] = fma(c1, wx, dyz); V[8] = diag + dzz;
+  }
+  double P0[12], Pn[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) P0[k] = pose[k];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double td = V[3 * i] * d[0] + V[3 * i + 1] * d[1] + V[3 * i + 2] * d[2];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) Pn[3 * i + jj] = Rd[3 * i] * P0[jj] + Rd[3 * i + 1] * P0[3 + jj] + Rd[3 * i + 2] * P0[6 + jj];
+    Pn[9 + i] = Rd[3 * i] * P0[9] + Rd[3 * i + 1] * P0[10] + Rd[3 * i + 2] * P0[11] + td;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) pose[k] = Pn[k];
+  return true;
+}
+
 // one value to the host WITH the sequence number in ONE 16-byte SYSTEM-scope store (sc0 sc1: straight out over PCIe); the host waits
 // until every pair carries the sequence value, so no ordering between the stores, no drain and no separate flag are needed.
 // (A plain or nt 16-byte store to this memory was observed never to reach the host while the kernel stays resident.  There is no
@@ -732,7 +747,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
       GnState* st = fin.gn;
       double step = 0.0;
       const bool delivered = !(LD == 32 && fin.p2p != nullptr && gn_rec[LD - 1] != 0.0);   // sharded loop: did every peer's record arrive?
-      const bool ok = delivered && gn_solve_update(gn_rec, gn_pose_s, &step);
+      const bool ok = delivered && gn_solve_update<0>(gn_rec, gn_pose_s, &step);
       const int iters = st->iters + 1;
       const int done = (!ok) || step < st->tol || iters >= st->max_iters;
       st->iters = iters; st->step = step; st->cost = gn_rec[27]; st->status = ok ? 0 : (delivered ? 1 : 2); st->done = done;

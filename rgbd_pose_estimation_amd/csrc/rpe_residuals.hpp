@@ -405,14 +405,14 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 // step | cost | iterations | status | weight sum to the host), 2 = a granule never arrived (2 s).
 template <int NACC, int BLK>
 __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it, int max_iters,
-                                                   double tol, double* __restrict__ s_pose) {
+                                                   double tol, double* __restrict__ s_pose, bool stamp_it = false) {
   constexpr int NW = BLK / 64;
   constexpr int RGN = BLK / NACC;
   constexpr int MODE = NACC == 17 ? 1 : 0;
   __shared__ double a_red[NW][NACC];
   __shared__ double a_part[RGN][NACC];
   __shared__ double a_runs[kAutoMaxRunSums];
-  __shared__ double a_tot[32], a_rec[32];
+  __shared__ double a_tot[32];
   __shared__ double a_step;
   __shared__ int a_ok;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -428,6 +428,9 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
     if ((int)blockIdx.x != leader) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
     else a_part[0][threadIdx.x] = own;
   }
+#ifdef RPE_STAMPS
+  if (stamp_it) RPE_STAMP(2);
+#endif
   bool lost = runs * NACC > kAutoMaxRunSums;   // a geometry the launcher never chooses: reported like a lost granule, not overrun
   if (!lost && (int)blockIdx.x == leader) {
     const int rows = min(R, G - leader);
@@ -439,6 +442,9 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
       store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
     }
   }
+#ifdef RPE_STAMPS
+  if (stamp_it) RPE_STAMP(3);
+#endif
   if (!lost) {
     const int total = runs * NACC;
     for (int i = threadIdx.x; i < total; i += BLK) {
@@ -453,29 +459,43 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
     }
   }
   lost = __syncthreads_or(lost);
-  if (!lost && threadIdx.x < 32) {
-    double t = 0.0;
-    if (threadIdx.x < NACC) for (int r = 0; r < runs; r++) t += a_runs[r * NACC + threadIdx.x];
-    a_tot[threadIdx.x] = t;
+#ifdef RPE_STAMPS
+  if (stamp_it) RPE_STAMP(4);
+#endif
+  // Wave 0 alone from here to the new pose (the other waves wait at the barrier below): lane j adds the runs' sums of value j in run
+  // order -- the order the host uses -- the totals cross the wave through LDS (no workgroup barrier inside a wave), and lane 0
+  // expands them in registers, solves and updates.  One workgroup barrier per iteration instead of four.
+  if (threadIdx.x < 64) {
+    if (!lost) {
+      double t = 0.0;
+      if (threadIdx.x < NACC) for (int r = 0; r < runs; r++) t += a_runs[r * NACC + threadIdx.x];
+      if (threadIdx.x < 32) a_tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(5);
+#endif
+    if (threadIdx.x == 0) {
+      double step = 0.0;
+      a_ok = !lost && gn_solve_update<MODE>(a_tot, s_pose, &step) ? 1 : 0;
+      a_step = step;
+    }
   }
   __syncthreads();
-  if (!lost && threadIdx.x < 32) a_rec[threadIdx.x] = record_entry<MODE>(a_tot, threadIdx.x);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double step = 0.0;
-    a_ok = !lost && gn_solve_update(a_rec, s_pose, &step) ? 1 : 0;
-    a_step = step;
-  }
-  __syncthreads();
+#ifdef RPE_STAMPS
+  if (stamp_it) RPE_STAMP(6);
+#endif
   const bool ok = a_ok != 0;
   const bool done = !ok || a_step < tol || it >= max_iters;
   if (done && blockIdx.x == 0 && threadIdx.x == 0 && fin.out_host) {
     for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, s_pose[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fin.out_host + 12, a_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 13, lost ? 0.0 : a_rec[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 13, lost ? 0.0 : record_entry<MODE>(a_tot, 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fin.out_host + 14, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (lost ? 2.0 : 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : a_rec[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : record_entry<MODE>(a_tot, 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

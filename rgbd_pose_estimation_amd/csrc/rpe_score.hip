@@ -505,4 +505,9 @@ hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double*
   return hipGetLastError();
 }
 
+void preload_score() {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, (const void*)mask_kernel<float, VOTE_33, true>) != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace rpe

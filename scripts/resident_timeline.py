@@ -41,8 +41,44 @@ def worker(n, kind):
     ctx.close()
 
 
+def worker_auto(n, kind):
+    """the AUTONOMOUS loop (rpe_gn_refine_device, one launch): stamps 0 iteration starts | 1 slice done | 2 granules stored | 3 run collected and
+    run record stored (collecting workgroups) | 4 every run record read | 5 record expanded | 6 solve + update done"""
+    import numpy as np
+    from rgbd_pose_estimation_amd import _lib as L, api
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from tail_timeline import scene
+    lib = L.lib()
+    lib.rpe_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+    R, t, arrs = scene(n)
+    ctx = api.Context(0).load(L.F32, **arrs)
+    p = api.pose12(R, t)
+    ctx.gn_refine_device([(kind, 1.0)], p, 0, 300, 0.0)
+    buf = np.zeros(4096 * 16, np.uint64)
+    lib.rpe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
+    rows = []
+    for _ in range(30):
+        ctx.gn_refine_device([(kind, 1.0)], p, 0, 2000, 0.0)
+        lib.rpe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
+        s = buf.reshape(4096, 16).astype(np.int64)
+        s = s[s[:, 0] > 0]
+        t0 = s[:, 0].min()
+        rel = lambda c: (s[:, c] - t0) * 0.01
+        names = ("iteration_starts", "slice_done", "granules_stored", "collected", "run_records_read", "record_expanded", "solved")
+        row = dict(G=len(s))
+        for c, nm in enumerate(names):
+            row[nm + "_med"] = float(np.median(rel(c))); row[nm + "_last"] = float(rel(c).max())
+        rows.append(row)
+    keys = sorted({k for r in rows for k in r})
+    print(json.dumps(dict(what="autonomous_resident_stamps", n=n, kind=kind, unit="us after the first workgroup began iteration 1000; medians over 30 loops",
+                          **{k: float(np.median([r[k] for r in rows if k in r])) for k in keys})), flush=True)
+    ctx.close()
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker-auto":
+        worker_auto(int(sys.argv[2]), int(sys.argv[3]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--worker":
         worker(int(sys.argv[2]), int(sys.argv[3]))
     else:
         from rgbd_pose_estimation_amd import build as B
@@ -51,3 +87,5 @@ if __name__ == "__main__":
             so = B.build_stamps(1)
         for n, kind in ((307200, 0), (1000000, 1)):
             subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(n), str(kind)], env=dict(os.environ, RPE_LIBRARY=so), check=False)
+        for n, kind in ((307200, 0), (1000, 0)):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--worker-auto", str(n), str(kind)], env=dict(os.environ, RPE_LIBRARY=so), check=False)

@@ -60,7 +60,7 @@ def test_bearing_refine_resident_equals_launch_per_iteration(oracle, n, f64):
         res.close(); per.close()
 
 
-COMBOS = [(L.RES_P2P, L.RES_BEARING), (L.RES_P2PLANE, L.RES_BEARING), (L.RES_P2P, L.RES_BEARING, L.RES_NORMAL), (L.RES_NORMAL,)]
+COMBOS = [(L.RES_P2P, L.RES_BEARING), (L.RES_P2PLANE, L.RES_BEARING), (L.RES_P2P, L.RES_BEARING, L.RES_NORMAL), (L.RES_P2P, L.RES_NORMAL)]
 
 
 @pytest.mark.parametrize("n", [3000, 307200, 1500000])
