@@ -326,7 +326,8 @@ int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, do
  * rpe_run_replay is rpe_run with the hypotheses of iteration i TAKEN from poses7[first[i] .. first[i+1]) instead of being sampled:
  * scoring on the GPU, best-so-far on strict '>', adaptive Iter, winner's masks and the optional least-squares stage as in rpe_run. */
 int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t seed, double* q7_out, int cap, int* first_out);
-int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d, double thre_2d,
+int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d,
+    double thre_2d,
                    double thre_nl, int* iter_io, double confidence, int ls, int score_mode, double* R9, double* t3, int* max_votes,
                    short* mask_out);
 
@@ -370,7 +371,8 @@ int rpe_associate(rpe_context* ctx, const double* pose12, double dist_thr, doubl
  * fused = 1 pairs and accumulates in ONE kernel per round (the pairs never exist in HBM: 48 B/pixel instead of 156); same
  * pairing function and per-pixel arithmetic as the two-kernel path, the sums differ in rounding only.  On return XW XC BV NW NC hold the pairs under the
  * RETURNED pose when fused, under the pose of the last round otherwise. */
-typedef struct { int kind; int max_iter; double tol; double dist_thr; double cos_thr; int use_normals; int device_resident; int fused; } rpe_icp_options;
+typedef struct { int kind; int max_iter; double tol; double dist_thr; double cos_thr; int use_normals; int device_resident; int fused;
+    } rpe_icp_options;
 int rpe_icp(rpe_context* ctx, const rpe_icp_options* opt, double* pose12, int* iters_out, double* last_step, double* final_cost,
             int64_t* matched);
 
@@ -383,7 +385,8 @@ int rpe_host_update_num_iters(int dtype, double p, double ep, int model_points, 
 void rpe_host_sort_indexes(const double* w, int n, int* out);                                     /* Utility.hpp:107-118 */
 int rpe_host_kneip_main(int dtype, const double* xw4, const double* bv4, double* sols12);         /* P3P.hpp:63-232     */
 int rpe_host_kneip(int dtype, const double* xw4, const double* bv4, double* R9, double* t3);      /* P3P.hpp:250-294    */
-void rpe_host_nl_2p(int dtype, const double* v18, double* R9, double* t3);                        /* AbsoluteOrientationNormal.hpp:77-142 */
+void rpe_host_nl_2p(int dtype, const double* v18, double* R9,
+    double* t3);                        /* AbsoluteOrientationNormal.hpp:77-142 */
 void rpe_host_shinji(int dtype, const double* xw, const double* xc, int K, double* R9, double* t3); /* AbsoluteOrientation.hpp:47-99 */
 void rpe_host_se3_exp(const double* a6, double* R9, double* t3);                                  /* sophus/se3.hpp:321-342 */
 void rpe_host_svd3(const double* A9, double* U9, double* s3, double* V9);

@@ -53,7 +53,8 @@ enum { LS_NONE = 0, LS_SHINJI_INLIERS = 1, LS_NL_BUGCOMPAT = 2, LS_NL_FIXED = 3,
        LS_GN_P2PLANE = 7, LS_GN_BEARING = 8 };
 
 template <class Tp>
-int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence, uint64_t seed,
+int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
+    uint64_t seed,
           int ls, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out) {
   const int n = p->n;
   HostMat<Tp> bv{(const Tp*)p->bv, n}, xc{(const Tp*)p->xc, n}, nc{(const Tp*)p->nc, n}, xw{(const Tp*)p->xw, n}, nw{(const Tp*)p->nw, n};
@@ -69,7 +70,8 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
   const bool has_n = p->nc && p->nw, has_bv = p->bv != nullptr, has_xc = p->xc != nullptr;
   const bool aoonly = method == M_SHINJI_RANSAC2 || method == M_SHINJI_PROSAC || (method == M_NONE && !has_bv);
   const bool pnp = method == M_KNEIP_RANSAC || method == M_KNEIP_PROSAC || (method == M_NONE && has_bv && !has_xc);
-  const bool ao = method == M_SHINJI_RANSAC || method == M_SK_RANSAC || method == M_SK_PROSAC || (method == M_NONE && has_bv && has_xc && !has_n);
+  const bool ao = method == M_SHINJI_RANSAC || method == M_SK_RANSAC || method == M_SK_PROSAC || (method == M_NONE && has_bv && has_xc
+      && !has_n);
   if (aoonly) {
     AOOnlyPoseAdapter<Tp> ad(xc, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -85,7 +87,8 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_P2P) Iter = gn_refine_p2p<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    if (mask_out) { const auto& cad = ad; masks_out(nullptr, &cad.inlierMask33(), nullptr); }   // host copies are fetched only when asked for
+    // host copies are fetched only when asked for
+    if (mask_out) { const auto& cad = ad; masks_out(nullptr, &cad.inlierMask33(), nullptr); }
   } else if (pnp) {
     PnPPoseAdapter<Tp> ad(bv, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -131,7 +134,8 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
       read_pose<Tp>(ad, R9, t3);
       ad.setMaxVotes(max_votes ? *max_votes : 1);
       if (mask_in) {
-        rpe::MatrixXs m(n, 3); for (int i = 0; i < n; i++) { m(i, 0) = mask_in[i]; m(i, 1) = mask_in[n + i]; m(i, 2) = mask_in[2 * n + i]; }
+        rpe::MatrixXs m(n, 3); for (int i = 0; i < n; i++) { m(i, 0) = mask_in[i]; m(i, 1) = mask_in[n + i];
+            m(i, 2) = mask_in[2 * n + i]; }
         ad.setInlier(m);
       }
     }
@@ -162,7 +166,8 @@ template <class Tp> void pose_out(const rpe::SE3<Tp>& s, double* R9, double* t3)
 }
 
 void write_rowmajor(AOOnlyPoseAdapter<float>& adapter, float* R_cw_, float* t_) {
-  const rpe::Matrix3<float> R = adapter.getRcw().matrix();  // row-major storage == the reference's Rp = R^T column-major dump (Library.cpp:35-39)
+  // row-major storage == the reference's Rp = R^T column-major dump (Library.cpp:35-39)
+  const rpe::Matrix3<float> R = adapter.getRcw().matrix();
   for (int i = 0; i < 9; i++) R_cw_[i] = R.a[i];
   for (int i = 0; i < 3; i++) t_[i] = adapter.gettw()[i];
 }
@@ -217,8 +222,10 @@ void rpe_host_random_elements(int n, int m, uint64_t seed, int draws, int* out) 
 void rpe_host_prosac_samples(int dtype, int m, int n, uint64_t seed, int draws, int* out) {
   rpe::Rand31 rnd(seed);
   std::vector<int> v;
-  if (dtype == RPE_F64) { ProsacSampler<double> ps(m, n); for (int d = 0; d < draws; d++) { ps.sample(&v, rnd); for (int k = 0; k < m; k++) out[d * m + k] = v[k]; } }
-  else { ProsacSampler<float> ps(m, n); for (int d = 0; d < draws; d++) { ps.sample(&v, rnd); for (int k = 0; k < m; k++) out[d * m + k] = v[k]; } }
+  if (dtype == RPE_F64) { ProsacSampler<double> ps(m, n); for (int d = 0; d < draws; d++) { ps.sample(&v, rnd);
+      for (int k = 0; k < m; k++) out[d * m + k] = v[k]; } }
+  else { ProsacSampler<float> ps(m, n); for (int d = 0; d < draws; d++) { ps.sample(&v, rnd);
+      for (int k = 0; k < m; k++) out[d * m + k] = v[k]; } }
 }
 int rpe_host_update_num_iters(int dtype, double p, double ep, int model_points, int max_iters) {
   return dtype == RPE_F64 ? RANSACUpdateNumIters<double>(p, ep, model_points, max_iters)
@@ -239,14 +246,16 @@ int rpe_host_kneip_main(int dtype, const double* xw4, const double* bv4, double*
   return cnt;
 }
 int rpe_host_kneip(int dtype, const double* xw4, const double* bv4, double* R9, double* t3) {
-  if (dtype == RPE_F64) { rpe::SE3<double> s; if (!kneip<double>(mat_from<double>(xw4, 4), mat_from<double>(bv4, 4), &s)) return 0; pose_out(s, R9, t3); return 1; }
+  if (dtype == RPE_F64) { rpe::SE3<double> s; if (!kneip<double>(mat_from<double>(xw4, 4), mat_from<double>(bv4, 4), &s)) return 0;
+      pose_out(s, R9, t3); return 1; }
   rpe::SE3<float> s; if (!kneip<float>(mat_from<float>(xw4, 4), mat_from<float>(bv4, 4), &s)) return 0; pose_out(s, R9, t3); return 1;
 }
 // v18: pt1_c nl1_c pt2_c pt1_w nl1_w pt2_w
 void rpe_host_nl_2p(int dtype, const double* v18, double* R9, double* t3) {
   if (dtype == RPE_F64) { rpe::Point3<double> a[6]; for (int i = 0; i < 6; i++) a[i] = rpe::Point3<double>(v18 + 3 * i);
     rpe::SE3<double> s; nl_2p<double>(a[0], a[1], a[2], a[3], a[4], a[5], &s); pose_out(s, R9, t3); }
-  else { rpe::Point3<float> a[6]; for (int i = 0; i < 6; i++) a[i] = rpe::Point3<float>((float)v18[3 * i], (float)v18[3 * i + 1], (float)v18[3 * i + 2]);
+  else { rpe::Point3<float> a[6]; for (int i = 0; i < 6; i++) a[i] = rpe::Point3<float>((float)v18[3 * i], (float)v18[3 * i + 1],
+      (float)v18[3 * i + 2]);
     rpe::SE3<float> s; nl_2p<float>(a[0], a[1], a[2], a[3], a[4], a[5], &s); pose_out(s, R9, t3); }
 }
 // shinji() on K host columns (3 x K column-major doubles)
@@ -276,15 +285,18 @@ void rpe_host_calc_err(const double* Rgt9, const double* tgt3, const double* Rse
   pct2[0] = p[0]; pct2[1] = p[1];
 }
 
-int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence, uint64_t seed,
+int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
+    uint64_t seed,
             int ls, int score_mode, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out) {
   if (!p || !R9 || !t3 || p->n <= 0 || !p->xw) return rpe::set_error(RPE_ERR_ARG, "rpe_run: bad argument");
   const int saved = rpe::Settings::get().score_mode;
   rpe::Settings::get().score_mode = score_mode;
   int rc;
   try {
-    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, mask_in, R9, t3, max_votes, mask_out)
-                             : run_t<float>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, mask_in, R9, t3, max_votes, mask_out);
+    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, mask_in, R9, t3,
+        max_votes, mask_out)
+                             : run_t<float>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, mask_in, R9, t3,
+                                 max_votes, mask_out);
   } catch (const rpe::DeviceError& e) {
     rc = rpe::set_error(e.code, e.what());
   } catch (const std::exception& e) {
@@ -297,7 +309,8 @@ int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, do
 
 // ---- explicit hypothesis streams (rpe::Settings::capture / replay, rpe/device.hpp)
 int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t seed, double* q7_out, int cap, int* first_out) {
-  if (!p || p->n <= 0 || !p->xw || iters < 0 || !q7_out || !first_out || method < 0 || method > 9) return rpe::set_error(RPE_ERR_ARG, "rpe_host_hypotheses: bad argument");
+  if (!p || p->n <= 0 || !p->xw || iters < 0 || !q7_out || !first_out || method < 0 || method > 9) return rpe::set_error(RPE_ERR_ARG,
+      "rpe_host_hypotheses: bad argument");
   rpe::Settings::HypothesisList list;
   rpe::Settings::get().capture = &list;
   int it = iters, mv = 0, rc = RPE_OK;
@@ -310,24 +323,28 @@ int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t se
   if (rc != RPE_OK) return rc;
   if (list.first.empty()) list.first.assign((size_t)iters + 1, 0);
   const int H = (int)(list.q7.size() / 7);
-  if (H > cap || (int)list.first.size() != iters + 1) return rpe::set_error(RPE_ERR_ARG, "rpe_host_hypotheses: output capacity too small");
+  if (H > cap || (int)list.first.size() != iters + 1) return rpe::set_error(RPE_ERR_ARG,
+      "rpe_host_hypotheses: output capacity too small");
   if (!list.q7.empty()) std::memcpy(q7_out, list.q7.data(), sizeof(double) * list.q7.size());
   std::memcpy(first_out, list.first.data(), sizeof(int) * list.first.size());
   return H;
 }
 
-int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d, double thre_2d,
+int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d,
+    double thre_2d,
                    double thre_nl, int* iter_io, double confidence, int ls, int score_mode, double* R9, double* t3, int* max_votes,
                    short* mask_out) {
   if (!poses7 || !first || list_iters < 0) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: bad argument");
   if (first[0] != 0) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: first[0] must be 0");
-  for (int i = 0; i < list_iters; i++)   // first[i] .. first[i + 1] index the hypothesis array: non-negative and non-decreasing, or the copy below runs wild
+  // first[i] .. first[i + 1] index the hypothesis array: non-negative and non-decreasing, or the copy below runs wild
+  for (int i = 0; i < list_iters; i++)
     if (first[i + 1] < first[i]) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: first[] must be non-decreasing");
   rpe::Settings::HypothesisList list;
   list.first.assign(first, first + list_iters + 1);
   list.q7.assign(poses7, poses7 + 7 * (size_t)first[list_iters]);
   rpe::Settings::get().replay = &list;
-  const int rc = rpe_run(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, 1, ls, score_mode, nullptr, R9, t3, max_votes, mask_out);
+  const int rc = rpe_run(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, 1, ls, score_mode, nullptr, R9, t3, max_votes,
+      mask_out);
   rpe::Settings::get().replay = nullptr;
   return rc;
 }

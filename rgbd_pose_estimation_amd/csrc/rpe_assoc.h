@@ -31,7 +31,8 @@ __device__ __forceinline__ void rot_to_world(const PoseF& T, float x, float y, f
 
 // Frame vertex (x, y, z) with normal (nx, ny, nz) under the pose guess T (Xc = R Xw + t): move it to the world, project it
 // into the model view (nearest pixel), fetch the model vertex m and normal g there, apply the gates.  m = g = 0 when unpaired.
-__device__ __forceinline__ bool associate_pixel(const PoseF& T, const AssocParams& P, const float* __restrict__ mv, const float* __restrict__ mn,
+__device__ __forceinline__ bool associate_pixel(const PoseF& T, const AssocParams& P, const float* __restrict__ mv,
+    const float* __restrict__ mn,
                                                 float x, float y, float z, float nx, float ny, float nz, float& mx, float& my, float& mz,
                                                 float& gx, float& gy, float& gz) {
 #pragma clang fp contract(off)

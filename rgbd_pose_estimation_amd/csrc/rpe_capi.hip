@@ -59,7 +59,8 @@ Rccl& rccl() {
   static Rccl r;
   if (!r.h) {
     // same soname as the copy PyTorch-ROCm bundles: if torch is in the process its librccl is reused
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break; }
     if (r.h) {
       r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
       r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
@@ -138,12 +139,14 @@ struct rpe_context {
   bool resident = false;
   int resident_lost = 0;          // resident loops that lost a granule / ended early and were finished with one launch per iteration
   int resident_cap = 0;           // workgroups of a resident kernel this device holds at once (rpe::resident_cap_device)
-  double* h_big = nullptr;        // pinned + mapped: tagged 16-byte pairs {value, sequence} -- the run records of collecting launches, added here on the host
+  // pinned + mapped: tagged 16-byte pairs {value, sequence} -- the run records of collecting launches, added here on the host
+  double* h_big = nullptr;
   size_t h_big_pairs = 0;
   bool collecting = false;        // the launch in flight publishes run records into h_big (collect_target)
   rpe_host_exchange* hostex = nullptr;   // host-side all-reduce between the node's rank processes (rpe_hostex_init)
   int hostex_world = 1;
-  bool hostex_shared_gpu = false; // two ranks on one GPU: no resident kernels (they would wait for each other's hosts without both being resident)
+  // two ranks on one GPU: no resident kernels (they would wait for each other's hosts without both being resident)
+  bool hostex_shared_gpu = false;
   // PROSAC order on the device (rpe_prosac_order): scratch
   float* ps_w = nullptr; size_t ps_w_cap = 0;
   unsigned int* ps_hist = nullptr;        // 2048 + 8 uints (histogram | control words)
@@ -254,7 +257,8 @@ int wait_host(rpe_context* c, int ld) {
     if (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) == want) return RPE_OK;
     if ((spins & 0xFFFFF) == 0xFFFFF) {  // every ~1M polls: has the stream died?
       hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s",
+          hipGetErrorString(q));
       if (q == hipSuccess && __atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != want)
         return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu)", want);
     }
@@ -277,7 +281,8 @@ int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int f
       while (__atomic_load_n(rec + 2 * k + 1, __ATOMIC_ACQUIRE) != want) {
         if ((++spins & 0xFFFFF) == 0) {
           hipError_t q = hipStreamQuery(c->stream);
-          if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+          if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s",
+              hipGetErrorString(q));
           if (q == hipSuccess && __atomic_load_n(rec + 2 * k + 1, __ATOMIC_ACQUIRE) != want) {
             (void)fail(RPE_ERR_HIP, "the kernel ended without publishing record %llu (run %d)", want, g);
             return resident ? kResidentLost : RPE_ERR_HIP;
@@ -318,15 +323,18 @@ int wait_collect(rpe_context* c, int ld) {
   for (unsigned long long spins = 1; __atomic_load_n(pairs + 1, __ATOMIC_ACQUIRE) != want; spins++) {
     if ((spins & 0xFFFFF) == 0) {
       hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s",
+          hipGetErrorString(q));
       if (q == hipSuccess && __atomic_load_n(pairs + 1, __ATOMIC_ACQUIRE) != want)
-        return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu; header %llx %llu, first pair %llx %llu)", want,
+        return fail(RPE_ERR_HIP,
+            "kernel finished without publishing its result (sequence %llu; header %llx %llu, first pair %llx %llu)", want,
                     pairs[0], pairs[1], pairs[2], pairs[3]);
     }
   }
   const unsigned long long hdr = __atomic_load_n(pairs, __ATOMIC_RELAXED);
   const int runs = (int)(hdr & 0xFFFF), nacc = (int)((hdr >> 16) & 0xFF), mode = (int)((hdr >> 24) & 0xFF);
-  if (runs < 1 || nacc < 1 || nacc > 64 || nacc > ld || (size_t)(1 + runs * nacc) > c->h_big_pairs) return fail(RPE_ERR_HIP, "malformed result header (%d runs of %d sums)", runs, nacc);
+  if (runs < 1 || nacc < 1 || nacc > 64 || nacc > ld || (size_t)(1 + runs * nacc) > c->h_big_pairs) return fail(RPE_ERR_HIP,
+      "malformed result header (%d runs of %d sums)", runs, nacc);
   double tot[64];
   int rc = wait_host_partials(c, runs, nacc, tot, 1);
   if (rc) return rc;
@@ -341,8 +349,10 @@ int wait_flag(rpe_context* c, unsigned long long* flag, unsigned long long want)
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return RPE_OK;
     if ((spins & 0xFFFFF) == 0xFFFFF) {
       hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s", hipGetErrorString(q));
-      if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu)", want);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s",
+          hipGetErrorString(q));
+      if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(RPE_ERR_HIP,
+          "kernel finished without publishing its result (sequence %llu)", want);
     }
   }
 }
@@ -380,7 +390,8 @@ template <class T> static T sqrt_cut(T thr) {
   return x;
 }
 
-// Host side of a RESIDENT loop (rpe_gn_refine, rpe_icp): ONE launch (`launch(rt, base)`) whose grid stays resident; the host hands every
+// Host side of a RESIDENT loop (rpe_gn_refine, rpe_icp): ONE launch (`launch(rt, base)`) whose grid stays resident; the host hands
+// every
 // pose to it through the control block in device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration),
 // receives the run records of every iteration, adds them, solves the 6x6 system and applies the SE(3) update, as the one-launch-per-
 // iteration loop does.  Pose i carries tag base + i, the records of iteration i carry sequence base + i.
@@ -398,7 +409,8 @@ static std::mutex& resident_mutex(int device) {
 }
 
 template <class Launch>
-static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale, double* pose12, int max_iter,
+static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale,
+    double* pose12, int max_iter,
                        double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what) {
   const unsigned long long base = c->seq;
   auto hand_over = [&](const double* p, unsigned long long tag) {
@@ -412,7 +424,8 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   rt.seq = base;
   // a rank that waits for a slow peer inside the host-side exchange (up to its 10 s) must not lose its own grid meanwhile
   if (c->hostex) rt.pose_wait_ticks = 1200000000ull;
-  if (const char* f = getenv("RPE_TEST_RESIDENT_FAULT")) { const int k = atoi(f); if (k >= 1 && k <= max_iter) rt.fault_tag = base + (unsigned long long)k; }
+  if (const char* f = getenv("RPE_TEST_RESIDENT_FAULT")) { const int k = atoi(f);
+      if (k >= 1 && k <= max_iter) rt.fault_tag = base + (unsigned long long)k; }
   static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
   const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
   const int runs = (grid + rows - 1) / rows;
@@ -436,7 +449,8 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     received++;
     if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
     cost = cost_scale * ne[27]; weight = ne[28];
-    if (!rpe::solve_normal_eq6(ne, d)) { status = fail(RPE_ERR_DEGENERATE, "%s are not positive definite at iteration %d (weight sum %g)", what, it, ne[28]); break; }
+    if (!rpe::solve_normal_eq6(ne, d)) { status = fail(RPE_ERR_DEGENERATE,
+        "%s are not positive definite at iteration %d (weight sum %g)", what, it, ne[28]); break; }
     rpe::se3_left_update(d, pose12);
     step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
     it = received;
@@ -444,7 +458,8 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     hand_over(pose12, base + (unsigned long long)received + 1);
     if (c->loop_prof) { const double t = clock_us(); c->prof_host_us += t - tp; tp = t; }
   }
-  if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);   // the grid is still waiting: release it
+  // the grid is still waiting: release it
+  if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);
   c->seq = base + (unsigned long long)max_iter + 1;   // stays ahead of every tag / sequence value this launch could use
   *it_out = it; *step_out = step; *cost_out = cost; *weight_out = weight;
   if (status == kResidentLost) {
@@ -477,7 +492,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   rpe_context* c = new rpe_context();
   c->device = device;
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-  else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return fail(RPE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
+  else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c;
+      return fail(RPE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
   if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 4096) c->max_blocks = v; }
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
@@ -486,7 +502,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   // granules [workgroup <= 4096][sums <= 44] followed by the autonomous loop's run records [2 parities][<= kAutoMaxRunSums = 1024]
   const size_t partial_doubles = std::max<size_t>((size_t)(4096 + 8) * rpe::kNlLd, (size_t)2 * 4096 * 44 + (size_t)2 * 2 * 1024);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, partial_doubles * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(c->d_partials, 0, partial_doubles * sizeof(double));   // granule tags start below every sequence value
+  // granule tags start below every sequence value
+  if (e == hipSuccess) e = hipMemset(c->d_partials, 0, partial_doubles * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
   c->h_big_pairs = 8192 + 64;
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_big, c->h_big_pairs * 16, hipHostMallocMapped | hipHostMallocCoherent);
@@ -497,12 +514,17 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_pose, 16 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_state, sizeof(rpe::GnState));
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
-  if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);   // staging for pose uploads; also written directly by the hypothesis generator
+  // staging for pose uploads; also written directly by the hypothesis generator
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double),
+      hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_votes, (size_t)rpe::kMaxScoreH * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(c->d_votes, 0, (size_t)rpe::kMaxScoreH * sizeof(int));   // the scoring kernels accumulate into zeroed counters
+  // the scoring kernels accumulate into zeroed counters
+  if (e == hipSuccess) e = hipMemset(c->d_votes, 0, (size_t)rpe::kMaxScoreH * sizeof(int));
   // pinned + device-mapped: the vote read-out kernel stores straight into it; the sequence word sits behind the counters
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
-  if (e == hipSuccess) { std::memset(c->h_votes, 0, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int)); c->h_flag2 = reinterpret_cast<unsigned long long*>(c->h_votes + rpe::kMaxScoreH); }
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_votes, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int),
+      hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) { std::memset(c->h_votes, 0, ((size_t)rpe::kMaxScoreH + 4) * sizeof(int));
+      c->h_flag2 = reinterpret_cast<unsigned long long*>(c->h_votes + rpe::kMaxScoreH); }
   // PROSAC order scratch (rpe_prosac_order): histogram + control words (zero between calls), candidate keys, order + status
   if (e == hipSuccess) e = hipMalloc((void**)&c->ps_hist, (2048 + 8) * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMemset(c->ps_hist, 0, (2048 + 8) * sizeof(unsigned int));
@@ -515,7 +537,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
     if (!(env && env[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
       void* p = nullptr;
       c->resident_cap = rpe::resident_cap_device();   // 0: not even one workgroup of the resident kernels per compute unit
-      if (c->resident_cap >= 1 && hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess &&
+      if (c->resident_cap >= 1 && hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess
+          && hipMemset(p, 0, 4096) == hipSuccess &&
           hipDeviceSynchronize() == hipSuccess) {
         c->ctl = (volatile unsigned long long*)p;
         c->resident = true;
@@ -541,7 +564,8 @@ void rpe_destroy(rpe_context* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < RPE_NUM_ARRAYS; i++) if (c->store[i]) (void)hipFree(c->store[i]);
-  for (int i = 0; i < 3; i++) { if (c->mask_store[i]) (void)hipFree(c->mask_store[i]); if (c->weight_store[i]) (void)hipFree(c->weight_store[i]); }
+  for (int i = 0; i < 3; i++) { if (c->mask_store[i]) (void)hipFree(c->mask_store[i]);
+      if (c->weight_store[i]) (void)hipFree(c->weight_store[i]); }
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -596,7 +620,8 @@ int rpe_upload(rpe_context* c, int slot, const void* host) {
   HIP_TRY(hipSetDevice(c->device));
   const size_t bytes = (size_t)c->n * 3 * elem_size(c->dtype);
   if (!c->store[slot] || c->cap[slot] < bytes) {
-    if (c->store[slot]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->store[slot])); c->store[slot] = nullptr; c->cap[slot] = 0; }
+    if (c->store[slot]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->store[slot])); c->store[slot] = nullptr;
+        c->cap[slot] = 0; }
     HIP_TRY(hipMalloc(&c->store[slot], bytes));
     c->cap[slot] = bytes;
   }
@@ -636,7 +661,8 @@ int rpe_upload_weight(rpe_context* c, int mod, const void* host_weight) {
   if (!host_weight) { c->weight[mod] = nullptr; return RPE_OK; }
   const size_t need = (size_t)c->n * elem_size(c->dtype);
   if (!c->weight_store[mod] || c->weight_cap[mod] < need) {
-    if (c->weight_store[mod]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->weight_store[mod])); c->weight_store[mod] = nullptr; }
+    if (c->weight_store[mod]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->weight_store[mod]));
+        c->weight_store[mod] = nullptr; }
     HIP_TRY(hipMalloc(&c->weight_store[mod], need ? need : 8));
     c->weight_cap[mod] = need;
   }
@@ -694,8 +720,10 @@ static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* p
   if ((rc = check_flags(c, kind, flags))) return rc;
   HIP_TRY(hipSetDevice(c->device));
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
-  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : collect_target(c), c->stream, e0, e1));
+  if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
+      e1 = c->ev1[c->ev_used]; c->ev_used++; }
+  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : collect_target(c), c->stream,
+      e0, e1));
   return RPE_OK;
 }
 
@@ -761,7 +789,8 @@ int rpe_gn_step(rpe_context* c, int kind, int flags, double* pose12, double* ne3
   double ne[32], d[6];
   int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
   if (rc) return rc;
-  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
+  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
+      ne[28]);
   rpe::se3_left_update(d, pose12);
   if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
   if (step_norm) *step_norm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
@@ -790,7 +819,8 @@ static int joint_spec(rpe_context* c, int nterms, const rpe_term* terms, int fla
     int rc = kind_arrays(c, k);
     if (rc) return rc;
     if ((rc = check_flags(c, k, flags))) return rc;
-    if (terms[t].robust < 0 || terms[t].robust > 2 || (terms[t].robust && !(terms[t].robust_k > 0))) return fail(RPE_ERR_ARG, "bad robust setting");
+    if (terms[t].robust < 0 || terms[t].robust > 2 || (terms[t].robust
+        && !(terms[t].robust_k > 0))) return fail(RPE_ERR_ARG, "bad robust setting");
     bits |= 1 << k; scale[k] = terms[t].scale; robust[k] = terms[t].robust; rk[k] = terms[t].robust_k > 0 ? terms[t].robust_k : 1.0;
   }
   if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
@@ -814,7 +844,8 @@ int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
   return RPE_OK;
 }
 
-int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol, int* iters_out,
+int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
+    int* iters_out,
                         double* last_step, double* final_cost) {
   int it = 0;
   double step = 0, cost = 0;
@@ -829,11 +860,13 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
     rpe::resident_geometry(c->arrays(), RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);   // the 29-sum geometry
     double weight = 0;
     auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
-      return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk, (const unsigned long long*)c->ctl, base,
+      return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk,
+          (const unsigned long long*)c->ctl, base,
                                                   max_iter, rt, c->stream);
     };
     { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
-      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations"); }
+      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight,
+          "normal equations"); }
     if (rc != kResidentLost) {
       if (iters_out) *iters_out = it;
       if (rc != RPE_OK) return rc;
@@ -864,9 +897,11 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
 
 // Device-resident Gauss-Newton: the pose and the loop state live in HBM; every iteration is ONE launch whose last workgroup
 // solves the 6x6 system and applies the exp-map update; the host only enqueues the launches and waits for the final record.
-int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol, int* iters_out,
+int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
+    int* iters_out,
                          double* last_step, double* final_cost) {
-  if (!c || !terms || nterms < 1 || nterms > 4 || !pose12 || max_iter < 1) return fail(RPE_ERR_ARG, "rpe_gn_refine_device: bad argument");
+  if (!c || !terms || nterms < 1 || nterms > 4 || !pose12 || max_iter < 1) return fail(RPE_ERR_ARG,
+      "rpe_gn_refine_device: bad argument");
   int bits = 0, robust[4] = {0, 0, 0, 0};
   double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1};
   for (int t = 0; t < nterms; t++) {
@@ -906,7 +941,8 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     c->seq = base + (unsigned long long)max_iter + 1;
     rt.seq = c->seq;                                  // published with the result
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
+        e1 = c->ev1[c->ev_used]; c->ev_used++; }
     std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
     HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0, e1));
     int rc = wait_host(c, rpe::kNeLd);
@@ -916,7 +952,8 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
       if (last_step) *last_step = c->h_out[12];
       if (final_cost) *final_cost = c->h_out[13];
       if (iters_out) *iters_out = (int)c->h_out[14];
-      if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
+      if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d",
+          (int)c->h_out[14] - 1);
       return RPE_OK;
     }
     // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per iteration
@@ -938,8 +975,10 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   if (last_step) *last_step = c->h_out[12];
   if (final_cost) *final_cost = c->h_out[13];
   if (iters_out) *iters_out = (int)c->h_out[14];
-  if (c->h_out[15] == 2.0) return fail(RPE_ERR_HIP, "peer-to-peer exchange timed out at iteration %d (a peer did not deliver its record)", (int)c->h_out[14] - 1);
-  if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d", (int)c->h_out[14] - 1);
+  if (c->h_out[15] == 2.0) return fail(RPE_ERR_HIP,
+      "peer-to-peer exchange timed out at iteration %d (a peer did not deliver its record)", (int)c->h_out[14] - 1);
+  if (c->h_out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d",
+      (int)c->h_out[14] - 1);
   return RPE_OK;
 }
 
@@ -998,12 +1037,14 @@ int rpe_debug_loop_profile(rpe_context* c, int enable, double* wait_us, double* 
   return RPE_OK;
 }
 
-int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter, double tol,
+int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
+    double tol,
                   int* iters_out, double* last_step, double* final_cost) {
   if (!c || nterms < 1 || nterms > 4 || !kinds || !pose12) return fail(RPE_ERR_ARG, "rpe_gn_refine: bad argument");
   if (nterms > 1 || kinds[0] == RPE_RES_NORMAL) {  // several residual kinds: ONE fused pass per iteration
     rpe_term terms[4];
-    for (int t = 0; t < nterms; t++) { terms[t].kind = kinds[t]; terms[t].scale = scales ? scales[t] : 1.0; terms[t].robust = 0; terms[t].robust_k = 1.0; }
+    for (int t = 0; t < nterms; t++) { terms[t].kind = kinds[t]; terms[t].scale = scales ? scales[t] : 1.0; terms[t].robust = 0;
+        terms[t].robust_k = 1.0; }
     return rpe_gn_refine_joint(c, nterms, terms, flags, pose12, max_iter, tol, iters_out, last_step, final_cost);
   }
   int it = 0;
@@ -1025,11 +1066,14 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     double weight = 0;
     auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
-      return rpe::launch_normal_eq_resident(c->arrays(), kind, flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream, e0, e1);
+      if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
+          e1 = c->ev1[c->ev_used]; c->ev_used++; }
+      return rpe::launch_normal_eq_resident(c->arrays(), kind, flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream,
+          e0, e1);
     };
     { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
-      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight, "normal equations"); }
+      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight,
+          "normal equations"); }
     if (rc != kResidentLost) {
       if (iters_out) *iters_out = it;
       if (rc != RPE_OK) return rc;
@@ -1126,7 +1170,8 @@ int rpe_p2p_export(rpe_context* c, void* handle64) {
 }
 
 int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
-  if (!c || !handles || world < 1 || world > rpe::kP2PMaxWorld || rank < 0 || rank >= world) return fail(RPE_ERR_ARG, "rpe_p2p_init: bad argument (1 <= world <= 8)");
+  if (!c || !handles || world < 1 || world > rpe::kP2PMaxWorld || rank < 0 || rank >= world) return fail(RPE_ERR_ARG,
+      "rpe_p2p_init: bad argument (1 <= world <= 8)");
   if (!c->p2p_box) return fail(RPE_ERR_STATE, "rpe_p2p_export first");
   HIP_TRY(hipSetDevice(c->device));
   for (int r = 0; r < rpe::kP2PMaxWorld; r++)   // a second init: drop the mappings of the first
@@ -1175,7 +1220,8 @@ int rpe_p2p_destroy(rpe_context* c) {
   if (!c->p2p_box && !c->d_p2p) return RPE_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int r = 0; r < rpe::kP2PMaxWorld; r++) if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]); c->p2p_peer[r] = nullptr; }
+  for (int r = 0; r < rpe::kP2PMaxWorld; r++) if (c->p2p_peer[r]) { (void)hipIpcCloseMemHandle(c->p2p_peer[r]);
+      c->p2p_peer[r] = nullptr; }
   if (c->d_p2p) { (void)hipFree(c->d_p2p); c->d_p2p = nullptr; }
   if (c->p2p_box) { (void)hipFree(c->p2p_box); c->p2p_box = nullptr; }
   c->p2p_world = 0; c->p2p_world_saved = 0; c->p2p_step = 0;
@@ -1192,7 +1238,8 @@ int rpe_hostex_init(rpe_context* c, int world, int rank, const char* name, int c
   int rc = rpe_host_exchange_open(name, world, rank, create, 10.0, &h);
   if (rc) return rc;
   char bus[64] = {0};
-  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, c->device) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof bus, "device%d", c->device); }
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, c->device) != hipSuccess) { (void)hipGetLastError();
+      std::snprintf(bus, sizeof bus, "device%d", c->device); }
   (void)rpe_host_exchange_set_label(h, bus);
   double probe[1] = {1.0};   // first exchange: every rank is here, and every rank's GPU label is in place
   rc = rpe_host_exchange_allreduce_f64(h, probe, 1);
@@ -1216,7 +1263,8 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
     int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
     if (rc) return rc;
     if ((rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) return rc;
-    if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
+    if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
+        ne[28]);
     rpe::se3_left_update(d, pose12);
     if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
     if (step_norm) *step_norm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
@@ -1232,7 +1280,8 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
     if ((rc = check_flags(c, kind, flags))) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used]; e1 = c->ev1[c->ev_used]; c->ev_used++; }
+    if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
+        e1 = c->ev1[c->ev_used]; c->ev_used++; }
     rpe::ReduceTarget rt = host_target(c);
     rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++;
     HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
@@ -1240,13 +1289,16 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
     if ((rc = normal_eq_launch(c, kind, flags, pose12, c->d_out))) return rc;
     NCCL_TRY(rccl().AllReduce(c->d_out, c->d_out, 32, ncclFloat64, ncclSum, c->comm, c->stream));
     const unsigned long long seq = ++c->seq;
-    HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq, c->stream));
+    HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq,
+        c->stream));
   }
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   double ne[32], d[6];
   for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
-  if (c->p2p_world >= 1 && ne[31] != 0.0) return fail(RPE_ERR_HIP, "peer-to-peer exchange timed out at step %llu (a peer did not deliver its record)", c->p2p_step - 1);
-  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)", ne[28]);
+  if (c->p2p_world >= 1 && ne[31] != 0.0) return fail(RPE_ERR_HIP,
+      "peer-to-peer exchange timed out at step %llu (a peer did not deliver its record)", c->p2p_step - 1);
+  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
+      ne[28]);
   rpe::se3_left_update(d, pose12);
   if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
   if (step_norm) *step_norm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
@@ -1317,7 +1369,8 @@ static int nccl_votes_or_clear(rpe_context* c, ncclResult_t r, int count) {
 // test hook: the value the exact kernels compare the squared 3D residual with (dtype 0: evaluated in float, 1: in double)
 double rpe_host_sqrt_cut(int dtype, double thre_3d) { return dtype == RPE_F64 ? sqrt_cut<double>(thre_3d) : (double)sqrt_cut<float>((float)thre_3d); }
 
-int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
+int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, double thre_3d, double cos_thr, double cos_nl,
+    int* votes_out) {
   int rc = vote_arrays(c, kind);
   if (rc) return rc;
   if (!poses7 || !votes_out || H < 0) return fail(RPE_ERR_ARG, "rpe_score: bad argument");
@@ -1336,20 +1389,26 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
         HIP_TRY(rpe::launch_score_small(c->arrays(), kind, exact, c->h_poses, nullptr, hb, thr, rt, c->stream));
         if ((rc = wait_host(c, rpe::kNeLd))) return rc;
         for (int i = 0; i < hb; i++) votes_out[h0 + i] = (int)c->h_out[i];
-        if (c->hostex && (rc = rpe_host_exchange_allreduce_i32(c->hostex, votes_out + h0, hb))) return rc;   // sharded: the shards' counts meet on the hosts
+        // sharded: the shards' counts meet on the hosts
+        if (c->hostex && (rc = rpe_host_exchange_allreduce_i32(c->hostex, votes_out + h0, hb))) return rc;
         continue;
       }
     }
     HIP_TRY(hipMemcpyAsync(c->d_poses, c->h_poses, per * hb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(rpe::launch_score(c->arrays(), kind, exact, c->d_poses, hb, thr, c->d_votes, c->score_blocks, c->stream));
-    if (!c->hostex && c->comm && c->p2p_world < 1 && (rc = nccl_votes_or_clear(c, rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb, ncclInt32, ncclSum, c->comm, c->stream), hb))) return rc;  // sharded correspondences
+    // sharded correspondences
+    if (!c->hostex && c->comm && c->p2p_world < 1 && (rc = nccl_votes_or_clear(c, rccl().AllReduce(c->d_votes, c->d_votes, (size_t)hb,
+        ncclInt32, ncclSum, c->comm, c->stream), hb))) return rc;
     // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counters into pinned host memory, raises
     // a sequence word the host spins on, and clears the counters for the next launch
     const unsigned long long seq = ++c->vote_seq;
-    if (!c->hostex && c->p2p_world >= 1) {   // sharded correspondences, one node: the read-out kernel also exchanges and sums the counters
-      if ((rc = votes_or_clear(c, rpe::launch_publish_votes_p2p(c->d_votes, hb, c->d_p2p, c->p2p_vote_step++, c->h_votes, c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream), hb))) return rc;
+    // sharded correspondences, one node: the read-out kernel also exchanges and sums the counters
+    if (!c->hostex && c->p2p_world >= 1) {
+      if ((rc = votes_or_clear(c, rpe::launch_publish_votes_p2p(c->d_votes, hb, c->d_p2p, c->p2p_vote_step++, c->h_votes,
+          c->h_votes + rpe::kMaxScoreH + 2, c->h_flag2, seq, c->stream), hb))) return rc;
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
-      if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP, "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
+      if (c->h_votes[rpe::kMaxScoreH + 2] != 0) return fail(RPE_ERR_HIP,
+          "peer-to-peer exchange of the vote counters timed out (a peer did not deliver)");
     } else {
       if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, hb, c->h_votes, c->h_flag2, seq, c->stream), hb))) return rc;
       if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
@@ -1365,13 +1424,15 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
                        double* q7_out, unsigned char* valid_out) {
   int rc = need_arrays(c, {RPE_XW, RPE_XC});
   if (rc) return rc;
-  if (!votes_out || !q7_out || !valid_out || iters < 1 || iters > rpe::kMaxScoreH) return fail(RPE_ERR_ARG, "rpe_ransac33_batch: bad argument (1 <= iters <= %d)", rpe::kMaxScoreH);
+  if (!votes_out || !q7_out || !valid_out || iters < 1 || iters > rpe::kMaxScoreH) return fail(RPE_ERR_ARG,
+      "rpe_ransac33_batch: bad argument (1 <= iters <= %d)", rpe::kMaxScoreH);
   if (c->n < 3) return fail(RPE_ERR_ARG, "rpe_ransac33_batch: fewer than 3 correspondences");
   // The generator samples THIS context's arrays: on a sharded context (rpe_comm_init / rpe_p2p_init) iteration i would be a different
   // pose on every rank and the summed votes would mix unrelated hypotheses.  Sharded RANSAC = host hypotheses (every rank the same
   // list) + rpe_score, which all-reduces the votes of IDENTICAL poses.
   if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1 || c->hostex)
-    return fail(RPE_ERR_STATE, "rpe_ransac33_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
+    return fail(RPE_ERR_STATE,
+        "rpe_ransac33_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
   HIP_TRY(hipSetDevice(c->device));
   const int exact = mode == RPE_SCORE_EXACT;
   double thr[3];
@@ -1385,14 +1446,17 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
   } else {
     HIP_TRY(rpe::launch_score(c->arrays(), RPE_VOTE_33, exact, c->d_poses, iters, thr, c->d_votes, c->score_blocks, c->stream));
     const unsigned long long seq = ++c->vote_seq;
-    if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream), iters))) return rc;
+    if ((rc = votes_or_clear(c, rpe::launch_publish_votes(c->d_votes, iters, c->h_votes, c->h_flag2, seq, c->stream),
+        iters))) return rc;
     if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
     std::memcpy(votes_out, c->h_votes, (size_t)iters * sizeof(int));
   }
   // the generator stored the hypotheses into pinned host memory before the scoring kernel ran (same stream): they are complete
   for (int i = 0; i < iters; i++) {
-    if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }
-    else { const float* h = (const float*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0f; }
+    if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i;
+        for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }
+    else { const float* h = (const float*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k];
+        valid_out[i] = h[7] != 0.0f; }
   }
   return RPE_OK;
 }
@@ -1400,7 +1464,8 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
 // Device-side generation + scoring of one batch of iterations of a plain-RANSAC solver with a 4-point sample, FAST scoring mode
 // (tolerance parity with the host's hypotheses, not bit parity): solver 0 = kneip_ransac, 1 = shinji_kneip_ransac, 2 = nl_kneip_ransac,
 // 3 = nl_shinji_ransac, 4 = nl_shinji_kneip_ransac (slots per iteration: 1, 2, 1, 2, 3)
-int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr, double cos_nl,
+int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr,
+    double cos_nl,
                          int* votes_out, double* q7_out, unsigned char* valid_out) {
   const int per = rpe::gen_p3p_slots(solver);
   if (per == 0) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: solver must be 0 .. 4");
@@ -1412,8 +1477,10 @@ int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_
   if (!votes_out || !q7_out || !valid_out || iters < 1 || (int64_t)iters * per > rpe::kMaxScoreH)
     return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: bad argument (1 <= iters x slots <= %d)", rpe::kMaxScoreH);
   if (c->n < 4) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: fewer than 4 correspondences");
-  if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1 || c->hostex)   // as rpe_ransac33_batch: the generator samples the local shard
-    return fail(RPE_ERR_STATE, "rpe_ransac_p3p_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
+  // as rpe_ransac33_batch: the generator samples the local shard
+  if (c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1 || c->hostex)
+    return fail(RPE_ERR_STATE,
+        "rpe_ransac_p3p_batch samples the local arrays and is not defined on a sharded context; generate hypotheses once and use rpe_score");
   HIP_TRY(hipSetDevice(c->device));
   const int slots = iters * per;
   double thr[3];
@@ -1425,13 +1492,16 @@ int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_
   if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
   std::memcpy(votes_out, c->h_votes, (size_t)slots * sizeof(int));
   for (int i = 0; i < slots; i++) {
-    if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }
-    else { const float* h = (const float*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0f; }
+    if (c->dtype == RPE_F64) { const double* h = (const double*)c->h_poses + 8 * (size_t)i;
+        for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k]; valid_out[i] = h[7] != 0.0; }
+    else { const float* h = (const float*)c->h_poses + 8 * (size_t)i; for (int k = 0; k < 7; k++) q7_out[7 * (size_t)i + k] = h[k];
+        valid_out[i] = h[7] != 0.0f; }
   }
   return RPE_OK;
 }
 
-int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
+int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,
+    int* votes_out) {
   int rc = vote_arrays(c, kind);
   if (rc) return rc;
   if (!pose7) return fail(RPE_ERR_ARG, "null pose");
@@ -1458,7 +1528,8 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
 int rpe_prosac_order(rpe_context* c, const float* weights, int n, int top_k, int* order_out) {
   if (!c || !weights || !order_out || n < 1 || top_k < 1) return fail(RPE_ERR_ARG, "rpe_prosac_order: bad argument");
   if (top_k > n) top_k = n;
-  if (top_k > rpe::kProsacMaxTopK) return fail(RPE_ERR_ARG, "rpe_prosac_order: top_k %d exceeds %d (sort the longer prefix on the host)", top_k, rpe::kProsacMaxTopK);
+  if (top_k > rpe::kProsacMaxTopK) return fail(RPE_ERR_ARG,
+      "rpe_prosac_order: top_k %d exceeds %d (sort the longer prefix on the host)", top_k, rpe::kProsacMaxTopK);
   HIP_TRY(hipSetDevice(c->device));
   if (c->ps_w_cap < (size_t)n) {
     if (c->ps_w) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->ps_w)); c->ps_w = nullptr; c->ps_w_cap = 0; }
@@ -1466,12 +1537,14 @@ int rpe_prosac_order(rpe_context* c, const float* weights, int n, int top_k, int
     c->ps_w_cap = (size_t)n;
   }
   HIP_TRY(hipMemcpyAsync(c->ps_w, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(rpe::launch_prosac_order(c->ps_w, n, top_k, c->ps_hist, c->ps_hist + 2048, c->ps_cand, c->ps_order, c->ps_order + rpe::kProsacMaxTopK, c->stream));
+  HIP_TRY(rpe::launch_prosac_order(c->ps_w, n, top_k, c->ps_hist, c->ps_hist + 2048, c->ps_cand, c->ps_order,
+      c->ps_order + rpe::kProsacMaxTopK, c->stream));
   std::vector<int> host((size_t)rpe::kProsacMaxTopK + 1);
   int rc = copy_to_host(c, host.data(), c->ps_order, host.size() * sizeof(int));
   if (rc) return rc;
   const int status = host[(size_t)rpe::kProsacMaxTopK];
-  if (status != 0) return fail(RPE_ERR_STATE, status == 1 ? "rpe_prosac_order: too many (near-)equal weights around the cut for the device sort; use the host order"
+  if (status != 0) return fail(RPE_ERR_STATE,
+      status == 1 ? "rpe_prosac_order: too many (near-)equal weights around the cut for the device sort; use the host order"
                                                           : "rpe_prosac_order: fewer candidates than top_k");
   std::memcpy(order_out, host.data(), (size_t)top_k * sizeof(int));
   return RPE_OK;
@@ -1483,7 +1556,8 @@ int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const 
   if (rc) return rc;
   // the kernel reads the normal arrays as a PAIR (one without the other would dereference a null pointer on the device)
   if ((c->arr[RPE_NW] != nullptr) != (c->arr[RPE_NC] != nullptr))
-    return fail(RPE_ERR_STATE, "rpe_nl_round: NW (normal_g) and NC (normal_c) must be uploaded together (have %s only)", c->arr[RPE_NW] ? "NW" : "NC");
+    return fail(RPE_ERR_STATE, "rpe_nl_round: NW (normal_g) and NC (normal_c) must be uploaded together (have %s only)",
+        c->arr[RPE_NW] ? "NW" : "NC");
   if (!c_opt3 || !Cw3 || !Cc3 || !Rwc9 || !out44) return fail(RPE_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   // masks default to all ones, exactly as a freshly constructed adapter
@@ -1503,7 +1577,8 @@ int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const 
 // ---------------------------------------------------------------------------------------------- Part 3: front end
 namespace {
 int camera_of(const rpe_camera* cam, rpe::Camera* out) {
-  if (!cam || cam->width < 1 || cam->height < 1 || !(cam->fx > 0) || !(cam->fy > 0) || (int64_t)cam->width * cam->height > (int64_t)1 << 28)
+  if (!cam || cam->width < 1 || cam->height < 1 || !(cam->fx > 0) || !(cam->fy > 0)
+      || (int64_t)cam->width * cam->height > (int64_t)1 << 28)
     return fail(RPE_ERR_ARG, "bad camera (need width, height >= 1 and fx, fy > 0)");
   out->fx = (float)cam->fx; out->fy = (float)cam->fy; out->cx = (float)cam->cx; out->cy = (float)cam->cy;
   out->width = cam->width; out->height = cam->height;
@@ -1531,7 +1606,8 @@ int claim_slots(rpe_context* c, int64_t n) {
   const size_t bytes = (size_t)n * 3 * sizeof(float);
   for (int s = 0; s < RPE_NUM_ARRAYS; s++) {
     if (!c->store[s] || c->cap[s] < bytes) {
-      if (c->store[s]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->store[s])); c->store[s] = nullptr; c->cap[s] = 0; }
+      if (c->store[s]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->store[s])); c->store[s] = nullptr; c->cap[s] = 0;
+          }
       HIP_TRY(hipMalloc(&c->store[s], bytes));
       c->cap[s] = bytes;
     }
@@ -1543,12 +1619,14 @@ int claim_slots(rpe_context* c, int64_t n) {
   for (int s = 0; s < RPE_NUM_ARRAYS; s++) c->arr[s] = c->store[s];
   return RPE_OK;
 }
-int associate_launch(rpe_context* c, const double* pose12, double dist_thr, double cos_thr, int use_normals, bool pose_on_device, bool count) {
+int associate_launch(rpe_context* c, const double* pose12, double dist_thr, double cos_thr, int use_normals, bool pose_on_device,
+    bool count) {
   auto& F = c->fe;
   const int64_t n = (int64_t)F.cam.width * F.cam.height;
   const float d = (float)dist_thr;
   if (count) HIP_TRY(hipMemsetAsync(F.d_count, 0, sizeof(int), c->stream));
-  HIP_TRY(rpe::launch_associate(F.fmap[0], F.fmap[1], F.fmap[2], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(pose12), pose_f(F.mpose), d * d,
+  HIP_TRY(rpe::launch_associate(F.fmap[0], F.fmap[1], F.fmap[2], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(pose12), pose_f(F.mpose),
+      d * d,
                                 (float)cos_thr, use_normals, pose_on_device ? c->d_gn_pose : nullptr,
                                 pose_on_device ? &c->d_gn_state->done : nullptr, (float*)c->arr[RPE_XW], (float*)c->arr[RPE_XC],
                                 (float*)c->arr[RPE_BV], (float*)c->arr[RPE_NW], (float*)c->arr[RPE_NC], count ? F.d_count : nullptr, c->stream));
@@ -1562,9 +1640,11 @@ int associate_ready(rpe_context* c) {
 }
 }  // namespace
 
-int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const rpe_camera* cam, double depth_scale, double dmin, double dmax,
+int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const rpe_camera* cam, double depth_scale, double dmin,
+    double dmax,
                         double max_jump) {
-  if (!c || !depth || (depth_type != RPE_DEPTH_U16 && depth_type != RPE_DEPTH_F32)) return fail(RPE_ERR_ARG, "rpe_frame_set_depth: bad argument");
+  if (!c || !depth || (depth_type != RPE_DEPTH_U16 && depth_type != RPE_DEPTH_F32)) return fail(RPE_ERR_ARG,
+      "rpe_frame_set_depth: bad argument");
   rpe::Camera k;
   int rc = camera_of(cam, &k);
   if (rc) return rc;
@@ -1581,7 +1661,8 @@ int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const
   if ((rc = ensure_maps(c, F.fmap, 3, &F.fcap, n))) return rc;
   F.have_frame = false;
   HIP_TRY(hipMemcpyAsync(F.d_depth, depth, bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(rpe::launch_frame_maps(F.d_depth, depth_type, k, (float)depth_scale, (float)dmin, (float)dmax, (float)max_jump, F.fmap[0], F.fmap[1],
+  HIP_TRY(rpe::launch_frame_maps(F.d_depth, depth_type, k, (float)depth_scale, (float)dmin, (float)dmax, (float)max_jump, F.fmap[0],
+      F.fmap[1],
                                  F.fmap[2], c->stream));
   F.cam = k; F.have_frame = true;
   return RPE_OK;
@@ -1640,7 +1721,8 @@ int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double 
   HIP_TRY(hipSetDevice(c->device));
   if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
   if ((rc = associate_launch(c, pose12, dist_thr, cos_thr, use_normals, false, matched != nullptr))) return rc;
-  if (matched) {   // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counter into pinned host memory and raises a sequence word
+  // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counter into pinned host memory and raises a sequence word
+  if (matched) {
     const unsigned long long seq = ++c->vote_seq;
     HIP_TRY(rpe::launch_publish_i32(c->fe.d_count, 1, c->h_votes, c->h_flag2, seq, c->stream));
     if ((rc = wait_flag(c, c->h_flag2, seq))) return rc;
@@ -1649,7 +1731,8 @@ int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double 
   return RPE_OK;
 }
 
-int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters_out, double* last_step, double* final_cost, int64_t* matched) {
+int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters_out, double* last_step, double* final_cost,
+    int64_t* matched) {
   int rc = associate_ready(c);
   if (rc) return rc;
   if (!o || !pose12 || o->max_iter < 1 || (o->kind != RPE_RES_P2P && o->kind != RPE_RES_P2PLANE) || !(o->dist_thr >= 0))
@@ -1667,7 +1750,8 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
   // one round's kernels, enqueued on the context's stream
   auto round = [&](const double* pose, const rpe::ReduceTarget& rt, bool pose_on_device) -> int {
     if (o->fused) {
-      HIP_TRY(rpe::launch_icp_fused(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr,
+      HIP_TRY(rpe::launch_icp_fused(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate,
+          (float)o->cos_thr,
                                     o->use_normals, o->kind, pose, rt, c->stream));
       return RPE_OK;
     }
@@ -1686,7 +1770,8 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
     std::unique_lock<std::mutex> one_resident_grid(resident_mutex(c->device), std::defer_lock);
     bool one_launch = false;
-    if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world < 1) {
+    if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm
+        && c->p2p_world < 1) {
       // ONE launch: the resident grid pairs, sums, solves and updates by itself (icp_resident_kernel with resident_auto_stage)
       one_launch = true;
       one_resident_grid.lock();   // until the result has arrived (end of this block's scope)
@@ -1696,7 +1781,8 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       rt.rows = grid * nacc <= 1024 ? 1 : rows_auto;
       c->seq = base + (unsigned long long)o->max_iter + 1;
       rt.seq = c->seq;
-      HIP_TRY(rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr, o->use_normals,
+      HIP_TRY(rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate,
+          (float)o->cos_thr, o->use_normals,
                                        o->kind, nullptr, base, o->max_iter, rt, c->stream));
     } else {
       for (int k = 0; k < o->max_iter; k++) if ((rc = round(pose12, rt, true))) return rc;
@@ -1715,19 +1801,23 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     }
     for (int i = 0; i < 12; i++) pose12[i] = c->h_out[i];
     step = c->h_out[12]; cost = c->h_out[13]; it = (int)c->h_out[14]; pairs = c->h_out[16];
-    if (c->h_out[15] == 2.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_HIP, "ICP device loop: a workgroup's sums never arrived at iteration %d", it); }
-    if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d", it - 1); }
+    if (c->h_out[15] == 2.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_HIP,
+        "ICP device loop: a workgroup's sums never arrived at iteration %d", it); }
+    if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE,
+        "ICP: normal equations are not positive definite at iteration %d", it - 1); }
   } else if (o->fused && c->resident && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
     // host-driven ICP in ONE launch: the frame's pixels stay in registers, every iteration the host hands the pose over, the grid pairs
     // its pixels with the model under that pose and sends the run records back (rpe_icp.hip icp_resident_kernel)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
-      return rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate, (float)o->cos_thr, o->use_normals,
+      return rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate,
+          (float)o->cos_thr, o->use_normals,
                                       o->kind, (const unsigned long long*)c->ctl, base, o->max_iter, rt, c->stream);
     };
     { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
-      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs, "ICP: normal equations"); }
+      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs,
+          "ICP: normal equations"); }
     if (rc != RPE_OK && rc != kResidentLost) { if (iters_out) *iters_out = it; return rc; }
     host_rounds = rc == kResidentLost;   // the grid was lost after `it` whole rounds: the rest one launch per round
   } else host_rounds = true;
@@ -1747,7 +1837,8 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       if (step < o->tol) { it++; break; }
     }
   }
-  if (o->fused && (rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, false, false))) return rc;  // leave the pairs in the slots
+  // leave the pairs in the slots
+  if (o->fused && (rc = associate_launch(c, pose12, o->dist_thr, o->cos_thr, o->use_normals, false, false))) return rc;
   if (iters_out) *iters_out = it;
   if (last_step) *last_step = step;
   if (final_cost) *final_cost = cost;

@@ -26,12 +26,14 @@ constexpr int kFeBlock = 256;
 
 __device__ __forceinline__ float qnan() { return __int_as_float(0x7fc00000); }
 
-template <class D> __device__ __forceinline__ float depth_at(const D* __restrict__ d, int idx, float scale) { return (float)d[idx] * scale; }
+template <class D> __device__ __forceinline__ float depth_at(const D* __restrict__ d, int idx,
+    float scale) { return (float)d[idx] * scale; }
 
 struct Vtx { float x, y, z; bool ok; };
 
 template <class D>
-__device__ __forceinline__ Vtx vertex_at(const D* __restrict__ depth, const Camera& cam, int u, int v, float scale, float dmin, float dmax) {
+__device__ __forceinline__ Vtx vertex_at(const D* __restrict__ depth, const Camera& cam, int u, int v, float scale, float dmin,
+    float dmax) {
   Vtx r;
   const float z = depth_at(depth, v * cam.width + u, scale);
   r.ok = z > dmin && z < dmax;  // false for NaN
@@ -62,7 +64,8 @@ __device__ __forceinline__ void load4(const float* __restrict__ in, int64_t g, i
 
 // ---------------------------------------------------------------------------------------------- F1
 template <class D>
-__global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restrict__ depth, Camera cam, float scale, float dmin, float dmax,
+__global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restrict__ depth, Camera cam, float scale, float dmin,
+    float dmax,
                                                               float max_jump, float* __restrict__ vmap, float* __restrict__ nmap,
                                                               float* __restrict__ bmap) {
   const int64_t n = (int64_t)cam.width * cam.height;
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- F2
-__global__ __launch_bounds__(kFeBlock) void to_world_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n, PoseF T,
+__global__ __launch_bounds__(kFeBlock) void to_world_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n,
+    PoseF T,
                                                             float* __restrict__ vw, float* __restrict__ nw) {
   const int64_t g = (int64_t)blockIdx.x * kFeBlock + threadIdx.x;
   if (g * 4 >= n) return;
@@ -180,15 +184,18 @@ int fe_grid(int64_t n) { return (int)((n + 4 * kFeBlock - 1) / (4 * kFeBlock)); 
 
 }  // namespace
 
-hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax, float max_jump,
+hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax,
+    float max_jump,
                              float* vmap, float* nmap, float* bmap, hipStream_t s) {
   const int64_t n = (int64_t)cam.width * cam.height;
   if (n == 0) return hipSuccess;
   if (depth_type == 0)
-    hipLaunchKernelGGL(frame_maps_kernel<unsigned short>, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, (const unsigned short*)d_depth, cam, scale, dmin,
+    hipLaunchKernelGGL(frame_maps_kernel<unsigned short>, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, (const unsigned short*)d_depth, cam,
+        scale, dmin,
                        dmax, max_jump, vmap, nmap, bmap);
   else
-    hipLaunchKernelGGL(frame_maps_kernel<float>, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, (const float*)d_depth, cam, scale, dmin, dmax, max_jump,
+    hipLaunchKernelGGL(frame_maps_kernel<float>, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, (const float*)d_depth, cam, scale, dmin, dmax,
+        max_jump,
                        vmap, nmap, bmap);
   return hipGetLastError();
 }
@@ -206,7 +213,8 @@ hipError_t launch_associate(const float* vmap, const float* nmap, const float* b
   if (n == 0) return hipSuccess;
   AssocParams P;
   P.mcam = mcam; P.M = M; P.dist_sq = dist_sq; P.cos_thr = cos_thr; P.use_normals = use_normals;
-  hipLaunchKernelGGL(associate_kernel, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, vmap, nmap, bmap, n, mv, mn, T, P, pose_dev, done, xw, xc, bv,
+  hipLaunchKernelGGL(associate_kernel, dim3(fe_grid(n)), dim3(kFeBlock), 0, s, vmap, nmap, bmap, n, mv, mn, T, P, pose_dev, done, xw,
+      xc, bv,
                      nw, nc, d_count);
   return hipGetLastError();
 }

@@ -74,7 +74,8 @@ int rpe_host_exchange_open(const char* name, int world, int rank, int create, do
     (void)shm_unlink(name);   // a stale segment of the same name (a crashed run)
     fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) return err(RPE_ERR_STATE, std::string("shm_open(create ") + name + "): " + std::strerror(errno));
-    if (ftruncate(fd, (off_t)sizeof(Segment)) != 0) { const int e = errno; close(fd); (void)shm_unlink(name); return err(RPE_ERR_STATE, std::string("ftruncate: ") + std::strerror(e)); }
+    if (ftruncate(fd, (off_t)sizeof(Segment)) != 0) { const int e = errno; close(fd); (void)shm_unlink(name);
+        return err(RPE_ERR_STATE, std::string("ftruncate: ") + std::strerror(e)); }
   } else {
     const double t0 = now_s();
     for (;;) {   // the creating rank may be a moment behind
@@ -91,7 +92,8 @@ int rpe_host_exchange_open(const char* name, int world, int rank, int create, do
   void* p = mmap(nullptr, sizeof(Segment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   const int e = errno;
   close(fd);
-  if (p == MAP_FAILED) { if (create) (void)shm_unlink(name); return err(RPE_ERR_STATE, std::string("mmap of the host exchange segment: ") + std::strerror(e)); }
+  if (p == MAP_FAILED) { if (create) (void)shm_unlink(name); return err(RPE_ERR_STATE,
+      std::string("mmap of the host exchange segment: ") + std::strerror(e)); }
   rpe_host_exchange* h = new rpe_host_exchange;
   h->seg = static_cast<Segment*>(p); h->name = name; h->world = world; h->rank = rank; h->timeout_s = timeout_s; h->owner = create != 0;
   if (create) {   // a fresh segment is zero-filled: step numbers start below every step
@@ -100,10 +102,12 @@ int rpe_host_exchange_open(const char* name, int world, int rank, int create, do
   } else {
     const double t0 = now_s();
     while (__atomic_load_n(&h->seg->h.magic, __ATOMIC_ACQUIRE) != kMagic) {
-      if (now_s() - t0 > timeout_s) { munmap(p, sizeof(Segment)); delete h; return err(RPE_ERR_STATE, "host exchange segment was never initialised by its creator"); }
+      if (now_s() - t0 > timeout_s) { munmap(p, sizeof(Segment)); delete h;
+          return err(RPE_ERR_STATE, "host exchange segment was never initialised by its creator"); }
       cpu_relax();
     }
-    if (h->seg->h.world != world) { munmap(p, sizeof(Segment)); delete h; return err(RPE_ERR_ARG, "host exchange segment belongs to a different world size"); }
+    if (h->seg->h.world != world) { munmap(p, sizeof(Segment)); delete h;
+        return err(RPE_ERR_ARG, "host exchange segment belongs to a different world size"); }
   }
   *out = h;
   return RPE_OK;
@@ -116,7 +120,8 @@ void rpe_host_exchange_close(rpe_host_exchange* h) {
   delete h;
 }
 
-// remove the NAME (the memory stays until the last rank unmaps it): call once every rank has opened the segment, e.g. after the first exchange
+// remove the NAME (the memory stays until the last rank unmaps it): call once every rank has opened the segment, e.g. after the first
+// exchange
 int rpe_host_exchange_unlink(rpe_host_exchange* h) {
   if (!h) return err(RPE_ERR_ARG, "null exchange");
   if (!h->unlinked) { (void)shm_unlink(h->name.c_str()); h->unlinked = true; }
@@ -140,7 +145,8 @@ int rpe_host_exchange_labels_collide(rpe_host_exchange* h) {
 
 int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n) {
   if (!h || !v || n < 1 || n > kMaxF64) return err(RPE_ERR_ARG, "rpe_host_exchange_allreduce_f64: bad argument (1 <= n <= 64)");
-  if (h->broken) return err(RPE_ERR_STATE, "host exchange: an earlier step timed out; close this exchange and open a new one on every rank");
+  if (h->broken) return err(RPE_ERR_STATE,
+      "host exchange: an earlier step timed out; close this exchange and open a new one on every rank");
   const unsigned long long step = ++h->rec_step;
   RecSlot* row = h->seg->rec[step & 1];
   RecSlot& mine = row[h->rank];
@@ -158,7 +164,8 @@ int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n) {
         if (t0 == 0) t0 = now_s();
         else if (now_s() - t0 > h->timeout_s) {
           char msg[160];
-          std::snprintf(msg, sizeof msg, "host exchange: rank %d did not deliver its record of step %llu within %.1f s", r, step, h->timeout_s);
+          std::snprintf(msg, sizeof msg, "host exchange: rank %d did not deliver its record of step %llu within %.1f s", r, step,
+              h->timeout_s);
           h->broken = true;   // the caller's v is untouched (the sums live in a local buffer until every rank has delivered)
           return err(RPE_ERR_STATE, msg);
         }
@@ -173,7 +180,8 @@ int rpe_host_exchange_allreduce_f64(rpe_host_exchange* h, double* v, int n) {
 
 int rpe_host_exchange_allreduce_i32(rpe_host_exchange* h, int* v, int n) {
   if (!h || !v || n < 1 || n > kMaxI32) return err(RPE_ERR_ARG, "rpe_host_exchange_allreduce_i32: bad argument (1 <= n <= 8192)");
-  if (h->broken) return err(RPE_ERR_STATE, "host exchange: an earlier step timed out; close this exchange and open a new one on every rank");
+  if (h->broken) return err(RPE_ERR_STATE,
+      "host exchange: an earlier step timed out; close this exchange and open a new one on every rank");
   const unsigned long long step = ++h->vote_step;
   VoteSlot* row = h->seg->votes[step & 1];
   VoteSlot& mine = row[h->rank];
@@ -190,7 +198,8 @@ int rpe_host_exchange_allreduce_i32(rpe_host_exchange* h, int* v, int n) {
         if (t0 == 0) t0 = now_s();
         else if (now_s() - t0 > h->timeout_s) {
           char msg[160];
-          std::snprintf(msg, sizeof msg, "host exchange: rank %d did not deliver its counters of step %llu within %.1f s", r, step, h->timeout_s);
+          std::snprintf(msg, sizeof msg, "host exchange: rank %d did not deliver its counters of step %llu within %.1f s", r, step,
+              h->timeout_s);
           h->broken = true;
           return err(RPE_ERR_STATE, msg);
         }

@@ -42,7 +42,8 @@ template <> struct Eps<double> { __device__ static double value() { return 1e-10
 // out_pose: scoring layout (exact: qw qx qy qz tx ty tz 0 ; fast: R row-major 9, t 3) in T.  h_q7: 8 T per iteration in pinned host
 // memory (qw qx qy qz tx ty tz valid).
 template <class T>
-__global__ __launch_bounds__(64) void gen_shinji_kernel(const T* __restrict__ xw, const T* __restrict__ xc, int n, unsigned long long state,
+__global__ __launch_bounds__(64) void gen_shinji_kernel(const T* __restrict__ xw, const T* __restrict__ xc, int n,
+    unsigned long long state,
                                                         unsigned long long inc, int iters, int exact, T* __restrict__ out_pose,
                                                         T* __restrict__ h_q7) {
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(64) void gen_shinji_kernel(const T* __restrict__ xw
   // RandomElements::run(K): position j swaps with rnd() % (j + 1), j = n-1 ... n-K, over a table that starts as the identity
   int pos[2 * K], val[2 * K], cnt = 0, sel[K];
   auto get = [&](int p) { for (int k = 0; k < cnt; k++) if (pos[k] == p) return val[k]; return p; };
-  auto set = [&](int p, int v) { for (int k = 0; k < cnt; k++) if (pos[k] == p) { val[k] = v; return; } pos[cnt] = p; val[cnt] = v; cnt++; };
+  auto set = [&](int p, int v) { for (int k = 0; k < cnt; k++) if (pos[k] == p) { val[k] = v; return; } pos[cnt] = p; val[cnt] = v;
+      cnt++; };
   for (int s = 0, top = n - 1; s < K; s++, top--) {
     const int pick = rng.next31() % (top + 1);
     const int vp = get(pick), vt = get(top);
@@ -99,7 +101,8 @@ __device__ inline Cx operator-(Cx a, Cx b) { return Cx{a.re - b.re, a.im - b.im}
 __device__ inline Cx operator-(Cx a) { return Cx{-a.re, -a.im}; }
 __device__ inline Cx operator*(Cx a, Cx b) { return Cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ inline Cx operator*(double s, Cx a) { return Cx{s * a.re, s * a.im}; }
-__device__ inline Cx operator/(Cx a, Cx b) { const double d = b.re * b.re + b.im * b.im; return Cx{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d}; }
+__device__ inline Cx operator/(Cx a, Cx b) { const double d = b.re * b.re + b.im * b.im;
+    return Cx{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d}; }
 __device__ inline Cx cpow(Cx a, double p) {   // principal branch
   const double r = hypot(a.re, a.im);
   if (r == 0.0) return Cx{0.0, 0.0};
@@ -139,7 +142,8 @@ __device__ inline V3d operator*(double s, V3d a) { return V3d{s * a.x, s * a.y, 
 __device__ inline double dot(V3d a, V3d b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ inline V3d cross(V3d a, V3d b) { return V3d{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ inline double norm(V3d a) { return sqrt(dot(a, a)); }
-__device__ inline V3d mulr(const V3d rows[3], V3d v) { return V3d{dot(rows[0], v), dot(rows[1], v), dot(rows[2], v)}; }   // matrix given by its rows
+// matrix given by its rows
+__device__ inline V3d mulr(const V3d rows[3], V3d v) { return V3d{dot(rows[0], v), dot(rows[1], v), dot(rows[2], v)}; }
 
 // up to four (R row-major, t) with Xc = R Xw + t from three world points and their unit bearings; returns how many
 __device__ inline int kneip_dev(const V3d Pw[3], const V3d bv[3], double rot_eps, double Rs[4][9], double ts[4][3]) {
@@ -206,7 +210,8 @@ __device__ inline int kneip_dev(const V3d Pw[3], const V3d bv[3], double rot_eps
     double QN[9], R[9];
     mat3_mul(Q, N9, QN);
     mat3_mul(T9, QN, R);
-    if (R[0] != R[0] || !is_rotation<double>(R, rot_eps)) continue;   // the SO3 constructor's test, with the array dtype's tolerance (bearings are unit to that precision)
+    // the SO3 constructor's test, with the array dtype's tolerance (bearings are unit to that precision)
+    if (R[0] != R[0] || !is_rotation<double>(R, rot_eps)) continue;
     for (int e = 0; e < 9; e++) Rs[count][e] = R[e];
     ts[count][0] = -(R[0] * Cw.x + R[1] * Cw.y + R[2] * Cw.z);
     ts[count][1] = -(R[3] * Cw.x + R[4] * Cw.y + R[5] * Cw.z);
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
   rng.advance((unsigned long long)K * (unsigned long long)i);
   int pos[2 * K], val[2 * K], cnt = 0, sel[K];
   auto get = [&](int p) { for (int k = 0; k < cnt; k++) if (pos[k] == p) return val[k]; return p; };
-  auto set = [&](int p, int v) { for (int k = 0; k < cnt; k++) if (pos[k] == p) { val[k] = v; return; } pos[cnt] = p; val[cnt] = v; cnt++; };
+  auto set = [&](int p, int v) { for (int k = 0; k < cnt; k++) if (pos[k] == p) { val[k] = v; return; } pos[cnt] = p; val[cnt] = v;
+      cnt++; };
   for (int s = 0, top = n - 1; s < K; s++, top--) {
     const int pick = rng.next31() % (top + 1);
     const int vp = get(pick), vt = get(top);
@@ -339,22 +345,28 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
 int gen_p3p_slots(int solver) {
   switch (solver) { case 0: case 2: return 1; case 1: case 3: return 2; case 4: return 3; default: return 0; }
 }
-hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters, void* d_poses, void* h_q7,
+hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters,
+    void* d_poses, void* h_q7,
                           hipStream_t s) {
   if (iters < 1) return hipSuccess;
   if (gen_p3p_slots(solver) == 0) return hipErrorInvalidValue;
   const int G = (iters + 63) / 64;
-  if (A.dtype) hipLaunchKernelGGL(gen_p3p_kernel<double>, dim3(G), dim3(64), 0, s, (const double*)A.a[0], (const double*)A.a[1], (const double*)A.a[2], (const double*)A.a[3], (const double*)A.a[4], (int)A.n, solver, state, inc, iters, (double*)d_poses, (double*)h_q7);
-  else hipLaunchKernelGGL(gen_p3p_kernel<float>, dim3(G), dim3(64), 0, s, (const float*)A.a[0], (const float*)A.a[1], (const float*)A.a[2], (const float*)A.a[3], (const float*)A.a[4], (int)A.n, solver, state, inc, iters, (float*)d_poses, (float*)h_q7);
+  if (A.dtype) hipLaunchKernelGGL(gen_p3p_kernel<double>, dim3(G), dim3(64), 0, s, (const double*)A.a[0], (const double*)A.a[1],
+      (const double*)A.a[2], (const double*)A.a[3], (const double*)A.a[4], (int)A.n, solver, state, inc, iters, (double*)d_poses, (double*)h_q7);
+  else hipLaunchKernelGGL(gen_p3p_kernel<float>, dim3(G), dim3(64), 0, s, (const float*)A.a[0], (const float*)A.a[1],
+      (const float*)A.a[2], (const float*)A.a[3], (const float*)A.a[4], (int)A.n, solver, state, inc, iters, (float*)d_poses, (float*)h_q7);
   return hipGetLastError();
 }
 
-hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
+hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact,
+    void* d_poses,
                              void* h_q7, hipStream_t s) {
   if (iters < 1) return hipSuccess;
   const int G = (iters + 63) / 64;
-  if (A.dtype) hipLaunchKernelGGL(gen_shinji_kernel<double>, dim3(G), dim3(64), 0, s, (const double*)A.a[0], (const double*)A.a[1], (int)A.n, state, inc, iters, exact, (double*)d_poses, (double*)h_q7);
-  else hipLaunchKernelGGL(gen_shinji_kernel<float>, dim3(G), dim3(64), 0, s, (const float*)A.a[0], (const float*)A.a[1], (int)A.n, state, inc, iters, exact, (float*)d_poses, (float*)h_q7);
+  if (A.dtype) hipLaunchKernelGGL(gen_shinji_kernel<double>, dim3(G), dim3(64), 0, s, (const double*)A.a[0], (const double*)A.a[1],
+      (int)A.n, state, inc, iters, exact, (double*)d_poses, (double*)h_q7);
+  else hipLaunchKernelGGL(gen_shinji_kernel<float>, dim3(G), dim3(64), 0, s, (const float*)A.a[0], (const float*)A.a[1], (int)A.n,
+      state, inc, iters, exact, (float*)d_poses, (float*)h_q7);
   return hipGetLastError();
 }
 

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(BLK) void icp_fused_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       float gx, gy, gz;
-      const bool ok = associate_pixel(T, P, mv, mn, V[3 * i], V[3 * i + 1], V[3 * i + 2], N[3 * i], N[3 * i + 1], N[3 * i + 2], vw[3 * i],
+      const bool ok = associate_pixel(T, P, mv, mn, V[3 * i], V[3 * i + 1], V[3 * i + 2], N[3 * i], N[3 * i + 1], N[3 * i + 2],
+          vw[3 * i],
                                       vw[3 * i + 1], vw[3 * i + 2], gx, gy, gz);
 #pragma unroll
       for (int k = 0; k < 3; k++) { vb[3 * i + k] = ok ? V[3 * i + k] : nan; vc[3 * i + k] = ok ? N[3 * i + k] : nan; }
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(BLK) void icp_resident_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         float gx, gy, gz;
-        const bool ok = associate_pixel(T, P, mv, mn, V[3 * i], V[3 * i + 1], V[3 * i + 2], N[3 * i], N[3 * i + 1], N[3 * i + 2], vw[3 * i],
+        const bool ok = associate_pixel(T, P, mv, mn, V[3 * i], V[3 * i + 1], V[3 * i + 2], N[3 * i], N[3 * i + 1], N[3 * i + 2],
+            vw[3 * i],
                                         vw[3 * i + 1], vw[3 * i + 2], gx, gy, gz);
 #pragma unroll
         for (int k = 0; k < 3; k++) { vb[3 * i + k] = ok ? V[3 * i + k] : nan; vc[3 * i + k] = ok ? N[3 * i + k] : nan; }
@@ -180,10 +182,12 @@ hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, con
   if ((int64_t)G > (groups + blk - 1) / blk) G = (int)((groups + blk - 1) / blk);
   if (G < 1) G = 1;
   if (blk == 512) {
-    if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 512>), dim3(G), dim3(512), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
+    if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 512>), dim3(G), dim3(512), 0, s, vmap, nmap, n, mv, mn, P,
+        pose, fin);
     else hipLaunchKernelGGL((icp_fused_kernel<KIND_P2PLANE, 512>), dim3(G), dim3(512), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
   } else {
-    if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
+    if (kind == KIND_P2P) hipLaunchKernelGGL((icp_fused_kernel<KIND_P2P, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P,
+        pose, fin);
     else hipLaunchKernelGGL((icp_fused_kernel<KIND_P2PLANE, 256>), dim3(G), dim3(256), 0, s, vmap, nmap, n, mv, mn, P, pose, fin);
   }
   return hipGetLastError();
@@ -195,7 +199,8 @@ void icp_resident_geometry(int64_t n, int kind, int max_blocks, int* grid, int* 
   A.n = n; A.dtype = 0;
   resident_geometry(A, kind, max_blocks, grid, nacc, max_rows, rows_auto);
 }
-hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam, const PoseF& M,
+hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam,
+    const PoseF& M,
                                float dist_sq, float cos_thr, int use_normals, int kind, const unsigned long long* ctl, unsigned long long first_tag,
                                int max_iters, const ReduceTarget& rt, hipStream_t s) {
   if (kind != KIND_P2P && kind != KIND_P2PLANE) return hipErrorInvalidValue;

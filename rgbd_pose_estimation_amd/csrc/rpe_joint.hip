@@ -85,7 +85,8 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
         const T bx = on ? bx0 : T(0), by = on ? by0 : T(0), bz = on ? bz0 : T(1);
         const double sx = on ? pxd : 0.0, sy = on ? pyd : 0.0, sz = on ? pzd : 1.0;  // keeps the normalisation finite when off
         const T w0 = on ? u23[i] : T(0);
-        const T w = w0 * robust_weight<T>(prm.robust[2], (T)prm.robust_k[2], [&]() { return bearing_residual_norm<T>(sx, sy, sz, bx, by, bz); });
+        const T w = w0 * robust_weight<T>(prm.robust[2], (T)prm.robust_k[2],
+            [&]() { return bearing_residual_norm<T>(sx, sy, sz, bx, by, bz); });
         bearing_point<T>(sx, sy, sz, bx, by, bz, (T)prm.scale[2] * w, w, s);
       }
     }
@@ -122,7 +123,8 @@ template <class T> struct JointArrays {
   const short *m23, *m33, *mnn;
   const T *w23, *w33, *wnn;
 };
-// ... and one group of P correspondences of them in registers: only what the term set reads is loaded (absent masks / weights read as 1)
+// ... and one group of P correspondences of them in registers: only what the term set reads is loaded (absent masks / weights read as
+// 1)
 template <class T> struct JointRegs {
   enum { P = Pk<T>::P };
   T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
@@ -154,7 +156,8 @@ template <class T> struct JointRegs {
 };
 
 template <class T, int TERMS, int BLK>
-__global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(JointArrays<T> A, int64_t n, PoseK<double> pose, JointParams prm, Finish fin) {
+__global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(JointArrays<T> A, int64_t n, PoseK<double> pose, JointParams prm,
+    Finish fin) {
   constexpr int P = Pk<T>::P;
   if (fin.gn != nullptr) {
     if (fin.gn->done) return;
@@ -172,13 +175,15 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(JointArrays<T> A, 
     JointRegs<T> q;
     q.template load<TERMS>(A, g, n);
     const int64_t left = n - g * P;
-    joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn, left < P ? (int)left : P, acc);
+    joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn,
+        left < P ? (int)left : P, acc);
   }
   reduce_and_finish<29, kNeLd, 0, BLK>(acc, fin);
 }
 
 // RESIDENT form (rpe_gn_refine_joint on one GPU): ONE launch for the whole refinement, as normal_eq_resident_kernel -- every iteration
-// the workgroups wait for the host's pose in the control block (resident_wait_pose), evaluate their slice of the joint objective and hand
+// the workgroups wait for the host's pose in the control block (resident_wait_pose), evaluate their slice of the joint objective and
+// hand
 // the 29 sums to the collecting stage (resident_cross_stage); the host adds the run records, solves and updates.  Frame-sized problems
 // (IN_REGS: one group per thread) read their arrays once per refinement.
 template <class T, int TERMS, int BLK, bool IN_REGS>
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
   const bool have = IN_REGS && g0 < groups;
   if (have) mine.template load<TERMS>(A, g0, n);
   for (int it = 1; it <= max_iters; it++) {
-    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;   // stop requested or no host
+    // stop requested or no host
+    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
@@ -207,14 +213,16 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
     if (IN_REGS) {
       const int64_t left = n - g0 * P;
       if (have)
-        joint_group<T, TERMS>(pose, prm, mine.vw, mine.vc, mine.vb, mine.vnw, mine.vnc, mine.k23, mine.k33, mine.knn, mine.u23, mine.u33,
+        joint_group<T, TERMS>(pose, prm, mine.vw, mine.vc, mine.vb, mine.vnw, mine.vnc, mine.k23, mine.k33, mine.knn, mine.u23,
+            mine.u33,
                               mine.unn, left < P ? (int)left : P, acc);
     } else {
       for (int64_t g = g0; g < groups; g += stride) {
         JointRegs<T> q;
         q.template load<TERMS>(A, g, n);
         const int64_t left = n - g * P;
-        joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn, left < P ? (int)left : P, acc);
+        joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn,
+            left < P ? (int)left : P, acc);
       }
     }
     if (!resident_cross_stage<29, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, false)) return;
@@ -229,22 +237,27 @@ template <class T> static JointArrays<T> joint_arrays(const DeviceArrays& A, boo
   return J;
 }
 template <class T, int TERMS, int BLK>
-static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s);
+static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt,
+    hipStream_t s);
 template <class T, int TERMS>
-static void joint_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s) {
+static void joint_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt,
+    hipStream_t s) {
   static const int env_blk = getenv("RPE_JOINT_BLOCK") ? atoi(getenv("RPE_JOINT_BLOCK")) : 0;
   // register-heavy kernel (up to three residual kinds, 29 fp64 accumulators): frames of the 640x480 class run 20 % faster with
   // 256-thread workgroups (one wave per SIMD, more workgroups in flight: 27.9 us vs 35.6 us at 307200), streaming sizes slightly
   // faster with 512 (10 M: 205 us vs 217 us)
-  const int blk = env_blk == 256 || env_blk == 512 ? env_blk : (rt.block == 256 || rt.block == 512 ? rt.block : (A.n <= 2000000 ? 256 : 512));
+  const int blk = env_blk == 256 || env_blk == 512 ? env_blk : (rt.block == 256
+      || rt.block == 512 ? rt.block : (A.n <= 2000000 ? 256 : 512));
   if (blk == 256) joint_launch_b<T, TERMS, 256>(A, flags, pose, prm, rt, s);
   else joint_launch_b<T, TERMS, 512>(A, flags, pose, prm, rt, s);
 }
 template <class T, int TERMS, int BLK>
-static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt, hipStream_t s) {
+static void joint_launch_b(const DeviceArrays& A, int flags, const PoseK<double>& pose, const JointParams& prm, const ReduceTarget& rt,
+    hipStream_t s) {
   const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
-  hipLaunchKernelGGL((normal_eq_joint_kernel<T, TERMS, BLK>), dim3(G), dim3(BLK), 0, s, joint_arrays<T>(A, um, uw), A.n, pose, prm, make_finish(rt));
+  hipLaunchKernelGGL((normal_eq_joint_kernel<T, TERMS, BLK>), dim3(G), dim3(BLK), 0, s, joint_arrays<T>(A, um, uw), A.n, pose, prm,
+      make_finish(rt));
 }
 template <class T>
 static hipError_t joint_t(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,
@@ -261,7 +274,8 @@ static hipError_t joint_t(const DeviceArrays& A, int terms, int flags, const dou
   }
   return hipGetLastError();
 }
-hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,
+hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4,
+    const int* robust4,
                                   const double* robust_k4, const ReduceTarget& rt, hipStream_t s) {
   return A.dtype ? joint_t<double>(A, terms, flags, pose12, scale4, robust4, robust_k4, rt, s)
                  : joint_t<float>(A, terms, flags, pose12, scale4, robust4, robust_k4, rt, s);
@@ -269,7 +283,8 @@ hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, c
 
 // resident form: grid / record geometry as the resident normal-equation kernel's 29-sum kinds (resident_geometry with a non-p2p kind)
 template <class T, int TERMS>
-static void joint_resident_launch(const DeviceArrays& A, int flags, const JointParams& prm, const unsigned long long* ctl, unsigned long long first_tag,
+static void joint_resident_launch(const DeviceArrays& A, int flags, const JointParams& prm, const unsigned long long* ctl,
+    unsigned long long first_tag,
                                   int max_iters, const ReduceTarget& rt, hipStream_t s) {
   constexpr int BLK = 512;
   const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
@@ -286,12 +301,15 @@ static void joint_resident_launch(const DeviceArrays& A, int flags, const JointP
   if (fin.rows < 1) fin.rows = 1;
   const JointArrays<T> J = joint_arrays<T>(A, um, uw);
   if (in_regs)
-    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, true>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag, max_iters, fin);
+    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, true>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag,
+        max_iters, fin);
   else
-    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, false>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag, max_iters, fin);
+    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, false>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag,
+        max_iters, fin);
 }
 template <class T>
-static hipError_t joint_resident_t(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4, const double* robust_k4,
+static hipError_t joint_resident_t(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4,
+    const double* robust_k4,
                                    const unsigned long long* ctl, unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s) {
   JointParams prm;
   for (int k = 0; k < 4; k++) { prm.scale[k] = scale4[k]; prm.robust[k] = robust4[k]; prm.robust_k[k] = robust_k4[k]; }

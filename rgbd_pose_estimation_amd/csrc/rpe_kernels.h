@@ -58,11 +58,15 @@ struct ReduceTarget {
   const P2PDesc* p2p = nullptr;   // multi-GPU: exchange + sum the record with the peers before publishing (h_out path only)
   unsigned long long p2p_step = 0;   // collective step counter, identical on every rank (tag + mailbox parity)
   int tail = -1;               // cross-workgroup stage of the ordinary kernels: -1 = default / RPE_TAIL
-  unsigned long long pose_wait_ticks = 200000000ull;   // resident kernels: wait for the host's next pose at most this long (100 MHz ticks; 2 s)
+  // resident kernels: wait for the host's next pose at most this long (100 MHz ticks; 2 s)
+  unsigned long long pose_wait_ticks = 200000000ull;
   unsigned long long fault_tag = 0;                    // test hook: see Finish
-  int rows = 0;                // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
-                               // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out must hold
-                               // 1 + ceil(grid / run length) x sums pairs), and the host adds them in order.  Host-consumed, single-GPU results only
+  // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
+  int rows = 0;
+                               // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out
+                               // must hold
+                               // 1 + ceil(grid / run length) x sums pairs), and the host adds them in order. Host-consumed, single-GPU
+                               // results only
 };
 // ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
@@ -72,9 +76,12 @@ hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const do
 // first_tag + i; the run records of iteration i (rt.rows) are published with sequence value rt.seq + i.  Needs host-writable device
 // memory (large BAR).
 constexpr unsigned long long kResidentStopBit = 1ull << 63;
-constexpr unsigned long long kResidentLostMarker = 0x7ff8dead00c0ffeeull;   // = kLostMarker (rpe_reduce.hpp): a run whose granules never arrived
-// How many 512-thread workgroups of the resident kernels the CURRENT device holds at once (occupancy of the heaviest instances x compute
-// units, at most 256; 0 = none fits: no resident loops).  Every resident launcher caps its grid with it: a collecting workgroup waits for
+// = kLostMarker (rpe_reduce.hpp): a run whose granules never arrived
+constexpr unsigned long long kResidentLostMarker = 0x7ff8dead00c0ffeeull;
+// How many 512-thread workgroups of the resident kernels the CURRENT device holds at once (occupancy of the heaviest instances x
+// compute
+// units, at most 256; 0 = none fits: no resident loops). Every resident launcher caps its grid with it: a collecting workgroup waits
+// for
 // workgroups of its own launch, so all of them must be on the compute units together.
 int resident_cap_device();
 // Each kernel unit is a code object of its own that the runtime loads on the first launch out of it (a few milliseconds, once per
@@ -82,13 +89,15 @@ int resident_cap_device();
 void preload_normal_eq(); void preload_icp(); void preload_joint(); void preload_score(); void preload_nl();
 void preload_frontend(); void preload_hypotheses(); void preload_prosac();
 void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
-hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
+hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl,
+    unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // test hook: one application of the device-resident loop's 6x6 LDL^T solve + SE(3) exp-map update (d_step_ok: |delta|, ok flag)
 hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, hipStream_t s);
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s);
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
-hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4, const int* robust4,
+hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4,
+    const int* robust4,
                                   const double* robust_k4, const ReduceTarget& rt, hipStream_t s);
 // RESIDENT form of the joint kernel (one launch per refinement; control block, tags and run records as launch_normal_eq_resident;
 // geometry = resident_geometry of a 29-sum kind)
@@ -100,11 +109,13 @@ hipError_t launch_normal_eq_joint_resident(const DeviceArrays& A, int terms, int
 // d_votes[0..H) must be zero on entry (launch_publish_votes leaves them so)
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s);
-// single-launch form for short lists (H <= score_small_cap): the hypotheses, staged in HOST memory in the layout above, travel as a kernel
+// single-launch form for short lists (H <= score_small_cap): the hypotheses, staged in HOST memory in the layout above, travel as a
+// kernel
 // argument (h_poses), or are read from HBM (d_poses: a device-generated batch; exactly one of the two is non-null); rt must be a
 // collecting target (rt.rows > 0); record[h] of the result = votes of hypothesis h
 int score_small_cap(int dtype, int exact);
-hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H, const double* thr3,
+hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H,
+    const double* thr3,
                               const ReduceTarget& rt, hipStream_t s);
 // pose12: fast = R row-major (9) t (3); exact = qw qx qy qz tx ty tz (rest ignored).  The vote total is record[0] of rt.
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
@@ -113,19 +124,22 @@ hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double*
 hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s);
 
 // copy `count` reduced values from HBM to pinned host memory and then store `seq` to *h_flag (the host spins on it)
-hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
+hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq,
+    hipStream_t s);
 // sharded scoring: exchange the `count` vote counters with the peers (same mailbox protocol as the records, one word per
 // hypothesis), add them in rank order, publish the totals, zero the counters.  *h_status is set to 1 if a peer timed out.
 hipError_t launch_publish_votes_p2p(int* d_votes, int count, const P2PDesc* p2p, unsigned long long step, int* h_dst, int* h_status,
                                     unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
 // publish the vote counters to pinned host memory, raise the sequence word, and zero the counters for the next launch_score
 hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
-hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s);
+hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq,
+    hipStream_t s);
 
 // ---- batched hypothesis generation (rpe_hypotheses.hip): `iters` RANSAC iterations of the 3-point closed form, sampled from the
 // PCG32 stream (state, inc) exactly as the host sampler would; poses to d_poses in the scoring layout of `exact`, and to
 // h_q7 (pinned, 8 values of the array dtype per iteration: qw qx qy qz tx ty tz valid) for the host's replay
-hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
+hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact,
+    void* d_poses,
                              void* h_q7, hipStream_t s);
 
 // FAST-mode generator of the plain-RANSAC solvers with a 4-point sample (tolerance parity): solver 0 = kneip_ransac (P3P), 1 =
@@ -133,7 +147,8 @@ hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, un
 // nl_shinji_kneip_ransac (3-point fit, P3P, nl_2p): gen_p3p_slots(solver) slots per iteration; same sample stream as the host (4 draws
 // per iteration); d_poses in the FAST scoring layout (12 values per slot), h_q7 pinned, 8 values per slot (qw qx qy qz tx ty tz valid)
 int gen_p3p_slots(int solver);
-hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters, void* d_poses, void* h_q7,
+hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters,
+    void* d_poses, void* h_q7,
                           hipStream_t s);
 
 // ---- PROSAC order (rpe_prosac.hip): the first top_k (<= kProsacMaxTopK) positions of "indices by weight descending, ties to the lower
@@ -141,14 +156,16 @@ hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long 
 // d_status: 0 ok, 1 = more candidates than the LDS sort holds (heavy ties around the cut): use the host order.
 constexpr int kProsacSortCap = 8192;
 constexpr int kProsacMaxTopK = 4096;
-hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl, unsigned long long* d_cand, int* d_order,
+hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl,
+    unsigned long long* d_cand, int* d_order,
                                int* d_status, hipStream_t s);
 
 // ---- front end (rpe_frontend.hip): depth frame -> maps -> projective association; fp32 throughout
 struct Camera { float fx, fy, cx, cy; int width, height; };
 struct PoseF { float R[9]; float t[3]; };   // Xc = R Xw + t, R row-major
 // depth_type 0 = uint16 (metres = value * scale), 1 = float32 (metres = value * scale); maps are 3 x (width*height) floats
-hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax, float max_jump,
+hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax,
+    float max_jump,
                              float* vmap, float* nmap, float* bmap, hipStream_t s);
 hipError_t launch_to_world(const float* vmap, const float* nmap, int64_t n, const PoseF& T, float* vw, float* nw, hipStream_t s);
 // d_count (may be null): incremented by the number of associated pixels.  pose_dev (may be null): T read from HBM (12 doubles).
@@ -164,7 +181,8 @@ hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, con
 
 // resident ICP loop (one launch; poses through the control block, run records to the host -- as launch_normal_eq_resident)
 void icp_resident_geometry(int64_t n, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
-hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam, const PoseF& M,
+hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam,
+    const PoseF& M,
                                float dist_sq, float cos_thr, int use_normals, int kind, const unsigned long long* ctl, unsigned long long first_tag,
                                int max_iters, const ReduceTarget& rt, hipStream_t s);
 

@@ -32,7 +32,8 @@ __device__ __forceinline__ void moments_group(const T (&vw)[3 * Pk<T>::P], const
 }
 
 template <class T, int BLK, bool MASK, bool WEIGHT>
-__global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const short* __restrict__ mask,
+__global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
+    const short* __restrict__ mask,
                                                       const T* __restrict__ weight, int64_t n, int skip_invalid, Finish fin) {
   constexpr int P = Pk<T>::P;
   typedef typename Pk<T>::V V;
@@ -103,7 +104,8 @@ template <class T> __device__ __forceinline__ NlConst<T> nl_const(const NlParams
   return k;
 }
 template <class T>
-__device__ __forceinline__ void nl_point(const NlConst<T>& prm, T x, T y, T z, bool on23, T w23v, T bx_, T by_, T bz_, bool on33, T w33v, T cx_, T cy_,
+__device__ __forceinline__ void nl_point(const NlConst<T>& prm, T x, T y, T z, bool on23, T w23v, T bx_, T by_, T bz_, bool on33,
+    T w33v, T cx_, T cy_,
                                          T cz_, bool onnn, T wnnv, T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T (&acc)[44]) {
   {  // 2D-3D inliers: M23 and the find_opt_cc sums.  w = 0 switches the term off.
     const bool on = on23;
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw,
     for (int k = 0; k < 44; k++) sg[k] = T(0);
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], bv != nullptr && a23[i] == 1, w23 ? u23[i] : T(1), vb[3 * i], vb[3 * i + 1],
+      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], bv != nullptr && a23[i] == 1, w23 ? u23[i] : T(1), vb[3 * i],
+          vb[3 * i + 1],
                   vb[3 * i + 2], xc != nullptr && a33[i] == 1, w33 ? u33[i] : T(1), vc[3 * i], vc[3 * i + 1], vc[3 * i + 2],
                   nw != nullptr && knn != nullptr && ann[i] == 1, wnn ? unn[i] : T(1), vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2],
                   vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], sg);
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw,
 // the common case -- all five arrays and all three masks present, weights all or none -- without bounds checks or pointer tests in
 // the loop, and with the next group's 15 vector loads in flight while the current group is reduced (as normal_eq_kernel does)
 template <class T, int BLK, bool WEIGHT>
-__global__ __launch_bounds__(BLK) void nl_round_full_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+__global__ __launch_bounds__(BLK) void nl_round_full_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
+    const T* __restrict__ bv,
                                                             const T* __restrict__ nw, const T* __restrict__ nc,
                                                             const short* __restrict__ k23, const short* __restrict__ k33,
                                                             const short* __restrict__ knn, const T* __restrict__ w23,
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(BLK) void nl_round_full_kernel(const T* __restrict_
     for (int k = 0; k < 44; k++) sg[k] = T(0);
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], m[0][i] == 1, WEIGHT ? wv[0][i] : T(1), vb[3 * i], vb[3 * i + 1], vb[3 * i + 2],
+      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], m[0][i] == 1, WEIGHT ? wv[0][i] : T(1), vb[3 * i], vb[3 * i + 1],
+          vb[3 * i + 2],
                   m[1][i] == 1, WEIGHT ? wv[1][i] : T(1), vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], m[2][i] == 1, WEIGHT ? wv[2][i] : T(1),
                   vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], sg);
     }
@@ -278,7 +283,8 @@ __global__ __launch_bounds__(BLK) void nl_round_full_kernel(const T* __restrict_
     for (int k = 0; k < 44; k++) sg[k] = T(0);
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], a23[i] == 1, WEIGHT ? u23[i] : T(1), vb[3 * i], vb[3 * i + 1], vb[3 * i + 2],
+      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], a23[i] == 1, WEIGHT ? u23[i] : T(1), vb[3 * i], vb[3 * i + 1],
+          vb[3 * i + 2],
                   a33[i] == 1, WEIGHT ? u33[i] : T(1), vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], ann[i] == 1, WEIGHT ? unn[i] : T(1),
                   vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], sg);
     }
@@ -292,22 +298,26 @@ __global__ __launch_bounds__(BLK) void nl_round_full_kernel(const T* __restrict_
 template <class E>
 __global__ void publish_kernel(const E* __restrict__ src, int count, E* __restrict__ h_dst, unsigned long long* __restrict__ h_flag,
                                unsigned long long seq) {
-  for (int i = threadIdx.x; i < count; i += blockDim.x) __hip_atomic_store(h_dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int i = threadIdx.x; i < count; i += blockDim.x) __hip_atomic_store(h_dst + i, src[i], __ATOMIC_RELAXED,
+      __HIP_MEMORY_SCOPE_SYSTEM);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq,
+    hipStream_t s) {
   hipLaunchKernelGGL((publish_kernel<double>), dim3(1), dim3(64), 0, s, d_src, count, h_dst, h_flag, seq);
   return hipGetLastError();
 }
-hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq,
+    hipStream_t s) {
   hipLaunchKernelGGL((publish_kernel<int>), dim3(1), dim3(256), 0, s, d_src, count, h_dst, h_flag, seq);
   return hipGetLastError();
 }
 // vote counters: publish to the host AND clear them for the next scoring launch (the counters are accumulated with atomics, so
 // they must start at zero; clearing here saves a memset per launch)
-__global__ void publish_votes_kernel(int* __restrict__ votes, int count, int* __restrict__ h_dst, unsigned long long* __restrict__ h_flag,
+__global__ void publish_votes_kernel(int* __restrict__ votes, int count, int* __restrict__ h_dst,
+    unsigned long long* __restrict__ h_flag,
                                      unsigned long long seq) {
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     __hip_atomic_store(h_dst + i, votes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -360,10 +370,12 @@ __global__ __launch_bounds__(1024) void publish_votes_p2p_kernel(int* __restrict
 }
 hipError_t launch_publish_votes_p2p(int* d_votes, int count, const P2PDesc* p2p, unsigned long long step, int* h_dst, int* h_status,
                                     unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(publish_votes_p2p_kernel, dim3(1), dim3(count > 256 ? 1024 : 256), 0, s, d_votes, count, p2p, step, h_dst, h_status, h_flag, seq);
+  hipLaunchKernelGGL(publish_votes_p2p_kernel, dim3(1), dim3(count > 256 ? 1024 : 256), 0, s, d_votes, count, p2p, step, h_dst,
+      h_status, h_flag, seq);
   return hipGetLastError();
 }
-hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq, hipStream_t s) {
+hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq,
+    hipStream_t s) {
   hipLaunchKernelGGL(publish_votes_kernel, dim3(1), dim3(count > 256 ? 1024 : 256), 0, s, d_votes, count, h_dst, h_flag, seq);
   return hipGetLastError();
 }
@@ -377,9 +389,12 @@ static void moments_launch(const DeviceArrays& A, int flags, const ReduceTarget&
   const int skip = (flags & F_SKIP_INVALID) ? 1 : 0;
   const T* xw = (const T*)A.a[0];
   const T* xc = (const T*)A.a[1];
-  if (mask && weight) hipLaunchKernelGGL((moments_kernel<T, BLK, true, true>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip, fin);
-  else if (mask) hipLaunchKernelGGL((moments_kernel<T, BLK, true, false>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip, fin);
-  else if (weight) hipLaunchKernelGGL((moments_kernel<T, BLK, false, true>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip, fin);
+  if (mask && weight) hipLaunchKernelGGL((moments_kernel<T, BLK, true, true>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n,
+      skip, fin);
+  else if (mask) hipLaunchKernelGGL((moments_kernel<T, BLK, true, false>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip,
+      fin);
+  else if (weight) hipLaunchKernelGGL((moments_kernel<T, BLK, false, true>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip,
+      fin);
   else hipLaunchKernelGGL((moments_kernel<T, BLK, false, false>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip, fin);
 }
 template <class T>

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
   RPE_STAMP(11);
 #endif
-  if (stride >= full && !(fin.tail & 8)) {   // frame-sized problems: one group per thread (reduce_grid), nothing to pipeline -- straight-line body
+  // frame-sized problems: one group per thread (reduce_grid), nothing to pipeline -- straight-line body
+  if (stride >= full && !(fin.tail & 8)) {
     if (g < full) {
       T vw[3 * P], vb[3 * P], vc[3 * P];
       unpack3(a0, a1, a2, vw);
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
 // IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
 // loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
 template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, bool AUTO>
-__global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
+__global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b,
+    const T* __restrict__ c,
                                                                  const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                                                                  const unsigned long long* __restrict__ ctl, unsigned long long first_tag,
                                                                  int max_iters, Finish fin) {
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     __syncthreads();
   }
   for (int it = 1; it <= max_iters; it++) {
-    if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;   // stop requested or no host: uniform for the workgroup
+    // stop requested or no host: uniform for the workgroup
+    if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go,
+        fin.pose_wait_ticks) != 1) return;
 #ifdef RPE_STAMPS
     const bool stamp_it = it == 1000;
     if (stamp_it) RPE_STAMP(0);
@@ -189,10 +193,12 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     const bool stamp_it = false;
 #endif
     if (autonomous) {
-      if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose, stamp_it) != 0) return;
+      if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose,
+          stamp_it) != 0) return;
       continue;
     }
-    if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, stamp_it)) return;
+    if (!resident_cross_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it,
+        stamp_it)) return;
   }
 }
 
@@ -210,7 +216,8 @@ namespace rpe {
 #endif
 
 template <class T, int KIND, int BLK>
-static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0,
+static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const ReduceTarget& rt, hipStream_t s,
+    hipEvent_t ev0,
                              hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
   const T* b = (const T*)(KIND == KIND_BEARING ? A.a[2] : A.a[1]);
@@ -253,13 +260,15 @@ static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const 
 }
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev0, hipEvent_t ev1) {
-  return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s, ev0, ev1);
+  return A.dtype ? normal_eq_t<double>(A, kind, flags, pose12, rt, s, ev0, ev1) : normal_eq_t<float>(A, kind, flags, pose12, rt, s,
+      ev0, ev1);
 }
 
 // resident form: ONE launch for up to max_iters iterations; ctl = the control block in fine-grained device memory, first_tag + i =
 // tag of pose i (i = 1 ...), rt.seq + i = sequence value published with record i
 template <class T, int KIND, int BLK>
-static void resident_launch(const DeviceArrays& A, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
+static void resident_launch(const DeviceArrays& A, int flags, const unsigned long long* ctl, unsigned long long first_tag,
+    int max_iters,
                             const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
   const T* b = (const T*)(KIND == KIND_BEARING ? A.a[2] : A.a[1]);
@@ -268,7 +277,8 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
   const int cap = std::max(1, resident_cap_device());
-  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);   // every workgroup resident at once: 8 waves per CU
+  // every workgroup resident at once: 8 waves per CU
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks < cap ? rt.max_blocks : cap, BLK);
   const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
   const bool in_regs = (int64_t)G * BLK >= groups;
   Finish fin = make_finish(rt);
@@ -291,7 +301,8 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
 #undef RPE_RES_LAUNCH3
 }
 template <class T>
-static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
+static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
+    int max_iters,
                              const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   if (kind == KIND_P2P) resident_launch<T, KIND_P2P, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else if (kind == KIND_P2PLANE) resident_launch<T, KIND_P2PLANE, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
@@ -324,12 +335,14 @@ int resident_cap_device() {
   }
   c = per_cu >= 1 ? cus : 0;
   if (c > 256) c = 256;
-  if (const char* e = getenv("RPE_RESIDENT_CAP")) { const int v = atoi(e); if (v >= 0 && v < c) c = v; }   // experiments / tests: a smaller device
+  // experiments / tests: a smaller device
+  if (const char* e = getenv("RPE_RESIDENT_CAP")) { const int v = atoi(e); if (v >= 0 && v < c) c = v; }
   cap[dev] = c; known[dev] = true;
   return c;
 }
 // grid the resident kernel runs with, the number of sums per record, the longest run of workgroups one collecting workgroup can take,
-// and the run length used unless the caller forces one: BLK / sums rows (one granule per collecting thread) times 1..4, aiming at <= 8 runs
+// and the run length used unless the caller forces one: BLK / sums rows (one granule per collecting thread) times 1..4, aiming at <= 8
+// runs
 void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto) {
   const int P = A.dtype ? 2 : 4;
   const int blk = resident_block(), cap = std::max(1, resident_cap_device());
@@ -342,7 +355,8 @@ void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* gri
   if (mult < 1) mult = 1;
   *rows_auto = rgn * mult;
 }
-hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
+hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl,
+    unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   return A.dtype ? resident_t<double>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1)
                  : resident_t<float>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);

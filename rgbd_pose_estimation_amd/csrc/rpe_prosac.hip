@@ -27,7 +27,8 @@ __device__ __forceinline__ unsigned long long prosac_key(float w, unsigned int i
 }
 
 // level 0: histogram of the keys' bits 63..53 over all keys; level 1: of bits 52..42 over the keys whose bits 63..53 equal ctl[0]
-__global__ __launch_bounds__(256) void prosac_hist_kernel(const float* __restrict__ w, int n, unsigned int* __restrict__ hist, const unsigned int* __restrict__ ctl,
+__global__ __launch_bounds__(256) void prosac_hist_kernel(const float* __restrict__ w, int n, unsigned int* __restrict__ hist,
+    const unsigned int* __restrict__ ctl,
                                                           int level) {
   __shared__ unsigned int h[kBins];
   for (int i = threadIdx.x; i < kBins; i += 256) h[i] = 0;
@@ -43,13 +44,16 @@ __global__ __launch_bounds__(256) void prosac_hist_kernel(const float* __restric
 }
 
 // level 0: ctl[0] = coarse bin in which the running count reaches top_k, ctl[3] = keys in the bins before it.
-// level 1: ctl[1] = fine bin (inside the coarse one) in which it does, ctl[4] = number of candidates = keys up to and including that fine bin;
+// level 1: ctl[1] = fine bin (inside the coarse one) in which it does, ctl[4] = number of candidates = keys up to and including that
+// fine bin;
 //          ctl[2] = compaction cursor (zeroed).  The histogram is left zero for the next pass / call.
-__global__ __launch_bounds__(256) void prosac_pick_kernel(unsigned int* __restrict__ hist, int top_k, unsigned int* __restrict__ ctl, int level) {
+__global__ __launch_bounds__(256) void prosac_pick_kernel(unsigned int* __restrict__ hist, int top_k, unsigned int* __restrict__ ctl,
+    int level) {
   __shared__ unsigned int h[kBins];
   __shared__ unsigned int part[256];
   unsigned int sum = 0;
-  for (int i = 0; i < kBins / 256; i++) { const unsigned int v = hist[threadIdx.x * (kBins / 256) + i]; h[threadIdx.x * (kBins / 256) + i] = v; sum += v; }
+  for (int i = 0; i < kBins / 256; i++) { const unsigned int v = hist[threadIdx.x * (kBins / 256) + i];
+      h[threadIdx.x * (kBins / 256) + i] = v; sum += v; }
   part[threadIdx.x] = sum;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -77,11 +81,13 @@ __global__ __launch_bounds__(256) void prosac_compact_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(1024) void prosac_sort_kernel(const unsigned long long* __restrict__ cand, const unsigned int* __restrict__ ctl, int top_k,
+__global__ __launch_bounds__(1024) void prosac_sort_kernel(const unsigned long long* __restrict__ cand,
+    const unsigned int* __restrict__ ctl, int top_k,
                                                            int* __restrict__ order, int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   const unsigned int count = ctl[4];
-  if (count > (unsigned int)kSortCap || count < (unsigned int)top_k) { if (threadIdx.x == 0) *status = count > (unsigned int)kSortCap ? 1 : 2; return; }
+  if (count > (unsigned int)kSortCap
+      || count < (unsigned int)top_k) { if (threadIdx.x == 0) *status = count > (unsigned int)kSortCap ? 1 : 2; return; }
   unsigned int m = 1;
   while (m < count) m <<= 1;
   for (unsigned int i = threadIdx.x; i < m; i += 1024) keys[i] = i < count ? cand[i] : ~0ull;
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(1024) void prosac_sort_kernel(const unsigned long l
 
 // d_w: n floats in HBM.  d_hist: kBins uints (zero on entry; left zero), d_ctl: 8 uints, d_cand: kSortCap keys, d_order: top_k ints,
 // d_status: 0 ok, 1 too many candidates (ties), 2 internal count mismatch.
-hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl, unsigned long long* d_cand, int* d_order,
+hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl,
+    unsigned long long* d_cand, int* d_order,
                                int* d_status, hipStream_t s) {
   const int G = n >= 256 * 512 ? 512 : (n + 255) / 256;
   hipLaunchKernelGGL(prosac_hist_kernel, dim3(G), dim3(256), 0, s, d_w, n, d_hist, d_ctl, 0);
@@ -114,7 +121,8 @@ hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int*
   hipLaunchKernelGGL(prosac_hist_kernel, dim3(G), dim3(256), 0, s, d_w, n, d_hist, d_ctl, 1);
   hipLaunchKernelGGL(prosac_pick_kernel, dim3(1), dim3(256), 0, s, d_hist, top_k, d_ctl, 1);
   hipLaunchKernelGGL(prosac_compact_kernel, dim3(G), dim3(256), 0, s, d_w, n, d_ctl, d_cand, kSortCap);
-  hipLaunchKernelGGL(prosac_sort_kernel, dim3(1), dim3(1024), (size_t)kSortCap * sizeof(unsigned long long), s, d_cand, d_ctl, top_k, d_order, d_status);
+  hipLaunchKernelGGL(prosac_sort_kernel, dim3(1), dim3(1024), (size_t)kSortCap * sizeof(unsigned long long), s, d_cand, d_ctl, top_k,
+      d_order, d_status);
   return hipGetLastError();
 }
 

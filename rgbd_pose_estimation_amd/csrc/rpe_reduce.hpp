@@ -26,7 +26,8 @@
 
 namespace rpe {
 
-// ---- diagnostic build only (-DRPE_STAMPS, scripts/tail_timeline.py): thread 0 of every workgroup stamps the 100 MHz constant clock at the
+// ---- diagnostic build only (-DRPE_STAMPS, scripts/tail_timeline.py): thread 0 of every workgroup stamps the 100 MHz constant clock at
+// the
 // phase boundaries of the reduction kernels into a buffer of its own (16 words per workgroup); no stamp exists in the product build.
 #ifdef RPE_STAMPS
 static __device__ unsigned long long g_stamps[4096 * 16];
@@ -100,7 +101,8 @@ __device__ __forceinline__ void load_mask_group(const short* __restrict__ m, int
   }
 }
 __device__ __forceinline__ void load_weight_group(const float* __restrict__ w, int64_t g, int64_t n, float (&v)[4]) {
-  if ((g + 1) * 4 <= n) { const float4 u = *reinterpret_cast<const float4*>(w + 4 * g); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
+  if ((g + 1) * 4 <= n) { const float4 u = *reinterpret_cast<const float4*>(w + 4 * g); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+      }
   else {
 #pragma unroll
     for (int i = 0; i < 4; i++) { int64_t idx = g * 4 + i; v[i] = idx < n ? w[idx] : 0.f; }
@@ -173,7 +175,8 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
 // one instruction: after swap(a, b) the sum of the two results holds a's pair sums in the lower half (even rows) and b's in
 // the upper half (odd rows).  The remaining steps pair lanes with DPP moves (row_ror:8, row_half_mirror, quad_perm) and a
 // select on the lane bit that tells the partners apart.  The order of the additions is fixed, so results stay reproducible.
-__device__ __forceinline__ double swap_add32(double x, double y) {   // lower 32 lanes end with x(l) + x(l+32), upper with y(l-32) + y(l)
+// lower 32 lanes end with x(l) + x(l+32), upper with y(l-32) + y(l)
+__device__ __forceinline__ double swap_add32(double x, double y) {
   const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
   const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
   return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
@@ -183,7 +186,8 @@ __device__ __forceinline__ double swap_add16(double x, double y) {   // even row
   const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
   return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
-template <int CTRL> __device__ __forceinline__ double pair_add(double x, double y, bool upper) {   // lanes with upper = 0 keep x, the others y
+// lanes with upper = 0 keep x, the others y
+template <int CTRL> __device__ __forceinline__ double pair_add(double x, double y, bool upper) {
   const double keep = upper ? y : x, give = upper ? x : y;
   return keep + dpp_move<CTRL, 0xf>(give);
 }
@@ -262,9 +266,12 @@ struct Finish {
   GnState* gn;                 // and its state
   const P2PDesc* p2p;          // multi-GPU peer-to-peer all-reduce of the record (null = single GPU / collective done elsewhere)
   unsigned long long p2p_step;
-  int tail;                    // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
-  int rows;                    // > 0: collecting workgroups + host-side final sum (collect_and_send / the resident kernel): cap on the run length
-  unsigned long long pose_wait_ticks;   // resident kernels: how long a workgroup waits for the host's next pose (100 MHz ticks) before it gives up
+  // cross-workgroup tail: 0 = all records summed by the last workgroup, 1 = per-shard sums first, 2 = 0 with one load batch
+  int tail;
+  // > 0: collecting workgroups + host-side final sum (collect_and_send / the resident kernel): cap on the run length
+  int rows;
+  // resident kernels: how long a workgroup waits for the host's next pose (100 MHz ticks) before it gives up
+  unsigned long long pose_wait_ticks;
   unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
 };
 // what a collecting workgroup sends to the host in place of its run's sums when a granule of the run never arrived: a quiet NaN with a
@@ -329,14 +336,15 @@ template <int MODE> __device__ __forceinline__ double record_entry(const double*
 }
 // ---- device-resident Gauss-Newton: solve H d = -g and T <- exp(d) T by ONE lane.
 // One lane runs this between two iterations of a loop that otherwise takes ~4 us, so what counts is the length of the DEPENDENT chain,
-// not the operation count (an instruction of one lane costs what an instruction of 64 costs, and the next dependent one waits ~8 cycles):
-//  * right-looking elimination of the upper triangle (the Schur complement of an SPD matrix stays symmetric) with the right-hand side as
+// not the operation count (an instruction of one lane costs what an instruction of 64 costs, and the next dependent one waits ~8
+// cycles):
+// * right-looking elimination of the upper triangle (the Schur complement of an SPD matrix stays symmetric) with the right-hand side as
 //    a seventh column: per pivot one reciprocal, then 5 - k independent factors and their independent updates -- six short steps
 //    instead of the left-looking column recurrences' chains of dependent multiply-subtracts; same pivots, hence the same pivot test as
 //    rpe/linalg.hpp solve_normal_eq6 (d_k > 1e-12 H_kk);
 //  * the reciprocals from v_rcp_f64 + two Newton steps (4 dependent FMAs) instead of the ~12-instruction IEEE division sequence;
 //  * back substitution column-wise (x_i = b_i / d_i, then every remaining b_r -= U_ri x_i independently);
-//  * exp(d) without any division, square root or sincos for |w| < 0.5 rad (every Gauss-Newton step in practice): sin(h)/h, cos(h) of the
+// * exp(d) without any division, square root or sincos for |w| < 0.5 rad (every Gauss-Newton step in practice): sin(h)/h, cos(h) of the
 //    half angle and (theta - sin theta)/theta^3 are even power series in the angle, evaluated by Horner in w.w; larger steps take the
 //    closed forms.
 // Fully unrolled so that every matrix entry is a register.  Results agree with the host's LDL^T + rpe::se3_exp to rounding (checked
@@ -351,7 +359,8 @@ static __device__ __forceinline__ double rcp_newton(double d) {
 // MODE: how `tot` (LDS) holds the normal equations -- 0 = the packed record itself, 1 = the 17 structured point-to-point sums (expanded
 // here, in registers: record_entry with compile-time indices costs a few adds, a separate expansion pass costs two barriers).
 template <int MODE>
-static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ tot /* LDS */, double* __restrict__ pose /* LDS, 12, in/out */,
+static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ tot /* LDS */, double* __restrict__ pose /* LDS, 12,
+    in/out */,
                                                     double* step_out) {
   double U[6][6], b[6], inv[6], d[6];
   {
@@ -404,7 +413,8 @@ static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ t
     Cc = fma(Cc, x, -1.0 / 479001600.0); Cc = fma(Cc, x, 1.0 / 3628800.0); Cc = fma(Cc, x, -1.0 / 40320.0); Cc = fma(Cc, x, 1.0 / 720.0);
     Cc = fma(Cc, x, -1.0 / 24.0); Cc = fma(Cc, x, 0.5); Cc = fma(Cc, -x, 1.0);                                  // cos(h)
     K = fma(K, th2, 1.0 / 1307674368000.0); K = fma(K, th2, -1.0 / 6227020800.0); K = fma(K, th2, 1.0 / 39916800.0);
-    K = fma(K, th2, -1.0 / 362880.0); K = fma(K, th2, 1.0 / 5040.0); K = fma(K, th2, -1.0 / 120.0); K = fma(K, th2, 1.0 / 6.0);   // (th - sin th)/th^3
+    // (th - sin th)/th^3
+    K = fma(K, th2, -1.0 / 362880.0); K = fma(K, th2, 1.0 / 5040.0); K = fma(K, th2, -1.0 / 120.0); K = fma(K, th2, 1.0 / 6.0);
     imag = 0.5 * S; real = Cc; c1 = 0.5 * S * S; c2 = K;
   } else {
     const double th = sqrt(th2);
@@ -458,7 +468,8 @@ __device__ __forceinline__ void store_tagged_pair(double* __restrict__ out_host,
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(pr) : "memory");
 }
 // 16-byte granules {value, tag} between workgroups of one launch (agent scope): written by ONE sc1 (write-through) store, read by ONE
-// sc1 load -- the tag travels with the value, so neither a drain nor an arrival counter is needed (cdna_hip_programming.md Guideline 16,
+// sc1 load -- the tag travels with the value, so neither a drain nor an arrival counter is needed (cdna_hip_programming.md Guideline
+// 16,
 // recipe R2, with 16-byte granules: observed untorn on gfx950).
 typedef unsigned int granule_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_granule16(unsigned long long* __restrict__ g, double val, unsigned long long tag) {
@@ -488,7 +499,8 @@ __device__ __forceinline__ void sum_records(const double* __restrict__ partials,
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = r0 + u * RG;
-        v[u] = r < count ? __hip_atomic_load(partials + (size_t)(first + r * step) * LD + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        v[u] = r < count ? __hip_atomic_load(partials + (size_t)(first + r * step) * LD + j, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < U; u++) s += v[u];
@@ -513,7 +525,8 @@ __device__ __forceinline__ void sum_records(const double* __restrict__ partials,
 // wait_collect).  One hand-off hop of ~1 us replaces the arrival counters + the last workgroup's re-read of all G records + the
 // drain before the flag (profiles/r02_tail_timeline.jsonl); the sums are a fixed function of (G, R) whichever workgroup finishes first.
 // Placement-independent: only the ceil(G / R) collecting workgroups ever wait, and only for workgroups that never wait themselves.
-// the collecting workgroup's read: thread (r, j) = (tid / NACC, tid % NACC) takes rows r, r + RGN, r + 2 RGN ... of the run (row 0 is the
+// the collecting workgroup's read: thread (r, j) = (tid / NACC, tid % NACC) takes rows r, r + RGN, r + 2 RGN ... of the run (row 0 is
+// the
 // workgroup's own record, already in part[0]), up to CH granules in flight at once (buffer loads with the sc1 bit, aux 16, re-issued
 // until every tag is this launch's), added in increasing row order into part[r][j].  Returns true if a granule never arrived (2 s).
 template <int NACC, int BLK, int CH = 4>
@@ -573,7 +586,8 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
 // granules (collect_rows), adds the rows in a fixed order and sends the run's NACC sums to pinned host memory as tagged 16-byte pairs
 // (slot 1 + run * NACC + j; slot 0 = a header pair from workgroup 0 that tells the host how many runs of how many sums to expect).
 // The host adds the runs in run order and expands the record (rpe_capi.hip wait_collect).  R = BLK / NACC rows (one granule per
-// collecting thread) times 1..4, aiming at <= 8 runs; longer still if the runs would not fit in ~512 pairs.  One hand-off hop of ~1 us replaces the arrival counters + the last
+// collecting thread) times 1..4, aiming at <= 8 runs; longer still if the runs would not fit in ~512 pairs. One hand-off hop of ~1 us
+// replaces the arrival counters + the last
 // workgroup's re-read of all G records + the drain before the flag (profiles/r02_tail_timeline.jsonl); the sums are a fixed function
 // of G whichever workgroup finishes first.  Placement-independent: only the collecting workgroups ever wait, and only for workgroups
 // that never wait themselves.
@@ -693,7 +707,8 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
       RPE_STAMP(7);
       sum_records<NACC, LD, BLK, 4>(fin.partials, shard, 8, in_shard, part, tot);
       __syncthreads();
-      if (threadIdx.x < LD) __hip_atomic_store(fin.partials + (size_t)(G + shard) * LD + threadIdx.x, tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x < LD) __hip_atomic_store(fin.partials + (size_t)(G + shard) * LD + threadIdx.x, tot[threadIdx.x],
+          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       RPE_STAMP(8);
@@ -746,7 +761,8 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     if (threadIdx.x == 0) {
       GnState* st = fin.gn;
       double step = 0.0;
-      const bool delivered = !(LD == 32 && fin.p2p != nullptr && gn_rec[LD - 1] != 0.0);   // sharded loop: did every peer's record arrive?
+      // sharded loop: did every peer's record arrive?
+      const bool delivered = !(LD == 32 && fin.p2p != nullptr && gn_rec[LD - 1] != 0.0);
       const bool ok = delivered && gn_solve_update<0>(gn_rec, gn_pose_s, &step);
       const int iters = st->iters + 1;
       const int done = (!ok) || step < st->tol || iters >= st->max_iters;
@@ -760,7 +776,8 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
         __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (delivered ? 1.0 : 2.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fin.out_host + 16, gn_rec[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // weight sum of the last round
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     return;
@@ -770,7 +787,8 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
     RPE_STAMP(9);
     __syncthreads();
     if (threadIdx.x == 0) {
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + LD), fin.seq, __ATOMIC_RELAXED,
+          __HIP_MEMORY_SCOPE_SYSTEM);
     }
     RPE_STAMP(10);
   }
@@ -802,8 +820,10 @@ static inline int reduce_grid(int64_t n, int P, int max_blocks, int block) {
   const int64_t groups = (n + P - 1) / P;
   const int64_t one = (groups + block - 1) / block, two = (groups + 2 * (int64_t)block - 1) / (2 * (int64_t)block);
   int64_t g = two < 128 ? one : two;
-  if (block <= 256 && one <= max_blocks) g = one;   // 256-thread workgroups (collecting stage): one group per thread while that is at most 2 workgroups per CU
-  static const int force = getenv("RPE_REDUCE_GROUPS") ? atoi(getenv("RPE_REDUCE_GROUPS")) : 0;   // experiments: 1 / 2 groups per thread
+  // 256-thread workgroups (collecting stage): one group per thread while that is at most 2 workgroups per CU
+  if (block <= 256 && one <= max_blocks) g = one;
+  // experiments: 1 / 2 groups per thread
+  static const int force = getenv("RPE_REDUCE_GROUPS") ? atoi(getenv("RPE_REDUCE_GROUPS")) : 0;
   if (force == 1) g = one; else if (force == 2) g = two;
   if (g < 1) g = 1;
   if (g > max_blocks) g = max_blocks;

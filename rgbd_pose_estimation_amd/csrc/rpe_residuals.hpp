@@ -56,7 +56,8 @@ template <class V> __device__ __forceinline__ void add_row2(const V (&J)[6], V r
   s[27] = __builtin_elementwise_fma(w * r, r, s[27]);
 }
 template <class C>
-__device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&cx)[2], const C (&cy)[2],
+__device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2],
+    const C (&cx)[2], const C (&cy)[2],
                                              const C (&cz)[2], const C (&nx)[2], const C (&ny)[2], const C (&nz)[2], const C (&w)[2],
                                              C __attribute__((ext_vector_type(2))) (&s)[29]) {
   typedef C V __attribute__((ext_vector_type(2)));
@@ -93,7 +94,8 @@ template <> struct LaneOps<float> {
   static __device__ __forceinline__ float sign1(float x) { return x < 0.f ? -1.f : 1.f; }
 };
 template <> struct LaneOps<double> {
-  static __device__ __forceinline__ double rsqrt(double x) {   // fp32 estimate + two Newton steps: ~1 ulp of fp64 without the IEEE sqrt + divide sequences
+  // fp32 estimate + two Newton steps: ~1 ulp of fp64 without the IEEE sqrt + divide sequences
+  static __device__ __forceinline__ double rsqrt(double x) {
     double y = (double)__builtin_amdgcn_rsqf((float)x);
     const double hx = 0.5 * x;
     y = y * fma(-hx * y, y, 1.5);
@@ -163,7 +165,8 @@ __device__ __forceinline__ C bearing_residual_norm(double pxd, double pyd, doubl
 }
 // a pair of correspondences as 2-vectors
 template <class C>
-__device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&bx)[2], const C (&by)[2],
+__device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2],
+    const C (&bx)[2], const C (&by)[2],
                                              const C (&bz)[2], const C (&w)[2], C __attribute__((ext_vector_type(2))) (&s)[29]) {
   typedef C V __attribute__((ext_vector_type(2)));
   const V BX = {bx[0], bx[1]}, BY = {by[0], by[1]}, BZ = {bz[0], bz[1]};
@@ -178,11 +181,13 @@ __device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x
     d1[e] = (C)dot_e_p(e1[0][e], e1[1][e], e1[2][e], pxd, pyd, pzd);
     d2[e] = (C)dot_e_p(e2[0][e], e2[1][e], e2[2][e], pxd, pyd, pzd);
   }
-  bearing_rows<V>(V{px[0], px[1]}, V{py[0], py[1]}, V{pz[0], pz[1]}, e1, e2, V{d1[0], d1[1]}, V{d2[0], d2[1]}, BX, BY, BZ, V{w[0], w[1]},
+  bearing_rows<V>(V{px[0], px[1]}, V{py[0], py[1]}, V{pz[0], pz[1]}, e1, e2, V{d1[0], d1[1]}, V{d2[0], d2[1]}, BX, BY, BZ,
+      V{w[0], w[1]},
                   V{w[0], w[1]}, s);
 }
 
-// The two pair kinds (point-to-plane, bearing): one group of P correspondences added into the 2-vector partial sums s2 (NOT widened: the
+// The two pair kinds (point-to-plane, bearing): one group of P correspondences added into the 2-vector partial sums s2 (NOT widened:
+// the
 // caller decides how many groups share one widening into the fp64 accumulators -- flush_pairs).
 template <class T, int KIND, bool MASK, bool WEIGHT>
 __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&vw)[3 * Pk<T>::P], const T (&vb)[3 * Pk<T>::P],
@@ -201,14 +206,18 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&
       if (MASK) w = m[i] == 1 ? w : T(0);
       w = (i < npresent && !all_nan(bx[e], by[e], bz[e])) ? w : T(0);
       const bool off = w == T(0);
-      // keeps NaN / inf of skipped columns out of the sums (selects, not branches); bearing: p = t + R (0, 0, 1) != 0 keeps 1 / |p| finite
+      // keeps NaN / inf of skipped columns out of the sums (selects, not branches); bearing: p = t + R (0, 0, 1) != 0 keeps 1 / |p|
+      // finite
       x[e] = off ? T(0) : vw[3 * i]; y[e] = off ? T(0) : vw[3 * i + 1]; z[e] = off ? (KIND == KIND_BEARING ? T(1) : T(0)) : vw[3 * i + 2];
       bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
-      if (KIND == KIND_P2PLANE) { nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1]; nz[e] = off ? T(0) : vc[3 * i + 2]; }
+      if (KIND == KIND_P2PLANE) { nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1];
+          nz[e] = off ? T(0) : vc[3 * i + 2]; }
       wi[e] = w;
     }
-    if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);   // 35 of the ~50 operations per point are the accumulation
-    else bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);                                              // two rows per point: 70 of ~100
+    // 35 of the ~50 operations per point are the accumulation
+    if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
+    // two rows per point: 70 of ~100
+    else bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
   }
 }
 // widen the pair sums into the fp64 accumulators and clear them.  A widening costs three instructions per sum (add the halves,
@@ -274,9 +283,11 @@ __device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const
 // bounded time (~2 s of the 100 MHz clock, then the kernel exits without publishing and the host reports an error).
 // ================================================================================================
 constexpr unsigned long long kResidentStop = 1ull << 63;
-// one group of P correspondences through the bounds-checked loaders when it is the ragged last one (g == full), plain 16-byte loads otherwise
+// one group of P correspondences through the bounds-checked loaders when it is the ragged last one (g == full), plain 16-byte loads
+// otherwise
 template <class T, int KIND, bool MASK, bool WEIGHT>
-__device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c, const short* __restrict__ mask,
+__device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
+    const short* __restrict__ mask,
                                                const T* __restrict__ weight, int64_t g, int64_t full, int64_t n, T (&vw)[3 * Pk<T>::P],
                                                T (&vb)[3 * Pk<T>::P], T (&vc)[3 * Pk<T>::P], short (&m)[Pk<T>::P], T (&wv)[Pk<T>::P]) {
   typedef typename Pk<T>::V V;
@@ -287,7 +298,8 @@ __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T
     const V y0 = b4[3 * g], y1 = b4[3 * g + 1], y2 = b4[3 * g + 2];
     unpack3(x0, x1, x2, vw);
     unpack3(y0, y1, y2, vb);
-    if (KIND == KIND_P2PLANE) { const V* c4 = reinterpret_cast<const V*>(c); const V z0 = c4[3 * g], z1 = c4[3 * g + 1], z2 = c4[3 * g + 2]; unpack3(z0, z1, z2, vc); }
+    if (KIND == KIND_P2PLANE) { const V* c4 = reinterpret_cast<const V*>(c);
+        const V z0 = c4[3 * g], z1 = c4[3 * g + 1], z2 = c4[3 * g + 2]; unpack3(z0, z1, z2, vc); }
     if (MASK) load_mask_full(mask, g, m);
     if (WEIGHT) load_weight_full(weight, g, wv);
   } else {
@@ -307,7 +319,8 @@ __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T
 // away (2 s); the value is uniform over the workgroup.
 constexpr int kAutoMaxRunSums = 1024;   // run records x sums an autonomous iteration reads per workgroup (resident_auto_stage)
 template <int BLK>
-__device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want, double* __restrict__ s_pose,
+__device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want,
+    double* __restrict__ s_pose,
                                                   int* __restrict__ s_go, unsigned long long wait_ticks = 200000000ull) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
@@ -344,7 +357,8 @@ __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __re
 // received every run record, i.e. after the granules have been read.  Returns false if a granule never arrived (the kernel ends without
 // publishing; the host reports that).
 template <int NACC, int BLK>
-__device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, unsigned long long seq,
+__device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag,
+    unsigned long long seq,
                                                      bool stamp_it) {
   constexpr int NW = BLK / 64;
   constexpr int RGN = BLK / NACC;                       // rows a collecting workgroup takes with one granule per thread
@@ -359,7 +373,8 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
     double own = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
-    const bool withheld = fin.fault_tag != 0 && tag == fin.fault_tag && blockIdx.x + 1 == gridDim.x;   // test hook: a granule that never comes
+    // test hook: a granule that never comes
+    const bool withheld = fin.fault_tag != 0 && tag == fin.fault_tag && blockIdx.x + 1 == gridDim.x;
     if ((int)blockIdx.x != leader) { if (!withheld) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag); }
     else g_part[0][threadIdx.x] = own;
   }
@@ -404,7 +419,8 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 // that its collector published after reading iteration i's.  Returns 0 = next iteration, 1 = finished (workgroup 0 published pose |
 // step | cost | iterations | status | weight sum to the host), 2 = a granule never arrived (2 s).
 template <int NACC, int BLK>
-__device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it, int max_iters,
+__device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it,
+    int max_iters,
                                                    double tol, double* __restrict__ s_pose, bool stamp_it = false) {
   constexpr int NW = BLK / 64;
   constexpr int RGN = BLK / NACC;

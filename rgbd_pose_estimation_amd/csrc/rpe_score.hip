@@ -53,7 +53,8 @@ template <class T> struct Hyp<T, false> {
 };
 // exact form: the reference's own operation sequence in Tp, no FMA contraction.
 //   R*x     = Eigen _transformVector (sophus/so3.hpp:238-240): uv = 2 (u x v); v + w uv + u x uv
-//   3D test = |Xc - (R Xw + t)| < thre_3d with norm = sqrt(x^2 + y^2 + z^2)      (AbsoluteOrientation.hpp:137-138), evaluated as x^2 + y^2 + z^2 < cut
+// 3D test = |Xc - (R Xw + t)| < thre_3d with norm = sqrt(x^2 + y^2 + z^2) (AbsoluteOrientation.hpp:137-138), evaluated as x^2 + y^2 +
+// z^2 < cut
 //   2D test = normalize(R Xw + t) . bv > cos_thr, normalisation by division        (:413-418)
 //   N-N     = Nc . (R Nw) > cos_nl                                                  (AbsoluteOrientationNormal.hpp:248-249)
 template <class T> struct Hyp<T, true> {
@@ -98,7 +99,8 @@ template <class T> struct Hyp<T, true> {
     const V2 cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
     ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
   }
-  __device__ __forceinline__ void rotm2(V2 x, V2 y, V2 z, V2& ox, V2& oy, V2& oz) const {   // so3().matrix() * x (kneip_ransac, P3P.hpp:365)
+  // so3().matrix() * x (kneip_ransac, P3P.hpp:365)
+  __device__ __forceinline__ void rotm2(V2 x, V2 y, V2 z, V2& ox, V2& oy, V2& oz) const {
 #pragma clang fp contract(off)
     ox = M[0] * x + M[1] * y + M[2] * z; oy = M[3] * x + M[4] * y + M[5] * z; oz = M[6] * x + M[7] * y + M[8] * z;
   }
@@ -109,7 +111,8 @@ template <class T> struct Hyp<T, true> {
     const V2 ss = ex * ex + ey * ey + ez * ez;
     a = ss.x < cut; b = ss.y < cut;
   }
-  // The reference's 2D test -- normalise by three IEEE divisions behind a square root, dot, compare (AbsoluteOrientation.hpp:413-418) --
+  // The reference's 2D test -- normalise by three IEEE divisions behind a square root, dot, compare (AbsoluteOrientation.hpp:413-418)
+  // --
   // costs five times the 3D test.  Its value cos_ref differs from the exact cosine c* = p.bv / |p| by at most 6.5 u (u = unit
   // roundoff of Tp: |p|^2 carries 3 roundings, the root and each quotient one more, products and the two sums one each; sum |p^_i bv_i|
   // <= 1), and a cheap estimate  ct = (p.bv) * rsqrt(|p|^2)  -- same |p|^2, hardware reciprocal square root to 1 ulp (fp64: fp32
@@ -128,7 +131,8 @@ template <class T> struct Hyp<T, true> {
       const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
       const T band = T(24) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 24 u
       const T hi = c + band, lo = c - band;
-      const T tiny = T(1e-30), huge = T(1e30);   // |p|^2 in metres^2; also the range in which the fp32 estimate behind the fp64 form is finite
+      // |p|^2 in metres^2; also the range in which the fp32 estimate behind the fp64 form is finite
+      const T tiny = T(1e-30), huge = T(1e30);
       const bool in0 = ct.x > hi, in1 = ct.y > hi;
       const bool sure0 = (in0 | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge), sure1 = (in1 | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge);
       if (__builtin_amdgcn_ballot_w64(!(sure0 & sure1)) == 0) { a = in0; b = in1; return; }
@@ -286,13 +290,15 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
   }
 }
 
-// Small batches (the first RANSAC batches: 8 .. 32 hypotheses): ONE launch and no device-side staging at all -- the hypotheses arrive as
+// Small batches (the first RANSAC batches: 8 .. 32 hypotheses): ONE launch and no device-side staging at all -- the hypotheses arrive
+// as
 // a kernel argument (no H2D copy), every wave counts as above (lane h holds hypothesis h's count), the per-wave counts go straight into
 // the collecting stage (collect_and_send: integers < 2^53 as doubles, exact), and the host adds the run records.  Replaces copy +
 // scoring kernel + read-out kernel + flag (42 us per batch of 16 at 640 x 480) for lists of up to HB hypotheses.
 template <class T, int HB, int STRIDE> struct SmallPoses { T v[HB * STRIDE]; };
 template <class T, int KIND, bool EXACT, int HB>
-__global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+__global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
+    const T* __restrict__ bv,
                                                              const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
                                                              SmallPoses<T, HB, Hyp<T, EXACT>::STRIDE> sp, const T* __restrict__ dposes, int H, int hs,
                                                              T thr33, T cthr, T cnl, Finish fin) {
@@ -373,7 +379,8 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
       const bool present = (g * P + i) < n;
       const bool valid = present & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
       const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-      fnn[i] = MD::mnn ? (valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl)) : false;
+      fnn[i] = MD::mnn ? (valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2],
+          cnl)) : false;
       f33[i] = MD::m33 ? (valid & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33)) : false;
       f23[i] = MD::m23 ? (present & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX)) : false;
       cnt += (int)fnn[i] + (int)f33[i] + (int)f23[i];
@@ -410,7 +417,8 @@ static void score_launch(const DeviceArrays& A, const void* d_poses, int H, cons
     hchunk = ((chunks64 + gy - 1) / gy) * 64;
     gy = (H + hchunk - 1) / hchunk;
   }
-  hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G, gy), dim3(kBlock), (size_t)hchunk * sizeof(int), s, (const T*)A.a[0], (const T*)A.a[1],
+  hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G, gy), dim3(kBlock), (size_t)hchunk * sizeof(int), s, (const T*)A.a[0],
+      (const T*)A.a[1],
                      (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, hchunk, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
 }
 template <class T, int KIND, bool EXACT>
@@ -449,7 +457,8 @@ hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* 
   return hipGetLastError();
 }
 template <class T, int KIND, bool EXACT>
-static void score_small_launch(const DeviceArrays& A, const void* h_poses, const void* d_poses, int H, const double* thr, const ReduceTarget& rt, int cap,
+static void score_small_launch(const DeviceArrays& A, const void* h_poses, const void* d_poses, int H, const double* thr,
+    const ReduceTarget& rt, int cap,
                                hipStream_t s) {
   constexpr int STRIDE = Hyp<T, EXACT>::STRIDE;
   const Finish fin = make_finish(rt);
@@ -477,7 +486,8 @@ int score_small_cap(int dtype, int exact) {
 // h_poses: H hypotheses staged in HOST memory in the scoring layout of `exact`, values of the array dtype (they travel in the kernel
 // argument) -- or null and d_poses: the same list in HBM (a device-generated batch).  The vote counts arrive through rt (a collecting
 // target): record[h] = votes of hypothesis h.
-hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H, const double* thr3,
+hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H,
+    const double* thr3,
                               const ReduceTarget& rt, hipStream_t s) {
   if (H < 1 || H > score_small_cap(A.dtype, exact) || rt.rows < 1 || (!h_poses == !d_poses)) return hipErrorInvalidValue;
   const int cap = 2048;   // workgroups (grid-stride beyond)

@@ -83,7 +83,8 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   void sortIdx(int top_k = -1) {
     const int want = top_k < 0 || top_k > (int)_weights_3d.size() ? (int)_weights_3d.size() : top_k;
     if (_idx_top >= want && (int)_idx.size() >= want && want > 0) return;
-    _idx = rpe::device_prosac_order<Tp>(this->device(), _weights_3d, top_k);   // top-k select + sort on the GPU for a dense frame's weights ...
+    // top-k select + sort on the GPU for a dense frame's weights ...
+    _idx = rpe::device_prosac_order<Tp>(this->device(), _weights_3d, top_k);
     if (_idx.empty()) _idx = sortIndexes<Tp>(_weights_3d, top_k);                  // ... the same prefix on the host otherwise
     _idx_top = (int)_idx.size();
   }
@@ -92,9 +93,12 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   // ---- additive accessors for the device backend
   const Tp* pointsCurrData() const { return _points_c.p; }
   const Tp* pointsGlobData() const { return _points_g.p; }
-  std::vector<short>& inlierMask33() { flushInlierIdx(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }   // host copy, for modification
-  const std::vector<short>& inlierMask33() const { return mask33(); }                                                  // host copy, read only
-  void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }                                             // device copy current
+  // host copy, for modification
+  std::vector<short>& inlierMask33() { flushInlierIdx(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }
+  // host copy, read only
+  const std::vector<short>& inlierMask33() const { return mask33(); }
+  // device copy current
+  void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }
   virtual void syncHostMasks() const { (void)mask33(); }
   const std::vector<Tp>& weights33() const { return _weights_3d; }
   Tp weightScale33() const { return Tp(1); }

@@ -76,7 +76,8 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
-  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K)); if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
+  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K));
+      if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
   ProsacSampler<Tp> ps(K, N);
   VoteSpec<Tp> spec;
   spec.kind = RPE_VOTE_33; spec.thre_3d = dist_thre_3d_; spec.modalities = 1; spec.model_points = K;
@@ -97,7 +98,8 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
   auto commit = [&](int cols, unsigned device_cols) { adapter.forgetInlierIdx(); adapter.setInlierFromDevice(cols, device_cols); };
   // plain RANSAC consumes exactly K draws per iteration, so every iteration's position in the random stream is known up front and
   // the whole iteration can run on the device; PROSAC's sampler rejects duplicates (a variable number of draws) and stays on the host
-  if (!prosac && Settings::get().device_hypotheses && N >= K && !Settings::get().capture && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+  if (!prosac && Settings::get().device_hypotheses && N >= K && !Settings::get().capture
+      && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   else ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   adapter.cvtInlier();
 }
@@ -147,7 +149,8 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
-  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K + 1)); if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
+  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K + 1));
+      if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
   ProsacSampler<Tp> ps(K + 1, N);
   VoteSpec<Tp> spec;
   spec.kind = RPE_VOTE_33_23; spec.thre_3d = dist_thre_3d_;
@@ -161,7 +164,8 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
   auto gen = [&](std::vector<SE3<Tp> >& out) {
     std::vector<int> sel;
     if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K + 1, &sel);
-    if (assign_sample<Tp>(adapter, sel, &X_w, &X_c, &bv)) { const SE3<Tp> fit = shinji<Tp>(X_w, X_c, K); if (fit.so3().valid()) out.push_back(fit); }
+    if (assign_sample<Tp>(adapter, sel, &X_w, &X_c, &bv)) { const SE3<Tp> fit = shinji<Tp>(X_w, X_c, K);
+        if (fit.so3().valid()) out.push_back(fit); }
     SE3<Tp> sk;
     if (kneip<Tp>(X_w, bv, &sk)) out.push_back(sk);
   };
@@ -171,7 +175,8 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
   };
   const Settings& cfg = Settings::get();
   if (!prosac && cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
-    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/1, gen, commit, Iter, confidence, /*mask_cols=*/2);   // FAST mode: later batches generated on the device
+    // FAST mode: later batches generated on the device
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/1, gen, commit, Iter, confidence, /*mask_cols=*/2);
   else
     ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
   PnPPoseAdapter<Tp>* pAdapter = &adapter;
@@ -181,11 +186,13 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
 }  // namespace rpe
 
 template <typename Tp>
-void shinji_kneip_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {  // :367-438
+// :367-438
+void shinji_kneip_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {
   rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, false);
 }
 template <typename Tp>
-void shinji_kneip_prosac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {  // :440-515
+// :440-515
+void shinji_kneip_prosac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {
   rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, true);
 }
 

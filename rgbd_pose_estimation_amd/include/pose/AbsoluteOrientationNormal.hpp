@@ -36,7 +36,8 @@ void sync_masks_and_weights(NormalAOPoseAdapter<Tp>& adapter) {
 }
 // one fused pass of kernel K5; returns the 44-value record described in include/rgbd_pose_hip.h
 template <typename Tp>
-void nl_round_on_device(NormalAOPoseAdapter<Tp>& adapter, const Point3<Tp>& c_opt, const Point3<Tp>& Cw, const Point3<Tp>& Cc, double out44[44]) {
+void nl_round_on_device(NormalAOPoseAdapter<Tp>& adapter, const Point3<Tp>& c_opt, const Point3<Tp>& Cw, const Point3<Tp>& Cc,
+    double out44[44]) {
   ensure_all_arrays<Tp>(adapter);
   sync_masks_and_weights<Tp>(adapter);
   const Matrix3<Tp> Rwc = adapter.getRcw().inverse().matrix();
@@ -70,7 +71,8 @@ rpe::Point3<Tp> find_opt_cc(NormalAOPoseAdapter<Tp>& adapter) {
 
 template <typename Tp>
 bool assign_sample(const NormalAOPoseAdapter<Tp>& adapter, const std::vector<int>& selected_cols_, rpe::MatrixX<Tp>* p_X_w_,
-                   rpe::MatrixX<Tp>* p_N_w_, rpe::MatrixX<Tp>* p_X_c_, rpe::MatrixX<Tp>* p_N_c_, rpe::MatrixX<Tp>* p_bv_) {  // reference :48-75
+                   // reference :48-75
+                   rpe::MatrixX<Tp>* p_N_w_, rpe::MatrixX<Tp>* p_X_c_, rpe::MatrixX<Tp>* p_N_c_, rpe::MatrixX<Tp>* p_bv_) {
   const int K = (int)selected_cols_.size() - 1;
   int nValid = 0;
   for (int s = 0; s < K; s++) {
@@ -110,7 +112,8 @@ void nl_2p(const rpe::Point3<Tp>& pt1_c, const rpe::Point3<Tp>& nl1_c, const rpe
 namespace rpe {
 // which = 0: nl_kneip_ransac (:215-284), 1: nl_shinji_ransac (:286-354), 2: nl_shinji_kneip_ransac (:356-445)
 template <typename Tp>
-void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, const Tp thre_2d_, const Tp nl_thre, int& Iter, Tp confidence) {
+void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, const Tp thre_2d_, const Tp nl_thre, int& Iter,
+    Tp confidence) {
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
@@ -147,7 +150,8 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
   };
   const Settings& cfg = Settings::get();
   if (cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
-    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/2 + which, gen, commit, Iter, confidence, /*mask_cols=*/3);   // FAST mode: later batches generated on the device
+    // FAST mode: later batches generated on the device
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/2 + which, gen, commit, Iter, confidence, /*mask_cols=*/3);
   else
     ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/3);
   if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->cvtInlier(); }

@@ -23,7 +23,8 @@ struct PinholeCamera {
   double fx = 585., fy = 585., cx = 320., cy = 240.;   // Simulator.hpp:160-162, SimpleMain.cpp:42
   int width = 640, height = 480;
 };
-struct DepthRange {   // metres = raw value * scale; vertices outside (dmin, dmax) are invalid; normals are dropped across jumps > max_jump
+// metres = raw value * scale; vertices outside (dmin, dmax) are invalid; normals are dropped across jumps > max_jump
+struct DepthRange {
   double scale, dmin, dmax, max_jump;
   static DepthRange millimetres() { return DepthRange{0.001, 0.3, 8.0, 0.1}; }   // the usual uint16 sensor frame
   static DepthRange metres() { return DepthRange{1.0, 0.3, 8.0, 0.1}; }
@@ -32,7 +33,8 @@ struct IcpOptions {
   int kind = RPE_RES_P2PLANE;
   int max_iter = 10;
   double tol = 1e-6, dist_thr = 0.1, cos_thr = 0.9;
-  // fused + host update = ONE resident launch for the whole loop (the fastest form: 11 us per round at 640 x 480); device_resident = true
+  // fused + host update = ONE resident launch for the whole loop (the fastest form: 11 us per round at 640 x 480); device_resident =
+  // true
   // keeps solve and update on the GPU instead (also one launch, the grid iterates by itself: 12 us per round; no busy host thread)
   bool use_normals = true, device_resident = false, fused = true;
 };
@@ -53,8 +55,10 @@ class DepthFrontEnd {
   DepthFrontEnd(const DepthFrontEnd&) = delete;
   DepthFrontEnd& operator=(const DepthFrontEnd&) = delete;
 
-  void setDepth(const unsigned short* depth, const PinholeCamera& cam, const DepthRange& r = DepthRange::millimetres()) { set(depth, RPE_DEPTH_U16, cam, r); }
-  void setDepth(const float* depth, const PinholeCamera& cam, const DepthRange& r = DepthRange::metres()) { set(depth, RPE_DEPTH_F32, cam, r); }
+  void setDepth(const unsigned short* depth, const PinholeCamera& cam,
+      const DepthRange& r = DepthRange::millimetres()) { set(depth, RPE_DEPTH_U16, cam, r); }
+  void setDepth(const float* depth, const PinholeCamera& cam,
+      const DepthRange& r = DepthRange::metres()) { set(depth, RPE_DEPTH_F32, cam, r); }
   // the current frame, seen from T_cw, becomes the model the next frames are registered against
   void setModelFromFrame(const Pose& T_cw) {
     double p[12]; pose12(T_cw, p);
@@ -63,7 +67,8 @@ class DepthFrontEnd {
   void setModel(const MatrixX<float>& vertex_w, const MatrixX<float>& normal_w, const PinholeCamera& cam, const Pose& T_cw) {
     double p[12]; pose12(T_cw, p);
     const rpe_camera k = cam_of(cam);
-    if (vertex_w.cols() != cam.width * cam.height || normal_w.cols() != vertex_w.cols()) throw DeviceError(RPE_ERR_ARG, "setModel: maps must be 3 x width*height");
+    if (vertex_w.cols() != cam.width * cam.height || normal_w.cols() != vertex_w.cols()) throw DeviceError(RPE_ERR_ARG,
+        "setModel: maps must be 3 x width*height");
     check(rpe_model_upload(_ctx, vertex_w.data(), normal_w.data(), &k, p), "rpe_model_upload");
   }
   MatrixX<float> map(int which) const {
@@ -95,7 +100,8 @@ class DepthFrontEnd {
     Pairs P;
     P.count = associate(guess, dist_thr, cos_thr, use_normals);
     MatrixX<float>* dst[RPE_NUM_ARRAYS] = {&P.xw, &P.xc, &P.bv, &P.nw, &P.nc};
-    for (int s = 0; s < RPE_NUM_ARRAYS; s++) { dst[s]->resize(3, _pixels); check(rpe_download(_ctx, s, dst[s]->data()), "rpe_download"); }
+    for (int s = 0; s < RPE_NUM_ARRAYS; s++) { dst[s]->resize(3, _pixels);
+        check(rpe_download(_ctx, s, dst[s]->data()), "rpe_download"); }
     return P;
   }
   // an adapter constructed over `P` runs its solvers on this front end's context: the arrays are already in HBM
@@ -118,7 +124,8 @@ class DepthFrontEnd {
   }
 
  private:
-  static rpe_camera cam_of(const PinholeCamera& c) { rpe_camera k; k.fx = c.fx; k.fy = c.fy; k.cx = c.cx; k.cy = c.cy; k.width = c.width; k.height = c.height; return k; }
+  static rpe_camera cam_of(const PinholeCamera& c) { rpe_camera k; k.fx = c.fx; k.fy = c.fy; k.cx = c.cx; k.cy = c.cy;
+      k.width = c.width; k.height = c.height; return k; }
   void set(const void* depth, int type, const PinholeCamera& cam, const DepthRange& r) {
     const rpe_camera k = cam_of(cam);
     check(rpe_frame_set_depth(_ctx, depth, type, &k, r.scale, r.dmin, r.dmax, r.max_jump), "rpe_frame_set_depth");

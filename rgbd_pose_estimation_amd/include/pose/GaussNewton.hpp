@@ -27,7 +27,8 @@ int gn_run(Adapter& adapter, int nterms, const int* kinds, const double* scales,
   for (int i = 0; i < 3; i++) pose[9 + i] = adapter.gettw()[i];
   int iters = 0;
   double step = 0, cost = 0;
-  check(rpe_gn_refine(adapter.device().ctx(), nterms, kinds, scales, use_inliers ? RPE_USE_MASK : 0, pose, max_iter, tol, &iters, &step, &cost),
+  check(rpe_gn_refine(adapter.device().ctx(), nterms, kinds, scales, use_inliers ? RPE_USE_MASK : 0, pose, max_iter, tol, &iters,
+      &step, &cost),
         "rpe_gn_refine");
   Matrix3<Tp> Rt;
   for (int i = 0; i < 9; i++) Rt.a[i] = (Tp)pose[i];
@@ -105,7 +106,8 @@ int gn_refine_full(NormalAOPoseAdapter<Tp>& adapter, const rpe::JointOptions& o 
   int iters = 0;
   double step = 0, cost = 0;
   const int flags = (o.use_inliers ? RPE_USE_MASK : 0) | ((o.use_weights && !adapter.weights33().empty()) ? RPE_USE_WEIGHT : 0);
-  rpe::check(rpe_gn_refine_joint(adapter.device().ctx(), 3, terms, flags, pose, o.max_iter, o.tol, &iters, &step, &cost), "rpe_gn_refine_joint");
+  rpe::check(rpe_gn_refine_joint(adapter.device().ctx(), 3, terms, flags, pose, o.max_iter, o.tol, &iters, &step, &cost),
+      "rpe_gn_refine_joint");
   rpe::Matrix3<Tp> Rt;
   for (int i = 0; i < 9; i++) Rt.a[i] = (Tp)pose[i];
   const rpe::Quat<Tp> q = rpe::quat_from_R<Tp>(Rt.a);

@@ -24,7 +24,8 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
   NormalAOPoseAdapter(const M& bearingVectors, const M& points_c, const M& normal_c, const M& points_g, const M& normal_g)
       : AOPoseAdapter<Tp>(bearingVectors, points_c, points_g), _normal_c(normal_c), _normal_g(normal_g) { initn(); }
   template <class M>
-  NormalAOPoseAdapter(const M& bearingVectors, const M& points_c, const M& normal_c, const M& points_g, const M& normal_g, const SO3_T& R)
+  NormalAOPoseAdapter(const M& bearingVectors, const M& points_c, const M& normal_c, const M& points_g, const M& normal_g,
+      const SO3_T& R)
       : AOPoseAdapter<Tp>(bearingVectors, points_c, points_g, R), _normal_c(normal_c), _normal_g(normal_g) { initn(); }
   template <class M>
   NormalAOPoseAdapter(const M& bearingVectors, const M& points_c, const M& normal_c, const M& points_g, const M& normal_g,
@@ -33,7 +34,8 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
   virtual ~NormalAOPoseAdapter() {}
 
   bool isInlierNN(int index) const { return maskNN()[index] == 1; }
-  Tp weightNN(int index) const { return _weights_nl.empty() ? Tp(1.0) : Tp(_weights_nl[index]) / std::numeric_limits<short>::max(); }  // :153-161
+  // :153-161
+  Tp weightNN(int index) const { return _weights_nl.empty() ? Tp(1.0) : Tp(_weights_nl[index]) / std::numeric_limits<short>::max(); }
   virtual Point3 getNormalCurr(int index) const { return _normal_c.col(index); }
   virtual Point3 getNormalGlob(int index) const { return _normal_g.col(index); }
   virtual void setInlier(const rpe::MatrixXs& inliers) {  // reference :179-195

@@ -178,7 +178,8 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
   const int N = adapter.getNumberCorrespondences();
   const int K = 4;
   RandomElements<int> re(N);
-  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K)); if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
+  if (prosac) { const double t0 = rpe::Settings::get().profile ? rpe::now_us() : 0; adapter.sortIdx(rpe::prosac_prefix(Iter, K));
+      if (rpe::Settings::get().profile) rpe::Settings::get().prof.sort += rpe::now_us() - t0; }
   ProsacSampler<Tp> ps(K, N);
   VoteSpec<Tp> spec;
   // kneip_ransac multiplies by so3().matrix() (:365) and kneip_prosac by so3() (:442): two arithmetic variants

@@ -63,7 +63,8 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   void sortIdx(int top_k = -1) {   // cached per weight set, see AOOnlyPoseAdapter::sortIdx
     const int want = top_k < 0 || top_k > (int)_weights.size() ? (int)_weights.size() : top_k;
     if (_idx_top >= want && (int)_idx.size() >= want && want > 0) return;
-    _idx = rpe::device_prosac_order<Tp>(this->device(), _weights, top_k);   // top-k select + sort on the GPU for a dense frame's weights ...
+    // top-k select + sort on the GPU for a dense frame's weights ...
+    _idx = rpe::device_prosac_order<Tp>(this->device(), _weights, top_k);
     if (_idx.empty()) _idx = sortIndexes<Tp>(_weights, top_k);                  // ... the same prefix on the host otherwise
     _idx_top = (int)_idx.size();
   }

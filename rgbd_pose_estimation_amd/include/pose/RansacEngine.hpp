@@ -47,7 +47,8 @@ template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
 //   reference's order; first[i] .. first[i+1] = the hypotheses of iteration i (first.size() == iters + 1); votes[h] = score of hyps[h].
 // commit(cols, device_cols): the winner's masks are on the device; the adapter adopts them (setInlierFromDevice).
 template <class Tp, class Adapter, class Produce, class Commit>
-void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce produce, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce produce, Commit commit, int& Iter, Tp confidence,
+    int mask_cols) {
   const int N = adapter.getNumberCorrespondences();
   Settings& cfg = Settings::get();
   const bool prof = cfg.profile;
@@ -101,7 +102,8 @@ void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce p
     const bool hasnn = spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;
     // the device masks ARE the result: the adapter adopts them without a download (its host copy is fetched on first access,
     // rpe::HostMask); columns of modalities this solver does not vote on become zero, as in the matrix the reference builds
-    const unsigned device_cols = (has23 && mask_cols >= 1 ? 1u : 0u) | (has33 && mask_cols >= 2 ? 2u : 0u) | (hasnn && mask_cols >= 3 ? 4u : 0u);
+    const unsigned device_cols = (has23 && mask_cols >= 1 ? 1u : 0u) | (has33 && mask_cols >= 2 ? 2u : 0u) | (hasnn
+        && mask_cols >= 3 ? 4u : 0u);
     commit(mask_cols, device_cols);
 
     lap(cfg.prof.mask);
@@ -138,13 +140,15 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
         if (replay_pos < have)
           for (int h = in.first[replay_pos]; h < in.first[replay_pos + 1]; h++) {
             const double* q = &in.q7[7 * (size_t)h];
-            hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]), Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
+            hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]),
+                Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
           }
         first.push_back((int)hyps.size());
       }
     } else
     for (int i = 0; i < iters; i++) { gen(hyps); first.push_back((int)hyps.size()); }
-    if (cfg.profile) { const double t1 = now_us(); cfg.prof.generate += t1 - t0; cfg.prof.score -= t1 - t0; }   // the caller books the whole call as "score"
+    // the caller books the whole call as "score"
+    if (cfg.profile) { const double t1 = now_us(); cfg.prof.generate += t1 - t0; cfg.prof.score -= t1 - t0; }
     if (hyps.empty()) return;
     q7.resize(hyps.size() * 7);
     for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
@@ -158,11 +162,14 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
 // The 3D-3D solvers (shinji_ransac / shinji_ransac2): sampling, the 3-point fit and the scoring all run on the device
 // (rpe_ransac33_batch); the hypotheses are bitwise the ones the host generator above would produce from the same random stream,
 // which is advanced here by the K draws per iteration the host sampler would have consumed.
-// Short batches (the first ones: at most kHostBatch iterations) are generated by the host's `gen` instead -- eight 3-point fits take the
-// CPU 4 us, while a device batch of eight is one thread per fit running a 3x3 Jacobi SVD (25 us of latency) -- and scored by rpe_score's
+// Short batches (the first ones: at most kHostBatch iterations) are generated by the host's `gen` instead -- eight 3-point fits take
+// the
+// CPU 4 us, while a device batch of eight is one thread per fit running a 3x3 Jacobi SVD (25 us of latency) -- and scored by
+// rpe_score's
 // single-launch form; the random stream is the same either way, so the two can alternate batch by batch.
 template <class Tp, class Adapter, class Gen, class Commit>
-void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence,
+    int mask_cols) {
   constexpr int kHostBatch = 32;
   Settings& cfg = Settings::get();
   rpe_context* ctx = adapter.device().ctx();
@@ -195,7 +202,8 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
     for (int i = 0; i < iters; i++) {
       if (valid[(size_t)i]) {
         const double* q = &q7[7 * (size_t)i];
-        hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]), Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
+        hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]),
+            Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
         votes.push_back(all_votes[(size_t)i]);
       }
       first.push_back((int)hyps.size());
@@ -206,9 +214,11 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
 
 // The plain-RANSAC solvers with a 4-point sample in FAST scoring mode (solver 0 kneip_ransac, 1 shinji_kneip_ransac, 2 nl_kneip_ransac,
 // 3 nl_shinji_ransac, 4 nl_shinji_kneip_ransac): batches beyond the first few are generated AND scored on the device
-// (rpe_ransac_p3p_batch; one slot per hypothesis an iteration can yield, invalid slots skipped in the replay).  The device P3P agrees with the host's to rounding only, which is why the vote-exact default never takes this path.
+// (rpe_ransac_p3p_batch; one slot per hypothesis an iteration can yield, invalid slots skipped in the replay). The device P3P agrees
+// with the host's to rounding only, which is why the vote-exact default never takes this path.
 template <class Tp, class Adapter, class Gen, class Commit>
-void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int solver, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int solver, Gen gen, Commit commit, int& Iter, Tp confidence,
+    int mask_cols) {
   constexpr int kHostBatch = 32;
   Settings& cfg = Settings::get();
   rpe_context* ctx = adapter.device().ctx();
@@ -236,7 +246,8 @@ void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int so
     q7.resize(slots * 7); valid.resize(slots); all_votes.resize(slots);
     for (int done = 0; done < iters;) {
       const int chunk = std::min(iters - done, 8192 / per);
-      check(rpe_ransac_p3p_batch(ctx, solver, g.state(), g.inc(), chunk, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, all_votes.data() + (size_t)done * per,
+      check(rpe_ransac_p3p_batch(ctx, solver, g.state(), g.inc(), chunk, (double)spec.thre_3d, (double)spec.cos_thr,
+          (double)spec.cos_nl, all_votes.data() + (size_t)done * per,
                                  q7.data() + 7 * (size_t)done * per, valid.data() + (size_t)done * per), "rpe_ransac_p3p_batch");
       g.advance(4ull * (uint64_t)chunk);   // the host sampler draws 4 per iteration
       done += chunk;
@@ -246,7 +257,8 @@ void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int so
         const size_t sl = (size_t)i * per + k;
         if (valid[sl]) {
           const double* q = &q7[7 * sl];
-          hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]), Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
+          hyps.push_back(SE3<Tp>(SO3<Tp>::fromQuaternionRaw((Tp)q[0], (Tp)q[1], (Tp)q[2], (Tp)q[3]),
+              Point3<Tp>((Tp)q[4], (Tp)q[5], (Tp)q[6])));
           votes.push_back(all_votes[sl]);
         }
       }

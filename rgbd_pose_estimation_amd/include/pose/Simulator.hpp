@@ -15,10 +15,12 @@
 namespace rpe {
 inline std::mt19937_64& sim_engine() { static std::mt19937_64 e(5489u); return e; }
 inline void sim_seed(uint64_t s) { sim_engine().seed(s); }
-template <typename T> inline T sim_uniform() { return std::uniform_real_distribution<T>(T(-1), T(1))(sim_engine()); }  // Eigen Random(): U[-1,1]
+// Eigen Random(): U[-1,1]
+template <typename T> inline T sim_uniform() { return std::uniform_real_distribution<T>(T(-1), T(1))(sim_engine()); }
 template <typename T> inline T sim_normal() { return (T)std::normal_distribution<double>(0., 1.)(sim_engine()); }
 template <typename T> inline Point3<T> sim_vec3(bool gaussian) {
-  return gaussian ? Point3<T>(sim_normal<T>(), sim_normal<T>(), sim_normal<T>()) : Point3<T>(sim_uniform<T>(), sim_uniform<T>(), sim_uniform<T>());
+  return gaussian ? Point3<T>(sim_normal<T>(), sim_normal<T>(), sim_normal<T>()) : Point3<T>(sim_uniform<T>(), sim_uniform<T>(),
+      sim_uniform<T>());
 }
 // the reference's outlier index draw goes through RandomElements (rand()); use the library stream for it
 inline std::vector<int> sim_pick(int number, int count) {
@@ -83,7 +85,8 @@ void simulate_nl_nl_correspondences(const rpe::SO3<T>& R_cw_, int number_, T noi
 template <typename T>
 rpe::Point3<T> generate_a_random_point(T min_depth_, T max_depth_, T tan_fov_x, T tan_fov_y) {  // reference :135-145
   const rpe::Point3<T> u = rpe::sim_vec3<T>(false);
-  return rpe::Point3<T>(u[0] * tan_fov_x * max_depth_, u[1] * tan_fov_y * max_depth_, (u[2] + T(1.)) / T(2.) * (max_depth_ - min_depth_) + min_depth_);
+  return rpe::Point3<T>(u[0] * tan_fov_x * max_depth_, u[1] * tan_fov_y * max_depth_,
+      (u[2] + T(1.)) / T(2.) * (max_depth_ - min_depth_) + min_depth_);
 }
 
 template <typename T>
@@ -100,7 +103,8 @@ rpe::MatrixX<T> simulate_rand_point_cloud_in_frustum(int number_, T f_, T min_de
   rpe::MatrixX<T> cloud(3, number_);
   for (int i = 0; i < number_; i++) {
     rpe::Point3<T> P;
-    do { P = generate_a_random_point<T>(min_depth_, max_depth_, tx, ty); } while (!(std::fabs(P[0] / P[2]) < tx && std::fabs(P[1] / P[2]) < ty));
+    do { P = generate_a_random_point<T>(min_depth_, max_depth_, tx, ty);
+        } while (!(std::fabs(P[0] / P[2]) < tx && std::fabs(P[1] / P[2]) < ty));
     cloud.setCol(i, P);
   }
   return cloud;
@@ -136,7 +140,8 @@ template <typename T>
 void simulate_2d_3d_3d_correspondences(const rpe::SO3<T>& R_cw_, const rpe::Point3<T>& t_w_, int number_, T noise_2d_, T noise_3d_,
                                        T outlier_ratio_, T min_depth_, T max_depth_, T f_, bool use_guassian_, rpe::MatrixX<T>* pQ_,
                                        rpe::MatrixX<T>* pU_, rpe::MatrixX<T>* pP_gt = NULL, rpe::MatrixX<T>* p_all_weights_ = NULL) {
-  simulate_2d_3d_correspondences<T>(R_cw_, t_w_, number_, noise_2d_, outlier_ratio_, min_depth_, max_depth_, f_, use_guassian_, pQ_, pU_, pP_gt,
+  simulate_2d_3d_correspondences<T>(R_cw_, t_w_, number_, noise_2d_, outlier_ratio_, min_depth_, max_depth_, f_, use_guassian_, pQ_,
+      pU_, pP_gt,
                                     p_all_weights_);
   for (int i = 0; i < number_; i++) {
     const rpe::Point3<T> rv = rpe::sim_vec3<T>(use_guassian_);
@@ -166,12 +171,14 @@ void simulate_3d_3d_correspondences(const rpe::SO3<T>& R_cw_, const rpe::Point3<
 
 // all three modalities (reference :316-367); used as NormalAOPoseAdapter(U, P, N, Q, M)
 template <typename T>
-void simulate_2d_3d_nl_correspondences(const rpe::SO3<T>& R_cw_, const rpe::Point3<T>& t_w_, int number_, T n2D_, T or_2D_, T n3D_, T or_3D_,
+void simulate_2d_3d_nl_correspondences(const rpe::SO3<T>& R_cw_, const rpe::Point3<T>& t_w_, int number_, T n2D_, T or_2D_, T n3D_,
+    T or_3D_,
                                        T nNl_, T or_Nl_, T min_depth_, T max_depth_, T f_, bool use_guassian_, rpe::MatrixX<T>* pQ_,
                                        rpe::MatrixX<T>* pM_, rpe::MatrixX<T>* pP_, rpe::MatrixX<T>* pN_, rpe::MatrixX<T>* pU_,
                                        rpe::MatrixX<T>* p_all_weights_ = NULL) {
   rpe::MatrixX<T> all_weights(number_, 3), P_gt, nl_c_gt;
-  simulate_2d_3d_correspondences<T>(R_cw_, t_w_, number_, n2D_, or_2D_, min_depth_, max_depth_, f_, use_guassian_, pQ_, pU_, &P_gt, &all_weights);
+  simulate_2d_3d_correspondences<T>(R_cw_, t_w_, number_, n2D_, or_2D_, min_depth_, max_depth_, f_, use_guassian_, pQ_, pU_, &P_gt,
+      &all_weights);
   simulate_nl_nl_correspondences<T>(R_cw_, number_, nNl_, or_Nl_, true, pM_, pN_, &nl_c_gt, &all_weights);
   pP_->resize(3, number_);
   for (int i = 0; i < number_; i++) {
@@ -197,12 +204,15 @@ T axial_noise_kinect(T theta_, T z_) {
 }
 
 template <typename T>
-void simulate_kinect_2d_3d_nl_correspondences(const rpe::SO3<T>& R_cw_, const rpe::Point3<T>& t_w_, int number_, T noise_2d_, T outlier_ratio_2d_,
+void simulate_kinect_2d_3d_nl_correspondences(const rpe::SO3<T>& R_cw_, const rpe::Point3<T>& t_w_, int number_, T noise_2d_,
+    T outlier_ratio_2d_,
                                               T outlier_ratio_3d_, T noise_nl_, T outlier_ratio_nl_, T min_depth_, T max_depth_, T f_,
                                               rpe::MatrixX<T>* p_pt_w_, rpe::MatrixX<T>* p_nl_w_, rpe::MatrixX<T>* p_pt_c_,
-                                              rpe::MatrixX<T>* p_nl_c_, rpe::MatrixX<T>* p_bv_, rpe::MatrixX<T>* p_weights_ = NULL) {  // :389-436
+                                              // :389-436
+                                              rpe::MatrixX<T>* p_nl_c_, rpe::MatrixX<T>* p_bv_, rpe::MatrixX<T>* p_weights_ = NULL) {
   rpe::MatrixX<T> all_weights(number_, 3), pt_c_gt, nl_c_gt;
-  simulate_2d_3d_correspondences<T>(R_cw_, t_w_, number_, noise_2d_, outlier_ratio_2d_, min_depth_, max_depth_, f_, true, p_pt_w_, p_bv_, &pt_c_gt,
+  simulate_2d_3d_correspondences<T>(R_cw_, t_w_, number_, noise_2d_, outlier_ratio_2d_, min_depth_, max_depth_, f_, true, p_pt_w_,
+      p_bv_, &pt_c_gt,
                                     &all_weights);
   simulate_nl_nl_correspondences<T>(R_cw_, number_, noise_nl_, outlier_ratio_nl_, true, p_nl_w_, p_nl_c_, &nl_c_gt, &all_weights);
   const T sigma_min = axial_noise_kinect<T>(T(.0), min_depth_);
@@ -211,7 +221,8 @@ void simulate_kinect_2d_3d_nl_correspondences(const rpe::SO3<T>& R_cw_, const rp
     const T theta = std::acos(nl_c_gt.col(i).dot(rpe::Point3<T>(0, 0, -1)));
     const T z = pt_c_gt(2, i);
     const T sl = lateral_noise_kinect<T>(theta, z, f_), sa = axial_noise_kinect<T>(theta, z);
-    p_pt_c_->setCol(i, pt_c_gt.col(i) + rpe::Point3<T>(sl * rpe::sim_normal<T>(), sl * rpe::sim_normal<T>(), sa * rpe::sim_normal<T>()));
+    p_pt_c_->setCol(i, pt_c_gt.col(i) + rpe::Point3<T>(sl * rpe::sim_normal<T>(), sl * rpe::sim_normal<T>(),
+        sa * rpe::sim_normal<T>()));
     all_weights(i, 1) = T(sigma_min / sa);
   }
   const int out = int(outlier_ratio_3d_ * number_ + .5);

@@ -67,7 +67,8 @@ inline uint64_t prosac_key(float w, int index) {
   return ((uint64_t)(~u) << 32) | (uint32_t)index;
 }
 template <class T> inline void sort_candidates(std::vector<std::pair<T, int> >& cand, int top_k, std::vector<int>& order) {
-  std::sort(cand.begin(), cand.end(), [](const std::pair<T, int>& a, const std::pair<T, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+  std::sort(cand.begin(), cand.end(), [](const std::pair<T, int>& a, const std::pair<T,
+      int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
   order.resize((size_t)top_k);
   for (int i = 0; i < top_k; i++) order[i] = cand[i].second;
 }
@@ -143,7 +144,8 @@ class RandomElements {
   }
  private:
   T get(int p) const { for (size_t i = 0; i < _pos.size(); i++) if (_pos[i] == p) return _val[i]; return T(p); }
-  void set(int p, T v) { for (size_t i = 0; i < _pos.size(); i++) if (_pos[i] == p) { _val[i] = v; return; } _pos.push_back(p); _val.push_back(v); }
+  void set(int p, T v) { for (size_t i = 0; i < _pos.size(); i++) if (_pos[i] == p) { _val[i] = v; return; } _pos.push_back(p);
+      _val.push_back(v); }
   std::vector<int> _pos;
   std::vector<T> _val;
   int _n;

@@ -39,7 +39,8 @@ struct Settings {
   // RPE_SCORE_EXACT (default): the vote kernels replay the reference's operation sequence in Tp, so consensus sets, adapted Iter and
   // inlier masks are bit-exact to the repository's CPU restatement of the reference, whose one non-trivial third-party algorithm --
   // Eigen 3.3's JacobiSVD on a 3 x 3 -- is itself a restatement of the published algorithm, unverified against a real Eigen build
-  // (none exists in this image: DESIGN.md section 3, "parity unpinned").  RPE_SCORE_FAST (opt-in, RPE_SCORE_FAST=1 in the environment sets the default):
+  // (none exists in this image: DESIGN.md section 3, "parity unpinned"). RPE_SCORE_FAST (opt-in, RPE_SCORE_FAST=1 in the environment
+  // sets the default):
   // rotation-matrix FMA form, 2.7x the scoring rate; votes can differ for correspondences within rounding of a threshold.
   int score_mode = std::getenv("RPE_SCORE_FAST") && std::getenv("RPE_SCORE_FAST")[0] == '1' ? RPE_SCORE_FAST : RPE_SCORE_EXACT;
   // RANSAC iterations generated + scored per round trip: starts at first_batch and doubles up to max_batch.  The adaptive bound
@@ -55,7 +56,8 @@ struct Settings {
   //                    nothing is scored and no device is touched (rpe_host_hypotheses);
   //   replay  != null: the engines take their hypotheses from *replay instead of sampling (rpe_run_replay); scoring, the
   //                    best-so-far / adaptive-Iter replay and the winner's masks run as usual.
-  struct HypothesisList { std::vector<double> q7; std::vector<int> first; };   // first[i] .. first[i+1]: hypotheses of iteration i; 7 doubles each
+  // first[i] .. first[i+1]: hypotheses of iteration i; 7 doubles each
+  struct HypothesisList { std::vector<double> q7; std::vector<int> first; };
   // Per THREAD (the entry points that set them -- rpe_host_hypotheses, rpe_run_replay -- run the solver on the calling thread): a
   // solver running concurrently on another thread keeps sampling and scoring its own hypotheses.
   static inline thread_local HypothesisList* capture = nullptr;
@@ -63,7 +65,8 @@ struct Settings {
   static Settings& get() { static Settings s; return s; }
 };
 
-inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
 
 // One adapter's correspondence arrays resident in HBM.  Uploaded once, reused by every solver run on that adapter
 // (TestMain.cpp runs seven solvers on one adapter, :186-221).
@@ -134,7 +137,8 @@ class DeviceSet {
   void adopt(rpe_context* ctx, int device, int64_t n, int dtype, const void* const host[RPE_NUM_ARRAYS]) {
     if (_ctx && !_borrowed) pool().release(_ctx, _device);
     _ctx = ctx; _device = device; _n = n; _dtype = dtype; _borrowed = true;
-    for (int i = 0; i < RPE_NUM_ARRAYS; i++) { _src[i] = host[i]; _fp_known[i] = false; }   // produced on the device: the host side is an address only
+    // produced on the device: the host side is an address only
+    for (int i = 0; i < RPE_NUM_ARRAYS; i++) { _src[i] = host[i]; _fp_known[i] = false; }
     for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
   }
   // make sure array `slot` in HBM is the host array at `host` (3 x n of Tp)
@@ -196,7 +200,8 @@ class DeviceSet {
 
 // PROSAC order on the device (rpe_prosac_order): the first top_k positions of "indices by weight, descending, ties to the lower index"
 // for a dense frame's weights -- the very prefix sortIndexes<float>(w, top_k) (pose/Utility.hpp) returns.  Empty result = not done
-// here (other Tp, short arrays, long prefixes, capture mode, heavy ties around the cut, RPE_HOST_PROSAC=1): the caller sorts on the host.
+// here (other Tp, short arrays, long prefixes, capture mode, heavy ties around the cut, RPE_HOST_PROSAC=1): the caller sorts on the
+// host.
 template <class Tp> inline std::vector<int> device_prosac_order(DeviceSet&, const std::vector<Tp>&, int) { return std::vector<int>(); }
 template <> inline std::vector<int> device_prosac_order<float>(DeviceSet& dev, const std::vector<float>& w, int top_k) {
   static const bool host_only = std::getenv("RPE_HOST_PROSAC") != nullptr;

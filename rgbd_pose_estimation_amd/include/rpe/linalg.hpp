@@ -55,7 +55,8 @@ RPE_HD inline Vec3d mul(const Mat3d& x, const Vec3d& v) {
   return Vec3d(x(0, 0) * v[0] + x(0, 1) * v[1] + x(0, 2) * v[2], x(1, 0) * v[0] + x(1, 1) * v[1] + x(1, 2) * v[2],
                x(2, 0) * v[0] + x(2, 1) * v[1] + x(2, 2) * v[2]);
 }
-RPE_HD inline Mat3d transposed(const Mat3d& x) { Mat3d r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = x(j, i); return r; }
+RPE_HD inline Mat3d transposed(const Mat3d& x) { Mat3d r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = x(j, i);
+    return r; }
 RPE_HD inline double det3(const Mat3d& m) {
   return m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
          m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
@@ -76,11 +77,13 @@ template <class T> RPE_HD inline T absv(T x) { return std::fabs(x); }
 template <class T> RPE_HD inline T maxv(T a, T b) { return a < b ? b : a; }   // std::max(a, b)
 // rows p, q:  x' = c x + s y ; y' = -s x + c y
 template <class T> RPE_HD inline void givens_rows(T* M, int p, int q, const Givens<T>& g) {
-  for (int k = 0; k < 3; k++) { const T x = M[3 * p + k], y = M[3 * q + k]; M[3 * p + k] = g.c * x + g.s * y; M[3 * q + k] = -g.s * x + g.c * y; }
+  for (int k = 0; k < 3; k++) { const T x = M[3 * p + k], y = M[3 * q + k]; M[3 * p + k] = g.c * x + g.s * y;
+      M[3 * q + k] = -g.s * x + g.c * y; }
 }
 // columns p, q:  x' = c x - s y ; y' = s x + c y
 template <class T> RPE_HD inline void givens_cols(T* M, int p, int q, const Givens<T>& g) {
-  for (int k = 0; k < 3; k++) { const T x = M[3 * k + p], y = M[3 * k + q]; M[3 * k + p] = g.c * x - g.s * y; M[3 * k + q] = g.s * x + g.c * y; }
+  for (int k = 0; k < 3; k++) { const T x = M[3 * k + p], y = M[3 * k + q]; M[3 * k + p] = g.c * x - g.s * y;
+      M[3 * k + q] = g.s * x + g.c * y; }
 }
 template <class T> RPE_HD inline SvdJ<T> jacobi_svd3(const T* A) {
   const T tiny = std::numeric_limits<T>::min(), prec = T(2) * std::numeric_limits<T>::epsilon();
@@ -104,7 +107,8 @@ template <class T> RPE_HD inline SvdJ<T> jacobi_svd3(const T* A) {
       const T tr = a + d, df = c - b;
       if (absv(df) < tiny) { g1.s = T(0); g1.c = T(1); }
       else { const T u = tr / df, h = std::sqrt(T(1) + u * u); g1.s = T(1) / h; g1.c = u / h; }
-      { const T a0 = a, b0 = b, c0 = c, d0 = d; a = g1.c * a0 + g1.s * c0; b = g1.c * b0 + g1.s * d0; c = -g1.s * a0 + g1.c * c0; d = -g1.s * b0 + g1.c * d0; }
+      { const T a0 = a, b0 = b, c0 = c, d0 = d; a = g1.c * a0 + g1.s * c0; b = g1.c * b0 + g1.s * d0; c = -g1.s * a0 + g1.c * c0;
+          d = -g1.s * b0 + g1.c * d0; }
       (void)c;
       Givens<T> jr;   // Jacobi rotation of the now symmetric block [a b; b d]
       const T two_b = T(2) * absv(b);

@@ -64,7 +64,8 @@ template <class Tp> struct Matrix3 {
     return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
   }
   Point3<Tp> operator*(const Point3<Tp>& p) const {
-    return Point3<Tp>(a[0] * p[0] + a[1] * p[1] + a[2] * p[2], a[3] * p[0] + a[4] * p[1] + a[5] * p[2], a[6] * p[0] + a[7] * p[1] + a[8] * p[2]);
+    return Point3<Tp>(a[0] * p[0] + a[1] * p[1] + a[2] * p[2], a[3] * p[0] + a[4] * p[1] + a[5] * p[2],
+        a[6] * p[0] + a[7] * p[1] + a[8] * p[2]);
   }
   Matrix3 operator*(const Matrix3& o) const {
     Matrix3 r;
@@ -117,7 +118,8 @@ template <class Tp> class SO3 {
   }
   static SO3 fromQuaternion(Tp w, Tp x, Tp y, Tp z) {
     SO3 r; Tp n = std::sqrt(w * w + x * x + y * y + z * z);
-    if (!(n >= LieEps<Tp>::value())) { r._q = Quat<Tp>{w, x, y, z}; r._ok = false; return r; }   // the reference aborts here (SOPHUS_ENSURE); the values are kept
+    // the reference aborts here (SOPHUS_ENSURE); the values are kept
+    if (!(n >= LieEps<Tp>::value())) { r._q = Quat<Tp>{w, x, y, z}; r._ok = false; return r; }
     r._q = Quat<Tp>{w / n, x / n, y / n, z / n};
     return r;
   }
@@ -129,7 +131,8 @@ template <class Tp> class SO3 {
   static SO3 exp(const Point3<Tp>& omega) {
     const Tp th2 = omega.squaredNorm(), th = std::sqrt(th2);
     Tp imag, real;
-    if (th < LieEps<Tp>::value()) { imag = Tp(0.5) - th2 / Tp(48) + th2 * th2 / Tp(3840); real = Tp(1) - th2 / Tp(8) + th2 * th2 / Tp(384); }
+    if (th < LieEps<Tp>::value()) { imag = Tp(0.5) - th2 / Tp(48) + th2 * th2 / Tp(3840);
+        real = Tp(1) - th2 / Tp(8) + th2 * th2 / Tp(384); }
     else { imag = std::sin(Tp(0.5) * th) / th; real = std::cos(Tp(0.5) * th); }
     return fromQuaternionRaw(real, imag * omega[0], imag * omega[1], imag * omega[2]);
   }
@@ -166,7 +169,8 @@ template <class Tp> class SE3 {
     for (int i = 0; i < 6; i++) ad[i] = a[i];
     se3_exp(ad, R, t);
     Matrix3<Tp> m; for (int i = 0; i < 9; i++) m.a[i] = (Tp)R[i];
-    SE3 r; r._R = SO3<Tp>::fromQuaternion(quat_from_R<Tp>(m.a).w, quat_from_R<Tp>(m.a).x, quat_from_R<Tp>(m.a).y, quat_from_R<Tp>(m.a).z);
+    SE3 r; r._R = SO3<Tp>::fromQuaternion(quat_from_R<Tp>(m.a).w, quat_from_R<Tp>(m.a).x, quat_from_R<Tp>(m.a).y,
+        quat_from_R<Tp>(m.a).z);
     r._t = Point3<Tp>((Tp)t[0], (Tp)t[1], (Tp)t[2]);
     return r;
   }
