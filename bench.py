@@ -813,7 +813,7 @@ def worker(args, affinity):
             "timing": {"repeats": args.repeats, "statistic": "median over repetitions of the whole K-step region (MAX over ranks each)",
                        "event_timed_repetitions": timed_reps, "event_timed_note": "every %d-th repetition also carries HIP events on its launches (instrumentation for roofline.avg_launch_us, about 8 us per launch); all repetitions enter the median" % event_every,
                        "ms_per_step_p10": percentile(samples, 0.1) / args.steps * 1e3, "ms_per_step_p90": percentile(samples, 0.9) / args.steps * 1e3,
-                       "ms_per_step_min": min(samples) / args.steps * 1e3, "host_thread": {k: v for k, v in affinity.items() if k != "gpu_local_cpu_ids"}, "loop_profile": loop_prof},
+                       "ms_per_step_min": min(samples) / args.steps * 1e3, "hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"), "host_thread": {k: v for k, v in affinity.items() if k != "gpu_local_cpu_ids"}, "loop_profile": loop_prof},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_per_step": (traffic / steps_per_launch) if traffic else None,
@@ -1012,6 +1012,10 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
 
 
 def main():
+    # Completion signals polled by the waiting thread instead of interrupt-driven (ROCm runtime knob, this process only, must be in the
+    # environment before the runtime initialises): the closing synchronisation of a 20-step region returns ~5 us sooner (A/B:
+    # profiles/r03_hsa_interrupt_ab.txt).  Left alone if the caller set it; reported in timing.hsa_enable_interrupt.
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)

@@ -34,3 +34,25 @@ for n, kind in ((307200, 0), (1000000, 1), (20000, 0)):
                               device_loop_calls=dcalls, device_loop_iterations=500 * dcalls, device_loop_pose_changed=dbad)
     ctx.close()
 print(json.dumps(out))
+
+# ---- round 3: the resident forms of the bearing kind and of the joint kernel, and the restructured one-launch device loop on them
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import util
+out3 = {}
+for n in (307200, 20000):
+    sc = util.scene_full(900 + n, n, np.float32, n2d=2.0, n3d=0.03, nan_frac=0.02)
+    p = api.pose12(*util.perturbed_pose(np.random.default_rng(n), sc.R, sc.t, 0.01, 0.03))
+    ctx = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    terms = [(L.RES_P2P, 1.0, 0, 1.0), (L.RES_BEARING, 4.0, L.ROBUST_HUBER, 0.01), (L.RES_NORMAL, 0.5, 0, 1.0)]
+    legs = {"bearing_resident": lambda: ctx.gn_refine([L.RES_BEARING], p, max_iter=300, tol=0.0)[0],
+            "joint_resident": lambda: ctx.gn_refine_joint(terms, p, max_iter=300, tol=0.0)[0],
+            "bearing_device_loop": lambda: ctx.gn_refine_device([(L.RES_BEARING, 1.0)], p, 0, 300, 0.0)[0]}
+    for name, f in legs.items():
+        first = f()
+        t0, calls, bad = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < seconds / 9:
+            bad += int(not np.array_equal(f(), first)); calls += 1
+        out3[f"{name}_{n}"] = dict(calls=calls, iterations=300 * calls, pose_changed=bad)
+    out3[f"lost_grids_{n}"] = ctx.resident_state()["lost"]
+    ctx.close()
+print(json.dumps({"round3": out3}))
