@@ -11,6 +11,27 @@ static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
 
 int main() {
+  {  // ---- content fingerprint of a host array (rpe::DeviceSet keys its resident copies by address AND content)
+    std::vector<float> a(3 * 307200);
+    for (size_t i = 0; i < a.size(); i++) a[i] = (float)(i % 1013) * 0.25f;
+    const size_t bytes = a.size() * sizeof(float);
+    const unsigned long long f0 = rpe::host_fingerprint(a.data(), bytes);
+    CHECK(f0 == rpe::host_fingerprint(a.data(), bytes));                    // a pure function of the content
+    std::vector<float> b(a);
+    CHECK(f0 == rpe::host_fingerprint(b.data(), bytes));                    // ... not of the address
+    b[0] += 1.0f;
+    CHECK(f0 != rpe::host_fingerprint(b.data(), bytes));                    // the first line is sampled
+    b = a; b.back() += 1.0f;
+    CHECK(f0 != rpe::host_fingerprint(b.data(), bytes));                    // and the last
+    CHECK(f0 != rpe::host_fingerprint(a.data(), bytes - sizeof(float)));    // the length enters
+    for (float& x : b) x += 0.5f;                                           // a refilled buffer (every line changes) is always caught
+    CHECK(f0 != rpe::host_fingerprint(b.data(), bytes));
+    CHECK(rpe::host_fingerprint(nullptr, 0) == rpe::host_fingerprint(a.data(), 0));
+    float tiny[3] = {1.f, 2.f, 3.f};                                        // arrays shorter than a cache line
+    const unsigned long long ft = rpe::host_fingerprint(tiny, sizeof tiny);
+    tiny[2] = 4.f;
+    CHECK(ft != rpe::host_fingerprint(tiny, sizeof tiny));
+  }
   // ---- sortIndexes: partial prefix, ties to the lower index
   rpe::Rand31 rnd(3);
   std::vector<float> w(5000);
