@@ -331,6 +331,13 @@ def hbm_roofline(local_rank):
     avg, mn, cnt = timed(ten, L.RES_P2P, 30)
     out["p2p_10M"] = row(10_000_000, 24, avg, mn, cnt, note="240 MB <= Infinity Cache: the steady state is served on-die, above the HBM read ceiling")
     big.close(); ten.close()
+    # PMC traffic of exactly these launches (same kernels, same sizes, one launch per call), from the committed profile
+    prof = profile_entries().get("hbm_stream", {})
+    for case, e in prof.items():
+        if case in out and isinstance(out[case], dict):
+            out[case]["traffic"] = e.get("traffic_bytes_per_launch")
+            out[case]["traffic_over_algorithmic"] = e.get("traffic_over_algorithmic")
+            out[case]["traffic_source"] = "profiles/r03_hbm_stream_pmc.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes over scripts/hbm_stream_probe.py)"
     return out
 
 

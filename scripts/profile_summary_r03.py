@@ -67,6 +67,13 @@ index = {"normal_eq_resident_p2p_f32": entries,
          "driver_command_with_extras": None if not full else {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5",
                                                                "rocprofv3_avg_launch_us": full["avg_ns"] * 1e-3, "calls": full["calls"], "file": full["file"],
                                                                "note": "all launches of this kernel name in the run: pre-warm, calibration, timed (20 steps each), the --warmup launch (5) and the convergence leg's"}}
+try:   # keep the HBM-stream entries (scripts/r03_hbm.sh) that a previous summary put into the index
+    prev = json.load(open(os.path.join(prof, "r03_bench_profiles.json")))
+    for k in ("hbm_stream", "hbm_stream_source"):
+        if k in prev:
+            index[k] = prev[k]
+except Exception:
+    pass
 json.dump(index, open(os.path.join(prof, "r03_bench_profiles.json"), "w"), indent=1)
 print(json.dumps(index, indent=1))
 for name in ("bench_driver_cmd.json", "bench_default_2000steps.json", "roofline_runs.jsonl", "config4_cold_steady.jsonl", "device_loop_ab.jsonl", "pytest_gpu.txt", "pytest_new.txt"):
