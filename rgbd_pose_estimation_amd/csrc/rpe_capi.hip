@@ -424,6 +424,9 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   rt.seq = base;
   // a rank that waits for a slow peer inside the host-side exchange (up to its 10 s) must not lose its own grid meanwhile
   if (c->hostex) rt.pose_wait_ticks = 1200000000ull;
+  // tests: a long pose wait, to see that a lost grid is RELEASED rather than timed out
+  if (const char* w = getenv("RPE_TEST_POSE_WAIT_S")) { const double sec = atof(w);
+      if (sec >= 0.5 && sec <= 60.0) rt.pose_wait_ticks = (unsigned long long)(sec * 1e8); }
   if (const char* f = getenv("RPE_TEST_RESIDENT_FAULT")) { const int k = atoi(f);
       if (k >= 1 && k <= max_iter) rt.fault_tag = base + (unsigned long long)k; }
   static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
@@ -459,7 +462,11 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     if (c->loop_prof) { const double t = clock_us(); c->prof_host_us += t - tp; tp = t; }
   }
   // the grid is still waiting: release it
-  if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);
+  // Release a grid that is still waiting.  After an early stop every workgroup waits for pose received + 1.  After a LOST grid the
+  // workgroups that delivered their sums of the unfinished iteration already wait for pose received + 2: stop with that number -- a
+  // workgroup still waiting for received + 1 leaves on it too (a larger tag means "this launch is over", resident_wait_pose).
+  if (status == kResidentLost) hand_over(nullptr, (base + (unsigned long long)received + 2) | rpe::kResidentStopBit);
+  else if (received < max_iter) hand_over(nullptr, (base + (unsigned long long)received + 1) | rpe::kResidentStopBit);
   c->seq = base + (unsigned long long)max_iter + 1;   // stays ahead of every tag / sequence value this launch could use
   *it_out = it; *step_out = step; *cost_out = cost; *weight_out = weight;
   if (status == kResidentLost) {
@@ -1721,7 +1728,8 @@ int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double 
   HIP_TRY(hipSetDevice(c->device));
   if ((rc = claim_slots(c, (int64_t)c->fe.cam.width * c->fe.cam.height))) return rc;
   if ((rc = associate_launch(c, pose12, dist_thr, cos_thr, use_normals, false, matched != nullptr))) return rc;
-  // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counter into pinned host memory and raises a sequence word
+  // read-out without a D2H copy or a stream synchronisation: a tiny kernel stores the counter into pinned host memory and raises a
+  // sequence word
   if (matched) {
     const unsigned long long seq = ++c->vote_seq;
     HIP_TRY(rpe::launch_publish_i32(c->fe.d_count, 1, c->h_votes, c->h_flag2, seq, c->stream));

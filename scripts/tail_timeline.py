@@ -73,8 +73,10 @@ def worker_stamps(n, kind, launches):
     buf = np.zeros(4096 * 16, np.uint64)
     lib.rpe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
     rows = []
+    steady = int(os.environ.get("RPE_STEADY", "1"))   # launches issued back to back before the stamps of the LAST one are read (no idle gap before it)
     for _ in range(launches):
-        ctx.normal_eq(kind, p)
+        for _ in range(steady):
+            ctx.normal_eq(kind, p)
         lib.rpe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
         s = buf.reshape(4096, 16).astype(np.int64)
         live = s[:, 0] > 0

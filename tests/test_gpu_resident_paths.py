@@ -110,18 +110,23 @@ def test_lost_grid_is_finished_with_one_launch_per_iteration(what):
                 return c.gn_refine([L.RES_BEARING], p0, max_iter=8, tol=0.0)
             return c.gn_refine_joint([(L.RES_P2P, 1.0, 0, 1.0), (L.RES_BEARING, 4.0, 0, 1.0)], p0, max_iter=8, tol=0.0)
         good = run()
+        # the workgroups' wait for the next pose is set to 9 s here: the call must come back after the collecting workgroup's 2 s, i.e.
+        # the host's stop tag RELEASES the workgroups that already wait for the pose after the unfinished iteration
         os.environ["RPE_TEST_RESIDENT_FAULT"] = "4"
+        os.environ["RPE_TEST_POSE_WAIT_S"] = "9"
         try:
             t0 = time.perf_counter()
             hit = run()
+            c.synchronize()   # the grid has left the GPU too
             dt = time.perf_counter() - t0
         finally:
             del os.environ["RPE_TEST_RESIDENT_FAULT"]
+            del os.environ["RPE_TEST_POSE_WAIT_S"]
         assert hit[1] == good[1] == 8
         _pose_close(hit[0], good[0])
         st = c.resident_state()
         assert st["lost"] == 1 and st["enabled"]
-        assert 1.5 < dt < 6.0   # the collecting workgroup's bounded wait (2 s), not the pose wait of every other workgroup on top
+        assert 1.5 < dt < 5.0   # the collecting workgroup's bounded wait (2 s), not the pose wait (9 s) of every other workgroup on top
         again = run()           # and the context goes on with resident loops
         _pose_close(again[0], good[0])
         assert c.resident_state()["lost"] == 1
