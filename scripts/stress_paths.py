@@ -35,18 +35,24 @@ def worker(seed0, count):
         q7 = np.array([api.pose7_from_Rt(*util.perturbed_pose(rng, sc.R, sc.t, 0.003 * h, 0.01 * h), L.F64 if f64 else L.F32) for h in range(int(rng.integers(1, 40)))])
         votes = ctx.score(L.VOTE_33_23, q7, 0.2, 0.9999, 2.0)
         ref = None
-        if n >= 6 and kind != 2:
+        if n >= 6:
             try:
                 ref = ctx.gn_refine([kind], p, None, flags, 12, 0.0)[0]
             except L.RpeError as e:
                 ref = "ERR " + str(e)[:60]
         dev = None   # the device loop: one launch (new) against one launch per iteration (old, RPE_DEVICE_LOOP_RESIDENT=0)
-        if n >= 6 and kind != 2:
+        if n >= 6:
             try:
                 dev = ctx.gn_refine_device([(kind, 1.0)], p, flags, 12, 0.0)[0]
             except L.RpeError as e:
                 dev = "ERR " + str(e)[:60]
-        out.append(dict(n=n, f64=f64, kind=kind, flags=flags, rec=np.asarray(rec).tolist(), mom=np.asarray(mom).tolist(), votes=votes.tolist(),
+        jnt = None   # the joint refinement: resident (new) against one launch per iteration
+        if n >= 6:
+            try:
+                jnt = ctx.gn_refine_joint([(L.RES_P2P if kind != 1 else L.RES_P2PLANE, 1.0, 0, 1.0), (L.RES_BEARING, 2.0, 0, 1.0)], p, flags, 10, 0.0)[0]
+            except L.RpeError as e:
+                jnt = "ERR " + str(e)[:60]
+        out.append(dict(n=n, f64=f64, kind=kind, flags=flags, jnt=jnt if isinstance(jnt, str) or jnt is None else np.asarray(jnt).tolist(), rec=np.asarray(rec).tolist(), mom=np.asarray(mom).tolist(), votes=votes.tolist(),
                         ref=ref if isinstance(ref, str) or ref is None else np.asarray(ref).tolist(),
                         dev=dev if isinstance(dev, str) or dev is None else np.asarray(dev).tolist()))
         ctx.close()
@@ -84,6 +90,10 @@ if __name__ == "__main__":
                         ok &= np.allclose(np.array(a["dev"]), np.array(a["ref"]), rtol=0, atol=1e-7)   # and against the host-driven loop of the same run
                 else:
                     ok &= (type(a["dev"]) == type(b["dev"]))
+                if isinstance(a["jnt"], list) and isinstance(b["jnt"], list):
+                    ok &= np.allclose(np.array(a["jnt"]), np.array(b["jnt"]), rtol=0, atol=1e-7)
+                else:
+                    ok &= (type(a["jnt"]) == type(b["jnt"]))
                 if not ok:
                     bad += 1
                     drec = float(np.max(np.abs(ra - rb) / (1e-300 + np.abs(rb).max())))
