@@ -580,6 +580,36 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
   return lost;
 }
 
+// Fixed-order sum over the nr (<= RGN) rows of part[..][NACC] (LDS), for every value j, by the whole collecting workgroup: blocks of six
+// rows first -- one thread per (block, value), six LDS reads in flight -- a workgroup barrier, then the block sums in block order.  A
+// collecting workgroup sits on the critical path of every launch and of every resident iteration; one thread per value walking up to 30
+// rows one dependent LDS read after the other cost 0.5 us there (stamps, profiles/r03_resident_timeline.jsonl).  The order is a fixed
+// function of (nr), so results stay bitwise reproducible.  Every thread of the workgroup must call it; threads < NACC get the totals.
+template <int NACC, int BLK>
+__device__ __forceinline__ double sum_rows(const double (*part)[NACC], int nr) {
+  constexpr int RGN = BLK / NACC, RB = 6, NB = (RGN + RB - 1) / RB;
+  static_assert(NB * NACC <= BLK, "one thread per (block of rows, value)");
+  __shared__ double s_blk[NB][NACC];
+  const int j = threadIdx.x % NACC, q = threadIdx.x / NACC;
+  if (q < NB) {
+    double v[RB];
+#pragma unroll
+    for (int u = 0; u < RB; u++) { const int k = q * RB + u; v[u] = k < nr ? part[k < RGN ? k : 0][j] : 0.0; }
+    double t = v[0];
+#pragma unroll
+    for (int u = 1; u < RB; u++) t += v[u];
+    s_blk[q][j] = t;
+  }
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x < NACC) {
+    t = s_blk[0][threadIdx.x];
+#pragma unroll
+    for (int b = 1; b < NB; b++) t += s_blk[b][threadIdx.x];
+  }
+  return t;
+}
+
 // ---- cross-workgroup stage for results the HOST consumes (single GPU): collecting workgroups + a host-side final sum.
 // Workgroups are taken in runs of R; the first of a run collects: the others store their NACC sums as 16-byte granules {value, launch
 // sequence number} (one sc1 store per lane; no drain, no arrival counter) and are done; the collecting workgroup reads its run's
@@ -622,12 +652,8 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   RPE_STAMP(7);
   if (__syncthreads_or(lost)) return;   // nothing published: the host reports the kernel as having finished without its result
   RPE_STAMP(8);
-  if (threadIdx.x < NACC) {
-    double t = 0.0;
-    const int nr = rows < RGN ? rows : RGN;
-    for (int k = 0; k < nr; k++) t += c_part[k][threadIdx.x];
-    store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x, t, fin.seq);
-  }
+  const double t = sum_rows<NACC, BLK>(c_part, rows < RGN ? rows : RGN);
+  if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x, t, fin.seq);
   if (blockIdx.x == 0 && threadIdx.x == 64) {   // header: runs | sums per run << 16 | record layout << 24
     const unsigned long long hdr = (unsigned long long)((G + R - 1) / R) | ((unsigned long long)NACC << 16) | ((unsigned long long)MODE << 24);
     store_tagged_pair(fin.out_host, 0, __longlong_as_double((long long)hdr), fin.seq);

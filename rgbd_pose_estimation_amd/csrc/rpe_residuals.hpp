@@ -392,13 +392,9 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(4);
 #endif
-    if (threadIdx.x < NACC) {
-      double t = 0.0;
-      const int nr = rows < RGN ? rows : RGN;
-      for (int k = 0; k < nr; k++) t += g_part[k][threadIdx.x];
-      // a run with a missing granule tells the host so (it releases the grid and finishes with one launch per iteration)
-      store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, ok ? t : __longlong_as_double((long long)kLostMarker), seq);
-    }
+    const double t = sum_rows<NACC, BLK>(g_part, rows < RGN ? rows : RGN);
+    // a run with a missing granule tells the host so (it releases the grid and finishes with one launch per iteration)
+    if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, ok ? t : __longlong_as_double((long long)kLostMarker), seq);
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(5);
 #endif
@@ -451,11 +447,9 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
   if (!lost && (int)blockIdx.x == leader) {
     const int rows = min(R, G - leader);
     lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part));
-    if (!lost && threadIdx.x < NACC) {
-      double t = 0.0;
-      const int nr = rows < RGN ? rows : RGN;
-      for (int k = 0; k < nr; k++) t += a_part[k][threadIdx.x];
-      store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
+    if (!lost) {   // uniform over the workgroup
+      const double t = sum_rows<NACC, BLK>(a_part, rows < RGN ? rows : RGN);
+      if (threadIdx.x < NACC) store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
     }
   }
 #ifdef RPE_STAMPS
