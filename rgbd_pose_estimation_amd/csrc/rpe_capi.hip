@@ -940,9 +940,10 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
   double pose_in[12];
   std::memcpy(pose_in, pose12, sizeof(pose_in));
-  if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && single && !sharded && !c->comm && !c->hostex && max_iter >= 2) {
+  if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && !sharded && !c->comm && !c->hostex && max_iter >= 2) {
+    // a single plain kind: the dedicated kernel (17 structured sums for point-to-point); anything else: the joint kernel (29 sums)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
-    rpe::resident_geometry(c->arrays(), terms[0].kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
+    rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     const unsigned long long base = c->seq;          // granule / run-record tags base + 1 ... base + max_iter
     rt.rows = grid * nacc <= 1024 ? 1 : rows_auto;   // as the host-driven loop: the run records are the ones its host would add
     c->seq = base + (unsigned long long)max_iter + 1;
@@ -951,7 +952,8 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
     std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
-    HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0, e1));
+    if (single) HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0, e1));
+    else HIP_TRY(rpe::launch_normal_eq_joint_resident(c->arrays(), bits, flags, scale, robust, rk, nullptr, base, max_iter, rt, c->stream));
     int rc = wait_host(c, rpe::kNeLd);
     if (rc) return rc;
     if (c->h_out[15] != 2.0) {

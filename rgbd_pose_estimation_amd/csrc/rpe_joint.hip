@@ -186,7 +186,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_kernel(JointArrays<T> A, 
 // hand
 // the 29 sums to the collecting stage (resident_cross_stage); the host adds the run records, solves and updates.  Frame-sized problems
 // (IN_REGS: one group per thread) read their arrays once per refinement.
-template <class T, int TERMS, int BLK, bool IN_REGS>
+template <class T, int TERMS, int BLK, bool IN_REGS, bool AUTO>
 __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArrays<T> A, int64_t n, JointParams prm,
                                                                        const unsigned long long* __restrict__ ctl,
                                                                        unsigned long long first_tag, int max_iters, Finish fin) {
@@ -199,9 +199,17 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
   JointRegs<T> mine;
   const bool have = IN_REGS && g0 < groups;
   if (have) mine.template load<TERMS>(A, g0, n);
+  // AUTO (rpe_gn_refine_device with several residual kinds): no host in the loop -- the first pose from HBM, every later one from the
+  // workgroup's own solve (resident_auto_stage), exactly as the single-kind resident kernel's autonomous form
+  double tol = 0.0;
+  if (AUTO) {
+    if (threadIdx.x < 12) s_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
+    tol = fin.gn->tol;
+    __syncthreads();
+  }
   for (int it = 1; it <= max_iters; it++) {
     // stop requested or no host
-    if (resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;
+    if (!AUTO && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = s_pose[k];
@@ -224,6 +232,10 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
         joint_group<T, TERMS>(pose, prm, q.vw, q.vc, q.vb, q.vnw, q.vnc, q.k23, q.k33, q.knn, q.u23, q.u33, q.unn,
             left < P ? (int)left : P, acc);
       }
+    }
+    if (AUTO) {
+      if (resident_auto_stage<29, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose) != 0) return;
+      continue;
     }
     if (!resident_cross_stage<29, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, false)) return;
   }
@@ -300,12 +312,11 @@ static void joint_resident_launch(const DeviceArrays& A, int flags, const JointP
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
   if (fin.rows < 1) fin.rows = 1;
   const JointArrays<T> J = joint_arrays<T>(A, um, uw);
-  if (in_regs)
-    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, true>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag,
-        max_iters, fin);
-  else
-    hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, false>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag,
-        max_iters, fin);
+#define RPE_JOINT_RES(R, AU) \
+  hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, R, AU>), dim3(G), dim3(BLK), 0, s, J, A.n, prm, ctl, first_tag, max_iters, fin)
+  if (fin.gn != nullptr) { if (in_regs) RPE_JOINT_RES(true, true); else RPE_JOINT_RES(false, true); }
+  else { if (in_regs) RPE_JOINT_RES(true, false); else RPE_JOINT_RES(false, false); }
+#undef RPE_JOINT_RES
 }
 template <class T>
 static hipError_t joint_resident_t(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4,

@@ -52,7 +52,13 @@ def worker(seed0, count):
                 jnt = ctx.gn_refine_joint([(L.RES_P2P if kind != 1 else L.RES_P2PLANE, 1.0, 0, 1.0), (L.RES_BEARING, 2.0, 0, 1.0)], p, flags, 10, 0.0)[0]
             except L.RpeError as e:
                 jnt = "ERR " + str(e)[:60]
-        out.append(dict(n=n, f64=f64, kind=kind, flags=flags, jnt=jnt if isinstance(jnt, str) or jnt is None else np.asarray(jnt).tolist(), rec=np.asarray(rec).tolist(), mom=np.asarray(mom).tolist(), votes=votes.tolist(),
+        jdev = None   # and the joint objective in the device loop: one launch (new) against one launch per iteration
+        if n >= 6:
+            try:
+                jdev = ctx.gn_refine_device([(L.RES_P2P if kind != 1 else L.RES_P2PLANE, 1.0), (L.RES_BEARING, 2.0)], p, flags, 10, 0.0)[0]
+            except L.RpeError as e:
+                jdev = "ERR " + str(e)[:60]
+        out.append(dict(n=n, f64=f64, kind=kind, flags=flags, jdev=jdev if isinstance(jdev, str) or jdev is None else np.asarray(jdev).tolist(), jnt=jnt if isinstance(jnt, str) or jnt is None else np.asarray(jnt).tolist(), rec=np.asarray(rec).tolist(), mom=np.asarray(mom).tolist(), votes=votes.tolist(),
                         ref=ref if isinstance(ref, str) or ref is None else np.asarray(ref).tolist(),
                         dev=dev if isinstance(dev, str) or dev is None else np.asarray(dev).tolist()))
         ctx.close()
@@ -94,6 +100,12 @@ if __name__ == "__main__":
                     ok &= np.allclose(np.array(a["jnt"]), np.array(b["jnt"]), rtol=0, atol=1e-7)
                 else:
                     ok &= (type(a["jnt"]) == type(b["jnt"]))
+                if isinstance(a["jdev"], list) and isinstance(b["jdev"], list):
+                    ok &= np.allclose(np.array(a["jdev"]), np.array(b["jdev"]), rtol=0, atol=1e-7)
+                    if isinstance(a["jnt"], list):
+                        ok &= np.allclose(np.array(a["jdev"]), np.array(a["jnt"]), rtol=0, atol=1e-7)   # and against the host-driven joint loop
+                else:
+                    ok &= (type(a["jdev"]) == type(b["jdev"]))
                 if not ok:
                     bad += 1
                     drec = float(np.max(np.abs(ra - rb) / (1e-300 + np.abs(rb).max())))
