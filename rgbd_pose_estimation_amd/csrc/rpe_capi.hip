@@ -277,7 +277,7 @@ int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int f
   bool lost = false;
   // All tags first, in branch-free sweeps (independent loads: the cache misses on lines the device has just written overlap), then the
   // sums in run order -- 0.1 us per resident step faster than waiting pair by pair (four A/B alternations,
-  // scripts/host_sweep_ab_r03.py);
+  // scripts/env_ab_r03.py);
   // RPE_HOST_SWEEP=0 selects the pair-by-pair wait.
   static const int sweep = getenv("RPE_HOST_SWEEP") ? atoi(getenv("RPE_HOST_SWEEP")) : 1;
   if (sweep) {

@@ -318,6 +318,21 @@ __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T
 // wave 0 read one 8-byte word each until both tags match.  Returns 1 = go (pose in s_pose), 2 = stop requested, 3 = the host went
 // away (2 s); the value is uniform over the workgroup.
 constexpr int kAutoMaxRunSums = 1024;   // run records x sums an autonomous iteration reads per workgroup (resident_auto_stage)
+// what a poll of the control block says: 0 = not yet, 1 = pose `want` is there, 2 = stop
+__device__ __forceinline__ int resident_judge_pose(unsigned long long w, unsigned long long want) {
+  const unsigned int lo = (unsigned int)w, hi = (unsigned int)(w >> 32);
+  const unsigned long long ta = ((unsigned long long)__builtin_amdgcn_readlane(hi, 0) << 32) | __builtin_amdgcn_readlane(lo, 0);
+  const unsigned long long tb = ((unsigned long long)__builtin_amdgcn_readlane(hi, 15) << 32) | __builtin_amdgcn_readlane(lo, 15);
+  if (ta != tb) return 0;
+  const unsigned long long num = ta & ~kResidentStop;
+  if (num == want) return (ta & kResidentStop) ? 2 : 1;
+  // Tags only grow within a context, and the host writes tag want + 1 only after it has this workgroup's sums of `want`: a larger
+  // tag can only belong to a LATER call -- this launch was stopped and the stop tag has already been overwritten.  Leave.
+  return num > want ? 2 : 0;
+}
+// One wave polls, one load at a time.  Tried and rejected (profiles/r03_poll_depth_ab.jsonl): 2 / 4 / 8 waves polling with staggered
+// starts, the first to see the pose handing it to the others through LDS -- 5.87 vs 5.70 us per step (four alternations), no gain: the
+// step waits for the LAST of 150 workgroups, and more pollers only add traffic on the control block.
 template <int BLK>
 __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want,
     double* __restrict__ s_pose,
@@ -329,14 +344,7 @@ __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __re
     unsigned long long w = 0;
     for (;;) {
       if (lane < 16) w = __hip_atomic_load(ctl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned long long ta = __shfl(w, 0, 64), tb = __shfl(w, 15, 64);
-      if (ta == tb) {
-        const unsigned long long num = ta & ~kResidentStop;
-        if (num == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
-        // Tags only grow within a context, and the host writes tag want + 1 only after it has this workgroup's sums of `want`: a larger
-        // tag can only belong to a LATER call -- this launch was stopped and the stop tag has already been overwritten.  Leave.
-        if (num > want) { go = 2; break; }
-      }
+      if ((go = resident_judge_pose(w, want)) != 0) break;
       if (wall_clock64() - t0 > wait_ticks) { go = 3; break; }   // the host went away: give up
       __builtin_amdgcn_s_sleep(2);
     }
