@@ -189,3 +189,35 @@ print(json.dumps({"state": c.resident_state(), "p2p": a[0].tolist(), "joint": b[
     assert small["state"]["lost"] == 0 and small["state"]["enabled"]
     for k in ("p2p", "joint", "device"):
         _pose_close(np.array(full[k]), np.array(small[k]))
+
+
+def test_host_wait_variants_agree_bitwise():
+    """The host adds the run records in run order whichever way it waits for them: all tags in branch-free sweeps (default) or pair by
+    pair (RPE_HOST_SWEEP = 0, read once per process)."""
+    import subprocess, sys, json
+    code = r'''
+import json, numpy as np, sys
+sys.path.insert(0, "tests")
+from rgbd_pose_estimation_amd import _lib as L, api
+import util
+out = {}
+for n in (3000, 307200):
+    sc = util.scene_full(61, n, np.float32, n2d=2.0, n3d=0.03, nan_frac=0.02)
+    p0 = api.pose12(*util.perturbed_pose(np.random.default_rng(9), sc.R, sc.t, 0.01, 0.03))
+    c = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nc=sc.N, nw=sc.M)
+    out[f"p2p_{n}"] = c.gn_refine([L.RES_P2P], p0, max_iter=12, tol=0.0)[0].tolist()
+    out[f"plane_{n}"] = c.gn_refine([L.RES_P2PLANE], p0, max_iter=12, tol=0.0)[0].tolist()
+    out[f"joint_{n}"] = c.gn_refine_joint([(L.RES_P2P, 1.0, 0, 1.0), (L.RES_BEARING, 4.0, 0, 1.0)], p0, max_iter=12, tol=0.0)[0].tolist()
+    out[f"ne_{n}"] = c.normal_eq(L.RES_P2PLANE, p0)[0].tolist()
+    c.close()
+print(json.dumps(out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for sweep in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RPE_HOST_SWEEP=sweep), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0].keys() == outs[1].keys()
+    for k in outs[0]:
+        assert np.array_equal(np.array(outs[0][k]), np.array(outs[1][k])), k
