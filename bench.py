@@ -355,24 +355,33 @@ def fp64_lines(local_rank):
         for name, kind, bpc in (("K1_p2p", L.RES_P2P, 48), ("K2_p2plane", L.RES_P2PLANE, 72)):
             for _ in range(5):
                 ctx.normal_eq(kind, pose)
-            ctx.timing_enable(50, 1)
-            for _ in range(50):
-                ctx.normal_eq(kind, pose)
-            cnt, tot_ms, mn_ms = ctx.timing_collect()
+            batch = []   # five batches of 20 event-timed launches, median batch average: one stalled launch (seen: 10 ms once) must not set the figure
+            for _ in range(5):
+                ctx.timing_enable(20, 1)
+                for _ in range(20):
+                    ctx.normal_eq(kind, pose)
+                cnt, tot_ms, mn_ms = ctx.timing_collect()
+                batch.append(tot_ms / max(cnt, 1) * 1e-3)
             ctx.timing_enable(0, 1)
-            avg = tot_ms / max(cnt, 1) * 1e-3
+            avg = sorted(batch)[len(batch) // 2]
             rows[name] = {"bytes_per_corr": bpc, "avg_launch_us": avg * 1e6, "achieved_GBs": bpc * n / avg / 1e9, "frac_of_peak": bpc * n / avg / 1e9 / HBM_PEAK_GBS,
-                          "corr_res_per_s": n / avg}
+                          "corr_res_per_s": n / avg, "statistic": "median of five 20-launch averages"}
         H = 512
         q7 = api.pose7_from_Rt(R, t, L.F64)
         poses = np.tile(q7, (H, 1)); poses[:, 4:] += 0.01 * np.random.default_rng(1).standard_normal((H, 3))
-        for _ in range(2):
+        # warm by TIME: after the light launches above the GPU sits in a low power state and takes tens of milliseconds of load to leave it
+        # (seen: the first 20 ms of passes 3.4x slower than the rest), then the median of nine single passes
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.2:
             ctx.score(L.VOTE_33, poses, THRE_3D, mode=L.SCORE_EXACT)
-        t0 = time.perf_counter()
-        for _ in range(5):
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter()
             ctx.score(L.VOTE_33, poses, THRE_3D, mode=L.SCORE_EXACT)
-        dt = (time.perf_counter() - t0) / 5
-        rows["K4_score_33_exact"] = {"hypotheses": H, "us_per_pass": dt * 1e6, "corr_hyp_per_s": n * H / dt}
+            ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[len(ts) // 2]
+        rows["K4_score_33_exact"] = {"hypotheses": H, "us_per_pass": dt * 1e6, "corr_hyp_per_s": n * H / dt, "us_per_pass_min_max": [min(ts) * 1e6, max(ts) * 1e6],
+                                     "statistic": "median of nine passes after 0.2 s of passes"}
         out[str(n)] = rows
         ctx.close()
     return out
