@@ -16,3 +16,17 @@ def test_host_logic_cpp(tmp_path):
                            "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "host_logic: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_lie_group_properties_cpp(tmp_path):
+    """rpe::SO3 / rpe::SE3 of the drop-in headers against the properties sophus/tests.hpp:43-198 checks (exp vs the matrix exponential,
+    action, product, inverse), Tp = double and float."""
+    from rgbd_pose_estimation_amd import build
+    lib = build.build()
+    exe = str(tmp_path / "lie_properties")
+    inc = os.path.join(ROOT, "rgbd_pose_estimation_amd", "include")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(inc, "pose"), "-I", inc,
+                           os.path.join(ROOT, "tests", "cpp", "lie_properties.cpp"), "-L", os.path.dirname(lib), "-lrgbdpose_hip",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "lie_properties: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
