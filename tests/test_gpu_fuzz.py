@@ -1,6 +1,8 @@
 """-m gpu: randomised shapes.  The parametrised tests pin a handful of sizes; here sizes are drawn around every boundary the kernels
 have (1 .. a few groups, wave and workgroup multiples +- 1, one workgroup's worth of groups +- 1), with random NaN columns, masks
 and weights, and every integer result must match the oracle exactly, every float record to the documented tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ from rgbd_pose_estimation_amd import _lib as L, api
 import util
 
 pytestmark = pytest.mark.gpu
+SEEDS = range(int(os.environ.get("RPE_FUZZ_SEEDS", "6")))   # a longer campaign: RPE_FUZZ_SEEDS=200 pytest tests/test_gpu_fuzz.py
 
 
 def sizes(rng, count):
@@ -17,7 +20,7 @@ def sizes(rng, count):
     return [int(p) for p in pick[:count]]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_votes_and_masks_exact(gpu_ctx_factory, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     kinds = [L.VOTE_33, L.VOTE_23, L.VOTE_33_23, L.VOTE_NN_23, L.VOTE_NN_33, L.VOTE_NN_33_23, L.VOTE_23_MATRIX]
@@ -54,7 +57,7 @@ def _kind_has(kind, mod):
     return {L.MOD_23: has23, L.MOD_33: has33, L.MOD_NN: hasnn}[mod]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_normal_equations_and_moments(gpu_ctx_factory, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     for n in sizes(rng, 8):
