@@ -95,3 +95,32 @@ def test_fuzz_normal_equations_and_moments(gpu_ctx_factory, oracle, seed):
         assert np.abs(m - ref).max() <= 1e-11 * (np.abs(ref).max() + 1) * max(1.0, np.sqrt(n)), (n, f64)
         assert m[17] == sel.sum()
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_whole_pipelines_equal(oracle, seed):
+    """Whole RANSAC / PROSAC runs on random noisy scenes (random solver, size, dtype, noise, outlier share, missing camera points,
+    thresholds, iteration cap, sampler seed): consensus size, adapted Iter, the three masks and the winning hypothesis equal the
+    oracle's -- every integer exactly, the hypothesis bit for bit."""
+    from test_gpu_pipelines import PIPELINES
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(3):
+        name, method, arrays, ls, thr = PIPELINES[int(rng.integers(0, len(PIPELINES)))]
+        f64 = bool(rng.integers(0, 2))
+        dt = np.float64 if f64 else np.float32
+        n = int(rng.choice([rng.integers(8, 64), rng.integers(64, 1000), rng.integers(1000, 6000)]))
+        sc = util.scene_full(int(rng.integers(1, 10**6)), n, dt, n2d=float(rng.choice([0.5, 1.0, 3.0])), n3d=float(rng.choice([0.01, 0.05, 0.1])),
+                             nnl_deg=float(rng.choice([1.0, 2.0, 5.0])), outliers=float(rng.choice([0.0, 0.1, 0.3])), nan_frac=float(rng.choice([0.0, 0.05, 0.2])))
+        data = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+        sel = {k: data[k] for k in arrays}
+        scale = float(rng.choice([0.5, 1.0, 2.0]))
+        kw = dict(iters=int(rng.choice([20, 100, 300])), confidence=float(rng.choice([0.99, 0.9999])), seed=int(rng.integers(1, 1000)),
+                  **{k: v * scale for k, v in thr.items()})
+        got = api.run(getattr(api, method), L.F64 if f64 else L.F32, weights=sc.weights, ls=api.LS_NONE, score_mode=L.SCORE_EXACT, **sel, **kw)
+        ref = oracle.run(oracle.Problem(f64, weights=sc.weights, **sel), getattr(oracle, method), ls=oracle.LS_NONE, **kw)
+        ctx = (name, n, f64, kw)
+        assert got["max_votes"] == ref["max_votes"], ctx
+        assert got["iters"] == ref["iters"], ctx
+        assert np.array_equal(got["masks"], ref["masks"]), ctx
+        if ref["max_votes"] > 0:
+            assert np.array_equal(got["R"], ref["R"]) and np.array_equal(got["t"], ref["t"]), ctx
