@@ -423,15 +423,33 @@ template <class T> static T sqrt_cut(T thr) {
 // iteration loop does.  Pose i carries tag base + i, the records of iteration i carry sequence base + i.
 // Cross-workgroup stage: runs of `rows` workgroups are added by the first workgroup of the run (granule hand-off, one hop), the run
 // records come to the host, which adds them in run order.  A handful of small records (grid x sums <= 1024 pairs, i.e. a few thousand
-// correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the GPU at all; otherwise runs of one
-// granule per collecting thread (30 workgroups for point-to-point: 5 run records at 640 x 480), up to four when that keeps the number
-// of runs at <= 8 -- a few hundred bytes over PCIe.  RPE_RESIDENT_ROWS forces a run length.
+// correspondences): rows = 1, every workgroup sends its own record and nothing is handed over on the GPU at all; otherwise one run
+// per XCD (eight run records: 136 pairs for point-to-point at 640 x 480), or -- small grids, RPE_RESIDENT_STRIDE=0 -- runs of
+// consecutive workgroups, one granule per collecting thread and up to four when that keeps the number of runs at <= 8
+// (resident_run_shape).
 // One resident loop per GPU at a time within this process: two resident grids launched together (two contexts, two threads) could each
 // get only part of their workgroups onto the CUs and then wait for workgroups that cannot start (the bounded waits would end both with
 // an error).  Other PROCESSES on the same GPU are the caller's to serialise.
 static std::mutex& resident_mutex(int device) {
   static std::mutex m[64];
   return m[device >= 0 && device < 64 ? device : 0];
+}
+
+// Run shape of a resident grid (resident_host_loop and the autonomous launches use the same one, so their run records are the same):
+// tiny problems send every workgroup's record (rows 1); grids of 32 workgroups and more are collected per XCD -- run r = workgroups r,
+// r + 8, ... (rpe_residuals.hpp run_shape; RPE_RESIDENT_STRIDE=0 keeps runs of consecutive workgroups); RPE_RESIDENT_ROWS forces a
+// run length of consecutive workgroups.  Returns the number of runs.
+static int resident_run_shape(int grid, int nacc, int max_rows, int rows_auto, rpe::ReduceTarget* rt) {
+  static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
+  static const int env_stride = getenv("RPE_RESIDENT_STRIDE") ? atoi(getenv("RPE_RESIDENT_STRIDE")) : 8;
+  rt->stride = 0;
+  if (env_rows >= 1) rt->rows = std::min(env_rows, max_rows);
+  else if (grid * nacc <= 1024) rt->rows = 1;
+  else if (env_stride > 1 && grid >= 4 * env_stride && (grid + env_stride - 1) / env_stride <= max_rows) {
+    rt->stride = env_stride; rt->rows = (grid + env_stride - 1) / env_stride;
+    return env_stride;
+  } else rt->rows = rows_auto;
+  return (grid + rt->rows - 1) / rt->rows;
 }
 
 template <class Launch>
@@ -455,10 +473,7 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
       if (sec >= 0.5 && sec <= 60.0) rt.pose_wait_ticks = (unsigned long long)(sec * 1e8); }
   if (const char* f = getenv("RPE_TEST_RESIDENT_FAULT")) { const int k = atoi(f);
       if (k >= 1 && k <= max_iter) rt.fault_tag = base + (unsigned long long)k; }
-  static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
-  const int rows = env_rows >= 1 ? std::min(env_rows, max_rows) : (grid * nacc <= 1024 ? 1 : rows_auto);
-  const int runs = (grid + rows - 1) / rows;
-  rt.rows = rows;
+  const int runs = resident_run_shape(grid, nacc, max_rows, rows_auto, &rt);
   rt.h_out = c->h_big;
   c->seq = base;
   {
@@ -971,7 +986,8 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     const unsigned long long base = c->seq;          // granule / run-record tags base + 1 ... base + max_iter
-    rt.rows = grid * nacc <= 1024 ? 1 : rows_auto;   // as the host-driven loop: the run records are the ones its host would add
+    // as the host-driven loop: the run records are the ones its host would add
+    (void)resident_run_shape(grid, nacc, max_rows, rows_auto, &rt);
     c->seq = base + (unsigned long long)max_iter + 1;
     rt.seq = c->seq;                                  // published with the result
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1816,7 +1832,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
       rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
       const unsigned long long base = c->seq;
-      rt.rows = grid * nacc <= 1024 ? 1 : rows_auto;
+      (void)resident_run_shape(grid, nacc, max_rows, rows_auto, &rt);
       c->seq = base + (unsigned long long)o->max_iter + 1;
       rt.seq = c->seq;
       HIP_TRY(rpe::launch_icp_resident(F.fmap[0], F.fmap[1], n, F.mmap[0], F.mmap[1], F.mcam, pose_f(F.mpose), dgate * dgate,

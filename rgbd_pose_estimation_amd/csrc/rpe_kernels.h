@@ -63,6 +63,7 @@ struct ReduceTarget {
   unsigned long long fault_tag = 0;                    // test hook: see Finish
   // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
   int rows = 0;
+  int stride = 0;              // resident kernels: > 1 = strided runs (see Finish)
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out
                                // must hold
                                // 1 + ceil(grid / run length) x sums pairs), and the host adds them in order. Host-consumed, single-GPU

@@ -270,6 +270,10 @@ struct Finish {
   int tail;
   // > 0: collecting workgroups + host-side final sum (collect_and_send / the resident kernel): cap on the run length
   int rows;
+  // resident kernels: > 1 = run r is the workgroups r, r + stride, r + 2 stride ... (the workgroups of ONE XCD when stride = 8: they
+  // are
+  // dispatched to the XCDs round robin), collected by workgroup r; 0 / 1 = runs of `rows` consecutive workgroups
+  int stride;
   // resident kernels: how long a workgroup waits for the host's next pose (100 MHz ticks) before it gives up
   unsigned long long pose_wait_ticks;
   unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
@@ -531,13 +535,13 @@ __device__ __forceinline__ void sum_records(const double* __restrict__ partials,
 // until every tag is this launch's), added in increasing row order into part[r][j].  Returns true if a granule never arrived (2 s).
 template <int NACC, int BLK, int CH = 4>
 __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gran, int G, int leader, int rows, unsigned long long tag,
-                                             double (*part)[NACC]) {
+                                             double (*part)[NACC], int step = 1) {   // row k of the run = workgroup leader + k * step
   constexpr int RGN = BLK / NACC;
   const int j = threadIdx.x % NACC, r = threadIdx.x / NACC;
   bool lost = false;
   if (CH == 1) {   // runs of at most RGN rows (the resident kernel): one granule per thread, polled by itself
     if (r >= 1 && r < rows) {
-      const unsigned long long* src = gran + 2 * ((size_t)(leader + r) * NACC + j);
+      const unsigned long long* src = gran + 2 * ((size_t)(leader + r * step) * NACC + j);
       const unsigned long long t0 = wall_clock64();
       granule_t q;
       for (unsigned int spins = 1;; spins++) {
@@ -559,7 +563,7 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
 #pragma unroll
         for (int u = 0; u < CH; u++) {
           const int row = k0 + u * RGN;
-          if (row < rows) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((leader + row) * NACC + j) * 16, 0, 16);
+          if (row < rows) q[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((leader + row * step) * NACC + j) * 16, 0, 16);
         }
 #pragma unroll
         for (int u = 0; u < CH; u++) {
@@ -580,7 +584,8 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
   return lost;
 }
 
-// Fixed-order sum over the nr (<= RGN) rows of part[..][NACC] (LDS), for every value j, by the whole collecting workgroup: blocks of six
+// Fixed-order sum over the nr (<= RGN) rows of part[..][NACC] (LDS), for every value j, by the whole collecting workgroup: blocks of
+// six
 // rows first -- one thread per (block, value), six LDS reads in flight -- a workgroup barrier, then the block sums in block order.  A
 // collecting workgroup sits on the critical path of every launch and of every resident iteration; one thread per value walking up to 30
 // rows one dependent LDS read after the other cost 0.5 us there (stamps, profiles/r03_resident_timeline.jsonl).  The order is a fixed
@@ -871,6 +876,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   static const int env_tail = getenv("RPE_TAIL") ? atoi(getenv("RPE_TAIL")) : 2;
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.rows = rt.rows > 0 ? rt.rows : 0;
+  f.stride = rt.stride > 1 ? rt.stride : 0;
   f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag;
   return f;
 }

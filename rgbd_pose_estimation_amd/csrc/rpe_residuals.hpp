@@ -354,6 +354,24 @@ __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __re
   __syncthreads();
   return *s_go;
 }
+// which run a workgroup of a resident grid belongs to, and which row of it: runs of R consecutive workgroups, or (stride S > 1) run r =
+// workgroups r, r + S, r + 2 S ... Workgroups go to the XCDs round robin (scripts/ubench/xcd_handoff.hip reads HW_REG_XCC_ID: workgroup
+// i runs on XCD i mod 8), so with S = 8 a run is the workgroups of ONE XCD and its granules cross no XCD boundary on their way to the
+// collecting workgroup: 0.28 us in flight instead of 0.39 - 0.50 (same file).  Only the latency depends on that placement -- the stores
+// and loads are the sc1 ones either way.
+struct RunShape { int run, row, leader, rows, runs, step; };
+__device__ __forceinline__ RunShape run_shape(const Finish& fin, int G) {
+  RunShape s;
+  const int b = (int)blockIdx.x;
+  if (fin.stride > 1) {
+    const int S = fin.stride < G ? fin.stride : G;
+    s.run = b % S; s.row = b / S; s.leader = s.run; s.rows = (G - s.run + S - 1) / S; s.runs = S; s.step = S;
+  } else {
+    const int R = fin.rows;
+    s.run = b / R; s.leader = s.run * R; s.row = b - s.leader; s.rows = min(R, G - s.leader); s.runs = (G + R - 1) / R; s.step = 1;
+  }
+  return s;
+}
 // Cross-workgroup stage of one resident iteration: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the
 // first of a run collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no
 // drain, no arrival counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls its granule(s)
@@ -374,7 +392,8 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
   __shared__ double g_part[RGN][NACC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
-  const int R = fin.rows, run = blockIdx.x / R, leader = run * R;
+  const RunShape rs = run_shape(fin, (int)gridDim.x);
+  const int run = rs.run, leader = rs.leader;
   wave_reduce_to<NACC>(acc, g_red[wave], lane);
   __syncthreads();
   if (threadIdx.x < NACC) {
@@ -391,8 +410,8 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 #endif
   bool ok = true;
   if ((int)blockIdx.x == leader) {
-    const int rows = min(R, (int)gridDim.x - leader);
-    const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part);
+    const int rows = rs.rows;
+    const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part, rs.step);
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(3);
 #endif
@@ -402,7 +421,8 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 #endif
     const double t = sum_rows<NACC, BLK>(g_part, rows < RGN ? rows : RGN);
     // a run with a missing granule tells the host so (it releases the grid and finishes with one launch per iteration)
-    if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, run * NACC + threadIdx.x, ok ? t : __longlong_as_double((long long)kLostMarker), seq);
+    if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, run * NACC + threadIdx.x,
+        ok ? t : __longlong_as_double((long long)kLostMarker), seq);
 #ifdef RPE_STAMPS
     if (stamp_it) RPE_STAMP(5);
 #endif
@@ -436,7 +456,9 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
   __shared__ double a_step;
   __shared__ int a_ok;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int G = (int)gridDim.x, R = fin.rows, run = blockIdx.x / R, leader = run * R, runs = (G + R - 1) / R;
+  const int G = (int)gridDim.x;
+  const RunShape rs = run_shape(fin, G);
+  const int run = rs.run, leader = rs.leader, runs = rs.runs;
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);          // [workgroup][NACC] granules of 2 words
   unsigned long long* rrec = gran + 2 * ((size_t)G * NACC + (size_t)(it & 1) * runs * NACC);   // [parity][run][NACC]
   wave_reduce_to<NACC>(acc, a_red[wave], lane);
@@ -453,8 +475,8 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
 #endif
   bool lost = runs * NACC > kAutoMaxRunSums;   // a geometry the launcher never chooses: reported like a lost granule, not overrun
   if (!lost && (int)blockIdx.x == leader) {
-    const int rows = min(R, G - leader);
-    lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part));
+    const int rows = rs.rows;
+    lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part, rs.step));
     if (!lost) {   // uniform over the workgroup
       const double t = sum_rows<NACC, BLK>(a_part, rows < RGN ? rows : RGN);
       if (threadIdx.x < NACC) store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
