@@ -237,7 +237,8 @@ rpe::ReduceTarget host_target(rpe_context* c) {
 rpe::ReduceTarget collect_target(rpe_context* c) {
   rpe::ReduceTarget rt = host_target(c);
   static const bool on = !(getenv("RPE_COLLECT") && atoi(getenv("RPE_COLLECT")) == 0);
-  if (on) { rt.h_out = c->h_big; rt.rows = 1 << 20; c->collecting = true; }
+  static const int stride = getenv("RPE_RESIDENT_STRIDE") ? atoi(getenv("RPE_RESIDENT_STRIDE")) : 8;
+  if (on) { rt.h_out = c->h_big; rt.rows = 1 << 20; rt.stride = stride; c->collecting = true; }
   return rt;
 }
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {

@@ -642,7 +642,13 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   if (mult < mult_cap) mult = mult_cap;
   int R = RGN * mult;
   if (R > fin.rows) R = fin.rows;
-  const int run = blockIdx.x / R, leader = run * R;
+  // grids of 32 workgroups and more: one run per XCD (run r = workgroups r, r + 8, ...: workgroups go to the XCDs round robin, so no
+  // granule crosses an XCD boundary on its way to its collecting workgroup -- rpe_residuals.hpp run_shape), when a run then fits the
+  // four granules per collecting thread
+  const int S = fin.stride;
+  const bool per_xcd = S > 1 && G >= 4 * S && (G + S - 1) / S <= 4 * RGN && (G + S - 1) / S <= fin.rows;
+  const int run = per_xcd ? (int)blockIdx.x % S : (int)blockIdx.x / R, leader = per_xcd ? run : run * R, step = per_xcd ? S : 1;
+  const int nruns = per_xcd ? S : (G + R - 1) / R;
   if (threadIdx.x < NACC) {
     double own = red[0][threadIdx.x];
 #pragma unroll
@@ -652,15 +658,15 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   }
   RPE_STAMP(4);
   if ((int)blockIdx.x != leader) return;
-  const int rows = min(R, G - leader);
-  const bool lost = collect_rows<NACC, BLK>(gran, G, leader, rows, fin.seq, c_part);
+  const int rows = per_xcd ? (G - run + S - 1) / S : min(R, G - leader);
+  const bool lost = collect_rows<NACC, BLK>(gran, G, leader, rows, fin.seq, c_part, step);
   RPE_STAMP(7);
   if (__syncthreads_or(lost)) return;   // nothing published: the host reports the kernel as having finished without its result
   RPE_STAMP(8);
   const double t = sum_rows<NACC, BLK>(c_part, rows < RGN ? rows : RGN);
   if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x, t, fin.seq);
   if (blockIdx.x == 0 && threadIdx.x == 64) {   // header: runs | sums per run << 16 | record layout << 24
-    const unsigned long long hdr = (unsigned long long)((G + R - 1) / R) | ((unsigned long long)NACC << 16) | ((unsigned long long)MODE << 24);
+    const unsigned long long hdr = (unsigned long long)nruns | ((unsigned long long)NACC << 16) | ((unsigned long long)MODE << 24);
     store_tagged_pair(fin.out_host, 0, __longlong_as_double((long long)hdr), fin.seq);
   }
   RPE_STAMP(9);
