@@ -372,8 +372,9 @@ __device__ __forceinline__ RunShape run_shape(const Finish& fin, int G) {
   }
   return s;
 }
-// Cross-workgroup stage of one resident iteration: COLLECTING workgroups + the host.  Workgroups are taken in runs of R = fin.rows; the
-// first of a run collects: the others store their NACC sums as 16-byte granules {value, iteration tag} (one sc1 store per lane, no
+// Cross-workgroup stage of one resident iteration: COLLECTING workgroups + the host. Workgroups are taken in runs (run_shape above: one
+// run per XCD, or runs of R = fin.rows consecutive workgroups); the first of a run collects: the others store their NACC sums as
+// 16-byte granules {value, iteration tag} (one sc1 store per lane, no
 // drain, no arrival counter) and go back to waiting for the next pose; every thread of the collecting workgroup polls its granule(s)
 // (collect_rows: sc1 loads until the tag is this iteration's), the rows are added in a fixed order, and the run's NACC sums go to the
 // host as tagged 16-byte pairs.  The host thread that owns the 6x6 solve adds the ceil(G / R) run records in run order.  So one
