@@ -302,7 +302,14 @@ int rpe_nl_round(rpe_context* ctx, const double* c_opt3, const double* Cw3, cons
  *         10 none (pose R9/t3 and mask_in are INPUTS: least-squares stage only)
  * ls:     0 none  1 shinji_ls / shinji_ls1 (inliers)  2 nl_shinji_kneip_ls (bug-compatible)  3 nl_shinji_kneip_ls (fixed)
  *         4 shinji_ls2 (all)  5 gn_refine_p2p  6 gn_refine_joint  7 gn_refine_p2plane  8 gn_refine_bearing
- * mask_in / mask_out: 3 x n shorts, row 0 = 2D-3D, 1 = 3D-3D, 2 = normal-normal.  seed: sampler stream. */
+ * mask_in / mask_out: 3 x n shorts, row 0 = 2D-3D, 1 = 3D-3D, 2 = normal-normal.  seed: sampler stream.
+ * RE-ENTRANT: every call builds its own random stream from `seed` and carries `score_mode` as a per-call option (rpe::RunOptions,
+ * rpe/device.hpp); nothing process-wide is written, so concurrent calls from several threads -- different seeds, different modes --
+ * each produce exactly what the same call produces alone (tests/cpp/reentrancy_host.cpp under ThreadSanitizer,
+ * tests/test_gpu_pipelines.py::test_concurrent_runs_with_different_seeds_and_modes).  The reference's samplers share the process-global
+ * rand() (pose/Utility.hpp:148,212,229; Library.cpp ao_ransac) and are not thread-safe; ao_ransac() here owns its stream too.  The
+ * C++ free functions (shinji_ransac2<Tp>(adapter, thr, Iter, conf) ...) keep the reference's semantics when called as the reference
+ * calls them -- one process-global stream, rpe::seed() in place of srand() -- and take the same options as a last, defaulted argument. */
 typedef struct {
   int n;
   int dtype;              /* RPE_F32 / RPE_F64 */

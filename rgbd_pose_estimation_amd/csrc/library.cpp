@@ -54,13 +54,17 @@ enum { LS_NONE = 0, LS_SHINJI_INLIERS = 1, LS_NL_BUGCOMPAT = 2, LS_NL_FIXED = 3,
 
 template <class Tp>
 int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
-    uint64_t seed,
+    uint64_t seed, int score_mode,
           int ls, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out) {
   const int n = p->n;
+  // everything this run may vary lives in the call: its own random stream (the `seed` argument) and its scoring mode.  Nothing
+  // process-wide is written, so concurrent calls neither interleave one stream nor see each other's mode.
+  rpe::Rand31 rng(seed);
+  rpe::RunOptions opt;
+  opt.rng = &rng; opt.score_mode = score_mode;
   HostMat<Tp> bv{(const Tp*)p->bv, n}, xc{(const Tp*)p->xc, n}, nc{(const Tp*)p->nc, n}, xw{(const Tp*)p->xw, n}, nw{(const Tp*)p->nw, n};
   HostWeights<Tp> w{(const Tp*)p->weights, n, p->wcols};
   int Iter = iter_io ? *iter_io : 0;
-  rpe::seed(seed);
   auto masks_out = [&](const std::vector<short>* m23, const std::vector<short>* m33, const std::vector<short>* mnn) {
     if (!mask_out) return;
     for (int i = 0; i < n; i++) {
@@ -76,8 +80,8 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     AOOnlyPoseAdapter<Tp> ad(xc, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
     if (p->weights) ad.setWeights(w);
-    if (method == M_SHINJI_RANSAC2) shinji_ransac2<Tp>(ad, (Tp)thre_3d, Iter, (Tp)confidence);
-    if (method == M_SHINJI_PROSAC) shinji_prosac<Tp>(ad, (Tp)thre_3d, Iter, (Tp)confidence);
+    if (method == M_SHINJI_RANSAC2) shinji_ransac2<Tp>(ad, (Tp)thre_3d, Iter, (Tp)confidence, opt);
+    if (method == M_SHINJI_PROSAC) shinji_prosac<Tp>(ad, (Tp)thre_3d, Iter, (Tp)confidence, opt);
     if (method == M_NONE) {
       read_pose<Tp>(ad, R9, t3);
       if (mask_in) { rpe::MatrixXs m(n, 2); for (int i = 0; i < n; i++) m(i, 1) = mask_in[n + i]; ad.setInlier(m); ad.cvtInlier(); }
@@ -93,8 +97,8 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     PnPPoseAdapter<Tp> ad(bv, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
     if (p->weights) ad.setWeights(w);
-    if (method == M_KNEIP_RANSAC) kneip_ransac<Tp>(ad, (Tp)thre_2d, Iter, (Tp)confidence);
-    if (method == M_KNEIP_PROSAC) kneip_prosac<Tp>(ad, (Tp)thre_2d, Iter, (Tp)confidence);
+    if (method == M_KNEIP_RANSAC) kneip_ransac<Tp>(ad, (Tp)thre_2d, Iter, (Tp)confidence, opt);
+    if (method == M_KNEIP_PROSAC) kneip_prosac<Tp>(ad, (Tp)thre_2d, Iter, (Tp)confidence, opt);
     if (method == M_NONE) {
       read_pose<Tp>(ad, R9, t3);
       if (mask_in) { rpe::MatrixXs m(n, 1); for (int i = 0; i < n; i++) m(i, 0) = mask_in[i]; ad.setInlier(m); ad.cvtInlier(); }
@@ -107,9 +111,9 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     AOPoseAdapter<Tp> ad(bv, xc, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
     if (p->weights) ad.setWeights(w);
-    if (method == M_SHINJI_RANSAC) shinji_ransac<Tp>(ad, (Tp)thre_3d, Iter, (Tp)confidence);
-    if (method == M_SK_RANSAC) shinji_kneip_ransac<Tp>(ad, (Tp)thre_3d, (Tp)thre_2d, Iter, (Tp)confidence);
-    if (method == M_SK_PROSAC) shinji_kneip_prosac<Tp>(ad, (Tp)thre_3d, (Tp)thre_2d, Iter, (Tp)confidence);
+    if (method == M_SHINJI_RANSAC) shinji_ransac<Tp>(ad, (Tp)thre_3d, Iter, (Tp)confidence, opt);
+    if (method == M_SK_RANSAC) shinji_kneip_ransac<Tp>(ad, (Tp)thre_3d, (Tp)thre_2d, Iter, (Tp)confidence, opt);
+    if (method == M_SK_PROSAC) shinji_kneip_prosac<Tp>(ad, (Tp)thre_3d, (Tp)thre_2d, Iter, (Tp)confidence, opt);
     if (method == M_NONE) {
       read_pose<Tp>(ad, R9, t3);
       if (mask_in) {
@@ -127,9 +131,9 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
   } else {
     NormalAOPoseAdapter<Tp> ad(bv, xc, nc, xw, nw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
-    if (method == M_NL_KNEIP_RANSAC) nl_kneip_ransac<Tp>(ad, (Tp)thre_2d, (Tp)thre_nl, Iter, (Tp)confidence);
-    if (method == M_NL_SHINJI_RANSAC) nl_shinji_ransac<Tp>(ad, (Tp)thre_3d, (Tp)thre_nl, Iter, (Tp)confidence);
-    if (method == M_NL_SK_RANSAC) nl_shinji_kneip_ransac<Tp>(ad, (Tp)thre_3d, (Tp)thre_2d, (Tp)thre_nl, Iter, (Tp)confidence);
+    if (method == M_NL_KNEIP_RANSAC) nl_kneip_ransac<Tp>(ad, (Tp)thre_2d, (Tp)thre_nl, Iter, (Tp)confidence, opt);
+    if (method == M_NL_SHINJI_RANSAC) nl_shinji_ransac<Tp>(ad, (Tp)thre_3d, (Tp)thre_nl, Iter, (Tp)confidence, opt);
+    if (method == M_NL_SK_RANSAC) nl_shinji_kneip_ransac<Tp>(ad, (Tp)thre_3d, (Tp)thre_2d, (Tp)thre_nl, Iter, (Tp)confidence, opt);
     if (method == M_NONE) {
       read_pose<Tp>(ad, R9, t3);
       ad.setMaxVotes(max_votes ? *max_votes : 1);
@@ -197,8 +201,12 @@ void ao_ransac(float* x_w_, float* x_c_, int n_, float* R_cw_, float* t_) {
     adapter.setFocal(f, f);
     int updated_iter = 1000;
     const float thre_3d = 0.1f, confidence = 0.99999f;
-    if (const char* s = getenv("RPE_SEED")) rpe::seed(strtoull(s, nullptr, 10)); else rpe::seed(1);
-    shinji_ransac2<float>(adapter, thre_3d, updated_iter, confidence);
+    // the reference draws from the process-global rand() here (not thread-safe, never seeded); this call owns its stream
+    rpe::Rand31 rng(1);
+    if (const char* s = getenv("RPE_SEED")) rng.reseed(strtoull(s, nullptr, 10));
+    rpe::RunOptions opt;
+    opt.rng = &rng;
+    shinji_ransac2<float>(adapter, thre_3d, updated_iter, confidence, opt);
     if (!quiet()) {
       std::cout << "updated_iter = " << updated_iter << std::endl;
       std::cout << "inliers = " << adapter.getMaxVotes() << std::endl;
@@ -289,20 +297,17 @@ int rpe_run(int method, const rpe_problem* p, double thre_3d, double thre_2d, do
     uint64_t seed,
             int ls, int score_mode, const short* mask_in, double* R9, double* t3, int* max_votes, short* mask_out) {
   if (!p || !R9 || !t3 || p->n <= 0 || !p->xw) return rpe::set_error(RPE_ERR_ARG, "rpe_run: bad argument");
-  const int saved = rpe::Settings::get().score_mode;
-  rpe::Settings::get().score_mode = score_mode;
   int rc;
   try {
-    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, mask_in, R9, t3,
-        max_votes, mask_out)
-                             : run_t<float>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, ls, mask_in, R9, t3,
-                                 max_votes, mask_out);
+    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, score_mode, ls, mask_in, R9,
+        t3, max_votes, mask_out)
+                             : run_t<float>(method, p, thre_3d, thre_2d, thre_nl, iter_io, confidence, seed, score_mode, ls, mask_in,
+                                 R9, t3, max_votes, mask_out);
   } catch (const rpe::DeviceError& e) {
     rc = rpe::set_error(e.code, e.what());
   } catch (const std::exception& e) {
     rc = rpe::set_error(RPE_ERR_STATE, e.what());
   }
-  rpe::Settings::get().score_mode = saved;
   return rc;
 }
 
@@ -316,8 +321,8 @@ int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t se
   int it = iters, mv = 0, rc = RPE_OK;
   double R9[9], t3[3];
   try {
-    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, 0, nullptr, R9, t3, &mv, nullptr)
-                             : run_t<float>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, 0, nullptr, R9, t3, &mv, nullptr);
+    rc = p->dtype == RPE_F64 ? run_t<double>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, -1, 0, nullptr, R9, t3, &mv, nullptr)
+                             : run_t<float>(method, p, 1.0, 1.0, 1.0, &it, 0.99, seed, -1, 0, nullptr, R9, t3, &mv, nullptr);
   } catch (const std::exception& e) { rc = rpe::set_error(RPE_ERR_STATE, e.what()); }
   rpe::Settings::get().capture = nullptr;
   if (rc != RPE_OK) return rc;

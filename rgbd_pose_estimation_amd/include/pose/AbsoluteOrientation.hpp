@@ -72,7 +72,8 @@ void pose_from_device_moments(Adapter& adapter, int flags) {
 }
 
 template <typename Tp, class Adapter>
-void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence, bool prosac) {
+void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence, bool prosac, const RunOptions& opt) {
+  Rand31& rnd = opt.stream();
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
@@ -86,7 +87,7 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
   MatrixX<Tp> Xw(3, K), Xc(3, K);
   auto gen = [&](std::vector<SE3<Tp> >& out) {
     std::vector<int> sel;
-    if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K, &sel);
+    if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); } else re.run(K, &sel, rnd);
     for (int s = 0; s < K; s++) {
       if (!adapter.isValid(sel[s])) return;  // invalid sample: the reference 'continue's
       Xw.setCol(s, adapter.getPointGlob(sel[s]));
@@ -99,23 +100,26 @@ void shinji_sac(Adapter& adapter, const Tp dist_thre_3d_, int& Iter, Tp confiden
   // plain RANSAC consumes exactly K draws per iteration, so every iteration's position in the random stream is known up front and
   // the whole iteration can run on the device; PROSAC's sampler rejects duplicates (a variable number of draws) and stays on the host
   if (!prosac && Settings::get().device_hypotheses && N >= K && !Settings::get().capture
-      && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
-  else ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+      && !Settings::get().replay) ransac_engine_device33<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2, opt);
+  else ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2, opt);
   adapter.cvtInlier();
 }
 }  // namespace rpe
 
 template <typename Tp>
-void shinji_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99) {  // reference :101-156
-  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, false);
+void shinji_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99,  // reference :101-156
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, false, opt);
 }
 template <typename Tp>
-void shinji_ransac2(AOOnlyPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99) {  // reference :158-213
-  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, false);
+void shinji_ransac2(AOOnlyPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99,  // reference :158-213
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, false, opt);
 }
 template <typename Tp>
-void shinji_prosac(AOOnlyPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99) {  // reference :215-271
-  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, true);
+void shinji_prosac(AOOnlyPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, int& Iter, Tp confidence = 0.99,  // reference :215-271
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::shinji_sac<Tp>(adapter, dist_thre_3d_, Iter, confidence, true, opt);
 }
 
 // least squares over the 3D-3D inliers (reference :273-296 / :298-320)
@@ -145,7 +149,9 @@ bool assign_sample(const AOPoseAdapter<Tp>& adapter, const std::vector<int>& sel
 
 namespace rpe {
 template <typename Tp>
-void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence, bool prosac) {
+void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence, bool prosac,
+    const RunOptions& opt) {
+  Rand31& rnd = opt.stream();
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
@@ -163,7 +169,7 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
   MatrixX<Tp> X_w(3, K + 1), X_c(3, K + 1), bv(3, K + 1);
   auto gen = [&](std::vector<SE3<Tp> >& out) {
     std::vector<int> sel;
-    if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K + 1, &sel);
+    if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); } else re.run(K + 1, &sel, rnd);
     if (assign_sample<Tp>(adapter, sel, &X_w, &X_c, &bv)) { const SE3<Tp> fit = shinji<Tp>(X_w, X_c, K);
         if (fit.so3().valid()) out.push_back(fit); }
     SE3<Tp> sk;
@@ -174,11 +180,11 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
     adapter.setInlierFromDevice(cols, device_cols);
   };
   const Settings& cfg = Settings::get();
-  if (!prosac && cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
+  if (!prosac && opt.mode() == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
     // FAST mode: later batches generated on the device
-    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/1, gen, commit, Iter, confidence, /*mask_cols=*/2);
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/1, gen, commit, Iter, confidence, /*mask_cols=*/2, opt);
   else
-    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2);
+    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/2, opt);
   PnPPoseAdapter<Tp>* pAdapter = &adapter;
   pAdapter->cvtInlier();
   adapter.cvtInlier();
@@ -187,13 +193,15 @@ void shinji_kneip_sac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const 
 
 template <typename Tp>
 // :367-438
-void shinji_kneip_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {
-  rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, false);
+void shinji_kneip_ransac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99,
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, false, opt);
 }
 template <typename Tp>
 // :440-515
-void shinji_kneip_prosac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {
-  rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, true);
+void shinji_kneip_prosac(AOPoseAdapter<Tp>& adapter, const Tp dist_thre_3d_, const Tp thre_2d_, int& Iter, Tp confidence = 0.99,
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::shinji_kneip_sac<Tp>(adapter, dist_thre_3d_, thre_2d_, Iter, confidence, true, opt);
 }
 
 #endif

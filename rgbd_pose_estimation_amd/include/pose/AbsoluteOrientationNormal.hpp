@@ -113,7 +113,8 @@ namespace rpe {
 // which = 0: nl_kneip_ransac (:215-284), 1: nl_shinji_ransac (:286-354), 2: nl_shinji_kneip_ransac (:356-445)
 template <typename Tp>
 void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, const Tp thre_2d_, const Tp nl_thre, int& Iter,
-    Tp confidence) {
+    Tp confidence, const RunOptions& opt) {
+  Rand31& rnd = opt.stream();
   const int N = adapter.getNumberCorrespondences();
   const int K = 3;
   RandomElements<int> re(N);
@@ -128,7 +129,7 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
   MatrixX<Tp> Xw(3, K + 1), Xc(3, K + 1), bv(3, K + 1), Nw(3, K + 1), Nc(3, K + 1);
   auto gen = [&](std::vector<SE3<Tp> >& out) {
     std::vector<int> sel;
-    re.run(K + 1, &sel);
+    re.run(K + 1, &sel, rnd);
     const bool all_valid = assign_sample<Tp>(adapter, sel, &Xw, &Nw, &Xc, &Nc, &bv);
     if (which == 0) {
       SE3<Tp> sk;
@@ -149,11 +150,11 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
     adapter.setInlierFromDevice(cols, device_cols);
   };
   const Settings& cfg = Settings::get();
-  if (cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
+  if (opt.mode() == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K + 1 && !cfg.capture && !cfg.replay)
     // FAST mode: later batches generated on the device
-    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/2 + which, gen, commit, Iter, confidence, /*mask_cols=*/3);
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/2 + which, gen, commit, Iter, confidence, /*mask_cols=*/3, opt);
   else
-    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/3);
+    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/3, opt);
   if (which != 1) { PnPPoseAdapter<Tp>* p = &adapter; p->cvtInlier(); }
   if (which != 0) { AOPoseAdapter<Tp>* p = &adapter; p->cvtInlier(); }
   adapter.cvtInlier();
@@ -161,17 +162,19 @@ void nl_sac(NormalAOPoseAdapter<Tp>& adapter, int which, const Tp thre_3d_, cons
 }  // namespace rpe
 
 template <typename Tp>
-void nl_kneip_ransac(NormalAOPoseAdapter<Tp>& adapter, const Tp thre_2d_, const Tp nl_thre, int& Iter, Tp confidence = 0.99) {
-  rpe::nl_sac<Tp>(adapter, 0, Tp(0), thre_2d_, nl_thre, Iter, confidence);
+void nl_kneip_ransac(NormalAOPoseAdapter<Tp>& adapter, const Tp thre_2d_, const Tp nl_thre, int& Iter, Tp confidence = 0.99,
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::nl_sac<Tp>(adapter, 0, Tp(0), thre_2d_, nl_thre, Iter, confidence, opt);
 }
 template <typename Tp>
-void nl_shinji_ransac(NormalAOPoseAdapter<Tp>& adapter, const Tp thre_3d_, const Tp nl_thre, int& Iter, Tp confidence = 0.99) {
-  rpe::nl_sac<Tp>(adapter, 1, thre_3d_, Tp(0), nl_thre, Iter, confidence);
+void nl_shinji_ransac(NormalAOPoseAdapter<Tp>& adapter, const Tp thre_3d_, const Tp nl_thre, int& Iter, Tp confidence = 0.99,
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::nl_sac<Tp>(adapter, 1, thre_3d_, Tp(0), nl_thre, Iter, confidence, opt);
 }
 template <typename Tp>
 void nl_shinji_kneip_ransac(NormalAOPoseAdapter<Tp>& adapter, const Tp thre_3d_, const Tp thre_2d_, const Tp nl_thre, int& Iter,
-                            Tp confidence = 0.99) {
-  rpe::nl_sac<Tp>(adapter, 2, thre_3d_, thre_2d_, nl_thre, Iter, confidence);
+                            Tp confidence = 0.99, const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::nl_sac<Tp>(adapter, 2, thre_3d_, thre_2d_, nl_thre, Iter, confidence, opt);
 }
 
 // Joint least squares over the three inlier sets (reference :447-552): weighted 3D centroids, then three rounds of

@@ -174,7 +174,8 @@ int RANSACUpdateNumIters(T p, T ep, const int modelPoints, const int maxIters) {
 
 namespace rpe {
 template <typename Tp>
-void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp confidence, bool prosac) {
+void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp confidence, bool prosac, const RunOptions& opt) {
+  Rand31& rnd = opt.stream();
   const int N = adapter.getNumberCorrespondences();
   const int K = 4;
   RandomElements<int> re(N);
@@ -190,7 +191,7 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
   adapter.device().template ensure<Tp>(RPE_BV, adapter.bearingData(), N);
   auto gen = [&](std::vector<SE3<Tp> >& out) {
     std::vector<int> sel;
-    if (prosac) { ps.sample(&sel); adapter.getSortedIdx(sel); } else re.run(K, &sel);
+    if (prosac) { ps.sample(&sel, rnd); adapter.getSortedIdx(sel); } else re.run(K, &sel, rnd);
     std::vector<SE3<Tp> > sols = kneip<Tp>(adapter, sel[0], sel[1], sel[2]);
     Tp best = Tp(1000000.0);
     int arg = -1;
@@ -206,21 +207,23 @@ void kneip_sac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp con
   // plain RANSAC in FAST scoring mode: batches beyond the first few are generated on the device too (4 draws per iteration: every
   // iteration's position in the random stream is known up front)
   const Settings& cfg = Settings::get();
-  if (!prosac && cfg.score_mode == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K && !cfg.capture && !cfg.replay)
-    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/0, gen, commit, Iter, confidence, /*mask_cols=*/1);
+  if (!prosac && opt.mode() == RPE_SCORE_FAST && cfg.device_hypotheses && N >= K && !cfg.capture && !cfg.replay)
+    ransac_engine_device_p3p<Tp>(adapter, spec, /*solver=*/0, gen, commit, Iter, confidence, /*mask_cols=*/1, opt);
   else
-    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/1);
+    ransac_engine<Tp>(adapter, spec, gen, commit, Iter, confidence, /*mask_cols=*/1, opt);
   adapter.cvtInlier();
 }
 }  // namespace rpe
 
 template <typename Tp>
-void kneip_ransac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {  // reference :320-392
-  rpe::kneip_sac<Tp>(adapter, thre_2d_, Iter, confidence, false);
+void kneip_ransac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp confidence = 0.99,  // reference :320-392
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::kneip_sac<Tp>(adapter, thre_2d_, Iter, confidence, false, opt);
 }
 template <typename Tp>
-void kneip_prosac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp confidence = 0.99) {  // reference :395-469
-  rpe::kneip_sac<Tp>(adapter, thre_2d_, Iter, confidence, true);
+void kneip_prosac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp confidence = 0.99,  // reference :395-469
+    const rpe::RunOptions& opt = rpe::RunOptions()) {
+  rpe::kneip_sac<Tp>(adapter, thre_2d_, Iter, confidence, true, opt);
 }
 
 // Sum of the per-correspondence sine residuals at the adapter's pose (reference :472-502 prints it; returned here).

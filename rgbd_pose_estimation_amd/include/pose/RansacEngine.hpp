@@ -48,7 +48,7 @@ template <class Tp> inline void pose7(const SE3<Tp>& s, double* q7) {
 // commit(cols, device_cols): the winner's masks are on the device; the adapter adopts them (setInlierFromDevice).
 template <class Tp, class Adapter, class Produce, class Commit>
 void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce produce, Commit commit, int& Iter, Tp confidence,
-    int mask_cols) {
+    int mask_cols, const RunOptions& opt) {
   const int N = adapter.getNumberCorrespondences();
   Settings& cfg = Settings::get();
   const bool prof = cfg.profile;
@@ -94,7 +94,7 @@ void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce p
     double b7[7];
     pose7<Tp>(best, b7);
     int total = 0;
-    check(rpe_inlier_mask(ctx, spec.kind, cfg.score_mode, b7, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, &total),
+    check(rpe_inlier_mask(ctx, spec.kind, opt.mode(), b7, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, &total),
           "rpe_inlier_mask");
     const bool has23 = spec.kind == RPE_VOTE_23 || spec.kind == RPE_VOTE_23_MATRIX || spec.kind == RPE_VOTE_33_23 ||
                        spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33_23;
@@ -113,7 +113,8 @@ void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce p
 // gen(out): advance the sampler by ONE reference iteration and append its 0..3 hypotheses, in the reference's order (host-side
 // minimal solvers); the batch is scored by rpe_score (kernel K4).
 template <class Tp, class Adapter, class Gen, class Commit>
-void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols) {
+void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence, int mask_cols,
+    const RunOptions& opt) {
   Settings& cfg = Settings::get();
   if (cfg.capture) {   // generation only (rpe_host_hypotheses): the stream of `Iter` iterations, no device
     std::vector<SE3<Tp> > hyps;
@@ -153,10 +154,10 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
     q7.resize(hyps.size() * 7);
     for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
     votes.resize(hyps.size());
-    check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+    check(rpe_score(ctx, spec.kind, opt.mode(), q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
                     (double)spec.cos_nl, votes.data()), "rpe_score");
   };
-  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
+  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols, opt);
 }
 
 // The 3D-3D solvers (shinji_ransac / shinji_ransac2): sampling, the 3-point fit and the scoring all run on the device
@@ -169,7 +170,7 @@ void ransac_engine(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit c
 // single-launch form; the random stream is the same either way, so the two can alternate batch by batch.
 template <class Tp, class Adapter, class Gen, class Commit>
 void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen, Commit commit, int& Iter, Tp confidence,
-    int mask_cols) {
+    int mask_cols, const RunOptions& opt) {
   constexpr int kHostBatch = 32;
   Settings& cfg = Settings::get();
   rpe_context* ctx = adapter.device().ctx();
@@ -186,15 +187,15 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
       q7.resize(hyps.size() * 7);
       for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
       votes.resize(hyps.size());
-      check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+      check(rpe_score(ctx, spec.kind, opt.mode(), q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
                       (double)spec.cos_nl, votes.data()), "rpe_score");
       return;
     }
-    Rand31& g = global_rng();
+    Rand31& g = opt.stream();
     q7.resize((size_t)iters * 7); valid.resize((size_t)iters); all_votes.resize((size_t)iters);
     for (int done = 0; done < iters;) {   // the device call takes at most kMaxScoreH iterations at a time
       const int chunk = std::min(iters - done, 8192);
-      check(rpe_ransac33_batch(ctx, g.state(), g.inc(), chunk, cfg.score_mode, (double)spec.thre_3d, all_votes.data() + done,
+      check(rpe_ransac33_batch(ctx, g.state(), g.inc(), chunk, opt.mode(), (double)spec.thre_3d, all_votes.data() + done,
                                q7.data() + 7 * (size_t)done, valid.data() + done), "rpe_ransac33_batch");
       g.advance((uint64_t)spec.model_points * (uint64_t)chunk);
       done += chunk;
@@ -209,7 +210,7 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
       first.push_back((int)hyps.size());
     }
   };
-  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
+  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols, opt);
 }
 
 // The plain-RANSAC solvers with a 4-point sample in FAST scoring mode (solver 0 kneip_ransac, 1 shinji_kneip_ransac, 2 nl_kneip_ransac,
@@ -218,7 +219,7 @@ void ransac_engine_device33(Adapter& adapter, const VoteSpec<Tp>& spec, Gen gen,
 // with the host's to rounding only, which is why the vote-exact default never takes this path.
 template <class Tp, class Adapter, class Gen, class Commit>
 void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int solver, Gen gen, Commit commit, int& Iter, Tp confidence,
-    int mask_cols) {
+    int mask_cols, const RunOptions& opt) {
   constexpr int kHostBatch = 32;
   Settings& cfg = Settings::get();
   rpe_context* ctx = adapter.device().ctx();
@@ -237,11 +238,11 @@ void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int so
       q7.resize(hyps.size() * 7);
       for (size_t h = 0; h < hyps.size(); h++) pose7<Tp>(hyps[h], &q7[7 * h]);
       votes.resize(hyps.size());
-      check(rpe_score(ctx, spec.kind, cfg.score_mode, q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
+      check(rpe_score(ctx, spec.kind, opt.mode(), q7.data(), (int)hyps.size(), (double)spec.thre_3d, (double)spec.cos_thr,
                       (double)spec.cos_nl, votes.data()), "rpe_score");
       return;
     }
-    Rand31& g = global_rng();
+    Rand31& g = opt.stream();
     const size_t slots = (size_t)iters * per;
     q7.resize(slots * 7); valid.resize(slots); all_votes.resize(slots);
     for (int done = 0; done < iters;) {
@@ -265,7 +266,7 @@ void ransac_engine_device_p3p(Adapter& adapter, const VoteSpec<Tp>& spec, int so
       first.push_back((int)hyps.size());
     }
   };
-  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols);
+  ransac_engine_batched<Tp>(adapter, spec, produce, commit, Iter, confidence, mask_cols, opt);
 }
 
 }  // namespace rpe

@@ -16,41 +16,8 @@
 #include <numeric>
 #include <utility>
 #include <vector>
+#include "../rpe/random.hpp"
 
-namespace rpe {
-class Rand31 {
- public:
-  explicit Rand31(uint64_t seed = 1, uint64_t stream = 54) { reseed(seed, stream); }
-  void reseed(uint64_t seed, uint64_t stream = 54) {
-    _state = 0; _inc = (stream << 1) | 1u;
-    step(); _state += seed; step();
-  }
-  int operator()() { return (int)(step() >> 1); }  // uniform in [0, 2^31)
-  // for samplers that run on the device from this stream's current position (one draw = one LCG step)
-  uint64_t state() const { return _state; }
-  uint64_t inc() const { return _inc; }
-  void advance(uint64_t draws) {   // skip `draws` draws in O(log draws)
-    uint64_t cur_mult = 6364136223846793005ULL, cur_plus = _inc, acc_mult = 1, acc_plus = 0;
-    while (draws > 0) {
-      if (draws & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
-      cur_plus = (cur_mult + 1) * cur_plus;
-      cur_mult *= cur_mult;
-      draws >>= 1;
-    }
-    _state = acc_mult * _state + acc_plus;
-  }
- private:
-  uint32_t step() {
-    const uint64_t old = _state;
-    _state = old * 6364136223846793005ULL + _inc;
-    const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
-    return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
-  }
-  uint64_t _state, _inc;
-};
-inline Rand31& global_rng() { static Rand31 g(1); return g; }
-inline void seed(uint64_t s) { global_rng().reseed(s); }
-}  // namespace rpe
 
 // indices that sort v in DESCENDING order (reference :107-118).  The reference's comparator leaves the order of equal
 // weights to std::sort; here ties go to the lower index, which makes the order unique -- so the first top_k entries can be

@@ -14,6 +14,7 @@
 #include <vector>
 #include <type_traits>
 #include "../../../include/rgbd_pose_hip.h"
+#include "random.hpp"
 
 namespace rpe {
 
@@ -63,6 +64,17 @@ struct Settings {
   static inline thread_local HypothesisList* capture = nullptr;
   static inline thread_local const HypothesisList* replay = nullptr;
   static Settings& get() { static Settings s; return s; }
+};
+
+// What ONE solver run may set for itself without touching process-wide state: the last, defaulted argument of every *_ransac /
+// *_prosac free function (the reference's signatures stay callable as they are).  The defaults are the reference's semantics -- one
+// process-global random stream (rand(), /root/reference/pose/Utility.hpp:148) and the process-wide scoring mode; a caller that runs
+// solvers on several threads gives each run its own stream, which is what rpe_run / rpe_host_hypotheses / ao_ransac do with their seed.
+struct RunOptions {
+  Rand31* rng = nullptr;   // null: rpe::global_rng()
+  int score_mode = -1;     // < 0: Settings::get().score_mode
+  Rand31& stream() const { return rng ? *rng : global_rng(); }
+  int mode() const { return score_mode >= 0 ? score_mode : Settings::get().score_mode; }
 };
 
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -195,3 +195,42 @@ def test_nan_columns_never_vote(oracle):
     nan_rows = np.isnan(sc.P).all(1)
     assert got["masks"][1][nan_rows].sum() == 0 and got["masks"][1][~nan_rows].sum() > 0.5 * (~nan_rows).sum()
     assert util.rot_err(got["R"], sc.R) < 5e-3
+
+
+def test_concurrent_runs_with_different_seeds_and_modes(oracle):
+    """The C ABI is re-entrant: four threads run rpe_run at once -- different solvers, seeds, dtypes, and EXACT beside FAST scoring.
+    Every EXACT run must equal the oracle's run for its own seed (votes, Iter, masks, the winning hypothesis), every FAST run must
+    equal the same FAST call made alone: a shared random stream or a shared scoring mode (round 3: rpe::global_rng(), a saved /
+    restored Settings::score_mode) would show up as a foreign stream's hypotheses or the neighbour's mode."""
+    import threading
+    n = 20000
+    jobs = []
+    for k, (pl, f64, mode, seed) in enumerate([(PIPELINES[0], False, L.SCORE_EXACT, 5), (PIPELINES[3], True, L.SCORE_EXACT, 6),
+                                               (PIPELINES[7], False, L.SCORE_FAST, 7), (PIPELINES[1], False, L.SCORE_EXACT, 8)]):
+        name, method, arrays, ls, thr = pl
+        sc = util.scene_full(1500 + k, n, np.float64 if f64 else np.float32, n2d=1.0, n3d=0.05, nnl_deg=2.0, outliers=0.3, nan_frac=0.05)
+        data = dict(xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+        sel = {a: data[a] for a in arrays}
+        kw = dict(iters=200, confidence=0.9999, seed=seed, **thr)
+        call = (lambda method=method, f64=f64, sc=sc, sel=sel, kw=kw, mode=mode:
+                api.run(getattr(api, method), L.F64 if f64 else L.F32, weights=sc.weights, ls=api.LS_NONE, score_mode=mode, **sel, **kw))
+        if mode == L.SCORE_EXACT:
+            want = oracle.run(oracle.Problem(f64, weights=sc.weights, **sel), getattr(oracle, method), ls=oracle.LS_NONE, **kw)
+        else:
+            want = call()
+        jobs.append((name, call, want))
+    bad = []
+
+    def work(name, call, want):
+        for _ in range(12):
+            got = call()
+            if not (got["max_votes"] == want["max_votes"] and got["iters"] == want["iters"] and np.array_equal(got["masks"], want["masks"])
+                    and np.array_equal(got["R"], want["R"]) and np.array_equal(got["t"], want["t"])):
+                bad.append(name)
+                return
+    th = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad

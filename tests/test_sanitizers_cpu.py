@@ -3,7 +3,8 @@ this pool).  Two programs are built with g++ -fsanitize=address,undefined -fno-s
   * tests/cpp/sanitize_host.cpp + csrc/library.cpp (product host side: drop-in headers, samplers, minimal solvers, RANSAC engine in
     capture mode, rpe_host_*) + csrc/rpe_hostex.cpp (the host-side exchange, three ranks as threads) + oracle/oracle_capi.cpp (the whole CPU restatement: pipelines, vote loops, replay);
   * tests/cpp/host_logic.cpp (PROSAC order, lazy index lists, sparse Fisher-Yates).
-librgbdpose_hip.so is linked for the GPU-facing symbols the headers reference; no GPU call is made."""
+librgbdpose_hip.so is linked for the GPU-facing symbols the headers reference; no GPU call is made.
+ThreadSanitizer (-fsanitize=thread) runs tests/cpp/reentrancy_host.cpp (concurrent C-ABI calls) and tests/cpp/host_logic.cpp."""
 import os
 import subprocess
 
@@ -13,12 +14,16 @@ SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-f
 ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", RPE_QUIET="1")
 
 
-def _build(tmp_path, name, sources):
+TSAN = ["-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-O1"]
+TSAN_ENV = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", RPE_QUIET="1")
+
+
+def _build(tmp_path, name, sources, san=None):
     from rgbd_pose_estimation_amd import build
     lib = build.build()
     inc = os.path.join(ROOT, "rgbd_pose_estimation_amd", "include")
     exe = str(tmp_path / name)
-    cmd = ["g++", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"] + SAN + ["-I", os.path.join(inc, "pose"), "-I", inc] + sources + \
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"] + (SAN if san is None else san) + ["-I", os.path.join(inc, "pose"), "-I", inc] + sources + \
           ["-L", os.path.dirname(lib), "-lrgbdpose_hip", "-Wl,-rpath," + os.path.dirname(lib), "-pthread", "-o", exe]
     subprocess.check_call(cmd)
     return exe
@@ -39,3 +44,22 @@ def test_host_logic_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=ENV)
     assert r.returncode == 0 and "host_logic: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_c_abi_is_reentrant_under_tsan(tmp_path):
+    """Eight threads in rpe_host_hypotheses at once (all solvers, both dtypes, different seeds): each gets the stream the call yields
+    alone and the oracle's stream for its seed, and ThreadSanitizer sees no race in the instrumented host side (library.cpp + the
+    drop-in headers).  The per-call rpe::Rand31 replaced the process-global stream the round-3 review found interleaving."""
+    exe = _build(tmp_path, "reentrancy_tsan", [os.path.join(ROOT, "tests", "cpp", "reentrancy_host.cpp"),
+                                              os.path.join(ROOT, "rgbd_pose_estimation_amd", "csrc", "library.cpp"),
+                                              os.path.join(ROOT, "oracle", "oracle_capi.cpp")], san=TSAN)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=TSAN_ENV)
+    assert r.returncode == 0 and "reentrancy_host: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_host_logic_under_tsan(tmp_path):
+    exe = _build(tmp_path, "host_logic_tsan", [os.path.join(ROOT, "tests", "cpp", "host_logic.cpp")], san=TSAN)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=TSAN_ENV)
+    assert r.returncode == 0 and "host_logic: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
