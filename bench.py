@@ -603,6 +603,11 @@ def worker(args, affinity):
         # sharded + host exchange: rpe_gn_refine on every rank (resident kernel when every rank has its own GPU)
         shared_gpu = os.environ.get("RPE_BENCH_SHARE_GPU") == "1"
         resident = ((not dist_path) or (hostex and not shared_gpu)) and os.environ.get("RPE_RESIDENT", "1") != "0"
+        # ... and the context must actually be able to run them (large BAR, co-residency cap >= 1, fewer than two lost grids); the state
+        # is read again after the timed region: a grid lost in it (another process on the GPU) means the labels below would describe a
+        # path that did not run
+        res_state0 = ctx.resident_state()
+        resident = resident and res_state0["enabled"] and res_state0.get("host_driven", True)
 
         # rpe_gn_refine called straight through ctypes with arguments prepared once: the timed region should hold the library's loop, not
         # numpy conversions (about 5 us per call, a quarter of a microsecond per step at --steps 20)
@@ -712,6 +717,9 @@ def worker(args, affinity):
                 ctx.timing_enable(0, 1)
         ev_avg_ms, ev_min_ms = ctx.timing_calibrate(200)
         elapsed = percentile(samples, 0.5)
+        res_state1 = ctx.resident_state()
+        resident_lost_in_run = res_state1["lost"] - res_state0["lost"]
+        resident_ran = resident and resident_lost_in_run == 0 and res_state1["enabled"]
 
         # where a step's time goes, seen from the host thread (resident loop only): waiting for the GPU vs its own work
         loop_prof = None
@@ -793,7 +801,14 @@ def worker(args, affinity):
         inl_total = int(ti.item())
 
     out = None
+    invalid = None
     if rank == 0:
+        if resident and not resident_ran:
+            # a resident grid was lost during this process (the library finished those refinements with one launch per iteration and
+            # returned RPE_OK): repetitions of BOTH paths are in the samples, so neither set of labels describes the run
+            invalid = ("%d resident grid(s) lost during the run (another process on this GPU?): the timed repetitions mix the resident loop with "
+                       "one launch per iteration; rerun on an idle GPU" % resident_lost_in_run)
+            resident = False
         steps_per_launch = args.steps if resident else 1
         k_avg_s = (k_total_ms / max(k_cnt, 1)) * 1e-3
         bytes_per_launch = BYTES_PER_CORR * n * steps_per_launch
@@ -822,6 +837,7 @@ def worker(args, affinity):
                        "collective_step_us": ({"rccl_us": coll_times.get("rccl_us"), "host_us": coll_times.get("host_us"), "p2p_us": coll_times.get("p2p_us")} if dist_path else None),
                        "collective_step_us_note": "same run, same shards, 400 steps each: rccl = kernel + ncclAllReduce + publish kernel per step; host = resident kernel per rank + records added by the host threads; p2p = in-kernel mailboxes (timed on request only: RPE_BENCH_COLLECTIVE=auto_p2p)" if dist_path else None,
                        "rccl_ranks": rccl_ranks, "rccl_ranks_source": "ncclCommCount on the library's communicator after one verified all-reduce" if rccl_ranks else None,
+                       "resident_state": {"before": res_state0, "after": res_state1, "lost_in_run": resident_lost_in_run, "resident_loop_ran": resident_ran},
                        "rccl_verified": rccl_verified, "pci_bus_ids": bus_ids or None, "collective_plan": plan if dist_path else None,
                        "host_loop": "rpe_gn_refine: ONE resident launch per refinement, poses handed over through device memory" if resident else
                                     ("rpe_gn_refine on every rank: one launch per step + exchange between the host threads (ranks share a GPU)" if hostex else
@@ -910,7 +926,13 @@ def worker(args, affinity):
     except Exception:
         pass
     if rank == 0:
+        if invalid:
+            out["valid"] = False
+            out["invalid_reason"] = invalid
+            print("bench.py: INVALID RUN: " + invalid, file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
+        if invalid:
+            sys.exit(3)
 
 
 def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):

@@ -225,9 +225,13 @@ int rpe_debug_loop_profile(rpe_context* ctx, int enable, double* wait_us, double
  * succeeds, a context that sees it twice stops using resident loops; cap: workgroups of a resident kernel the device holds at once
  * (occupancy x compute units, at most 256; RPE_RESIDENT_CAP lowers it). */
 int rpe_debug_resident_state(rpe_context* ctx, int* enabled, int* lost, int* cap);
+/* Test hook, per context: the last workgroup of the next host-driven resident loops withholds its sums of `iteration` (> 0), and the
+ * workgroups wait `pose_wait_s` seconds (0.5 .. 60; 0 = default 2 s) for the next pose.  (0, 0) = off.  Nothing in the library reads
+ * a fault from the environment. */
+int rpe_debug_inject_resident_fault(rpe_context* ctx, int iteration, double pose_wait_s);
 
-/* HIP-event timing of the normal-equation kernel, on the context's stream: after enable(max_records, stride)
- * every stride-th rpe_normal_eq* call launches its kernel with an event pair that receives the dispatch's own begin / end
+/* HIP-event timing of the one-launch reduction kernels (rpe_normal_eq*, rpe_p2p_moments, rpe_nl_round, rpe_inlier_mask), on the
+ * context's stream: after enable(max_records, stride) every stride-th such call launches its kernel with an event pair that receives the dispatch's own begin / end
  * timestamps (hipExtLaunchKernelGGL: what rocprofv3 reports for the kernel, no marker packets); collect() synchronises,
  * returns the number of pairs and their total / minimum elapsed milliseconds, and rearms.  enable(0, 1) = off. */
 int rpe_timing_enable(rpe_context* ctx, int max_records, int stride);

@@ -139,6 +139,10 @@ struct rpe_context {
   bool resident = false;
   int resident_lost = 0;          // resident loops that lost a granule / ended early and were finished with one launch per iteration
   int resident_cap = 0;           // workgroups of a resident kernel this device holds at once (rpe::resident_cap_device)
+  bool host_resident = false;     // the HOST-driven resident loops can run here: large BAR + control block (c->ctl)
+  // fault injection of the tests, set through rpe_debug_inject_resident_fault only (never from the environment)
+  int test_fault_iter = 0;        // > 0: the last workgroup withholds its sums of this iteration of the next resident loops
+  double test_pose_wait_s = 0;    // > 0: length of the workgroups' bounded wait for the next pose
   // pinned + mapped: tagged 16-byte pairs {value, sequence} -- the run records of collecting launches, added here on the host
   double* h_big = nullptr;
   size_t h_big_pairs = 0;
@@ -225,6 +229,17 @@ int need_arrays(rpe_context* c, std::initializer_list<int> slots) {
   return RPE_OK;
 }
 
+// RPE_RESIDENT_STRIDE (experiments): runs of every stride-th workgroup; 0 / 1 = runs of consecutive workgroups.  Clamped to 2 .. 16: a
+// stride is a number of RUNS, every run sends up to 44 sums to the host as tagged pairs, and the pinned pair buffer (h_big) and the
+// autonomous loop's run records (kAutoMaxRunSums) are sized for at most ~16 runs of the widest record.
+int run_stride_from_env() {
+  const char* e = getenv("RPE_RESIDENT_STRIDE");
+  if (!e) return 8;
+  const int v = atoi(e);
+  if (v <= 1) return 0;
+  return v > 16 ? 16 : v;
+}
+
 rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
@@ -237,7 +252,7 @@ rpe::ReduceTarget host_target(rpe_context* c) {
 rpe::ReduceTarget collect_target(rpe_context* c) {
   rpe::ReduceTarget rt = host_target(c);
   static const bool on = !(getenv("RPE_COLLECT") && atoi(getenv("RPE_COLLECT")) == 0);
-  static const int stride = getenv("RPE_RESIDENT_STRIDE") ? atoi(getenv("RPE_RESIDENT_STRIDE")) : 8;
+  static const int stride = run_stride_from_env();
   if (on) { rt.h_out = c->h_big; rt.rows = 1 << 20; rt.stride = stride; c->collecting = true; }
   return rt;
 }
@@ -442,7 +457,7 @@ static std::mutex& resident_mutex(int device) {
 // run length of consecutive workgroups.  Returns the number of runs.
 static int resident_run_shape(int grid, int nacc, int max_rows, int rows_auto, rpe::ReduceTarget* rt) {
   static const int env_rows = getenv("RPE_RESIDENT_ROWS") ? atoi(getenv("RPE_RESIDENT_ROWS")) : 0;
-  static const int env_stride = getenv("RPE_RESIDENT_STRIDE") ? atoi(getenv("RPE_RESIDENT_STRIDE")) : 8;
+  static const int env_stride = run_stride_from_env();
   rt->stride = 0;
   if (env_rows >= 1) rt->rows = std::min(env_rows, max_rows);
   else if (grid * nacc <= 1024) rt->rows = 1;
@@ -451,6 +466,13 @@ static int resident_run_shape(int grid, int nacc, int max_rows, int rows_auto, r
     return env_stride;
   } else rt->rows = rows_auto;
   return (grid + rt->rows - 1) / rt->rows;
+}
+
+// A resident grid of this context was lost (not all of it on the compute units at once, or a workgroup held up beyond its bounded
+// wait) and the refinement was finished with one launch per iteration.  The second loss switches resident loops off for the context,
+// host-driven and autonomous alike (rpe_debug_resident_state reports enabled = 0 from then on).
+static void note_lost_grid(rpe_context* c) {
+  if (++c->resident_lost >= 2) c->resident = false;
 }
 
 template <class Launch>
@@ -469,11 +491,9 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   rt.seq = base;
   // a rank that waits for a slow peer inside the host-side exchange (up to its 10 s) must not lose its own grid meanwhile
   if (c->hostex) rt.pose_wait_ticks = 1200000000ull;
-  // tests: a long pose wait, to see that a lost grid is RELEASED rather than timed out
-  if (const char* w = getenv("RPE_TEST_POSE_WAIT_S")) { const double sec = atof(w);
-      if (sec >= 0.5 && sec <= 60.0) rt.pose_wait_ticks = (unsigned long long)(sec * 1e8); }
-  if (const char* f = getenv("RPE_TEST_RESIDENT_FAULT")) { const int k = atoi(f);
-      if (k >= 1 && k <= max_iter) rt.fault_tag = base + (unsigned long long)k; }
+  // tests (rpe_debug_inject_resident_fault): a long pose wait, to see that a lost grid is RELEASED rather than timed out
+  if (c->test_pose_wait_s > 0) rt.pose_wait_ticks = (unsigned long long)(c->test_pose_wait_s * 1e8);
+  if (c->test_fault_iter >= 1 && c->test_fault_iter <= max_iter) rt.fault_tag = base + (unsigned long long)c->test_fault_iter;
   const int runs = resident_run_shape(grid, nacc, max_rows, rows_auto, &rt);
   rt.h_out = c->h_big;
   c->seq = base;
@@ -515,7 +535,7 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     // Not all of the grid was on the compute units at once (another process on the GPU, a smaller partition than the occupancy query
     // promised) or a workgroup was held up for more than its bounded wait.  pose12 holds the pose after `it` whole iterations: the
     // caller finishes with one launch per iteration.  A context that sees this twice stops using resident loops.
-    if (++c->resident_lost >= 2) c->resident = false;
+    note_lost_grid(c);
   }
   return status;
 }
@@ -580,17 +600,21 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->ps_cand, (size_t)rpe::kProsacSortCap * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc((void**)&c->ps_order, ((size_t)rpe::kProsacMaxTopK + 1) * sizeof(int));
   if (e != hipSuccess) { rpe_destroy(c); return fail(RPE_ERR_HIP, "workspace allocation: %s", hipGetErrorString(e)); }
-  {  // resident loop: needs device memory the CPU can store into (large BAR); RPE_RESIDENT=0 switches it off
+  {  // Resident loops.  The co-residency cap is a property of the device (0: not even one workgroup of the resident kernels per
+     // compute unit) and gates both forms; the AUTONOMOUS form (rpe_gn_refine_device, device_resident ICP) needs nothing else.  The
+     // HOST-driven form also needs device memory the CPU can store into (large BAR: the control block); RPE_RESIDENT=0 switches that
+     // form off and leaves the autonomous one alone (RPE_DEVICE_LOOP_RESIDENT=0 is its switch).
+    c->resident_cap = rpe::resident_cap_device();
+    c->resident = c->resident_cap >= 1;
     int large_bar = 0;
     const char* env = getenv("RPE_RESIDENT");
-    if (!(env && env[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
+    if (c->resident && !(env && env[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess
+        && large_bar) {
       void* p = nullptr;
-      c->resident_cap = rpe::resident_cap_device();   // 0: not even one workgroup of the resident kernels per compute unit
-      if (c->resident_cap >= 1 && hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess
-          && hipMemset(p, 0, 4096) == hipSuccess &&
+      if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) == hipSuccess && hipMemset(p, 0, 4096) == hipSuccess &&
           hipDeviceSynchronize() == hipSuccess) {
         c->ctl = (volatile unsigned long long*)p;
-        c->resident = true;
+        c->host_resident = true;
       } else { (void)hipGetLastError(); if (p) (void)hipFree(p); }
     } else (void)hipGetLastError();
   }
@@ -729,13 +753,22 @@ int rpe_download_mask(rpe_context* c, int mod, short* host_mask) {
 }
 
 // ---------------------------------------------------------------------------------------------- K1'
+// the event pair of the next timed launch (rpe_timing_enable), or nulls
+static void timing_pair(rpe_context* c, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = nullptr; *e1 = nullptr;
+  if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { *e0 = c->ev0[c->ev_used];
+      *e1 = c->ev1[c->ev_used]; c->ev_used++; }
+}
+
 int rpe_p2p_moments(rpe_context* c, int flags, double* out18) {
   int rc = need_arrays(c, {RPE_XW, RPE_XC});
   if (rc) return rc;
   if (!out18) return fail(RPE_ERR_ARG, "null out18");
   if ((rc = check_flags(c, RPE_RES_P2P, flags))) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_moments(c->arrays(), flags, collect_target(c), c->stream));
+  hipEvent_t e0, e1;
+  timing_pair(c, &e0, &e1);
+  HIP_TRY(rpe::launch_moments(c->arrays(), flags, collect_target(c), c->stream, e0, e1));
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   for (int i = 0; i < 18; i++) out18[i] = c->h_out[i];
   return RPE_OK;
@@ -768,9 +801,8 @@ static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* p
   if (!pose12) return fail(RPE_ERR_ARG, "null argument");
   if ((rc = check_flags(c, kind, flags))) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
-      e1 = c->ev1[c->ev_used]; c->ev_used++; }
+  hipEvent_t e0, e1;
+  timing_pair(c, &e0, &e1);
   HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : collect_target(c), c->stream,
       e0, e1));
   return RPE_OK;
@@ -898,7 +930,7 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
                         double* last_step, double* final_cost) {
   int it = 0;
   double step = 0, cost = 0;
-  if (c && c->resident && max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
+  if (c && c->resident && c->host_resident && max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
     // ONE launch for the whole refinement, as rpe_gn_refine: the grid of the joint kernel stays resident, the host hands every pose
     // over through the control block, adds the run records, solves and updates
     JointSpec sp;
@@ -982,7 +1014,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
   double pose_in[12];
   std::memcpy(pose_in, pose12, sizeof(pose_in));
-  if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && !sharded && !c->comm && !c->hostex && max_iter >= 2) {
+  if (auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2) {
     // a single plain kind: the dedicated kernel (17 structured sums for point-to-point); anything else: the joint kernel (29 sums)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
@@ -1011,7 +1043,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
       return RPE_OK;
     }
     // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per iteration
-    ++c->resident_lost;
+    note_lost_grid(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose_in, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
@@ -1056,13 +1088,25 @@ int rpe_debug_device_gn_update(rpe_context* c, const double* ne32, double* pose1
   return RPE_OK;
 }
 
-// State of the resident loops of a context: enabled (large BAR, at least one workgroup per compute unit, fewer than two lost grids),
-// how many refinements were finished with one launch per iteration after their grid was lost, and the co-residency cap of the device.
+// State of the resident loops of a context: enabled (at least one workgroup of the resident kernels per compute unit and fewer than two
+// lost grids; bit 1 of *enabled: the host-driven form is available too -- large BAR, RPE_RESIDENT != 0), how many refinements were
+// finished with one launch per iteration after their grid was lost, and the co-residency cap of the device.
 int rpe_debug_resident_state(rpe_context* c, int* enabled, int* lost, int* cap) {
   if (!c) return fail(RPE_ERR_ARG, "null context");
-  if (enabled) *enabled = c->resident ? 1 : 0;
+  if (enabled) *enabled = c->resident ? (c->host_resident ? 3 : 1) : 0;
   if (lost) *lost = c->resident_lost;
   if (cap) *cap = c->resident_cap;
+  return RPE_OK;
+}
+
+// Fault injection for the tests, per context (the production path reads no environment variable for this): iteration > 0 = the last
+// workgroup of the next HOST-driven resident loops withholds its sums of that iteration (its collecting workgroup gives up after its
+// bounded wait, the host finishes with one launch per iteration); pose_wait_s > 0 = length of the workgroups' bounded wait for the next
+// pose (0.5 .. 60 s).  (0, 0) switches both off.
+int rpe_debug_inject_resident_fault(rpe_context* c, int iteration, double pose_wait_s) {
+  if (!c || iteration < 0 || pose_wait_s < 0 || (pose_wait_s > 0 && (pose_wait_s < 0.5 || pose_wait_s > 60.0)))
+    return fail(RPE_ERR_ARG, "rpe_debug_inject_resident_fault: bad argument");
+  c->test_fault_iter = iteration; c->test_pose_wait_s = pose_wait_s;
   return RPE_OK;
 }
 
@@ -1107,7 +1151,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   // sharded contexts: only with the host-side exchange (every rank's host thread adds the peers' records to its own each iteration);
   // RCCL / in-kernel peer-to-peer contexts take rpe_gn_steps_dist
   const bool sharded_ok = c->hostex ? !c->hostex_shared_gpu : (!c->comm && c->p2p_world_saved < 1);
-  if (c->resident && max_iter >= 2 && sharded_ok) {
+  if (c->resident && c->host_resident && max_iter >= 2 && sharded_ok) {
     // ONE launch for the whole loop: the grid stays resident, the host hands every new pose to it through the control block in
     // device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration) and solves / updates as before.
     int rc = kind_arrays(c, kinds[0]);
@@ -1571,7 +1615,9 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   double staged[12];
   stage_poses(RPE_F64, exact, pose7, 1, staged);  // layout only; the launcher rounds to the array dtype
-  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, staged, thr, collect_target(c), c->stream));
+  hipEvent_t e0, e1;
+  timing_pair(c, &e0, &e1);
+  HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, staged, thr, collect_target(c), c->stream, e0, e1));
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   c->h_votes[0] = (int)c->h_out[0];
   if (votes_out) *votes_out = c->h_votes[0];
@@ -1622,7 +1668,9 @@ int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const 
   for (int i = 0; i < 3; i++) { prm[i] = c_opt3[i]; prm[3 + i] = Cw3[i]; prm[6 + i] = Cc3[i]; }
   for (int i = 0; i < 9; i++) prm[9 + i] = Rwc9[i];
   for (int i = 18; i < 24; i++) prm[i] = 0;
-  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, collect_target(c), c->stream));
+  hipEvent_t e0, e1;
+  timing_pair(c, &e0, &e1);
+  HIP_TRY(rpe::launch_nl_round(c->arrays(), prm, collect_target(c), c->stream, e0, e1));
   if ((rc = wait_host(c, rpe::kNlLd))) return rc;
   for (int i = 0; i < 44; i++) out44[i] = c->h_out[i];
   return RPE_OK;
@@ -1825,7 +1873,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
     std::unique_lock<std::mutex> one_resident_grid(resident_mutex(c->device), std::defer_lock);
     bool one_launch = false;
-    if (auto_on && c->resident_cap >= 1 && c->resident_lost < 2 && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm
+    if (auto_on && c->resident && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm
         && c->p2p_world < 1) {
       // ONE launch: the resident grid pairs, sums, solves and updates by itself (icp_resident_kernel with resident_auto_stage)
       one_launch = true;
@@ -1845,7 +1893,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     if ((rc = wait_host(c, rpe::kNeLd))) return rc;
     if (one_launch && c->h_out[15] == 2.0) {
       // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per round
-      ++c->resident_lost;
+      note_lost_grid(c);
       HIP_TRY(hipStreamSynchronize(c->stream));
       HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
@@ -1860,7 +1908,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
         "ICP device loop: a workgroup's sums never arrived at iteration %d", it); }
     if (c->h_out[15] != 0.0) { if (iters_out) *iters_out = it; return fail(RPE_ERR_DEGENERATE,
         "ICP: normal equations are not positive definite at iteration %d", it - 1); }
-  } else if (o->fused && c->resident && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
+  } else if (o->fused && c->resident && c->host_resident && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
     // host-driven ICP in ONE launch: the frame's pixels stay in registers, every iteration the host hands the pose over, the grid pairs
     // its pixels with the model under that pose and sends the run records back (rpe_icp.hip icp_resident_kernel)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;

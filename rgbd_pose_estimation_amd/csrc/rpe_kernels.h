@@ -69,7 +69,13 @@ struct ReduceTarget {
                                // 1 + ceil(grid / run length) x sums pairs), and the host adds them in order. Host-consumed, single-GPU
                                // results only
 };
-// ev_begin / ev_end (optional): recorded on s immediately around the kernel (bench roofline timing).
+// ev_begin / ev_end (optional): the launch goes through hipExtLaunchKernelGGL and the two events receive the dispatch's own begin /
+// end timestamps -- what rocprofv3 reports for the kernel (bench roofline timing)
+#define RPE_LAUNCH_EV(KERNEL, GRID, BLOCK, SHMEM, STREAM, EV0, EV1, ...)                                              \
+  do {                                                                                                                \
+    if ((EV0) && (EV1)) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, EV0, EV1, 0, __VA_ARGS__);            \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, __VA_ARGS__);                                         \
+  } while (0)
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                             hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // RESIDENT form of the same kernels: one launch serves up to max_iters Gauss-Newton iterations; between iterations every workgroup
@@ -95,7 +101,8 @@ hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // test hook: one application of the device-resident loop's 6x6 LDL^T solve + SE(3) exp-map update (d_step_ok: |delta|, ok flag)
 hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, hipStream_t s);
-hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s);
+hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr,
+                          hipEvent_t ev_end = nullptr);
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
 hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4,
     const int* robust4,
@@ -120,9 +127,10 @@ hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const 
                               const ReduceTarget& rt, hipStream_t s);
 // pose12: fast = R row-major (9) t (3); exact = qw qx qy qz tx ty tz (rest ignored).  The vote total is record[0] of rt.
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
-                       hipStream_t s);
+                       hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // params24 = c_opt(3) Cw(3) Cc(3) Rwc(9) pad; record = 64 doubles
-hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s);
+hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s,
+                           hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 
 // copy `count` reduced values from HBM to pinned host memory and then store `seq` to *h_flag (the host spins on it)
 hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq,

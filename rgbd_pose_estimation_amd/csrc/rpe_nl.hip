@@ -381,7 +381,7 @@ hipError_t launch_publish_votes(int* d_votes, int count, int* h_dst, unsigned lo
 }
 
 template <class T, int BLK>
-static void moments_launch(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
+static void moments_launch(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const short* mask = (flags & F_USE_MASK) ? A.mask[1] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[1] : nullptr;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
@@ -389,52 +389,52 @@ static void moments_launch(const DeviceArrays& A, int flags, const ReduceTarget&
   const int skip = (flags & F_SKIP_INVALID) ? 1 : 0;
   const T* xw = (const T*)A.a[0];
   const T* xc = (const T*)A.a[1];
-  if (mask && weight) hipLaunchKernelGGL((moments_kernel<T, BLK, true, true>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n,
-      skip, fin);
-  else if (mask) hipLaunchKernelGGL((moments_kernel<T, BLK, true, false>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip,
-      fin);
-  else if (weight) hipLaunchKernelGGL((moments_kernel<T, BLK, false, true>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip,
-      fin);
-  else hipLaunchKernelGGL((moments_kernel<T, BLK, false, false>), dim3(G), dim3(BLK), 0, s, xw, xc, mask, weight, A.n, skip, fin);
+  if (mask && weight) RPE_LAUNCH_EV((moments_kernel<T, BLK, true, true>), dim3(G), dim3(BLK), 0, s, e0, e1, xw, xc, mask, weight, A.n, skip, fin);
+  else if (mask) RPE_LAUNCH_EV((moments_kernel<T, BLK, true, false>), dim3(G), dim3(BLK), 0, s, e0, e1, xw, xc, mask, weight, A.n, skip, fin);
+  else if (weight) RPE_LAUNCH_EV((moments_kernel<T, BLK, false, true>), dim3(G), dim3(BLK), 0, s, e0, e1, xw, xc, mask, weight, A.n, skip, fin);
+  else RPE_LAUNCH_EV((moments_kernel<T, BLK, false, false>), dim3(G), dim3(BLK), 0, s, e0, e1, xw, xc, mask, weight, A.n, skip, fin);
 }
 template <class T>
-static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
+static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const int blk = pick_block(rt, true);
-  if (blk == 1024) moments_launch<T, 1024>(A, flags, rt, s);
-  else if (blk == 512) moments_launch<T, 512>(A, flags, rt, s);
-  else moments_launch<T, 256>(A, flags, rt, s);
+  if (blk == 1024) moments_launch<T, 1024>(A, flags, rt, s, e0, e1);
+  else if (blk == 512) moments_launch<T, 512>(A, flags, rt, s, e0, e1);
+  else moments_launch<T, 256>(A, flags, rt, s, e0, e1);
   return hipGetLastError();
 }
-hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s) {
-  return A.dtype ? moments_t<double>(A, flags, rt, s) : moments_t<float>(A, flags, rt, s);
+hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  return A.dtype ? moments_t<double>(A, flags, rt, s, e0, e1) : moments_t<float>(A, flags, rt, s, e0, e1);
 }
 
 template <class T, int BLK>
-static void nl_round_launch(const DeviceArrays& A, const NlParams& prm, const ReduceTarget& rt, hipStream_t s) {
+static void nl_round_launch(const DeviceArrays& A, const NlParams& prm, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0,
+    hipEvent_t e1) {
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
   const bool all_arrays = A.a[0] && A.a[1] && A.a[2] && A.a[3] && A.a[4] && A.mask[0] && A.mask[1] && A.mask[2];
   const int nweights = (A.weight[0] != nullptr) + (A.weight[1] != nullptr) + (A.weight[2] != nullptr);
 #define RPE_NL_ARGS (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], (const short*)A.mask[0],      \
                     (const short*)A.mask[1], (const short*)A.mask[2], (const T*)A.weight[0], (const T*)A.weight[1], (const T*)A.weight[2], A.n, prm, \
                     make_finish(rt)
-  if (all_arrays && nweights == 0) hipLaunchKernelGGL((nl_round_full_kernel<T, BLK, false>), dim3(G), dim3(BLK), 0, s, RPE_NL_ARGS);
-  else if (all_arrays && nweights == 3) hipLaunchKernelGGL((nl_round_full_kernel<T, BLK, true>), dim3(G), dim3(BLK), 0, s, RPE_NL_ARGS);
-  else hipLaunchKernelGGL((nl_round_kernel<T, BLK>), dim3(G), dim3(BLK), 0, s, RPE_NL_ARGS);
+  if (all_arrays && nweights == 0) RPE_LAUNCH_EV((nl_round_full_kernel<T, BLK, false>), dim3(G), dim3(BLK), 0, s, e0, e1, RPE_NL_ARGS);
+  else if (all_arrays && nweights == 3) RPE_LAUNCH_EV((nl_round_full_kernel<T, BLK, true>), dim3(G), dim3(BLK), 0, s, e0, e1, RPE_NL_ARGS);
+  else RPE_LAUNCH_EV((nl_round_kernel<T, BLK>), dim3(G), dim3(BLK), 0, s, e0, e1, RPE_NL_ARGS);
 #undef RPE_NL_ARGS
 }
 template <class T>
-static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s) {
+static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0,
+    hipEvent_t e1) {
   NlParams prm;
   for (int i = 0; i < 3; i++) { prm.c_opt[i] = params24[i]; prm.Cw[i] = params24[3 + i]; prm.Cc[i] = params24[6 + i]; }
   for (int i = 0; i < 9; i++) prm.Rwc[i] = params24[9 + i];
   // 44 fp64 accumulators + a software-pipelined group need ~250 VGPRs: 256-thread workgroups (one wave per SIMD, no spills) beat
   // 512-thread ones here (10 M correspondences: 135 us vs 137 us unweighted, 158 us vs 172 us weighted; 307 200: 29 us vs 31 us)
-  if (rt.block == 512) nl_round_launch<T, 512>(A, prm, rt, s);
-  else nl_round_launch<T, 256>(A, prm, rt, s);
+  if (rt.block == 512) nl_round_launch<T, 512>(A, prm, rt, s, e0, e1);
+  else nl_round_launch<T, 256>(A, prm, rt, s, e0, e1);
   return hipGetLastError();
 }
-hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s) {
-  return A.dtype ? nl_round_t<double>(A, params24, rt, s) : nl_round_t<float>(A, params24, rt, s);
+hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0,
+    hipEvent_t e1) {
+  return A.dtype ? nl_round_t<double>(A, params24, rt, s, e0, e1) : nl_round_t<float>(A, params24, rt, s, e0, e1);
 }
 
 void preload_nl() {

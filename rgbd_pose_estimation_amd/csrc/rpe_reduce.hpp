@@ -646,7 +646,8 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   // granule crosses an XCD boundary on its way to its collecting workgroup -- rpe_residuals.hpp run_shape), when a run then fits the
   // four granules per collecting thread
   const int S = fin.stride;
-  const bool per_xcd = S > 1 && G >= 4 * S && (G + S - 1) / S <= 4 * RGN && (G + S - 1) / S <= fin.rows;
+  // (S runs of NACC sums must also keep to the ~512 pairs of the consecutive-run shape: the pair buffer on the host is sized for that)
+  const bool per_xcd = S > 1 && S * NACC <= 512 + NACC && G >= 4 * S && (G + S - 1) / S <= 4 * RGN && (G + S - 1) / S <= fin.rows;
   const int run = per_xcd ? (int)blockIdx.x % S : (int)blockIdx.x / R, leader = per_xcd ? run : run * R, step = per_xcd ? S : 1;
   const int nruns = per_xcd ? S : (G + R - 1) / R;
   if (threadIdx.x < NACC) {

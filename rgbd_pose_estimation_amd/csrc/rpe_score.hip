@@ -134,7 +134,13 @@ template <class T> struct Hyp<T, true> {
       // |p|^2 in metres^2; also the range in which the fp32 estimate behind the fp64 form is finite
       const T tiny = T(1e-30), huge = T(1e30);
       const bool in0 = ct.x > hi, in1 = ct.y > hi;
-      const bool sure0 = (in0 | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge), sure1 = (in1 | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge);
+      // the bound above holds for UNIT bearings (sum |p^_i bv_i| <= |bv|): both errors scale with |bv|, so a lane counts as decided only
+      // if |bv|^2 is within 1e-3 of 1 (24 u still covers 14 u x 1.0005); any other bearing -- the API does not normalise them -- takes
+      // the reference's own sequence.  Hypothesis-independent: hoisted out of the hypothesis loop.
+      const V2 b2 = bx * bx + by * by + bz * bz;
+      const bool unit0 = (b2.x > T(0.999)) & (b2.x < T(1.001)), unit1 = (b2.y > T(0.999)) & (b2.y < T(1.001));
+      const bool sure0 = (in0 | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge) & unit0,
+                 sure1 = (in1 | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge) & unit1;
       if (__builtin_amdgcn_ballot_w64(!(sure0 & sure1)) == 0) { a = in0; b = in1; return; }
     }
 #endif
@@ -422,10 +428,11 @@ static void score_launch(const DeviceArrays& A, const void* d_poses, int H, cons
                      (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, hchunk, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
 }
 template <class T, int KIND, bool EXACT>
-static void mask_launch(const DeviceArrays& A, const double* pose12, const double* thr, const ReduceTarget& rt, int G, hipStream_t s) {
+static void mask_launch(const DeviceArrays& A, const double* pose12, const double* thr, const ReduceTarget& rt, int G, hipStream_t s,
+    hipEvent_t e0, hipEvent_t e1) {
   PoseArg<T> pa;
   for (int i = 0; i < 12; i++) pa.v[i] = (T)pose12[i];
-  hipLaunchKernelGGL((mask_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
+  RPE_LAUNCH_EV((mask_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), 0, s, e0, e1, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
                      (const T*)A.a[3], (const T*)A.a[4], A.n, pa, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2],
                      make_finish(rt));
 }
@@ -501,16 +508,16 @@ hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const 
   return hipGetLastError();
 }
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
-                       hipStream_t s) {
+                       hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const int cap = rt.max_blocks < 1024 ? 1024 : rt.max_blocks;  // streaming + stores: 4 workgroups of 256 per CU
   if (A.dtype) {
     const int G = grid_for(A.n, 2, cap);
-    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, pose12, thr3, rt, G, s) }
-    else { RPE_KIND_SWITCH(mask_launch, double, false, A, pose12, thr3, rt, G, s) }
+    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, pose12, thr3, rt, G, s, e0, e1) }
+    else { RPE_KIND_SWITCH(mask_launch, double, false, A, pose12, thr3, rt, G, s, e0, e1) }
   } else {
     const int G = grid_for(A.n, 4, cap);
-    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, pose12, thr3, rt, G, s) }
-    else { RPE_KIND_SWITCH(mask_launch, float, false, A, pose12, thr3, rt, G, s) }
+    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, pose12, thr3, rt, G, s, e0, e1) }
+    else { RPE_KIND_SWITCH(mask_launch, float, false, A, pose12, thr3, rt, G, s, e0, e1) }
   }
   return hipGetLastError();
 }

@@ -244,7 +244,7 @@ print("ok")
 
 
 def test_resident_icp_lost_grid_is_finished_round_by_round(gpu_ctx_factory):
-    """The host-driven fused ICP in one resident launch, with a workgroup withholding its sums in round 3 (RPE_TEST_RESIDENT_FAULT): the
+    """The host-driven fused ICP in one resident launch, with a workgroup withholding its sums in round 3 (rpe_debug_inject_resident_fault): the
     collecting workgroup tells the host, the grid is released, the remaining rounds run one launch each -- the call succeeds with the
     undisturbed result (poses to rounding: the per-round kernel adds in another order) and the context counts one lost grid."""
     import time
@@ -252,13 +252,13 @@ def test_resident_icp_lost_grid_is_finished_round_by_round(gpu_ctx_factory):
     (V, N, B, MV, MN), pA, pB = load_pair(ctx, FULL_CAM, noise=0.002)
     good = ctx.icp(pA, L.RES_P2PLANE, 8, 0.0, 0.15, 0.8, device_resident=False, fused=True)
     lost0 = ctx.resident_state()["lost"]
-    os.environ["RPE_TEST_RESIDENT_FAULT"] = "3"
+    ctx.inject_resident_fault(3, 0.0)
     try:
         t0 = time.perf_counter()
         hit = ctx.icp(pA, L.RES_P2PLANE, 8, 0.0, 0.15, 0.8, device_resident=False, fused=True)
         dt = time.perf_counter() - t0
     finally:
-        del os.environ["RPE_TEST_RESIDENT_FAULT"]
+        ctx.inject_resident_fault(0, 0.0)
     assert hit[1] == good[1] == 8 and 1.5 < dt < 6.0
     assert rot_err(hit[0][:9].reshape(3, 3), good[0][:9].reshape(3, 3)) < 1e-8 and np.linalg.norm(hit[0][9:] - good[0][9:]) < 1e-8
     assert abs(hit[4] - good[4]) <= 2

@@ -42,7 +42,7 @@ def test_bearing_refine_resident_equals_launch_per_iteration(oracle, n, f64):
     p0 = api.pose12(*util.perturbed_pose(np.random.default_rng(n), sc.R, sc.t, 0.01, 0.03))
     res, per = _ctx(), _ctx({"RPE_RESIDENT": "0"})
     try:
-        assert res.resident_state()["enabled"] and not per.resident_state()["enabled"]
+        assert res.resident_state()["host_driven"] and not per.resident_state()["host_driven"]
         out = []
         for c in (res, per):
             c.load(L.F64 if f64 else L.F32, xw=sc.Q, bv=sc.U)
@@ -95,7 +95,7 @@ def test_joint_refine_resident_equals_launch_per_iteration(n, combo):
 
 @pytest.mark.parametrize("what", ["p2p", "bearing", "joint"])
 def test_lost_grid_is_finished_with_one_launch_per_iteration(what):
-    """RPE_TEST_RESIDENT_FAULT = k: the last workgroup withholds its sums of iteration k.  Its collecting workgroup gives up after its
+    """rpe_debug_inject_resident_fault(k): the last workgroup withholds its sums of iteration k.  Its collecting workgroup gives up after its
     bounded wait and tells the host, which releases the grid and finishes the refinement with one launch per iteration: the call succeeds
     with the result an undisturbed run gives, and the context counts one lost grid."""
     n = 307200
@@ -112,16 +112,14 @@ def test_lost_grid_is_finished_with_one_launch_per_iteration(what):
         good = run()
         # the workgroups' wait for the next pose is set to 9 s here: the call must come back after the collecting workgroup's 2 s, i.e.
         # the host's stop tag RELEASES the workgroups that already wait for the pose after the unfinished iteration
-        os.environ["RPE_TEST_RESIDENT_FAULT"] = "4"
-        os.environ["RPE_TEST_POSE_WAIT_S"] = "9"
+        c.inject_resident_fault(4, 9.0)
         try:
             t0 = time.perf_counter()
             hit = run()
             c.synchronize()   # the grid has left the GPU too
             dt = time.perf_counter() - t0
         finally:
-            del os.environ["RPE_TEST_RESIDENT_FAULT"]
-            del os.environ["RPE_TEST_POSE_WAIT_S"]
+            c.inject_resident_fault(0, 0.0)
         assert hit[1] == good[1] == 8
         _pose_close(hit[0], good[0])
         st = c.resident_state()

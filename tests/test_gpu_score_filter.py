@@ -57,3 +57,35 @@ def test_votes_on_the_threshold_are_the_oracles(gpu_ctx_factory, oracle, kind, f
     assert np.array_equal(v, vo), (v[:8], vo[:8])
     # the case is what it claims to be: the votes differ between hypotheses a few ulps apart, i.e. points do sit on the threshold
     assert len(set(v.tolist())) >= 3
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("scale", [0.5, 1.7, 4.0])
+def test_non_unit_bearings_keep_the_oracles_votes(gpu_ctx_factory, oracle, scale, f64):
+    """The division-free filter's error bound assumes unit bearings; the API does not normalise them.  With every bearing scaled by
+    `scale` the tested value cos(angle) * |bv| moves with it, so the cosines are put around cos_thr / scale ... i.e. ON the threshold
+    again, where the estimate's error (which grows with |bv|) would decide comparisons wrongly if such lanes were not sent down the
+    reference's own operation sequence (round-3 advisor finding)."""
+    dt = np.float64 if f64 else np.float32
+    n = 20000
+    cos_thr = float(np.cos(np.arctan(8.0 / 585.0)))
+    target = min(cos_thr / scale, 0.9999)              # normalize(p) . (scale u) == cos_thr  <=>  normalize(p) . u == cos_thr / scale
+    sc = _near_threshold_scene(n, dt, 78, target)
+    sc.U = (sc.U.astype(np.float64) * scale).astype(dt)
+    if scale < 1.0:
+        cos_thr = target * scale                       # the clipped target: keep the values on the threshold
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    rng = np.random.default_rng(2)
+    q_true = oracle.pose7_from_Rt(sc.R, sc.t, f64)
+    poses = np.tile(q_true, (40, 1))
+    poses[1:, :4] += 1e-7 * rng.standard_normal((39, 4))
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    poses = np.ascontiguousarray(poses.astype(dt).astype(np.float64))
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    for kind, okind in ((L.VOTE_23, oracle.V_23), (L.VOTE_33_23, oracle.V_33_23), (L.VOTE_NN_33_23, oracle.V_NN_33_23)):
+        v = ctx.score(kind, poses, 0.05, cos_thr, 0.999, mode=L.SCORE_EXACT)
+        vo = oracle.votes(prob, okind, poses, thre_3d=0.05, cos_thr=cos_thr, cos_nl=0.999)
+        assert np.array_equal(v, vo), (kind, v[:8], vo[:8])
+        assert len(set(v.tolist())) >= 3               # points do sit on the threshold
+        tot = ctx.inlier_mask(kind, poses[0], 0.05, cos_thr, 0.999, mode=L.SCORE_EXACT)
+        assert tot == vo[0]
