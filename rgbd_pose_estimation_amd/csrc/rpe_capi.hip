@@ -103,6 +103,7 @@ struct rpe_context {
   int max_blocks = 256;          // reduction kernels: cap on workgroups = one per CU (multiples of 256 only: 320 or 384 lose 20-30 %)
   int score_blocks = 2048;       // scoring / mask kernels (256-thread workgroups)
   int block = 0;                 // reduction workgroup size override (RPE_BLOCK), 0 = default
+  int64_t f32_min = -1;          // two-float fp32 transform from this many correspondences (RPE_F32_TRANSFORM; -1 = default)
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
   double* d_out = nullptr;       // 64 doubles
   double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
@@ -243,6 +244,7 @@ int run_stride_from_env() {
 rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
+  rt.f32_min = c->f32_min;
   rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
   c->collecting = false;
   return rt;
@@ -259,6 +261,7 @@ rpe::ReduceTarget collect_target(rpe_context* c) {
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
+  rt.f32_min = c->f32_min;
   rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
   c->collecting = false;
   return rt;
@@ -566,6 +569,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 4096) c->max_blocks = v; }
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
+  if (const char* f = getenv("RPE_F32_TRANSFORM")) { const long long v = atoll(f);
+      c->f32_min = v <= 0 ? INT64_MAX : (v == 1 ? 0 : (int64_t)v); }
   hipError_t e = hipSuccess;
   // scratch of the cross-workgroup stages, whichever layout a launch uses: (4096 + 8 shard) records of kNlLd doubles, or 16-byte
   // granules [workgroup <= 4096][sums <= 44] followed by the autonomous loop's run records [2 parities][<= kAutoMaxRunSums = 1024]

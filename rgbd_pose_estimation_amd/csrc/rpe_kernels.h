@@ -63,6 +63,9 @@ struct ReduceTarget {
   unsigned long long fault_tag = 0;                    // test hook: see Finish
   // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
   int rows = 0;
+  // fp32 arrays: launches of at least this many correspondences form p = R Xw + t and the residual with the two-float fp32 transform
+  // (rpe_residuals.hpp); < 0 = the default (kF32TransformMin).  Per context: RPE_F32_TRANSFORM at rpe_create (0 never, 1 always, n)
+  int64_t f32_min = -1;
   int stride = 0;              // resident kernels: > 1 = strided runs (see Finish)
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out
                                // must hold

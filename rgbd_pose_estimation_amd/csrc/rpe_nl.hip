@@ -7,7 +7,9 @@ namespace rpe {
 // K1' : closed-form moments (both passes of shinji() in one): w | w Xw | w Xc | w Xc Xw^T | w |Xc|^2 | count
 // fp32 x fp32 products are exact in fp64, so only the fp64 summation rounds.
 // ================================================================================================
-template <class T, bool MASK, bool WEIGHT>
+// CLEAN: every value of the group is finite (group_dirty, rpe_reduce.hpp, said so for the whole wave): no NaN guard and no selects on
+// the coordinates -- a masked-off correspondence is switched off by its weight alone (0 x finite = 0), the sums are the same bits
+template <class T, bool MASK, bool WEIGHT, bool CLEAN = false>
 __device__ __forceinline__ void moments_group(const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P],
                                               const T (&wv)[Pk<T>::P], int npresent, int skip_invalid, double (&acc)[18]) {
   constexpr int P = Pk<T>::P;
@@ -15,10 +17,10 @@ __device__ __forceinline__ void moments_group(const T (&vw)[3 * Pk<T>::P], const
   for (int i = 0; i < P; i++) {
     double x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
     double cx = vc[3 * i], cy = vc[3 * i + 1], cz = vc[3 * i + 2];
-    bool use = i < npresent && !(skip_invalid && all_nan(cx, cy, cz));
+    bool use = CLEAN ? true : (i < npresent && !(skip_invalid && all_nan(cx, cy, cz)));
     if (MASK) use = use && m[i] == 1;
     const double wi = use ? (WEIGHT ? (double)wv[i] : 1.0) : 0.0;
-    x = use ? x : 0.0; y = use ? y : 0.0; z = use ? z : 0.0; cx = use ? cx : 0.0; cy = use ? cy : 0.0; cz = use ? cz : 0.0;
+    if (!CLEAN) { x = use ? x : 0.0; y = use ? y : 0.0; z = use ? z : 0.0; cx = use ? cx : 0.0; cy = use ? cy : 0.0; cz = use ? cz : 0.0; }
     const double wcx = wi * cx, wcy = wi * cy, wcz = wi * cz;
     acc[0] += wi;
     acc[1] = fma(wi, x, acc[1]); acc[2] = fma(wi, y, acc[2]); acc[3] = fma(wi, z, acc[3]);
@@ -67,7 +69,10 @@ __global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, 
     T vw[3 * P], vc[3 * P];
     unpack3(a0, a1, a2, vw);
     unpack3(b0, b1, b2, vc);
-    moments_group<T, MASK, WEIGHT>(vw, vc, m, wv, P, skip_invalid, acc);
+    // wave-uniform: no NaN / infinity in what any lane loaded -> the form without guards and selects
+    if (__builtin_amdgcn_ballot_w64(group_dirty<V>(a0, a1, a2, b0, b1, b2)) == 0) moments_group<T, MASK, WEIGHT, true>(vw, vc, m, wv, P,
+        skip_invalid, acc);
+    else moments_group<T, MASK, WEIGHT, false>(vw, vc, m, wv, P, skip_invalid, acc);
     a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
 #pragma unroll
     for (int i = 0; i < P; i++) { if (MASK) m[i] = nm[i]; if (WEIGHT) wv[i] = nwv[i]; }

@@ -24,7 +24,23 @@ hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d
   return hipGetLastError();
 }
 
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT>
+// One group through the CLEAN form if no lane of the wave holds a NaN or an infinity in what it loaded (group_dirty), through the guarded
+// form otherwise; the branch is wave-uniform (one ballot).
+template <class T, int KIND, bool MASK, bool WEIGHT, bool F32T, int NS>
+__device__ __forceinline__ void stream_group(const PoseK<double>& pose, const PoseHL& hl, bool dirty, const T (&vw)[3 * Pk<T>::P],
+                                             const T (&vb)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P],
+                                             const T (&wv)[Pk<T>::P], T __attribute__((ext_vector_type(2))) (&s2)[NS]) {
+  constexpr int P = Pk<T>::P;
+#ifdef RPE_ANALYZE_CLEAN_ONLY   // instruction counting only (scripts/loop_instruction_mix.py): the CLEAN form alone
+  pair_group<T, KIND, MASK, WEIGHT, true, F32T, NS>(pose, hl, vw, vb, vc, m, wv, P, s2);
+#else
+  if (__builtin_amdgcn_ballot_w64(dirty) == 0) pair_group<T, KIND, MASK, WEIGHT, true, F32T, NS>(pose, hl, vw, vb, vc, m, wv, P, s2);
+  else pair_group<T, KIND, MASK, WEIGHT, false, F32T, NS>(pose, hl, vw, vb, vc, m, wv, P, s2);
+#endif
+}
+
+// F32T: the two-float fp32 transform (rpe_residuals.hpp; fp32 arrays, launches of >= kF32TransformMin correspondences)
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool F32T>
 __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                                                         const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                                                         PoseK<double> pose, Finish fin) {
@@ -39,6 +55,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
   }
   RPE_STAMP(0);
+  PoseHL hl;
+  if constexpr (F32T) hl = split_pose(pose);
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
@@ -64,25 +82,27 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
   RPE_STAMP(11);
 #endif
+  // All three kinds run on PAIRS of correspondences as 2-vectors (packed fp32 instructions for fp32 arrays); the pair sums of up to
+  // kShare consecutive groups share one widening into the fp64 accumulators (flush_pairs: three instructions per sum).
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  constexpr int kShare = 4;
+  V2 carry[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) carry[k] = V2{T(0), T(0)};
+  int carried = 0;
   // frame-sized problems: one group per thread (reduce_grid), nothing to pipeline -- straight-line body
   if (stride >= full && !(fin.tail & 8)) {
     if (g < full) {
       T vw[3 * P], vb[3 * P], vc[3 * P];
       unpack3(a0, a1, a2, vw);
       unpack3(b0, b1, b2, vb);
-      if (KIND == KIND_P2PLANE) unpack3(c0, c1, c2, vc);
-      normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, P, acc);
+      bool dirty;
+      if (KIND == KIND_P2PLANE) { unpack3(c0, c1, c2, vc); dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2, c0, c1, c2); }
+      else dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2);
+      stream_group<T, KIND, MASK, WEIGHT, F32T, NACC>(pose, hl, dirty, vw, vb, vc, m, wv, carry);
+      carried = 1;
     }
     g = full;
-  }
-  // pair kinds: the fp32 pair sums of TWO consecutive groups share one widening into the fp64 accumulators (flush_pairs)
-  constexpr bool PAIRS = KIND != KIND_P2P;
-  typedef T V2 __attribute__((ext_vector_type(2)));
-  V2 carry[PAIRS ? 29 : 1];
-  bool carried = false;
-  if (PAIRS) {
-#pragma unroll
-    for (int k = 0; k < (PAIRS ? 29 : 1); k++) carry[k] = V2{T(0), T(0)};
   }
   while (g < full) {
     const int64_t gn = g + stride;
@@ -98,32 +118,30 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     T vw[3 * P], vb[3 * P], vc[3 * P];
     unpack3(a0, a1, a2, vw);
     unpack3(b0, b1, b2, vb);
-    if (KIND == KIND_P2PLANE) unpack3(c0, c1, c2, vc);
-    if constexpr (PAIRS) {
-      pair_group<T, KIND, MASK, WEIGHT>(pose, vw, vb, vc, m, wv, P, reinterpret_cast<V2(&)[29]>(carry));
-      if (carried) flush_pairs<T>(reinterpret_cast<V2(&)[29]>(carry), reinterpret_cast<double(&)[29]>(acc));
-      carried = !carried;
-    } else {
-      normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, P, acc);
-    }
+    bool dirty;
+    if (KIND == KIND_P2PLANE) { unpack3(c0, c1, c2, vc); dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2, c0, c1, c2); }
+    else dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2);
+    stream_group<T, KIND, MASK, WEIGHT, F32T, NACC>(pose, hl, dirty, vw, vb, vc, m, wv, carry);
+    if (++carried == kShare) { flush_pairs<T, NACC>(carry, acc); carried = 0; }
     a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
     if (KIND == KIND_P2PLANE) { c0 = nc0; c1 = nc1; c2 = nc2; }
 #pragma unroll
     for (int i = 0; i < P; i++) { if (MASK) m[i] = nm[i]; if (WEIGHT) wv[i] = nwv[i]; }
     g = gn;
   }
-  if constexpr (PAIRS) { if (carried) flush_pairs<T>(reinterpret_cast<V2(&)[29]>(carry), reinterpret_cast<double(&)[29]>(acc)); }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences
+  if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences: bounds-checked loads, guarded form
     T vw[3 * P], vb[3 * P], vc[3 * P];
-    short m[P];
-    T wv[P];
+    short lm[P];
+    T lwv[P];
     load_group<T>(xw, full, n, vw);
     load_group<T>(b, full, n, vb);
     if (KIND == KIND_P2PLANE) load_group<T>(c, full, n, vc);
-    if (MASK) load_scalars<T, short>(mask, full, n, m, (short)0);
-    if (WEIGHT) load_scalars<T, T>(weight, full, n, wv, T(0));
-    normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, m, wv, (int)(n - full * P), acc);
+    if (MASK) load_scalars<T, short>(mask, full, n, lm, (short)0);
+    if (WEIGHT) load_scalars<T, T>(weight, full, n, lwv, T(0));
+    pair_group<T, KIND, MASK, WEIGHT, false, F32T, NACC>(pose, hl, vw, vb, vc, lm, lwv, (int)(n - full * P), carry);
+    carried = 1;
   }
+  if (carried) flush_pairs<T, NACC>(carry, acc);
   RPE_STAMP(1);
   reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
 }
@@ -227,18 +245,25 @@ static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<doubl
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
   const Finish fin = make_finish(rt);
+  // the two-float fp32 transform: fp32 arrays, launches of >= kF32TransformMin correspondences (per context, rt.f32_min: RPE_F32_TRANSFORM at
+  // rpe_create = 0 never, 1 always, n from n correspondences); never inside a device-resident loop's launches (fin.gn: small steps of a loop that may run on
+  // few correspondences)
+  const int64_t f32_min = rt.f32_min < 0 ? kF32TransformMin : rt.f32_min;
+  const bool f32t = sizeof(T) == 4 && A.n >= f32_min && rt.gn == nullptr;
   // timed launches (bench.py's roofline leg) go through hipExtLaunchKernelGGL: the two events then carry the dispatch's own begin / end
   // timestamps -- what rocprofv3 reports for the kernel -- instead of bracketing it with two marker packets (which adds their latency)
-#define RPE_NE_LAUNCH(M, W)                                                                                                            \
-  do {                                                                                                                                 \
-    if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_kernel<T, KIND, BLK, M, W>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, pose, fin); \
-    else hipLaunchKernelGGL((normal_eq_kernel<T, KIND, BLK, M, W>), dim3(G), dim3(BLK), 0, s, xw, b, c, mask, weight, A.n, pose, fin);     \
+#define RPE_NE_LAUNCH2(M, W, F) RPE_LAUNCH_EV((normal_eq_kernel<T, KIND, BLK, M, W, F>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, pose, fin)
+#define RPE_NE_LAUNCH(M, W)                                                            \
+  do {                                                                                 \
+    if constexpr (sizeof(T) == 4) { if (f32t) RPE_NE_LAUNCH2(M, W, true); else RPE_NE_LAUNCH2(M, W, false); } \
+    else RPE_NE_LAUNCH2(M, W, false);                                                  \
   } while (0)
   if (mask && weight) RPE_NE_LAUNCH(true, true);
   else if (mask) RPE_NE_LAUNCH(true, false);
   else if (weight) RPE_NE_LAUNCH(false, true);
   else RPE_NE_LAUNCH(false, false);
 #undef RPE_NE_LAUNCH
+#undef RPE_NE_LAUNCH2
 }
 template <class T>
 static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
