@@ -497,7 +497,9 @@ def worker(args, affinity):
             ref = shard.normal_eq(pose12(R0, t0)).clone().to(cdev)
             dist.all_reduce(ref)
             ref = ref.cpu().numpy()
-            good = int(delivered and np.all(np.abs(rec[:29] - ref[:29]) <= 1e-9 * (1.0 + np.abs(ref[:29]))))
+            # (the two records come from different kernels -- resident / one launch per step -- whose fp32 pair sums are widened at
+            # different points: they agree to the rounding of fp32 products, a missing or doubled shard is off by O(1))
+            good = int(delivered and np.max(np.abs(rec[:29] - ref[:29])) <= 2e-6 * np.max(np.abs(ref[:29])))
             flag = torch.tensor([good], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1

@@ -103,7 +103,13 @@ struct rpe_context {
   int max_blocks = 256;          // reduction kernels: cap on workgroups = one per CU (multiples of 256 only: 320 or 384 lose 20-30 %)
   int score_blocks = 2048;       // scoring / mask kernels (256-thread workgroups)
   int block = 0;                 // reduction workgroup size override (RPE_BLOCK), 0 = default
-  int64_t f32_min = -1;          // two-float fp32 transform from this many correspondences (RPE_F32_TRANSFORM; -1 = default)
+  int prefetch = 1;              // streaming normal-equation kernel: groups loaded ahead (RPE_PREFETCH = 1 | 2)
+  // What is known about the CONTENT of each array, for the choice between the CLEAN flavour of the normal-equation kernels (no NaN
+  // guards) and the guarded one (clean_first below): 0 unknown, 1 verified finite, 2 holds a NaN or an infinity (the reference's
+  // NaN-marked "invalid measurement" columns, AOPoseAdapter.hpp:147-152).  Reset by every upload / bind / device-side producer.
+  unsigned char arr_state[RPE_NUM_ARRAYS] = {0, 0, 0, 0, 0};
+  bool arr_bound[RPE_NUM_ARRAYS] = {false, false, false, false, false};   // caller-owned device memory: may change between calls
+  bool guard_always = false;     // RPE_GUARD_ALWAYS=1: never launch the CLEAN flavour (experiments, A/B)
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
   double* d_out = nullptr;       // 64 doubles
   double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
@@ -244,7 +250,7 @@ int run_stride_from_env() {
 rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
-  rt.f32_min = c->f32_min;
+  rt.prefetch = c->prefetch;
   rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
   c->collecting = false;
   return rt;
@@ -261,7 +267,7 @@ rpe::ReduceTarget collect_target(rpe_context* c) {
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
-  rt.f32_min = c->f32_min;
+  rt.prefetch = c->prefetch;
   rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
   c->collecting = false;
   return rt;
@@ -288,6 +294,7 @@ int wait_host(rpe_context* c, int ld) {
 // arrive (a fixed order).  Records that are not there yet are waited for one by one, so the summation overlaps the arrival of the
 // later ones.
 constexpr int kResidentLost = -1000;   // internal (never returned through the C ABI): the resident grid lost a granule or ended early
+constexpr int kResidentDirty = -1001;  // internal: the CLEAN flavour's first record was not finite -- the arrays need the guarded flavour
 int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int first_slot = 0, bool resident = false) {
   unsigned long long* pairs = reinterpret_cast<unsigned long long*>(c->h_big) + 2 * (size_t)first_slot;
   const unsigned long long want = c->seq;
@@ -402,6 +409,47 @@ int wait_flag(rpe_context* c, unsigned long long* flag, unsigned long long want)
   }
 }
 
+// ---- CLEAN-first protocol.  The CLEAN flavour of a normal-equation kernel carries no NaN guards (17 % fewer instructions per group,
+// rpe_residuals.hpp pair_group); it is exact for arrays whose values are all finite, and for any other content at least one sum of its
+// record is non-finite (a NaN or an infinity anywhere multiplies into the sums even at weight 0).  So a launch whose record the host
+// reads anyway takes the CLEAN flavour first, looks at the record, and repeats the launch in the guarded flavour if it is not finite --
+// one wasted launch per upload of NaN-marked arrays, after which the arrays are known to need the guards.  A launch whose record is
+// consumed on the device (collectives, the autonomous loops) takes the CLEAN flavour only over arrays already verified.
+enum { kArrUnknown = 0, kArrClean = 1, kArrDirty = 2 };
+unsigned kind_slot_bits(int kind) {
+  switch (kind) {
+    case RPE_RES_P2P: return (1u << RPE_XW) | (1u << RPE_XC);
+    case RPE_RES_P2PLANE: return (1u << RPE_XW) | (1u << RPE_XC) | (1u << RPE_NC);
+    case RPE_RES_BEARING: return (1u << RPE_XW) | (1u << RPE_BV);
+  }
+  return 0;
+}
+bool take_clean(const rpe_context* c, int kind, bool host_verifies) {
+  const unsigned bits = kind_slot_bits(kind);
+  if (c->guard_always || bits == 0) return false;
+  bool all_verified = true;
+  for (int s = 0; s < RPE_NUM_ARRAYS; s++) if (bits & (1u << s)) {
+    if (c->arr_state[s] == kArrDirty) return false;
+    if (c->arr_state[s] != kArrClean) all_verified = false;
+  }
+  return host_verifies || all_verified;
+}
+bool record_finite(const double* rec, int count) {
+  double s = 0.0;
+  for (int i = 0; i < count; i++) s += rec[i];
+  return std::isfinite(s);
+}
+// what a CLEAN launch's record said about the arrays of `kind`.  Caller-owned (bound) arrays are never promoted: they may change
+// between calls without the context hearing of it.
+void note_clean_launch(rpe_context* c, int kind, bool finite) {
+  const unsigned bits = kind_slot_bits(kind);
+  for (int s = 0; s < RPE_NUM_ARRAYS; s++) if (bits & (1u << s)) {
+    if (!finite) c->arr_state[s] = kArrDirty;
+    else if (!c->arr_bound[s]) c->arr_state[s] = kArrClean;
+  }
+}
+void arrays_changed(rpe_context* c, int slot, bool bound) { c->arr_state[slot] = kArrUnknown; c->arr_bound[slot] = bound; }
+
 int kind_arrays(rpe_context* c, int kind) {
   switch (kind) {
     case RPE_RES_P2P: return need_arrays(c, {RPE_XW, RPE_XC});
@@ -481,7 +529,8 @@ static void note_lost_grid(rpe_context* c) {
 template <class Launch>
 static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale,
     double* pose12, int max_iter,
-                       double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what) {
+                       double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what,
+                       bool clean = false) {
   const unsigned long long base = c->seq;
   auto hand_over = [&](const double* p, unsigned long long tag) {
     if (p) for (int k = 0; k < 12; k++) { unsigned long long w; std::memcpy(&w, &p[k], 8); c->ctl[1 + k] = w; }   // words 1..7 | 8..12
@@ -499,6 +548,7 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   if (c->test_fault_iter >= 1 && c->test_fault_iter <= max_iter) rt.fault_tag = base + (unsigned long long)c->test_fault_iter;
   const int runs = resident_run_shape(grid, nacc, max_rows, rows_auto, &rt);
   rt.h_out = c->h_big;
+  rt.clean = clean;   // normal-equation kernels: the flavour without NaN guards; its FIRST record is checked below
   c->seq = base;
   {
     const hipError_t e = launch(rt, base);
@@ -513,6 +563,9 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     double tot[32];
     if ((rc = wait_host_partials(c, runs, nacc, tot, 0, true))) { status = rc; break; }
     if (nacc == 17) expand_p2p17(tot, ne); else { for (int i = 0; i < 32; i++) ne[i] = i < nacc ? tot[i] : 0.0; }
+    // CLEAN flavour: a NaN or an infinity anywhere in the arrays shows in the very first record (before any pose update could
+    // produce one): stop the grid; the caller repeats the refinement with the guarded flavour, from the same start pose
+    if (clean && received == 0 && !record_finite(ne, 29)) { status = kResidentDirty; received++; break; }
     if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) { status = rc; received++; break; }
     received++;
     if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
@@ -569,8 +622,8 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 4096) c->max_blocks = v; }
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
-  if (const char* f = getenv("RPE_F32_TRANSFORM")) { const long long v = atoll(f);
-      c->f32_min = v <= 0 ? INT64_MAX : (v == 1 ? 0 : (int64_t)v); }
+  if (const char* f = getenv("RPE_PREFETCH")) { const int v = atoi(f); if (v == 1 || v == 2) c->prefetch = v; }
+  if (const char* f = getenv("RPE_GUARD_ALWAYS")) c->guard_always = atoi(f) != 0;
   hipError_t e = hipSuccess;
   // scratch of the cross-workgroup stages, whichever layout a launch uses: (4096 + 8 shard) records of kNlLd doubles, or 16-byte
   // granules [workgroup <= 4096][sums <= 44] followed by the autonomous loop's run records [2 parities][<= kAutoMaxRunSums = 1024]
@@ -686,7 +739,7 @@ int rpe_set_problem(rpe_context* c, int64_t n, int dtype) {
   HIP_TRY(hipSetDevice(c->device));
   // a new problem (also one of the same size: new frame) invalidates every array, mask and weight; storage is kept
   HIP_TRY(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < RPE_NUM_ARRAYS; i++) c->arr[i] = nullptr;
+  for (int i = 0; i < RPE_NUM_ARRAYS; i++) { c->arr[i] = nullptr; arrays_changed(c, i, false); }
   for (int i = 0; i < 3; i++) { c->mask[i] = nullptr; c->weight[i] = nullptr; }
   c->n = n; c->dtype = dtype;
   return RPE_OK;
@@ -704,6 +757,7 @@ int rpe_upload(rpe_context* c, int slot, const void* host) {
     c->cap[slot] = bytes;
   }
   c->arr[slot] = c->store[slot];
+  arrays_changed(c, slot, false);
   HIP_TRY(hipMemcpyAsync(c->arr[slot], host, bytes, hipMemcpyHostToDevice, c->stream));
   return RPE_OK;
 }
@@ -719,6 +773,7 @@ int rpe_bind(rpe_context* c, int slot, const void* device_ptr) {
   if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS) return fail(RPE_ERR_ARG, "rpe_bind: bad argument");
   if (device_ptr && ((uintptr_t)device_ptr & 15u)) return fail(RPE_ERR_ALIGN, "device pointer %p is not 16-byte aligned", device_ptr);
   c->arr[slot] = const_cast<void*>(device_ptr);  // not owned; the context's own storage for this slot stays allocated but idle
+  arrays_changed(c, slot, true);
   return RPE_OK;
 }
 
@@ -795,7 +850,7 @@ int rpe_pose_from_moments(const double* m, double* R9, double* t3) {
 
 // ---------------------------------------------------------------------------------------------- K1/K2/K3
 static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12);
-static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
+static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32, bool clean) {
   if (kind == RPE_RES_NORMAL && !d_out32) {
     const rpe_term t = {RPE_RES_NORMAL, 1.0, RPE_ROBUST_NONE, 1.0};
     return joint_launch_checked(c, 1, &t, flags, pose12);
@@ -808,14 +863,15 @@ static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* p
   HIP_TRY(hipSetDevice(c->device));
   hipEvent_t e0, e1;
   timing_pair(c, &e0, &e1);
-  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, d_out32 ? device_target(c, d_out32) : collect_target(c), c->stream,
-      e0, e1));
+  rpe::ReduceTarget rt = d_out32 ? device_target(c, d_out32) : collect_target(c);
+  rt.clean = clean;
+  HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
   return RPE_OK;
 }
 
 int rpe_normal_eq_device(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
   if (!d_out32) return fail(RPE_ERR_ARG, "null d_out32");
-  return normal_eq_launch(c, kind, flags, pose12, d_out32);
+  return normal_eq_launch(c, kind, flags, pose12, d_out32, c && take_clean(c, kind, false));   // nobody on the host sees this record
 }
 
 int rpe_timing_enable(rpe_context* c, int max_records, int stride) {
@@ -885,9 +941,18 @@ int rpe_gn_step(rpe_context* c, int kind, int flags, double* pose12, double* ne3
 
 int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, double* out32) {
   if (!out32) return fail(RPE_ERR_ARG, "null out32");
-  int rc = normal_eq_launch(c, kind, flags, pose12, nullptr);  // null device target = publish to pinned host memory
+  const bool clean = c && take_clean(c, kind, true);   // CLEAN flavour first: this record is looked at right here
+  int rc = normal_eq_launch(c, kind, flags, pose12, nullptr, clean);  // null device target = publish to pinned host memory
   if (rc) return rc;
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  if (clean) {
+    const bool finite = record_finite(c->h_out, 29);
+    note_clean_launch(c, kind, finite);
+    if (!finite) {   // a NaN or an infinity in the arrays (or in the weights): once more with the guards
+      if ((rc = normal_eq_launch(c, kind, flags, pose12, nullptr, false))) return rc;
+      if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+    }
+  }
   for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
   return RPE_OK;
 }
@@ -1032,6 +1097,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
     std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
+    if (single) rt.clean = take_clean(c, terms[0].kind, false);   // no host in this loop: CLEAN only over verified arrays
     if (single) HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0,
         e1));
     else HIP_TRY(rpe::launch_normal_eq_joint_resident(c->arrays(), bits, flags, scale, robust, rk, nullptr, base, max_iter, rt,
@@ -1057,6 +1123,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   }
   for (int it = 0; it < max_iter; it++) {
     if (sharded) { rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++; }
+    if (single) rt.clean = take_clean(c, terms[0].kind, false);
     if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose_in, rt, c->stream));
     else HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose_in, scale, robust, rk, rt, c->stream));
   }
@@ -1174,9 +1241,15 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
       return rpe::launch_normal_eq_resident(c->arrays(), kind, flags, (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream,
           e0, e1);
     };
-    { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
-      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight,
-          "normal equations"); }
+    for (int attempt = 0; attempt < 2; attempt++) {
+      const bool clean = take_clean(c, kind, true);   // CLEAN flavour first; its first record is checked
+      { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+        rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight,
+            "normal equations", clean); }
+      if (clean) note_clean_launch(c, kind, rc != kResidentDirty);
+      if (rc != kResidentDirty) break;   // else: NaN-marked arrays -- once more, guarded, from the untouched start pose
+      it = 0;
+    }
     if (rc != kResidentLost) {
       if (iters_out) *iters_out = it;
       if (rc != RPE_OK) return rc;
@@ -1387,9 +1460,10 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
     rpe::ReduceTarget rt = host_target(c);
     rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++;
+    rt.clean = take_clean(c, kind, false);   // the record is summed with the peers' inside the kernel
     HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
   } else {
-    if ((rc = normal_eq_launch(c, kind, flags, pose12, c->d_out))) return rc;
+    if ((rc = normal_eq_launch(c, kind, flags, pose12, c->d_out, take_clean(c, kind, false)))) return rc;
     NCCL_TRY(rccl().AllReduce(c->d_out, c->d_out, 32, ncclFloat64, ncclSum, c->comm, c->stream));
     const unsigned long long seq = ++c->seq;
     HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq,
@@ -1723,7 +1797,8 @@ int claim_slots(rpe_context* c, int64_t n) {
     for (int i = 0; i < 3; i++) { c->mask[i] = nullptr; c->weight[i] = nullptr; }
   }
   c->n = n; c->dtype = RPE_F32;
-  for (int s = 0; s < RPE_NUM_ARRAYS; s++) c->arr[s] = c->store[s];
+  // (the association kernel rewrites them every round, NaN-marking the pixels without a partner: never promoted to "verified")
+  for (int s = 0; s < RPE_NUM_ARRAYS; s++) { c->arr[s] = c->store[s]; arrays_changed(c, s, true); }
   return RPE_OK;
 }
 int associate_launch(rpe_context* c, const double* pose12, double dist_thr, double cos_thr, int use_normals, bool pose_on_device,

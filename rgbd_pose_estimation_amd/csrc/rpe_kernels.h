@@ -63,9 +63,11 @@ struct ReduceTarget {
   unsigned long long fault_tag = 0;                    // test hook: see Finish
   // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
   int rows = 0;
-  // fp32 arrays: launches of at least this many correspondences form p = R Xw + t and the residual with the two-float fp32 transform
-  // (rpe_residuals.hpp); < 0 = the default (kF32TransformMin).  Per context: RPE_F32_TRANSFORM at rpe_create (0 never, 1 always, n)
-  int64_t f32_min = -1;
+  int prefetch = 1;            // streaming normal-equation kernel: groups loaded ahead (1 or 2; RPE_PREFETCH at rpe_create)
+  // normal-equation kernels (one launch and resident): the flavour WITHOUT NaN guards.  Only for arrays known or about to be verified
+  // to hold finite values: the shim launches it first and repeats the launch in the guarded flavour if the record comes back
+  // non-finite (rpe_capi.hip clean_first); results nobody on the host inspects use it only for arrays already verified
+  bool clean = false;
   int stride = 0;              // resident kernels: > 1 = strided runs (see Finish)
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out
                                // must hold

@@ -24,29 +24,34 @@ hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d
   return hipGetLastError();
 }
 
-// One group through the CLEAN form if no lane of the wave holds a NaN or an infinity in what it loaded (group_dirty), through the guarded
-// form otherwise; the branch is wave-uniform (one ballot).
-template <class T, int KIND, bool MASK, bool WEIGHT, bool F32T, int NS>
-__device__ __forceinline__ void stream_group(const PoseK<double>& pose, const PoseHL& hl, bool dirty, const T (&vw)[3 * Pk<T>::P],
-                                             const T (&vb)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P],
-                                             const T (&wv)[Pk<T>::P], T __attribute__((ext_vector_type(2))) (&s2)[NS]) {
-  constexpr int P = Pk<T>::P;
-#ifdef RPE_ANALYZE_CLEAN_ONLY   // instruction counting only (scripts/loop_instruction_mix.py): the CLEAN form alone
-  pair_group<T, KIND, MASK, WEIGHT, true, F32T, NS>(pose, hl, vw, vb, vc, m, wv, P, s2);
-#else
-  if (__builtin_amdgcn_ballot_w64(dirty) == 0) pair_group<T, KIND, MASK, WEIGHT, true, F32T, NS>(pose, hl, vw, vb, vc, m, wv, P, s2);
-  else pair_group<T, KIND, MASK, WEIGHT, false, F32T, NS>(pose, hl, vw, vb, vc, m, wv, P, s2);
-#endif
-}
+// the vectors of one group as loaded (three 16-byte loads per array), before they are unpacked
+template <class T, int KIND, bool MASK, bool WEIGHT> struct GroupRegs {
+  typedef typename Pk<T>::V V;
+  V a0, a1, a2, b0, b1, b2, c0, c1, c2;
+  short m[Pk<T>::P];
+  T wv[Pk<T>::P];
+  __device__ __forceinline__ void load(const V* __restrict__ xw4, const V* __restrict__ b4, const V* __restrict__ c4,
+                                       const short* __restrict__ mask, const T* __restrict__ weight, int64_t g) {
+    a0 = xw4[3 * g]; a1 = xw4[3 * g + 1]; a2 = xw4[3 * g + 2];
+    b0 = b4[3 * g]; b1 = b4[3 * g + 1]; b2 = b4[3 * g + 2];
+    if (KIND == KIND_P2PLANE) { c0 = c4[3 * g]; c1 = c4[3 * g + 1]; c2 = c4[3 * g + 2]; }
+    if (MASK) load_mask_full(mask, g, m);
+    if (WEIGHT) load_weight_full(weight, g, wv);
+  }
+};
 
-// F32T: the two-float fp32 transform (rpe_residuals.hpp; fp32 arrays, launches of >= kF32TransformMin correspondences)
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool F32T>
+// PF: how many groups ahead the loads run (1: the next group's loads are in flight while this one is reduced; 2: the next two).  The
+// streaming loop is bound by the bytes a wave has in flight -- one round trip of the memory system per trip (Little's law: 6.3 MB
+// in flight chip-wide with one group per lane at 256 x 256 threads) -- not by instruction issue (profiles/r04_streaming_loop.md).
+// CLEAN: the flavour without NaN guards (pair_group); the shim launches it first and falls back to the guarded one (rpe_capi.hip).
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool CLEAN, int PF>
 __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                                                         const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                                                         PoseK<double> pose, Finish fin) {
   constexpr int P = Pk<T>::P;
   constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
   typedef typename Pk<T>::V V;
+  typedef GroupRegs<T, KIND, MASK, WEIGHT> G;
   if (fin.gn != nullptr) {  // device-resident Gauss-Newton: finished loops cost an empty launch; the pose lives in HBM
     if (fin.gn->done) return;
 #pragma unroll
@@ -55,8 +60,6 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
   }
   RPE_STAMP(0);
-  PoseHL hl;
-  if constexpr (F32T) hl = split_pose(pose);
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) acc[k] = 0.0;
@@ -65,23 +68,6 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   const V* __restrict__ xw4 = reinterpret_cast<const V*>(xw);
   const V* __restrict__ b4 = reinterpret_cast<const V*>(b);
   const V* __restrict__ c4 = reinterpret_cast<const V*>(c);
-  // software pipeline: the loads of the NEXT group are in flight while the current one is reduced, so a CU's waves do not
-  // all alternate between "everyone waits on HBM" and "everyone computes" (measured +x% at 20 M correspondences)
-  int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  V a0, a1, a2, b0, b1, b2, c0, c1, c2;
-  short m[P];
-  T wv[P];
-  if (g < full) {
-    a0 = xw4[3 * g]; a1 = xw4[3 * g + 1]; a2 = xw4[3 * g + 2];
-    b0 = b4[3 * g]; b1 = b4[3 * g + 1]; b2 = b4[3 * g + 2];
-    if (KIND == KIND_P2PLANE) { c0 = c4[3 * g]; c1 = c4[3 * g + 1]; c2 = c4[3 * g + 2]; }
-    if (MASK) load_mask_full(mask, g, m);
-    if (WEIGHT) load_weight_full(weight, g, wv);
-  }
-#if defined(RPE_STAMPS) && RPE_STAMPS >= 2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
-  RPE_STAMP(11);
-#endif
   // All three kinds run on PAIRS of correspondences as 2-vectors (packed fp32 instructions for fp32 arrays); the pair sums of up to
   // kShare consecutive groups share one widening into the fp64 accumulators (flush_pairs: three instructions per sum).
   typedef T V2 __attribute__((ext_vector_type(2)));
@@ -90,46 +76,36 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
 #pragma unroll
   for (int k = 0; k < NACC; k++) carry[k] = V2{T(0), T(0)};
   int carried = 0;
-  // frame-sized problems: one group per thread (reduce_grid), nothing to pipeline -- straight-line body
-  if (stride >= full && !(fin.tail & 8)) {
-    if (g < full) {
-      T vw[3 * P], vb[3 * P], vc[3 * P];
-      unpack3(a0, a1, a2, vw);
-      unpack3(b0, b1, b2, vb);
-      bool dirty;
-      if (KIND == KIND_P2PLANE) { unpack3(c0, c1, c2, vc); dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2, c0, c1, c2); }
-      else dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2);
-      stream_group<T, KIND, MASK, WEIGHT, F32T, NACC>(pose, hl, dirty, vw, vb, vc, m, wv, carry);
-      carried = 1;
-    }
-    g = full;
-  }
-  while (g < full) {
-    const int64_t gn = g + stride;
-    const int64_t gl = gn < full ? gn : g;  // clamp: the last iteration re-reads its own (cached) group instead of branching
-    const V na0 = xw4[3 * gl], na1 = xw4[3 * gl + 1], na2 = xw4[3 * gl + 2];
-    const V nb0 = b4[3 * gl], nb1 = b4[3 * gl + 1], nb2 = b4[3 * gl + 2];
-    V nc0, nc1, nc2;
-    if (KIND == KIND_P2PLANE) { nc0 = c4[3 * gl]; nc1 = c4[3 * gl + 1]; nc2 = c4[3 * gl + 2]; }
-    short nm[P];
-    T nwv[P];
-    if (MASK) load_mask_full(mask, gl, nm);
-    if (WEIGHT) load_weight_full(weight, gl, nwv);
+  auto reduce_group = [&](const G& r) {
     T vw[3 * P], vb[3 * P], vc[3 * P];
-    unpack3(a0, a1, a2, vw);
-    unpack3(b0, b1, b2, vb);
-    bool dirty;
-    if (KIND == KIND_P2PLANE) { unpack3(c0, c1, c2, vc); dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2, c0, c1, c2); }
-    else dirty = group_dirty<V>(a0, a1, a2, b0, b1, b2);
-    stream_group<T, KIND, MASK, WEIGHT, F32T, NACC>(pose, hl, dirty, vw, vb, vc, m, wv, carry);
+    unpack3(r.a0, r.a1, r.a2, vw);
+    unpack3(r.b0, r.b1, r.b2, vb);
+    if (KIND == KIND_P2PLANE) unpack3(r.c0, r.c1, r.c2, vc);
+    pair_group<T, KIND, MASK, WEIGHT, CLEAN, NACC>(pose, vw, vb, vc, r.m, r.wv, P, carry);
     if (++carried == kShare) { flush_pairs<T, NACC>(carry, acc); carried = 0; }
-    a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
-    if (KIND == KIND_P2PLANE) { c0 = nc0; c1 = nc1; c2 = nc2; }
-#pragma unroll
-    for (int i = 0; i < P; i++) { if (MASK) m[i] = nm[i]; if (WEIGHT) wv[i] = nwv[i]; }
-    g = gn;
+  };
+  // software pipeline: the loads of the next PF groups are in flight while the current one is reduced
+  int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  G cur, nx1, nx2;
+  if (g < full) {
+    cur.load(xw4, b4, c4, mask, weight, g);
+    if (PF >= 2) { const int64_t g1 = g + stride < full ? g + stride : g; nx1.load(xw4, b4, c4, mask, weight, g1); }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences: bounds-checked loads, guarded form
+#if defined(RPE_STAMPS) && RPE_STAMPS >= 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
+  RPE_STAMP(11);
+#endif
+  while (g < full) {
+    // clamp: past its last group a thread re-reads that (cached) group instead of branching
+    const int64_t ahead = g + PF * stride;
+    const int64_t gl = ahead < full ? ahead : g;
+    if (PF >= 2) nx2.load(xw4, b4, c4, mask, weight, gl); else nx1.load(xw4, b4, c4, mask, weight, gl);
+    reduce_group(cur);
+    cur = nx1;
+    if (PF >= 2) nx1 = nx2;
+    g += stride;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences: bounds-checked loads (zeros past the end)
     T vw[3 * P], vb[3 * P], vc[3 * P];
     short lm[P];
     T lwv[P];
@@ -138,7 +114,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     if (KIND == KIND_P2PLANE) load_group<T>(c, full, n, vc);
     if (MASK) load_scalars<T, short>(mask, full, n, lm, (short)0);
     if (WEIGHT) load_scalars<T, T>(weight, full, n, lwv, T(0));
-    pair_group<T, KIND, MASK, WEIGHT, false, F32T, NACC>(pose, hl, vw, vb, vc, lm, lwv, (int)(n - full * P), carry);
+    pair_group<T, KIND, MASK, WEIGHT, CLEAN, NACC>(pose, vw, vb, vc, lm, lwv, (int)(n - full * P), carry);
     carried = 1;
   }
   if (carried) flush_pairs<T, NACC>(carry, acc);
@@ -148,7 +124,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
 
 // IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
 // loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, bool AUTO>
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, bool AUTO, bool CLEAN>
 __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b,
     const T* __restrict__ c,
                                                                  const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
@@ -194,14 +170,14 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #pragma unroll
     for (int k = 0; k < NACC; k++) acc[k] = 0.0;
     if (IN_REGS) {
-      if (rpresent > 0) normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, rw, rb, rc, rm, rwv, rpresent, acc);
+      if (rpresent > 0) normal_eq_group<T, KIND, MASK, WEIGHT, NACC, CLEAN>(pose, rw, rb, rc, rm, rwv, rpresent, acc);
     } else {
       for (int64_t g = g0; g < groups; g += stride) {
         T vw[3 * P], vb[3 * P], vc[3 * P];
         short mm[P];
         T ww[P];
         load_any_group<T, KIND, MASK, WEIGHT>(xw, b, c, mask, weight, g, full, n, vw, vb, vc, mm, ww);
-        normal_eq_group<T, KIND, MASK, WEIGHT, NACC>(pose, vw, vb, vc, mm, ww, g < full ? P : (int)(n - full * P), acc);
+        normal_eq_group<T, KIND, MASK, WEIGHT, NACC, CLEAN>(pose, vw, vb, vc, mm, ww, g < full ? P : (int)(n - full * P), acc);
       }
     }
 #ifdef RPE_STAMPS
@@ -245,25 +221,19 @@ static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<doubl
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
   const Finish fin = make_finish(rt);
-  // the two-float fp32 transform: fp32 arrays, launches of >= kF32TransformMin correspondences (per context, rt.f32_min: RPE_F32_TRANSFORM at
-  // rpe_create = 0 never, 1 always, n from n correspondences); never inside a device-resident loop's launches (fin.gn: small steps of a loop that may run on
-  // few correspondences)
-  const int64_t f32_min = rt.f32_min < 0 ? kF32TransformMin : rt.f32_min;
-  const bool f32t = sizeof(T) == 4 && A.n >= f32_min && rt.gn == nullptr;
   // timed launches (bench.py's roofline leg) go through hipExtLaunchKernelGGL: the two events then carry the dispatch's own begin / end
   // timestamps -- what rocprofv3 reports for the kernel -- instead of bracketing it with two marker packets (which adds their latency)
-#define RPE_NE_LAUNCH2(M, W, F) RPE_LAUNCH_EV((normal_eq_kernel<T, KIND, BLK, M, W, F>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, pose, fin)
-#define RPE_NE_LAUNCH(M, W)                                                            \
-  do {                                                                                 \
-    if constexpr (sizeof(T) == 4) { if (f32t) RPE_NE_LAUNCH2(M, W, true); else RPE_NE_LAUNCH2(M, W, false); } \
-    else RPE_NE_LAUNCH2(M, W, false);                                                  \
-  } while (0)
+  const int pf = rt.prefetch == 2 ? 2 : 1;
+#define RPE_NE_LAUNCH3(M, W, C, F) RPE_LAUNCH_EV((normal_eq_kernel<T, KIND, BLK, M, W, C, F>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, pose, fin)
+#define RPE_NE_LAUNCH2(M, W, C) do { if (pf == 2) RPE_NE_LAUNCH3(M, W, C, 2); else RPE_NE_LAUNCH3(M, W, C, 1); } while (0)
+#define RPE_NE_LAUNCH(M, W) do { if (rt.clean) RPE_NE_LAUNCH2(M, W, true); else RPE_NE_LAUNCH2(M, W, false); } while (0)
   if (mask && weight) RPE_NE_LAUNCH(true, true);
   else if (mask) RPE_NE_LAUNCH(true, false);
   else if (weight) RPE_NE_LAUNCH(false, true);
   else RPE_NE_LAUNCH(false, false);
 #undef RPE_NE_LAUNCH
 #undef RPE_NE_LAUNCH2
+#undef RPE_NE_LAUNCH3
 }
 template <class T>
 static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
@@ -310,11 +280,8 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   constexpr int kMaxRows = 4 * (BLK / (KIND == KIND_P2P ? 17 : 29));   // up to 4 granules per collecting thread
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
   if (fin.rows < 1) fin.rows = 1;
-#define RPE_RES_LAUNCH3(M, W, R, AU)                                                                                                         \
-  do {                                                                                                                                       \
-    if (ev0 && ev1) hipExtLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU>), dim3(G), dim3(BLK), 0, s, ev0, ev1, 0, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
-    else hipLaunchKernelGGL((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU>), dim3(G), dim3(BLK), 0, s, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin);     \
-  } while (0)
+#define RPE_RES_LAUNCH4(M, W, R, AU, C) RPE_LAUNCH_EV((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU, C>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin)
+#define RPE_RES_LAUNCH3(M, W, R, AU) do { if (rt.clean) RPE_RES_LAUNCH4(M, W, R, AU, true); else RPE_RES_LAUNCH4(M, W, R, AU, false); } while (0)
 #define RPE_RES_LAUNCH2(M, W, R) do { if (fin.gn != nullptr) RPE_RES_LAUNCH3(M, W, R, true); else RPE_RES_LAUNCH3(M, W, R, false); } while (0)
 #define RPE_RES_LAUNCH(M, W) do { if (in_regs) RPE_RES_LAUNCH2(M, W, true); else RPE_RES_LAUNCH2(M, W, false); } while (0)
   if (mask && weight) RPE_RES_LAUNCH(true, true);
@@ -324,6 +291,7 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
 #undef RPE_RES_LAUNCH
 #undef RPE_RES_LAUNCH2
 #undef RPE_RES_LAUNCH3
+#undef RPE_RES_LAUNCH4
 }
 template <class T>
 static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
@@ -350,9 +318,9 @@ int resident_cap_device() {
   int cus = 0, c = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
   int per_cu = 1;
-  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, false, false>,
-                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, 512, true, false, true, true>,
-                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, 512, true, true, false, false>};
+  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, false, false, false>,
+                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, 512, true, false, true, true, false>,
+                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, 512, true, true, false, false, false>};
   for (const void* k : heavy) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 512, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }

@@ -12,24 +12,6 @@ namespace rpe {
 // The pose stays fp64 and p = R x + t, r = p - Xc are formed in fp64: the subtraction cancels ~3 digits
 // (|p| ~ 10 m, |r| ~ 5 cm), so doing it in fp32 would dominate the error budget.  p and r are then rounded
 // to the compute type C for the products (fp32 for fp32 arrays), and the sums are widened to fp64 per group.
-template <class C>
-__device__ __forceinline__ void p2p_point(const PoseK<double>& T, C x, C y, C z, C cx, C cy, C cz, C w, C (&s)[17]) {
-  double pxd, pyd, pzd;
-  transform<C>(T, x, y, z, pxd, pyd, pzd);
-  const C px = (C)pxd, py = (C)pyd, pz = (C)pzd;
-  const C rx = (C)(pxd - (double)cx), ry = (C)(pyd - (double)cy), rz = (C)(pzd - (double)cz);
-  const C wpx = w * px, wpy = w * py, wpz = w * pz;
-  const C wrx = w * rx, wry = w * ry, wrz = w * rz;
-  s[0] += w;
-  s[1] += wpx; s[2] += wpy; s[3] += wpz;
-  s[4] = fma(wpx, px, s[4]); s[5] = fma(wpx, py, s[5]); s[6] = fma(wpx, pz, s[6]);
-  s[7] = fma(wpy, py, s[7]); s[8] = fma(wpy, pz, s[8]); s[9] = fma(wpz, pz, s[9]);
-  s[10] += wrx; s[11] += wry; s[12] += wrz;
-  s[13] += py * wrz - pz * wry;
-  s[14] += pz * wrx - px * wrz;
-  s[15] += px * wry - py * wrx;
-  s[16] = fma(wrx, rx, fma(wry, ry, fma(wrz, rz, s[16])));
-}
 // general packed record: H upper triangle (21) | g (6) | w r^2 | w
 template <class C> __device__ __forceinline__ void add_row(const C (&J)[6], C r, C w, C (&s)[29]) {
   int k = 0;
@@ -220,86 +202,20 @@ __device__ __forceinline__ void p2p_pair(const PoseK<double>& T, const C (&x)[2]
   p2p_accumulate<V>(V{px[0], px[1]}, V{py[0], py[1]}, V{pz[0], pz[1]}, V{rx[0], rx[1]}, V{ry[0], ry[1]}, V{rz[0], rz[1]}, V{w[0], w[1]}, s);
 }
 
-// ================================================================================================
-// fp32 transform with a TWO-FLOAT pose (fp32 arrays, streaming launches of >= kF32TransformMin correspondences).
-// The streaming loops are bound by instruction issue, and a third of their instructions were the fp64 transform and residual with
-// the conversions around them (profiles/r03_sq_counters_1M.json).  Here the pose is carried as hi + lo floats (R = Rh + Rl, t = th + tl,
-// split once per thread) and  p_hi = Rh x + th,  p_lo = Rl x + tl  are two chains of packed fp32 FMAs on pairs of correspondences; the
-// cancelling residual is formed as (p_hi - Xc) + p_lo: the first difference is exact or nearly so (the operands agree in their leading
-// bits), the second adds the pose's own rounding back.  What this does NOT remove is the rounding INSIDE the p_hi chain (~1e-6 m at
-// |p| ~ 10 m, against 3e-9 m of the fp64 form) -- but that rounding is a fixed function of (Rh, th, x): once the iteration has settled to
-// within fp32 resolution of the pose, Rh and th no longer change, the perturbation is the same in every iteration, and Gauss-Newton
-// converges -- to the optimum of a problem whose residuals are offset by a fixed ~1e-6 m of zero-mean noise per correspondence, i.e.
-// 1e-6 / sqrt(N) from the fp64 optimum -- with |delta| falling to ~1e-13 as before (scripts/experiments/fp32_transform_gate.py: pose
-// within 4e-8 rad / 3e-10 relative t of the fp64 loop at 100 000 and 1 M correspondences, the |delta| < 1e-9 stop reached in the same
-// number of iterations; GPU parity: tests/test_gpu_f32_transform.py).  The lo part is what makes this work: with Rh alone the loop
-// stalls at |delta| ~ 3e-7, the quantisation of the pose.  fp64 stays for the accumulators, for fp64 arrays and for smaller launches.
-// ================================================================================================
-constexpr int64_t kF32TransformMin = 400000;
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct PoseHL { float Rh[9], Rl[9], th[3], tl[3]; };
-__device__ __forceinline__ PoseHL split_pose(const PoseK<double>& T) {
-  PoseHL P;
-#pragma unroll
-  for (int k = 0; k < 9; k++) { P.Rh[k] = (float)T.R[k]; P.Rl[k] = (float)(T.R[k] - (double)P.Rh[k]); }
-#pragma unroll
-  for (int k = 0; k < 3; k++) { P.th[k] = (float)T.t[k]; P.tl[k] = (float)(T.t[k] - (double)P.th[k]); }
-  return P;
-}
-__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
-__device__ __forceinline__ void transform_hl(const PoseHL& P, f2 x, f2 y, f2 z, f2 (&ph)[3], f2 (&pl)[3]) {
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    ph[i] = __builtin_elementwise_fma(splat2(P.Rh[3 * i]), x, __builtin_elementwise_fma(splat2(P.Rh[3 * i + 1]), y,
-        __builtin_elementwise_fma(splat2(P.Rh[3 * i + 2]), z, splat2(P.th[i]))));
-    pl[i] = __builtin_elementwise_fma(splat2(P.Rl[3 * i]), x, __builtin_elementwise_fma(splat2(P.Rl[3 * i + 1]), y,
-        __builtin_elementwise_fma(splat2(P.Rl[3 * i + 2]), z, splat2(P.tl[i]))));
-  }
-}
-// the cancelling residual vector (p_hi - Xc) + p_lo -- this order, no contraction to worry about (no products)
-__device__ __forceinline__ void residual_hl(const f2 (&ph)[3], const f2 (&pl)[3], f2 cx, f2 cy, f2 cz, f2 (&rv)[3]) {
-  rv[0] = (ph[0] - cx) + pl[0]; rv[1] = (ph[1] - cy) + pl[1]; rv[2] = (ph[2] - cz) + pl[2];
-}
-__device__ __forceinline__ void p2p_pair_f32(const PoseHL& P, f2 x, f2 y, f2 z, f2 cx, f2 cy, f2 cz, f2 w, f2 (&s)[17]) {
-  f2 ph[3], pl[3], rv[3];
-  transform_hl(P, x, y, z, ph, pl);
-  residual_hl(ph, pl, cx, cy, cz, rv);
-  p2p_accumulate<f2>(ph[0], ph[1], ph[2], rv[0], rv[1], rv[2], w, s);
-}
-__device__ __forceinline__ void p2plane_pair_f32(const PoseHL& P, f2 x, f2 y, f2 z, f2 cx, f2 cy, f2 cz, f2 nx, f2 ny, f2 nz, f2 w,
-                                                 f2 (&s)[29]) {
-  f2 ph[3], pl[3], rv[3];
-  transform_hl(P, x, y, z, ph, pl);
-  residual_hl(ph, pl, cx, cy, cz, rv);
-  const f2 r = __builtin_elementwise_fma(nx, rv[0], __builtin_elementwise_fma(ny, rv[1], nz * rv[2]));
-  const f2 J[6] = {nx, ny, nz, ph[1] * nz - ph[2] * ny, ph[2] * nx - ph[0] * nz, ph[0] * ny - ph[1] * nx};  // [n ; p x n]
-  add_row2<f2>(J, r, w, s);
-  s[28] += w;
-}
-// bearing: the two dots e_i . p cancel like the residuals above (p^ ~ bv is orthogonal to e_i): e_i . p_hi + e_i . p_lo
-__device__ __forceinline__ void bearing_pair_f32(const PoseHL& P, f2 x, f2 y, f2 z, f2 bx, f2 by, f2 bz, f2 w, f2 (&s)[29]) {
-  f2 e1[3], e2[3], ph[3], pl[3];
-  tangent_basis<f2>(bx, by, bz, e1, e2);
-  transform_hl(P, x, y, z, ph, pl);
-  const f2 d1 = __builtin_elementwise_fma(e1[0], ph[0], __builtin_elementwise_fma(e1[1], ph[1], e1[2] * ph[2])) +
-                __builtin_elementwise_fma(e1[0], pl[0], __builtin_elementwise_fma(e1[1], pl[1], e1[2] * pl[2]));
-  const f2 d2 = __builtin_elementwise_fma(e2[0], ph[0], __builtin_elementwise_fma(e2[1], ph[1], e2[2] * ph[2])) +
-                __builtin_elementwise_fma(e2[0], pl[0], __builtin_elementwise_fma(e2[1], pl[1], e2[2] * pl[2]));
-  bearing_rows<f2>(ph[0], ph[1], ph[2], e1, e2, d1, d2, bx, by, bz, w, w, s);
-}
-
 // All three kinds on pairs: one group of P correspondences added into the 2-vector partial sums s2 (NOT widened:
 // the
 // caller decides how many groups share one widening into the fp64 accumulators -- flush_pairs).
-// CLEAN: every value of the group is finite (group_dirty said so for the whole wave): no NaN guards and no selects; a correspondence
-// is switched off by its weight alone (0 x finite = 0).  F32T: the two-float fp32 transform above (fp32 arrays only).
-template <class T, int KIND, bool MASK, bool WEIGHT, bool CLEAN = false, bool F32T = false, int NS = 29>
-__device__ __forceinline__ void pair_group(const PoseK<double>& pose, const PoseHL& hl, const T (&vw)[3 * Pk<T>::P],
-                                           const T (&vb)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P],
-                                           const T (&wv)[Pk<T>::P], int npresent, T __attribute__((ext_vector_type(2))) (&s2)[NS]) {
+// CLEAN: the caller vouches that every value of the arrays is finite (the C-ABI shim launches the CLEAN flavour of a kernel first and
+// looks at the record it reads anyway: a NaN or an infinity anywhere in the arrays makes at least one sum non-finite -- 0 x NaN = NaN --
+// and the launch is repeated in the guarded flavour, rpe_capi.hip clean_first).  No NaN guards and no selects: a correspondence is
+// switched off by its weight alone (0 x finite = 0: the same bits the guarded form adds); entries past the end of the arrays were
+// loaded as zeros and get weight 0.  17 % of the guarded group's instructions.
+template <class T, int KIND, bool MASK, bool WEIGHT, bool CLEAN, int NS>
+__device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&vw)[3 * Pk<T>::P], const T (&vb)[3 * Pk<T>::P],
+                                           const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P], const T (&wv)[Pk<T>::P],
+                                           int npresent, T __attribute__((ext_vector_type(2))) (&s2)[NS]) {
   constexpr int P = Pk<T>::P;
   static_assert(NS == (KIND == KIND_P2P ? 17 : 29), "sums per kind");
-  static_assert(!F32T || sizeof(T) == 4, "the fp32 transform serves fp32 arrays");
 #pragma unroll
   for (int j = 0; j < P / 2; j++) {
     T x[2], y[2], z[2], bx[2], by[2], bz[2], nx[2], ny[2], nz[2], wi[2];
@@ -310,6 +226,7 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const Pose
       T w = WEIGHT ? wv[i] : T(1);
       if (MASK) w = m[i] == 1 ? w : T(0);
       if (CLEAN) {
+        w = i < npresent ? w : T(0);   // (folds away for full groups: npresent is the constant P there)
         x[e] = vw[3 * i]; y[e] = vw[3 * i + 1]; z[e] = vw[3 * i + 2];
         if (KIND == KIND_P2PLANE) { nx[e] = vc[3 * i]; ny[e] = vc[3 * i + 1]; nz[e] = vc[3 * i + 2]; }
       } else {
@@ -324,19 +241,11 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const Pose
       }
       wi[e] = w;
     }
-    if constexpr (F32T) {
-      const f2 X = {x[0], x[1]}, Y = {y[0], y[1]}, Z = {z[0], z[1]}, BX = {bx[0], bx[1]}, BY = {by[0], by[1]}, BZ = {bz[0], bz[1]};
-      const f2 W = {wi[0], wi[1]};
-      if constexpr (KIND == KIND_P2P) p2p_pair_f32(hl, X, Y, Z, BX, BY, BZ, W, s2);
-      else if constexpr (KIND == KIND_P2PLANE) p2plane_pair_f32(hl, X, Y, Z, BX, BY, BZ, f2{nx[0], nx[1]}, f2{ny[0], ny[1]}, f2{nz[0], nz[1]}, W, s2);
-      else bearing_pair_f32(hl, X, Y, Z, BX, BY, BZ, W, s2);
-    } else {
-      if constexpr (KIND == KIND_P2P) p2p_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
-      // 35 of the ~50 operations per point are the accumulation
-      else if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
-      // two rows per point: 70 of ~100
-      else bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
-    }
+    if constexpr (KIND == KIND_P2P) p2p_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
+    // 35 of the ~50 operations per point are the accumulation
+    else if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
+    // two rows per point: 70 of ~100
+    else bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
   }
 }
 // widen the pair sums into the fp64 accumulators and clear them.  A widening costs three instructions per sum (add the halves,
@@ -348,44 +257,19 @@ __device__ __forceinline__ void flush_pairs(T __attribute__((ext_vector_type(2))
   for (int k = 0; k < NS; k++) { acc[k] += (double)(s2[k].x + s2[k].y); s2[k] = V{T(0), T(0)}; }
 }
 
-// The main loop runs over FULL groups only and is branch-free (mask / weight presence are template flags), so the
-// compiler issues all 16-byte loads of an iteration up front behind one wait; the <= P-1 leftover correspondences
-// are handled once, by thread 0 of workgroup 0, through the bounds-checked loaders.
-template <class T, int KIND, bool MASK, bool WEIGHT, int NACC>
+// One group of P correspondences into the fp64 accumulators (the resident kernels, the fused ICP kernels, single groups): all three
+// kinds on pairs of correspondences (pair_group), widened at the end of the group.  CLEAN: see pair_group.
+template <class T, int KIND, bool MASK, bool WEIGHT, int NACC, bool CLEAN = false>
 __device__ __forceinline__ void normal_eq_group(const PoseK<double>& pose, const T (&vw)[3 * Pk<T>::P], const T (&vb)[3 * Pk<T>::P],
                                                 const T (&vc)[3 * Pk<T>::P], const short (&m)[Pk<T>::P], const T (&wv)[Pk<T>::P],
                                                 int npresent, double (&acc)[NACC]) {
-  constexpr int P = Pk<T>::P;
-  if constexpr (KIND == KIND_P2PLANE || KIND == KIND_BEARING) {   // pairs of correspondences as 2-vectors
-    typedef T V __attribute__((ext_vector_type(2)));
-    V s2[29];
+  typedef T V __attribute__((ext_vector_type(2)));
+  V s2[NACC];
 #pragma unroll
-    for (int k = 0; k < 29; k++) s2[k] = V{T(0), T(0)};
-    PoseHL unused_hl;   // (F32T = false: never read)
-    pair_group<T, KIND, MASK, WEIGHT, false, false, 29>(pose, unused_hl, vw, vb, vc, m, wv, npresent, s2);
-    flush_pairs<T, 29>(s2, reinterpret_cast<double(&)[29]>(acc));
-    return;
-  }
-  T s[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; k++) s[k] = T(0);
-#pragma unroll
-  for (int i = 0; i < P; i++) {   // point-to-point: 17 structured sums per correspondence
-    T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-    T bx = vb[3 * i], by = vb[3 * i + 1], bz = vb[3 * i + 2];
-    T wi = WEIGHT ? wv[i] : T(1);
-    if (MASK) wi = m[i] == 1 ? wi : T(0);
-    wi = (i < npresent && !all_nan(bx, by, bz)) ? wi : T(0);
-    const bool off = wi == T(0);
-    // keeps NaN / inf of skipped columns out of the sums (selects, not branches)
-    x = off ? T(0) : x; y = off ? T(0) : y; z = off ? T(0) : z;
-    bx = off ? T(0) : bx; by = off ? T(0) : by; bz = off ? T(1) : bz;
-    p2p_point<T>(pose, x, y, z, bx, by, bz, wi, reinterpret_cast<T(&)[17]>(s));
-  }
-#pragma unroll
-  for (int k = 0; k < NACC; k++) acc[k] += (double)s[k];
+  for (int k = 0; k < NACC; k++) s2[k] = V{T(0), T(0)};
+  pair_group<T, KIND, MASK, WEIGHT, CLEAN, NACC>(pose, vw, vb, vc, m, wv, npresent, s2);
+  flush_pairs<T, NACC>(s2, acc);
 }
-
 // ================================================================================================
 // K1 / K2 / K3, RESIDENT form: the host-driven Gauss-Newton loop in ONE launch.
 // The north-star loop keeps the 6x6 solve and the SE(3) exp-map on the host, so every iteration needs a host round trip; with one
