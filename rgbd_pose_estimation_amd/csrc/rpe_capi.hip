@@ -103,7 +103,6 @@ struct rpe_context {
   int max_blocks = 256;          // reduction kernels: cap on workgroups = one per CU (multiples of 256 only: 320 or 384 lose 20-30 %)
   int score_blocks = 2048;       // scoring / mask kernels (256-thread workgroups)
   int block = 0;                 // reduction workgroup size override (RPE_BLOCK), 0 = default
-  int prefetch = 1;              // streaming normal-equation kernel: groups loaded ahead (RPE_PREFETCH = 1 | 2)
   // What is known about the CONTENT of each array, for the choice between the CLEAN flavour of the normal-equation kernels (no NaN
   // guards) and the guarded one (clean_first below): 0 unknown, 1 verified finite, 2 holds a NaN or an infinity (the reference's
   // NaN-marked "invalid measurement" columns, AOPoseAdapter.hpp:147-152).  Reset by every upload / bind / device-side producer.
@@ -250,7 +249,6 @@ int run_stride_from_env() {
 rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
-  rt.prefetch = c->prefetch;
   rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
   c->collecting = false;
   return rt;
@@ -267,7 +265,6 @@ rpe::ReduceTarget collect_target(rpe_context* c) {
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
-  rt.prefetch = c->prefetch;
   rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
   c->collecting = false;
   return rt;
@@ -622,7 +619,6 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 4096) c->max_blocks = v; }
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
-  if (const char* f = getenv("RPE_PREFETCH")) { const int v = atoi(f); if (v == 1 || v == 2) c->prefetch = v; }
   if (const char* f = getenv("RPE_GUARD_ALWAYS")) c->guard_always = atoi(f) != 0;
   hipError_t e = hipSuccess;
   // scratch of the cross-workgroup stages, whichever layout a launch uses: (4096 + 8 shard) records of kNlLd doubles, or 16-byte

@@ -63,7 +63,6 @@ struct ReduceTarget {
   unsigned long long fault_tag = 0;                    // test hook: see Finish
   // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
   int rows = 0;
-  int prefetch = 1;            // streaming normal-equation kernel: groups loaded ahead (1 or 2; RPE_PREFETCH at rpe_create)
   // normal-equation kernels (one launch and resident): the flavour WITHOUT NaN guards.  Only for arrays known or about to be verified
   // to hold finite values: the shim launches it first and repeats the launch in the guarded flavour if the record comes back
   // non-finite (rpe_capi.hip clean_first); results nobody on the host inspects use it only for arrays already verified

@@ -24,34 +24,25 @@ hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d
   return hipGetLastError();
 }
 
-// the vectors of one group as loaded (three 16-byte loads per array), before they are unpacked
-template <class T, int KIND, bool MASK, bool WEIGHT> struct GroupRegs {
-  typedef typename Pk<T>::V V;
-  V a0, a1, a2, b0, b1, b2, c0, c1, c2;
-  short m[Pk<T>::P];
-  T wv[Pk<T>::P];
-  __device__ __forceinline__ void load(const V* __restrict__ xw4, const V* __restrict__ b4, const V* __restrict__ c4,
-                                       const short* __restrict__ mask, const T* __restrict__ weight, int64_t g) {
-    a0 = xw4[3 * g]; a1 = xw4[3 * g + 1]; a2 = xw4[3 * g + 2];
-    b0 = b4[3 * g]; b1 = b4[3 * g + 1]; b2 = b4[3 * g + 2];
-    if (KIND == KIND_P2PLANE) { c0 = c4[3 * g]; c1 = c4[3 * g + 1]; c2 = c4[3 * g + 2]; }
-    if (MASK) load_mask_full(mask, g, m);
-    if (WEIGHT) load_weight_full(weight, g, wv);
-  }
-};
-
-// PF: how many groups ahead the loads run (1: the next group's loads are in flight while this one is reduced; 2: the next two).  The
-// streaming loop is bound by the bytes a wave has in flight -- one round trip of the memory system per trip (Little's law: 6.3 MB
-// in flight chip-wide with one group per lane at 256 x 256 threads) -- not by instruction issue (profiles/r04_streaming_loop.md).
-// CLEAN: the flavour without NaN guards (pair_group); the shim launches it first and falls back to the guarded one (rpe_capi.hip).
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool CLEAN, int PF>
+// a 16-byte vector in registers made opaque to the optimiser (no instruction is emitted)
+template <class V> __device__ __forceinline__ void pin16(V& v) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  u4 t = __builtin_bit_cast(u4, v);
+  asm("" : "+v"(t));
+  v = __builtin_bit_cast(V, t);
+}
+// The streaming loop is bound by the bytes the memory system delivers, not by instruction issue: at 1 M correspondences the CLEAN
+// flavour executes 24 % fewer vector instructions per wave than the guarded one and takes the same time, and loading two groups
+// ahead instead of one changes nothing either (profiles/r04_streaming_ab.jsonl) -- only the bearing kind, with two
+// Jacobian rows per correspondence, still feels its arithmetic.
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool CLEAN>
 __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                                                         const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                                                         PoseK<double> pose, Finish fin) {
   constexpr int P = Pk<T>::P;
   constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
   typedef typename Pk<T>::V V;
-  typedef GroupRegs<T, KIND, MASK, WEIGHT> G;
   if (fin.gn != nullptr) {  // device-resident Gauss-Newton: finished loops cost an empty launch; the pose lives in HBM
     if (fin.gn->done) return;
 #pragma unroll
@@ -68,42 +59,60 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   const V* __restrict__ xw4 = reinterpret_cast<const V*>(xw);
   const V* __restrict__ b4 = reinterpret_cast<const V*>(b);
   const V* __restrict__ c4 = reinterpret_cast<const V*>(c);
-  // All three kinds run on PAIRS of correspondences as 2-vectors (packed fp32 instructions for fp32 arrays); the pair sums of up to
-  // kShare consecutive groups share one widening into the fp64 accumulators (flush_pairs: three instructions per sum).
+  // All three kinds run on PAIRS of correspondences as 2-vectors (packed fp32 instructions for fp32 arrays).  The pair sums of kShare
+  // consecutive groups share one widening into the fp64 accumulators (flush_pairs: three instructions per sum): four for the bearing
+  // kind, whose loop feels its instruction count; two for point-to-plane; point-to-point widens every group, so that its record is the
+  // same fp64 sum of per-group fp32 sums whatever the grid -- the sums of shards add up to the sum of the whole to fp64 rounding
+  // (tests/test_gpu_fullsize.py::test_config5_shards_add_up_10M).
   typedef T V2 __attribute__((ext_vector_type(2)));
-  constexpr int kShare = 4;
+  constexpr int kShare = KIND == KIND_BEARING ? 4 : (KIND == KIND_P2PLANE ? 2 : 1);
   V2 carry[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; k++) carry[k] = V2{T(0), T(0)};
   int carried = 0;
-  auto reduce_group = [&](const G& r) {
-    T vw[3 * P], vb[3 * P], vc[3 * P];
-    unpack3(r.a0, r.a1, r.a2, vw);
-    unpack3(r.b0, r.b1, r.b2, vb);
-    if (KIND == KIND_P2PLANE) unpack3(r.c0, r.c1, r.c2, vc);
-    pair_group<T, KIND, MASK, WEIGHT, CLEAN, NACC>(pose, vw, vb, vc, r.m, r.wv, P, carry);
-    if (++carried == kShare) { flush_pairs<T, NACC>(carry, acc); carried = 0; }
-  };
-  // software pipeline: the loads of the next PF groups are in flight while the current one is reduced
+  // software pipeline: the loads of the NEXT group are in flight while the current one is reduced, so a CU's waves do not all
+  // alternate between "everyone waits on memory" and "everyone computes"
   int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  G cur, nx1, nx2;
+  V a0, a1, a2, b0, b1, b2, c0, c1, c2;
+  short m[P];
+  T wv[P];
   if (g < full) {
-    cur.load(xw4, b4, c4, mask, weight, g);
-    if (PF >= 2) { const int64_t g1 = g + stride < full ? g + stride : g; nx1.load(xw4, b4, c4, mask, weight, g1); }
+    a0 = xw4[3 * g]; a1 = xw4[3 * g + 1]; a2 = xw4[3 * g + 2];
+    b0 = b4[3 * g]; b1 = b4[3 * g + 1]; b2 = b4[3 * g + 2];
+    if (KIND == KIND_P2PLANE) { c0 = c4[3 * g]; c1 = c4[3 * g + 1]; c2 = c4[3 * g + 2]; }
+    if (MASK) load_mask_full(mask, g, m);
+    if (WEIGHT) load_weight_full(weight, g, wv);
   }
 #if defined(RPE_STAMPS) && RPE_STAMPS >= 2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
   RPE_STAMP(11);
 #endif
   while (g < full) {
-    // clamp: past its last group a thread re-reads that (cached) group instead of branching
-    const int64_t ahead = g + PF * stride;
-    const int64_t gl = ahead < full ? ahead : g;
-    if (PF >= 2) nx2.load(xw4, b4, c4, mask, weight, gl); else nx1.load(xw4, b4, c4, mask, weight, gl);
-    reduce_group(cur);
-    cur = nx1;
-    if (PF >= 2) nx1 = nx2;
-    g += stride;
+    const int64_t gn = g + stride;
+    const int64_t gl = gn < full ? gn : g;  // clamp: the last trip re-reads its own (cached) group instead of branching
+    const V na0 = xw4[3 * gl], na1 = xw4[3 * gl + 1], na2 = xw4[3 * gl + 2];
+    const V nb0 = b4[3 * gl], nb1 = b4[3 * gl + 1], nb2 = b4[3 * gl + 2];
+    V nc0, nc1, nc2;
+    if (KIND == KIND_P2PLANE) { nc0 = c4[3 * gl]; nc1 = c4[3 * gl + 1]; nc2 = c4[3 * gl + 2]; }
+    short nm[P];
+    T nwv[P];
+    if (MASK) load_mask_full(mask, gl, nm);
+    if (WEIGHT) load_weight_full(weight, gl, nwv);
+    // the current group's vectors as opaque 16-byte values at their point of use: without this the optimiser narrows and re-splits
+    // the loads of the CLEAN bearing flavour into 12- and 8-byte pieces at odd offsets (three times the launch time)
+    pin16(a0); pin16(a1); pin16(a2); pin16(b0); pin16(b1); pin16(b2);
+    if (KIND == KIND_P2PLANE) { pin16(c0); pin16(c1); pin16(c2); }
+    T vw[3 * P], vb[3 * P], vc[3 * P];
+    unpack3(a0, a1, a2, vw);
+    unpack3(b0, b1, b2, vb);
+    if (KIND == KIND_P2PLANE) unpack3(c0, c1, c2, vc);
+    pair_group<T, KIND, MASK, WEIGHT, CLEAN, NACC>(pose, vw, vb, vc, m, wv, P, carry);
+    if (++carried == kShare) { flush_pairs<T, NACC>(carry, acc); carried = 0; }
+    a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
+    if (KIND == KIND_P2PLANE) { c0 = nc0; c1 = nc1; c2 = nc2; }
+#pragma unroll
+    for (int i = 0; i < P; i++) { if (MASK) m[i] = nm[i]; if (WEIGHT) wv[i] = nwv[i]; }
+    g = gn;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences: bounds-checked loads (zeros past the end)
     T vw[3 * P], vb[3 * P], vc[3 * P];
@@ -223,9 +232,7 @@ static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<doubl
   const Finish fin = make_finish(rt);
   // timed launches (bench.py's roofline leg) go through hipExtLaunchKernelGGL: the two events then carry the dispatch's own begin / end
   // timestamps -- what rocprofv3 reports for the kernel -- instead of bracketing it with two marker packets (which adds their latency)
-  const int pf = rt.prefetch == 2 ? 2 : 1;
-#define RPE_NE_LAUNCH3(M, W, C, F) RPE_LAUNCH_EV((normal_eq_kernel<T, KIND, BLK, M, W, C, F>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, pose, fin)
-#define RPE_NE_LAUNCH2(M, W, C) do { if (pf == 2) RPE_NE_LAUNCH3(M, W, C, 2); else RPE_NE_LAUNCH3(M, W, C, 1); } while (0)
+#define RPE_NE_LAUNCH2(M, W, C) RPE_LAUNCH_EV((normal_eq_kernel<T, KIND, BLK, M, W, C>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, pose, fin)
 #define RPE_NE_LAUNCH(M, W) do { if (rt.clean) RPE_NE_LAUNCH2(M, W, true); else RPE_NE_LAUNCH2(M, W, false); } while (0)
   if (mask && weight) RPE_NE_LAUNCH(true, true);
   else if (mask) RPE_NE_LAUNCH(true, false);
@@ -233,7 +240,6 @@ static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<doubl
   else RPE_NE_LAUNCH(false, false);
 #undef RPE_NE_LAUNCH
 #undef RPE_NE_LAUNCH2
-#undef RPE_NE_LAUNCH3
 }
 template <class T>
 static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
