@@ -50,7 +50,9 @@ typedef enum {
   RPE_ERR_HIP = -2,
   RPE_ERR_ARG = -3,
   RPE_ERR_STATE = -4,         /* a required array was never uploaded / bound */
-  RPE_ERR_DEGENERATE = -5,    /* normal equations not positive definite (a pivot <= 1e-12 of its diagonal counts: rank-deficient sets), or NaN result */
+  RPE_ERR_DEGENERATE = -5,    /* normal equations not positive definite, or NaN result.  A pivot at or below 16 eps of the ARRAYS' dtype x its
+                               * diagonal entry (9.5e-7 for fp32 arrays, 1e-12 for fp64) counts: the cancelled pivots of rank-deficient sets -- one
+                               * repeated point, a line, a single plane seen point-to-plane -- are rounding noise of the products, of either sign */
   RPE_ERR_ALIGN = -6          /* bound device pointer not 16-byte aligned */
 } rpe_status;
 
@@ -121,7 +123,8 @@ int rpe_normal_eq(rpe_context* ctx, int kind, int flags, const double* pose12, d
 /* Same, result left in HBM at d_out32 (32 doubles, must not be NULL) for a caller-side collective (RCCL
  * all-reduce); asynchronous on the context's stream. */
 int rpe_normal_eq_device(rpe_context* ctx, int kind, int flags, const double* pose12, double* d_out32);
-/* Host: solve H*delta = -g (Cholesky); RPE_ERR_DEGENERATE if H is not positive definite. */
+/* Host: solve H*delta = -g (LDL^T); RPE_ERR_DEGENERATE if H is not positive definite.  ne32[29], as rpe_normal_eq* fill it in, is the
+ * relative pivot floor that goes with the record's product dtype (0 = 1e-12). */
 int rpe_gn_solve(const double* ne32, double* delta6);
 /* Host: pose <- exp(delta) * pose  (Sophus SE3::exp, sophus/se3.hpp:321-342). */
 int rpe_gn_apply(const double* delta6, double* pose12);

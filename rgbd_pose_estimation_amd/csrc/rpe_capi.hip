@@ -249,6 +249,7 @@ int run_stride_from_env() {
 rpe::ReduceTarget host_target(rpe_context* c) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
+  rt.pivot_floor = rpe::pivot_floor(c->dtype == RPE_F64);
   rt.d_out = nullptr; rt.h_out = c->h_out; rt.seq = ++c->seq;
   c->collecting = false;
   return rt;
@@ -265,6 +266,7 @@ rpe::ReduceTarget collect_target(rpe_context* c) {
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   rpe::ReduceTarget rt;
   rt.d_partials = c->d_partials; rt.d_ticket = c->d_ticket; rt.max_blocks = c->max_blocks; rt.block = c->block;
+  rt.pivot_floor = rpe::pivot_floor(c->dtype == RPE_F64);
   rt.d_out = d_out; rt.h_out = nullptr; rt.seq = 0;
   c->collecting = false;
   return rt;
@@ -567,7 +569,7 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     received++;
     if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
     cost = cost_scale * ne[27]; weight = ne[28];
-    if (!rpe::solve_normal_eq6(ne, d)) { status = fail(RPE_ERR_DEGENERATE,
+    if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) { status = fail(RPE_ERR_DEGENERATE,
         "%s are not positive definite at iteration %d (weight sum %g)", what, it, ne[28]); break; }
     rpe::se3_left_update(d, pose12);
     step = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
@@ -927,7 +929,7 @@ int rpe_gn_step(rpe_context* c, int kind, int flags, double* pose12, double* ne3
   double ne[32], d[6];
   int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
   if (rc) return rc;
-  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
+  if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
       ne[28]);
   rpe::se3_left_update(d, pose12);
   if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
@@ -950,6 +952,7 @@ int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, dou
     }
   }
   for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
+  out32[29] = rpe::pivot_floor(c->dtype == RPE_F64);   // for rpe_gn_solve: the floor that goes with this record's product dtype
   return RPE_OK;
 }
 
@@ -988,6 +991,7 @@ int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
   if (rc) return rc;
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
+  out32[29] = rpe::pivot_floor(c->dtype == RPE_F64);
   return RPE_OK;
 }
 
@@ -1028,7 +1032,7 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
     int rc = rpe_normal_eq_joint(c, nterms, terms, flags, pose12, ne);
     if (rc) return rc;
     cost = ne[27];
-    if (!rpe::solve_normal_eq6(ne, d)) {
+    if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) {
       if (iters_out) *iters_out = it;
       return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, ne[28]);
     }
@@ -1147,7 +1151,7 @@ int rpe_debug_device_gn_update(rpe_context* c, const double* ne32, double* pose1
   for (int i = 0; i < 12; i++) buf[32 + i] = pose12[i];
   buf[44] = buf[45] = 0;
   HIP_TRY(hipMemcpyAsync(c->d_out, buf, sizeof(buf), hipMemcpyHostToDevice, c->stream));   // d_out holds 64 doubles
-  HIP_TRY(rpe::launch_gn_update_probe(c->d_out, c->d_out + 32, c->d_out + 44, c->stream));
+  HIP_TRY(rpe::launch_gn_update_probe(c->d_out, c->d_out + 32, c->d_out + 44, ne32[29] > 1e-12 && ne32[29] < 1e-3 ? ne32[29] : 1e-12, c->stream));
   HIP_TRY(hipMemcpyAsync(buf, c->d_out, sizeof(buf), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (buf[45] == 0.0) return fail(RPE_ERR_DEGENERATE, "device solve: normal equations are not positive definite");
@@ -1180,7 +1184,9 @@ int rpe_debug_inject_resident_fault(rpe_context* c, int iteration, double pose_w
 
 int rpe_gn_solve(const double* ne32, double* delta6) {
   if (!ne32 || !delta6) return fail(RPE_ERR_ARG, "null argument");
-  if (!rpe::solve_normal_eq6(ne32, delta6)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite");
+  // ne32[29]: the relative pivot floor of the arithmetic that produced the record (rpe_normal_eq* fill it in; 0 = 1e-12)
+  if (!rpe::solve_normal_eq6(ne32, delta6, ne32[29] > 1e-12 && ne32[29] < 1e-3 ? ne32[29] : 1e-12)) return fail(RPE_ERR_DEGENERATE,
+      "normal equations are not positive definite");
   return RPE_OK;
 }
 
@@ -1261,7 +1267,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     if (rc) return rc;
     if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) return rc;
     cost = sc * ne[27];
-    if (!rpe::solve_normal_eq6(ne, d)) {
+    if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) {
       if (iters_out) *iters_out = it;
       return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at iteration %d (weight sum %g)", it, ne[28]);
     }
@@ -1435,7 +1441,7 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
     int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
     if (rc) return rc;
     if ((rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) return rc;
-    if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
+    if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
         ne[28]);
     rpe::se3_left_update(d, pose12);
     if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
@@ -1470,7 +1476,7 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
   for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
   if (c->p2p_world >= 1 && ne[31] != 0.0) return fail(RPE_ERR_HIP,
       "peer-to-peer exchange timed out at step %llu (a peer did not deliver its record)", c->p2p_step - 1);
-  if (!rpe::solve_normal_eq6(ne, d)) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
+  if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
       ne[28]);
   rpe::se3_left_update(d, pose12);
   if (ne32_out) std::memcpy(ne32_out, ne, sizeof(ne));
@@ -2007,7 +2013,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
       double ne[32], d[6];
       for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
       cost = ne[27]; pairs = ne[28];
-      if (!rpe::solve_normal_eq6(ne, d)) {
+      if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) {
         if (iters_out) *iters_out = it;
         return fail(RPE_ERR_DEGENERATE, "ICP: normal equations are not positive definite at iteration %d (%g pairs)", it, pairs);
       }

@@ -61,6 +61,7 @@ struct ReduceTarget {
   // resident kernels: wait for the host's next pose at most this long (100 MHz ticks; 2 s)
   unsigned long long pose_wait_ticks = 200000000ull;
   unsigned long long fault_tag = 0;                    // test hook: see Finish
+  double pivot_floor = 1e-12;  // device-side 6x6 solves: relative pivot floor (rpe::pivot_floor of the arrays' dtype, rpe/linalg.hpp)
   // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
   int rows = 0;
   // normal-equation kernels (one launch and resident): the flavour WITHOUT NaN guards.  Only for arrays known or about to be verified
@@ -104,7 +105,7 @@ hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags,
     unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // test hook: one application of the device-resident loop's 6x6 LDL^T solve + SE(3) exp-map update (d_step_ok: |delta|, ok flag)
-hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, hipStream_t s);
+hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, double pivot_floor, hipStream_t s);
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr,
                           hipEvent_t ev_end = nullptr);
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind

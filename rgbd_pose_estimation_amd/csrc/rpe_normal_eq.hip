@@ -6,7 +6,8 @@ namespace rpe {
 
 // test hook (rpe_debug_device_gn_update): the device-resident loop's solve + SE(3) update on a record and pose of the caller's, so that
 // the LDL^T solve and the exponential map the last workgroup runs can be checked against the oracle / golden values in isolation
-__global__ void gn_update_probe_kernel(const double* __restrict__ rec, double* __restrict__ pose, double* __restrict__ step_ok) {
+__global__ void gn_update_probe_kernel(const double* __restrict__ rec, double* __restrict__ pose, double* __restrict__ step_ok,
+                                       double rel_floor) {
   __shared__ double s_rec[32];
   __shared__ double s_pose[12];
   if (threadIdx.x < 32) s_rec[threadIdx.x] = rec[threadIdx.x];
@@ -14,13 +15,13 @@ __global__ void gn_update_probe_kernel(const double* __restrict__ rec, double* _
   __syncthreads();
   if (threadIdx.x == 0) {
     double step = 0.0;
-    const bool ok = gn_solve_update<0>(s_rec, s_pose, &step);
+    const bool ok = gn_solve_update<0>(s_rec, s_pose, &step, rel_floor);
     step_ok[0] = step; step_ok[1] = ok ? 1.0 : 0.0;
     if (ok) for (int k = 0; k < 12; k++) pose[k] = s_pose[k];
   }
 }
-hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d_step_ok, hipStream_t s) {
-  hipLaunchKernelGGL(gn_update_probe_kernel, dim3(1), dim3(64), 0, s, d_rec, d_pose, d_step_ok);
+hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d_step_ok, double pivot_floor, hipStream_t s) {
+  hipLaunchKernelGGL(gn_update_probe_kernel, dim3(1), dim3(64), 0, s, d_rec, d_pose, d_step_ok, pivot_floor);
   return hipGetLastError();
 }
 

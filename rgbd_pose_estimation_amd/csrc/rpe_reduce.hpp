@@ -293,6 +293,7 @@ struct Finish {
   // resident kernels: how long a workgroup waits for the host's next pose (100 MHz ticks) before it gives up
   unsigned long long pose_wait_ticks;
   unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
+  double pivot_floor;                   // device-side 6x6 solves: relative pivot floor (rpe::pivot_floor, rpe/linalg.hpp)
 };
 // what a collecting workgroup sends to the host in place of its run's sums when a granule of the run never arrived: a quiet NaN with a
 // payload no arithmetic produces; the host then releases the grid and finishes the refinement with one launch per iteration
@@ -381,7 +382,7 @@ static __device__ __forceinline__ double rcp_newton(double d) {
 template <int MODE>
 static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ tot /* LDS */, double* __restrict__ pose /* LDS, 12,
     in/out */,
-                                                    double* step_out) {
+                                                    double* step_out, double rel_floor) {
   double U[6][6], b[6], inv[6], d[6];
   {
     int k = 0;
@@ -399,7 +400,7 @@ static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ t
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const double piv = U[k][k];
-    ok = ok && (piv > 1e-12 * diag0[k]) && (piv < 1e300);   // relative pivot floor, as rpe/linalg.hpp solve_normal_eq6
+    ok = ok && (piv > rel_floor * diag0[k]) && (piv < 1e300);   // relative pivot floor, as rpe/linalg.hpp solve_normal_eq6
     inv[k] = rcp_newton(piv);
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
@@ -817,7 +818,7 @@ __device__ __forceinline__ void reduce_and_finish(double (&acc)[NACC], const Fin
       double step = 0.0;
       // sharded loop: did every peer's record arrive?
       const bool delivered = !(LD == 32 && fin.p2p != nullptr && gn_rec[LD - 1] != 0.0);
-      const bool ok = delivered && gn_solve_update<0>(gn_rec, gn_pose_s, &step);
+      const bool ok = delivered && gn_solve_update<0>(gn_rec, gn_pose_s, &step, fin.pivot_floor);
       const int iters = st->iters + 1;
       const int done = (!ok) || step < st->tol || iters >= st->max_iters;
       st->iters = iters; st->step = step; st->cost = gn_rec[27]; st->status = ok ? 0 : (delivered ? 1 : 2); st->done = done;
@@ -900,7 +901,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.rows = rt.rows > 0 ? rt.rows : 0;
   f.stride = rt.stride > 1 ? rt.stride : 0;
-  f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag;
+  f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag; f.pivot_floor = rt.pivot_floor;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

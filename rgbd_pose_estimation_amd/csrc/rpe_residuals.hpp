@@ -524,7 +524,7 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
 #endif
     if (threadIdx.x == 0) {
       double step = 0.0;
-      a_ok = !lost && gn_solve_update<MODE>(a_tot, s_pose, &step) ? 1 : 0;
+      a_ok = !lost && gn_solve_update<MODE>(a_tot, s_pose, &step, fin.pivot_floor) ? 1 : 0;
       a_step = step;
     }
   }

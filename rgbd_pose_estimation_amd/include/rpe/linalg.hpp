@@ -305,8 +305,17 @@ RPE_HD inline void se3_left_update(const double delta[6], double pose[12]) {
   for (int k = 0; k < 3; k++) pose[9 + k] = tn[k];
 }
 
-// Solve the 6x6 SPD system H d = -g given the packed record (H upper triangle row-major 21 | g 6).  false if not SPD.
-RPE_HD inline bool solve_normal_eq6(const double* ne, double d[6]) {
+// Relative pivot floor of the 6x6 solves: a pivot of a RANK-DEFICIENT system (one repeated point, points on a line, a single plane seen
+// point-to-plane) cancels to the rounding noise of the sums it is made of, and whether that noise comes out positive depends on the
+// order of the sums -- so the floor sits above the noise of the PRODUCT dtype: the entries of H are sums of products rounded to the
+// array dtype (relative noise between eps / sqrt(N) and eps of a diagonal entry), hence 16 eps of that dtype (9.5e-7 for fp32 arrays,
+// 1e-12 at least).  A system refused by this floor has a direction determined to less than six (fp32) digits of its diagonal: its
+// update would be rounding noise.  The same floor on the host (solve_normal_eq6) and on the device (gn_solve_update, rpe_reduce.hpp).
+RPE_HD inline double pivot_floor(bool f64_products) { return f64_products ? 1e-12 : 16.0 * 5.9604644775390625e-08; }
+
+// Solve the 6x6 SPD system H d = -g given the packed record (H upper triangle row-major 21 | g 6).  false if not SPD, i.e. if a pivot
+// is not above rel_floor x its diagonal entry.
+RPE_HD inline bool solve_normal_eq6(const double* ne, double d[6], double rel_floor = 1e-12) {
   double A[6][6];
   int k = 0;
   for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) { A[i][j] = ne[k]; A[j][i] = ne[k]; k++; }
@@ -318,7 +327,7 @@ RPE_HD inline bool solve_normal_eq6(const double* ne, double d[6]) {
     for (int m = 0; m < j; m++) dj -= L[j][m] * L[j][m] * D[m];
     // a pivot that cancelled to rounding noise (rank-deficient sets: one repeated point, points on a line, a single plane for
     // point-to-plane) is "not positive definite" too: dividing by it would hand back a finite but meaningless update
-    if (!(dj > 1e-12 * A[j][j]) || !(dj < 1e300)) return false;
+    if (!(dj > rel_floor * A[j][j]) || !(dj < 1e300)) return false;
     D[j] = dj;
     L[j][j] = 1.0;
     for (int i = j + 1; i < 6; i++) {

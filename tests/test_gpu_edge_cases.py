@@ -1,6 +1,8 @@
 """-m gpu: the degenerate inputs of the path -- no valid correspondence at all, nothing selected by the mask, thresholds that admit nothing or
 everything, rank-deficient point sets, the longest hypothesis list -- through the C ABI, against the oracle where it defines a result and
 against a loud error where the reference would have produced NaNs or aborted (AbsoluteOrientation.hpp:53 assert, SOPHUS_ENSURE)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -90,23 +92,49 @@ def test_rank_deficient_sets_are_refused_not_nan(gpu_ctx_factory):
     one = np.tile(np.array([[0.3, -0.2, 2.0]], np.float32), (n, 1))
     line = (np.linspace(0, 1, n, dtype=np.float32)[:, None] * np.array([[1.0, 2.0, 0.5]], np.float32)) + np.float32(1.0)
     off = np.array([[0.01, -0.02, 0.005]], np.float32)
-    # The cancelled pivots of these sets are the rounding noise of the fp32 products, and its sign depends on the order of the sums (the
-    # resident kernel and the one-launch kernel differ).  Either the call is refused, or the noise pivot was positive and the result is
-    # one of the equally good minimisers (one repeated point: any rotation about it; a line: any rotation about the line): finite and
-    # fitting -- never NaN.
+    # The cancelled pivots of these sets are the rounding noise of the fp32 products, whose sign depends on the order of the sums (the
+    # resident kernel, the one-launch kernel and the device loop differ): the pivot floor sits above that noise -- 16 eps of the
+    # product dtype x the diagonal (rpe::pivot_floor) -- so every path refuses both sets, whatever the order (round-3 review, item 6).
+    paths = {
+        "resident": (lambda ctx: ctx.gn_refine([L.RES_P2P], api.pose12(np.eye(3), np.zeros(3)), None, 0, 5, 1e-9), {}),
+        "one launch per iteration": (lambda ctx: ctx.gn_refine([L.RES_P2P], api.pose12(np.eye(3), np.zeros(3)), None, 0, 5, 1e-9), {"RPE_RESIDENT": "0"}),
+        "device loop": (lambda ctx: ctx.gn_refine_device([(L.RES_P2P, 1.0)], api.pose12(np.eye(3), np.zeros(3)), 0, 5, 1e-9), {}),
+        "device loop, one launch per iteration": (lambda ctx: ctx.gn_refine_device([(L.RES_P2P, 1.0)], api.pose12(np.eye(3), np.zeros(3)), 0, 5, 1e-9),
+                                                  {"RPE_DEVICE_LOOP_RESIDENT": "0"}),
+    }
     for pts in (one, line):
-        ctx = gpu_ctx_factory().load(L.F32, xw=pts, xc=pts + off)
-        for f in (lambda: ctx.gn_refine([L.RES_P2P], api.pose12(np.eye(3), np.zeros(3)), None, 0, 5, 1e-9)[0],
-                  lambda: ctx.gn_refine_device([(L.RES_P2P, 1.0)], api.pose12(np.eye(3), np.zeros(3)), 0, 5, 1e-9)[0]):
+        for name, (f, env) in paths.items():
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
             try:
-                p = f()
-            except L.RpeError as e:
-                assert "positive definite" in str(e)
-                continue
-            assert np.isfinite(p).all()
-            R, t = p[:9].reshape(3, 3), p[9:]
-            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-9
-            assert np.abs(pts.astype(np.float64) @ R.T + t - (pts + off).astype(np.float64)).max() < 1e-5
+                ctx = api.Context(0)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        del os.environ[k]
+                    else:
+                        os.environ[k] = v
+            try:
+                ctx.load(L.F32, xw=pts, xc=pts + off)
+                with pytest.raises(L.RpeError) as e:
+                    f(ctx)
+                assert "positive definite" in str(e.value), (name, str(e.value))
+                rec, _ = ctx.normal_eq(L.RES_P2P, api.pose12(np.eye(3), np.zeros(3)))
+                with pytest.raises(L.RpeError):
+                    api.gn_solve(rec)            # the record carries its floor (slot 29) for the context-free solve too
+            finally:
+                ctx.close()
+    # fp64 arrays: the same sets, the floor of fp64 products (1e-12)
+    for pts in (one, line):
+        ctx = gpu_ctx_factory().load(L.F64, xw=pts.astype(np.float64), xc=(pts + off).astype(np.float64))
+        with pytest.raises(L.RpeError):
+            ctx.gn_refine([L.RES_P2P], api.pose12(np.eye(3), np.zeros(3)), None, 0, 5, 1e-9)
+    # and a well-posed far-field problem is NOT refused: a 2 m object 40 m away (translation / rotation coupling (s / d)^2 = 2.5e-3)
+    rng = np.random.default_rng(5)
+    far = (rng.uniform(-1, 1, (n, 3)) + np.array([0.0, 0.0, 40.0])).astype(np.float32)
+    ctx = gpu_ctx_factory().load(L.F32, xw=far, xc=far + off)
+    p, it, step, _ = ctx.gn_refine([L.RES_P2P], api.pose12(np.eye(3), np.zeros(3)), None, 0, 10, 1e-9)
+    assert np.isfinite(p).all() and np.abs(far.astype(np.float64) @ p[:9].reshape(3, 3).T + p[9:] - (far + off).astype(np.float64)).max() < 1e-4
     # one plane seen point-to-plane: three of the six directions are unobservable
     rng = np.random.default_rng(3)
     xy = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
