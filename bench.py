@@ -341,6 +341,58 @@ def hbm_roofline(local_rank):
     return out
 
 
+def reference_api_roofline(local_rank, sizes=(307200, 1_000_000, 10_000_000), launches=30):
+    """LIVE event-timed launches of the kernels behind the REFERENCE'S OWN least-squares API (round-3 review, item 2): K1' moments_kernel
+    (shinji / shinji_ls* / ao(): pose/AbsoluteOrientation.hpp:56-73; 24 B per correspondence), K5 nl_round_kernel (nl_shinji_kneip_ls +
+    find_opt_cc: pose/AbsoluteOrientationNormal.hpp:457-505; five arrays + three short masks = 66 B) and K4b mask_kernel of the 3D-3D
+    vote (the winner's mask; two arrays + one short written = 26 B), at 307 200 / 1 M / 10 M correspondences, steady (the set left in
+    the Infinity Cache by the previous launch) and cold (a 480 MB pass of another context before every launch; skipped where the set
+    exceeds the cache anyway).  HIP events = the dispatch's own begin / end timestamps (rpe_timing_enable)."""
+    import numpy as np
+    from rgbd_pose_estimation_amd import _lib as L, api
+    out = {"peak_GBs": HBM_PEAK_GBS, "timing": "HIP events on the kernel's stream (hipExtLaunchKernelGGL begin / end), mean over the launches",
+           "bytes_per_corr": {"K1p_moments": 24, "K5_nl_round": 66, "K4b_mask_33": 26}}
+    Re, te, Qe, Pe, _ = cheap_scene(20_000_000, seed=9)
+    evictor = api.Context(local_rank).load(L.F32, xw=Qe, xc=Pe)
+    del Qe, Pe
+    rng = np.random.default_rng(11)
+    for n in sizes:
+        R, t, Q, P, Nc = cheap_scene(n)
+        bv = (P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32)
+        Nw = np.ascontiguousarray((Nc.astype(np.float64) @ R).astype(np.float32))
+        ctx = api.Context(local_rank).load(L.F32, xw=Q, xc=P, bv=bv, nw=Nw, nc=Nc)
+        for m in range(3):
+            ctx.upload_mask(m, (rng.random(n) < 0.8).astype(np.int16))
+        q7 = api.pose7_from_Rt(R, t, L.F32)
+        Rwc, c_opt = R.T, -(R.T @ t)
+        Cw, Cc = Q[:1000].mean(0), P[:1000].mean(0)
+        cases = (("K1p_moments", 24, "rpe::moments_kernel<float, 256, true, false>", lambda: ctx.p2p_moments(L.USE_MASK), 26),
+                 ("K5_nl_round", 66, "rpe::nl_round_full_kernel<float, 256, false>", lambda: ctx.nl_round(c_opt, Cw, Cc, Rwc), 66),
+                 ("K4b_mask_33", 26, "rpe::mask_kernel<float, 0, true>", lambda: ctx.inlier_mask(L.VOTE_33, q7, thre_3d=THRE_3D), 26))
+        for name, _, kernel, fn, bpc in cases:
+            for state in ("steady", "cold"):
+                if state == "cold" and bpc * n > 400e6:
+                    continue
+                for _ in range(5):
+                    fn()
+                k = launches if state == "steady" else max(10, launches // 2)
+                ctx.timing_enable(k, 1)
+                for _ in range(k):
+                    if state == "cold":
+                        evictor.p2p_moments()
+                    fn()
+                cnt, tot_ms, mn_ms = ctx.timing_collect()
+                ctx.timing_enable(0, 1)
+                avg = tot_ms / max(cnt, 1) * 1e-3
+                out["%s_%d_%s" % (name, n, state)] = dict(kernel=kernel, n=n, bytes_per_corr=bpc, working_set_MB=bpc * n / 1e6, launches=cnt, avg_launch_us=avg * 1e6,
+                                                          min_launch_us=mn_ms * 1e3, achieved_GBs=bpc * n / avg / 1e9, frac_of_peak=bpc * n / avg / 1e9 / HBM_PEAK_GBS)
+        ctx.close()
+    evictor.close()
+    out["note"] = ("K1' is timed with the 3D-3D inlier mask (shinji_ls / shinji_ls1: 24 B + 2 B); K4b re-writes the mask it reads next, so its masks are "
+                   "restored by nothing -- the masked kernels run before it at every size")
+    return out
+
+
 def fp64_lines(local_rank):
     """Tp = double (what TestMain.cpp:52-326 instantiates): event-timed K1 / K2 launches (48 / 72 B per correspondence) and the exact
     3D-3D scoring rate at 307 200 and 1 M correspondences."""
@@ -900,6 +952,10 @@ def worker(args, affinity):
                     out["roofline_hbm"] = hbm_roofline(local_rank)
                 except Exception as e:  # noqa: BLE001
                     out["roofline_hbm"] = {"error": repr(e)}
+                try:   # the kernels behind the reference's own API (moments, nl_round, winner's mask) on the same roofline
+                    out["roofline_hbm"]["reference_api_kernels"] = reference_api_roofline(local_rank)
+                except Exception as e:  # noqa: BLE001
+                    out["roofline_hbm"]["reference_api_kernels"] = {"error": repr(e)}
             if not args.no_extras:
                 extras(out, args, ctx, sc, n, R0, t0, pose, local_rank)
                 try:

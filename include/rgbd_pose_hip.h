@@ -116,8 +116,14 @@ enum {
   RPE_RES_P2P = 0,      /* r = R*Xw + t - Xc                         (3)  arrays XW, XC      24 B/corr fp32 */
   RPE_RES_P2PLANE = 1,  /* r = Nc . (R*Xw + t - Xc)                  (1)  arrays XW, XC, NC  36 B/corr      */
   RPE_RES_BEARING = 2,  /* r = normalize(R*Xw + t) x bv  (P3P.hpp:482-485) (3)  arrays XW, BV  24 B/corr      */
-  RPE_RES_NORMAL = 3    /* r = R*Nw - Nc   (alignment scored at AbsoluteOrientationNormal.hpp:248) (3)  arrays NW, NC  24 B/corr;
+  RPE_RES_NORMAL = 3,   /* r = R*Nw - Nc   (alignment scored at AbsoluteOrientationNormal.hpp:248) (3)  arrays NW, NC  24 B/corr;
                            rotation only.  Served by the joint kernel (rpe_normal_eq_joint); mask / weight of modality NN */
+  RPE_RES_REPROJ = 4    /* 2D-3D pixel reprojection, r = (p_x/p_z - bv_x/bv_z, p_y/p_z - bv_y/bv_z), p = R*Xw + t   (2)  arrays XW, BV
+                           24 B/corr; mask / weight of modality 23.  The pixel conversion of TestMain.cpp:35-36 with the principal point at
+                           the origin (PoseAdapterBase.hpp:44), in NORMALISED image coordinates: the focal length multiplies r and J alike,
+                           so the step does not depend on it -- scale the term by f^2 (rpe_term.scale, `scales` of rpe_gn_refine) for H, g
+                           and the cost in pixels.  Correspondences with p_z <= 1e-6 or bv_z <= 1e-6 (not in front of the camera) contribute
+                           nothing and do not count.  Alternative to RPE_RES_BEARING for the 2D-3D term of the joint kernel. */
 };
 int rpe_normal_eq(rpe_context* ctx, int kind, int flags, const double* pose12, double* out32);
 /* Same, result left in HBM at d_out32 (32 doubles, must not be NULL) for a caller-side collective (RCCL
@@ -308,7 +314,7 @@ int rpe_nl_round(rpe_context* ctx, const double* c_opt3, const double* Cw3, cons
  *         6 shinji_kneip_prosac  7 nl_kneip_ransac  8 nl_shinji_ransac  9 nl_shinji_kneip_ransac
  *         10 none (pose R9/t3 and mask_in are INPUTS: least-squares stage only)
  * ls:     0 none  1 shinji_ls / shinji_ls1 (inliers)  2 nl_shinji_kneip_ls (bug-compatible)  3 nl_shinji_kneip_ls (fixed)
- *         4 shinji_ls2 (all)  5 gn_refine_p2p  6 gn_refine_joint  7 gn_refine_p2plane  8 gn_refine_bearing
+ *         4 shinji_ls2 (all)  5 gn_refine_p2p  6 gn_refine_joint  7 gn_refine_p2plane  8 gn_refine_bearing  9 gn_refine_reproj
  * mask_in / mask_out: 3 x n shorts, row 0 = 2D-3D, 1 = 3D-3D, 2 = normal-normal.  seed: sampler stream.
  * RE-ENTRANT: every call builds its own random stream from `seed` and carries `score_mode` as a per-call option (rpe::RunOptions,
  * rpe/device.hpp); nothing process-wide is written, so concurrent calls from several threads -- different seeds, different modes --

@@ -10,6 +10,9 @@
 //                    pose/PnPPoseAdapter.hpp:204-210 ; the refinement itself is new (F3)
 //   normal-normal    r = R Nw - Nc: the alignment the reference scores with Nc.(R Nw) (AbsoluteOrientationNormal.hpp:248)
 //                    and fits through MNN in nl_shinji_kneip_ls (:498-503); as a GN term it is new
+//   reprojection     r = (p_x/p_z - bv_x/bv_z, p_y/p_z - bv_y/bv_z): the pixel residual of SURVEY.md Appendix B row 4 in normalised
+//                    image coordinates (f = 1; pixel conversion /root/reference/TestMain.cpp:35-36, principal point at the origin:
+//                    pose/PoseAdapterBase.hpp:44); no reference refinement uses it: PARITY UNPINNED, pinned by numerical Jacobians
 // Conventions: Xc = R Xw + t ; left perturbation T <- exp(delta) T, delta = (upsilon, omega) in the
 // Sophus order (sophus/se3.hpp:314-316) ; p = R Xw + t ; dp/ddelta = [ I | -[p]x ].
 // Output layout (29 doubles): H upper triangle row-major (21) | g = J^T r (6) | sum w r^2 | sum w.
@@ -18,7 +21,9 @@
 
 namespace orc {
 
-enum GnKind { GN_P2P = 0, GN_P2PLANE = 1, GN_BEARING = 2, GN_NORMAL = 3 };
+enum GnKind { GN_P2P = 0, GN_P2PLANE = 1, GN_BEARING = 2, GN_NORMAL = 3, GN_REPROJ = 4 };
+// pixel reprojection (GN_REPROJ): a correspondence whose point is not in front of the camera or whose bearing has no forward component
+constexpr double kReprojMinZ = 1e-6;
 enum GnRobust { ROBUST_NONE = 0, ROBUST_HUBER = 1, ROBUST_CAUCHY = 2 };
 // IRLS weight of a residual block of norm s: Huber min(1, k/s), Cauchy 1/(1 + (s/k)^2)
 inline double robust_weight(int robust, double k, double s) {
@@ -74,6 +79,18 @@ void gn_normal_eq(int kind, const Tin* a, const Tin* b, const Tin* c, const shor
       double J[6];
       for (int k = 0; k < 6; k++) J[k] = nx * Jp[0][k] + ny * Jp[1][k] + nz * Jp[2][k];
       ne->add_row(J, r, w);
+    } else if (kind == GN_REPROJ) {
+      if (!(p[2] > kReprojMinZ) || !(bz > kReprojMinZ)) continue;   // not in front of the camera: contributes nothing, does not count
+      const double u = p[0] / p[2], v = p[1] / p[2];
+      const double r[2] = {u - bx / bz, v - by / bz};
+      w *= robust_weight(robust, robust_k, std::sqrt(r[0] * r[0] + r[1] * r[1]));
+      // d(u, v)/dp = 1/p_z [[1, 0, -u], [0, 1, -v]]
+      const double A[2][3] = {{1.0 / p[2], 0.0, -u / p[2]}, {0.0, 1.0 / p[2], -v / p[2]}};
+      for (int q = 0; q < 2; q++) {
+        double J[6];
+        for (int k = 0; k < 6; k++) J[k] = A[q][0] * Jp[0][k] + A[q][1] * Jp[1][k] + A[q][2] * Jp[2][k];
+        ne->add_row(J, r[q], w);
+      }
     } else if (kind == GN_NORMAL) {
       // a = Nw, b = Nc ; q = R Nw ; r = q - Nc ; dq/ddelta = [0 | -[q]x]
       double q[3] = {R[0] * x + R[1] * y + R[2] * z, R[3] * x + R[4] * y + R[5] * z, R[6] * x + R[7] * y + R[8] * z};

@@ -15,7 +15,7 @@ F32, F64 = 0, 1
 XW, XC, BV, NW, NC = 0, 1, 2, 3, 4
 MOD_23, MOD_33, MOD_NN = 0, 1, 2
 USE_MASK, USE_WEIGHT, SKIP_INVALID = 1, 2, 4
-RES_P2P, RES_P2PLANE, RES_BEARING, RES_NORMAL = 0, 1, 2, 3
+RES_P2P, RES_P2PLANE, RES_BEARING, RES_NORMAL, RES_REPROJ = 0, 1, 2, 3, 4
 ROBUST_NONE, ROBUST_HUBER, ROBUST_CAUCHY = 0, 1, 2
 VOTE_33, VOTE_23, VOTE_33_23, VOTE_NN_23, VOTE_NN_33, VOTE_NN_33_23, VOTE_23_MATRIX = 0, 1, 2, 3, 4, 5, 6
 SCORE_FAST, SCORE_EXACT = 0, 1

@@ -394,7 +394,7 @@ def ao_ransac(xw, xc):
 # ---- adapter-level pipelines (rpe_run): method / ls ids shared with the oracle's C API
 M_SHINJI_RANSAC, M_SHINJI_RANSAC2, M_SHINJI_PROSAC, M_KNEIP_RANSAC, M_KNEIP_PROSAC = 0, 1, 2, 3, 4
 M_SK_RANSAC, M_SK_PROSAC, M_NL_KNEIP_RANSAC, M_NL_SHINJI_RANSAC, M_NL_SK_RANSAC, M_NONE = 5, 6, 7, 8, 9, 10
-LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL, LS_GN_P2P, LS_GN_JOINT, LS_GN_P2PLANE, LS_GN_BEARING = range(9)
+LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL, LS_GN_P2P, LS_GN_JOINT, LS_GN_P2PLANE, LS_GN_BEARING, LS_GN_REPROJ = range(10)
 
 
 def run(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weights=None, f=585.0, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0,

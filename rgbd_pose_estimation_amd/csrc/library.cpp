@@ -50,7 +50,7 @@ template <class Tp, class Adapter> void read_pose(Adapter& ad, const double* R9,
 enum { M_SHINJI_RANSAC = 0, M_SHINJI_RANSAC2 = 1, M_SHINJI_PROSAC = 2, M_KNEIP_RANSAC = 3, M_KNEIP_PROSAC = 4, M_SK_RANSAC = 5,
        M_SK_PROSAC = 6, M_NL_KNEIP_RANSAC = 7, M_NL_SHINJI_RANSAC = 8, M_NL_SK_RANSAC = 9, M_NONE = 10 };
 enum { LS_NONE = 0, LS_SHINJI_INLIERS = 1, LS_NL_BUGCOMPAT = 2, LS_NL_FIXED = 3, LS_SHINJI_ALL = 4, LS_GN_P2P = 5, LS_GN_JOINT = 6,
-       LS_GN_P2PLANE = 7, LS_GN_BEARING = 8 };
+       LS_GN_P2PLANE = 7, LS_GN_BEARING = 8, LS_GN_REPROJ = 9 };
 
 template <class Tp>
 int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, double thre_nl, int* iter_io, double confidence,
@@ -104,6 +104,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
       if (mask_in) { rpe::MatrixXs m(n, 1); for (int i = 0; i < n; i++) m(i, 0) = mask_in[i]; ad.setInlier(m); ad.cvtInlier(); }
     }
     if (ls == LS_GN_BEARING) Iter = gn_refine_bearing<Tp>(ad);
+    if (ls == LS_GN_REPROJ) Iter = gn_refine_reproj<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
     if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), nullptr, nullptr); }
@@ -125,6 +126,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_P2P) Iter = gn_refine_p2p<Tp>(ad);
     if (ls == LS_GN_JOINT) Iter = gn_refine_joint<Tp>(ad);
     if (ls == LS_GN_BEARING) Iter = gn_refine_bearing<Tp>(ad);
+    if (ls == LS_GN_REPROJ) Iter = gn_refine_reproj<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
     if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), &cad.inlierMask33(), nullptr); }

@@ -419,7 +419,7 @@ unsigned kind_slot_bits(int kind) {
   switch (kind) {
     case RPE_RES_P2P: return (1u << RPE_XW) | (1u << RPE_XC);
     case RPE_RES_P2PLANE: return (1u << RPE_XW) | (1u << RPE_XC) | (1u << RPE_NC);
-    case RPE_RES_BEARING: return (1u << RPE_XW) | (1u << RPE_BV);
+    case RPE_RES_BEARING: case RPE_RES_REPROJ: return (1u << RPE_XW) | (1u << RPE_BV);
   }
   return 0;
 }
@@ -453,14 +453,14 @@ int kind_arrays(rpe_context* c, int kind) {
   switch (kind) {
     case RPE_RES_P2P: return need_arrays(c, {RPE_XW, RPE_XC});
     case RPE_RES_P2PLANE: return need_arrays(c, {RPE_XW, RPE_XC, RPE_NC});
-    case RPE_RES_BEARING: return need_arrays(c, {RPE_XW, RPE_BV});
+    case RPE_RES_BEARING: case RPE_RES_REPROJ: return need_arrays(c, {RPE_XW, RPE_BV});
     case RPE_RES_NORMAL: return need_arrays(c, {RPE_XW, RPE_NW, RPE_NC});
   }
   return fail(RPE_ERR_ARG, "unknown residual kind %d", kind);
 }
 
 int check_flags(rpe_context* c, int kind, int flags) {
-  const int mod = kind == RPE_RES_BEARING ? RPE_MOD_23 : (kind == RPE_RES_NORMAL ? RPE_MOD_NN : RPE_MOD_33);
+  const int mod = (kind == RPE_RES_BEARING || kind == RPE_RES_REPROJ) ? RPE_MOD_23 : (kind == RPE_RES_NORMAL ? RPE_MOD_NN : RPE_MOD_33);
   if ((flags & RPE_USE_MASK) && !c->mask[mod]) return fail(RPE_ERR_STATE, "RPE_USE_MASK but no mask for modality %d", mod);
   if ((flags & RPE_USE_WEIGHT) && !c->weight[mod]) return fail(RPE_ERR_STATE, "RPE_USE_WEIGHT but no weight for modality %d", mod);
   return RPE_OK;
@@ -956,15 +956,15 @@ int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, dou
   return RPE_OK;
 }
 
-struct JointSpec { int bits = 0, robust[4] = {0, 0, 0, 0}; double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1}; };
+struct JointSpec { int bits = 0, robust[5] = {0, 0, 0, 0, 0}; double scale[5] = {0, 0, 0, 0, 0}, rk[5] = {1, 1, 1, 1, 1}; };   // by kind 0..4
 static int joint_spec(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, JointSpec* out) {
   if (!c || !terms || nterms < 1 || nterms > 4 || !pose12) return fail(RPE_ERR_ARG, "rpe_normal_eq_joint: bad argument");
   int& bits = out->bits;
-  int (&robust)[4] = out->robust;
-  double (&scale)[4] = out->scale, (&rk)[4] = out->rk;
+  int (&robust)[5] = out->robust;
+  double (&scale)[5] = out->scale, (&rk)[5] = out->rk;
   for (int t = 0; t < nterms; t++) {
     const int k = terms[t].kind;
-    if (k < 0 || k > 3) return fail(RPE_ERR_ARG, "unknown residual kind %d", k);
+    if (k < 0 || k > 4) return fail(RPE_ERR_ARG, "unknown residual kind %d", k);
     if (bits & (1 << k)) return fail(RPE_ERR_ARG, "residual kind %d listed twice", k);
     int rc = kind_arrays(c, k);
     if (rc) return rc;
@@ -974,6 +974,7 @@ static int joint_spec(rpe_context* c, int nterms, const rpe_term* terms, int fla
     bits |= 1 << k; scale[k] = terms[t].scale; robust[k] = terms[t].robust; rk[k] = terms[t].robust_k > 0 ? terms[t].robust_k : 1.0;
   }
   if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
+  if ((bits & 4) && (bits & 16)) return fail(RPE_ERR_ARG, "bearing and reprojection are alternatives for the 2D-3D term");
   return RPE_OK;
 }
 static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12) {
@@ -1053,17 +1054,18 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
                          double* last_step, double* final_cost) {
   if (!c || !terms || nterms < 1 || nterms > 4 || !pose12 || max_iter < 1) return fail(RPE_ERR_ARG,
       "rpe_gn_refine_device: bad argument");
-  int bits = 0, robust[4] = {0, 0, 0, 0};
-  double scale[4] = {0, 0, 0, 0}, rk[4] = {1, 1, 1, 1};
+  int bits = 0, robust[5] = {0, 0, 0, 0, 0};
+  double scale[5] = {0, 0, 0, 0, 0}, rk[5] = {1, 1, 1, 1, 1};
   for (int t = 0; t < nterms; t++) {
     const int k = terms[t].kind;
-    if (k < 0 || k > 3 || (bits & (1 << k))) return fail(RPE_ERR_ARG, "bad residual kind list");
+    if (k < 0 || k > 4 || (bits & (1 << k))) return fail(RPE_ERR_ARG, "bad residual kind list");
     int rc = kind_arrays(c, k);
     if (rc) return rc;
     if ((rc = check_flags(c, k, flags))) return rc;
     bits |= 1 << k; scale[k] = terms[t].scale; robust[k] = terms[t].robust; rk[k] = terms[t].robust_k > 0 ? terms[t].robust_k : 1.0;
   }
   if ((bits & 1) && (bits & 2)) return fail(RPE_ERR_ARG, "point-to-point and point-to-plane are alternatives for the 3D-3D term");
+  if ((bits & 4) && (bits & 16)) return fail(RPE_ERR_ARG, "bearing and reprojection are alternatives for the 2D-3D term");
   HIP_TRY(hipSetDevice(c->device));
   rpe::GnState st;
   st.tol = tol; st.step = 0; st.cost = 0; st.max_iters = max_iter; st.iters = 0; st.done = 0; st.status = 0;

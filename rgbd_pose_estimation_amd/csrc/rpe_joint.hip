@@ -10,8 +10,8 @@ namespace rpe {
 // objective nl_shinji_kneip_ls alternates over (M33 + sigma (M23 + MNN), AbsoluteOrientationNormal.hpp:484-510).
 // Record: H upper triangle (21) | g (6) | sum scale w r^2 | sum w.   Up to 60 B/corr + masks/weights.
 // ================================================================================================
-enum { TERM_P2P = 1, TERM_P2PLANE = 2, TERM_BEARING = 4, TERM_NORMAL = 8 };
-struct JointParams { double scale[4]; int robust[4]; double robust_k[4]; };  // indexed by residual kind 0..3
+enum { TERM_P2P = 1, TERM_P2PLANE = 2, TERM_BEARING = 4, TERM_NORMAL = 8, TERM_REPROJ = 16 };   // 1 << residual kind
+struct JointParams { double scale[5]; int robust[5]; double robust_k[5]; };  // indexed by residual kind 0..4
 
 // `robust` is a kernel argument (wave-uniform): the branch is a scalar one, and the common case -- no robust weight -- pays
 // neither the square root its argument needs nor the two divisions
@@ -90,6 +90,17 @@ __device__ __forceinline__ void joint_group(const PoseK<double>& pose, const Joi
         bearing_point<T>(sx, sy, sz, bx, by, bz, (T)prm.scale[2] * w, w, s);
       }
     }
+    if (TERMS & TERM_REPROJ) {   // the 2D-3D term as a pixel reprojection residual (alternative to the bearing form; same arrays)
+      const T bx0 = vb[3 * i], by0 = vb[3 * i + 1], bz0 = vb[3 * i + 2];
+      const bool on = present & (k23[i] == 1) & !all_nan(bx0, by0, bz0);
+      if (__builtin_amdgcn_ballot_w64(on) != 0) {
+        const T bx = on ? bx0 : T(0), by = on ? by0 : T(0), bz = on ? bz0 : T(1);
+        const double sx = on ? pxd : 0.0, sy = on ? pyd : 0.0, sz = on ? pzd : 1.0;
+        const T w0 = on ? u23[i] : T(0);
+        const T w = w0 * robust_weight<T>(prm.robust[4], (T)prm.robust_k[4], [&]() { return reproj_residual_norm<T>(sx, sy, sz, bx, by, bz); });
+        reproj_point<T>(sx, sy, sz, bx, by, bz, (T)prm.scale[4] * w, w, s);
+      }
+    }
     if (TERMS & TERM_NORMAL) {
       const T mx = vnw[3 * i], my = vnw[3 * i + 1], mz = vnw[3 * i + 2];
       const T cx0 = vnc[3 * i], cy0 = vnc[3 * i + 1], cz0 = vnc[3 * i + 2];
@@ -141,7 +152,7 @@ template <class T> struct JointRegs {
       if (A.m33) load_mask_group(A.m33, g, n, k33);
       if (A.w33) load_weight_group(A.w33, g, n, u33);
     }
-    if (TERMS & TERM_BEARING) {
+    if (TERMS & (TERM_BEARING | TERM_REPROJ)) {
       load_group<T>(A.bv, g, n, vb);
       if (A.m23) load_mask_group(A.m23, g, n, k23);
       if (A.w23) load_weight_group(A.w23, g, n, u23);
@@ -276,11 +287,12 @@ static hipError_t joint_t(const DeviceArrays& A, int terms, int flags, const dou
                           const double* robust_k4, const ReduceTarget& rt, hipStream_t s) {
   const PoseK<double> pose = make_pose<double>(pose12);
   JointParams prm;
-  for (int k = 0; k < 4; k++) { prm.scale[k] = scale4[k]; prm.robust[k] = robust4[k]; prm.robust_k[k] = robust_k4[k]; }
+  for (int k = 0; k < 5; k++) { prm.scale[k] = scale4[k]; prm.robust[k] = robust4[k]; prm.robust_k[k] = robust_k4[k]; }   // (arrays of 5: kinds 0..4)
   switch (terms) {
 #define RPE_JOINT_CASE(M) case M: joint_launch<T, M>(A, flags, pose, prm, rt, s); break;
     RPE_JOINT_CASE(1) RPE_JOINT_CASE(2) RPE_JOINT_CASE(4) RPE_JOINT_CASE(8) RPE_JOINT_CASE(5) RPE_JOINT_CASE(6) RPE_JOINT_CASE(9)
     RPE_JOINT_CASE(10) RPE_JOINT_CASE(12) RPE_JOINT_CASE(13) RPE_JOINT_CASE(14)
+    RPE_JOINT_CASE(16) RPE_JOINT_CASE(17) RPE_JOINT_CASE(18) RPE_JOINT_CASE(24) RPE_JOINT_CASE(25) RPE_JOINT_CASE(26)   // ... with the reprojection form of the 2D-3D term
 #undef RPE_JOINT_CASE
     default: return hipErrorInvalidValue;  // empty set, or point-to-point together with point-to-plane
   }
@@ -305,7 +317,7 @@ static void joint_resident_launch(const DeviceArrays& A, int flags, const JointP
   const int64_t groups = (A.n + Pk<T>::P - 1) / Pk<T>::P;
   // one group per thread kept in registers across the iterations -- except the three-array fp32 term sets, whose resident groups would
   // spill (measured with scripts/kernel_resources.py: 180-316 bytes per lane); those re-read their cache-resident slice every iteration
-  constexpr bool regs_fit = !(sizeof(T) == 4 && (TERMS == 12 || TERMS == 13 || TERMS == 14));
+  constexpr bool regs_fit = !(sizeof(T) == 4 && (TERMS == 12 || TERMS == 13 || TERMS == 14 || TERMS == 24 || TERMS == 25 || TERMS == 26));
   const bool in_regs = regs_fit && (int64_t)G * BLK >= groups;
   Finish fin = make_finish(rt);
   constexpr int kMaxRows = 4 * (BLK / 29);
@@ -323,11 +335,12 @@ static hipError_t joint_resident_t(const DeviceArrays& A, int terms, int flags, 
     const double* robust_k4,
                                    const unsigned long long* ctl, unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s) {
   JointParams prm;
-  for (int k = 0; k < 4; k++) { prm.scale[k] = scale4[k]; prm.robust[k] = robust4[k]; prm.robust_k[k] = robust_k4[k]; }
+  for (int k = 0; k < 5; k++) { prm.scale[k] = scale4[k]; prm.robust[k] = robust4[k]; prm.robust_k[k] = robust_k4[k]; }   // (arrays of 5: kinds 0..4)
   switch (terms) {
 #define RPE_JOINT_CASE(M) case M: joint_resident_launch<T, M>(A, flags, prm, ctl, first_tag, max_iters, rt, s); break;
     RPE_JOINT_CASE(1) RPE_JOINT_CASE(2) RPE_JOINT_CASE(4) RPE_JOINT_CASE(8) RPE_JOINT_CASE(5) RPE_JOINT_CASE(6) RPE_JOINT_CASE(9)
     RPE_JOINT_CASE(10) RPE_JOINT_CASE(12) RPE_JOINT_CASE(13) RPE_JOINT_CASE(14)
+    RPE_JOINT_CASE(16) RPE_JOINT_CASE(17) RPE_JOINT_CASE(18) RPE_JOINT_CASE(24) RPE_JOINT_CASE(25) RPE_JOINT_CASE(26)   // ... with the reprojection form of the 2D-3D term
 #undef RPE_JOINT_CASE
     default: return hipErrorInvalidValue;
   }

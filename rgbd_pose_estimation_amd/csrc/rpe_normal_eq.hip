@@ -224,9 +224,9 @@ static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<doubl
     hipEvent_t ev0,
                              hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
-  const T* b = (const T*)(KIND == KIND_BEARING ? A.a[2] : A.a[1]);
+  const T* b = (const T*)((KIND == KIND_BEARING || KIND == KIND_REPROJ) ? A.a[2] : A.a[1]);
   const T* c = (const T*)A.a[4];
-  const int mod = KIND == KIND_BEARING ? 0 : 1;
+  const int mod = (KIND == KIND_BEARING || KIND == KIND_REPROJ) ? 0 : 1;
   const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
@@ -254,10 +254,13 @@ static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const 
   } else if (kind == KIND_P2PLANE) {
     if (blk == 512) normal_eq_launch<T, KIND_P2PLANE, 512>(A, flags, pose, rt, s, ev0, ev1);
     else normal_eq_launch<T, KIND_P2PLANE, 256>(A, flags, pose, rt, s, ev0, ev1);
-  } else {
+  } else if (kind == KIND_BEARING) {
     if (blk == 512) normal_eq_launch<T, KIND_BEARING, 512>(A, flags, pose, rt, s, ev0, ev1);
     else normal_eq_launch<T, KIND_BEARING, 256>(A, flags, pose, rt, s, ev0, ev1);
-  }
+  } else if (kind == KIND_REPROJ) {
+    if (blk == 512) normal_eq_launch<T, KIND_REPROJ, 512>(A, flags, pose, rt, s, ev0, ev1);
+    else normal_eq_launch<T, KIND_REPROJ, 256>(A, flags, pose, rt, s, ev0, ev1);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
@@ -273,9 +276,9 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
     int max_iters,
                             const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
-  const T* b = (const T*)(KIND == KIND_BEARING ? A.a[2] : A.a[1]);
+  const T* b = (const T*)((KIND == KIND_BEARING || KIND == KIND_REPROJ) ? A.a[2] : A.a[1]);
   const T* c = (const T*)A.a[4];
-  const int mod = KIND == KIND_BEARING ? 0 : 1;
+  const int mod = (KIND == KIND_BEARING || KIND == KIND_REPROJ) ? 0 : 1;
   const short* mask = (flags & F_USE_MASK) ? A.mask[mod] : nullptr;
   const T* weight = (flags & F_USE_WEIGHT) ? (const T*)A.weight[mod] : nullptr;
   const int cap = std::max(1, resident_cap_device());
@@ -307,6 +310,7 @@ static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const u
   if (kind == KIND_P2P) resident_launch<T, KIND_P2P, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else if (kind == KIND_P2PLANE) resident_launch<T, KIND_P2PLANE, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else if (kind == KIND_BEARING) resident_launch<T, KIND_BEARING, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
+  else if (kind == KIND_REPROJ) resident_launch<T, KIND_REPROJ, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

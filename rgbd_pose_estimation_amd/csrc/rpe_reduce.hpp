@@ -45,7 +45,7 @@ static __device__ unsigned long long g_stamps[4096 * 16];
 #define RPE_STAMP(k) do {} while (0)
 #endif
 
-enum { KIND_P2P = 0, KIND_P2PLANE = 1, KIND_BEARING = 2 };
+enum { KIND_P2P = 0, KIND_P2PLANE = 1, KIND_BEARING = 2, KIND_REPROJ = 4 };   // = RPE_RES_* (3 is the normal-normal term of the joint kernel)
 enum { F_USE_MASK = 1, F_USE_WEIGHT = 2, F_SKIP_INVALID = 4 };
 
 template <class T> struct Pk;

@@ -147,6 +147,70 @@ __device__ __forceinline__ C bearing_residual_norm(double pxd, double pyd, doubl
   const C inv = LaneOps<C>::rsqrt(fma(px, px, fma(py, py, pz * pz)));
   return sqrt((d1 * d1 + d2 * d2) * (bx * bx + by * by + bz * bz)) * inv;
 }
+
+// ---- K3', pixel reprojection residual (the pixel conversion of /root/reference/TestMain.cpp:35-36 with the
+// principal point at the origin, PoseAdapterBase.hpp:44), in NORMALISED image coordinates (f = 1: the focal length multiplies r and J
+// alike, so the step does not depend on it; callers that want pixel units scale the term by f^2):
+//     r = (p_x / p_z - bv_x / bv_z ,  p_y / p_z - bv_y / bv_z) ,   J = 1 / p_z [[1, 0, -u], [0, 1, -v]] [I | -[p]x] ,  (u, v) = (p_x, p_y) / p_z
+// i.e. two rows J_i = a_i^T [I | -[p]x] with a_1 = (1, 0, -u) / p_z, a_2 = (0, 1, -v) / p_z -- the shape of the bearing rows.  What
+// cancels is the numerator of r_1 = (p_x bv_z - bv_x p_z) / (p_z bv_z): formed in fp64 from the fp64 point, the quotient's denominator
+// and everything in J take the array dtype and the hardware reciprocal.  A correspondence whose point is not in front of the camera
+// (p_z <= kReprojMinZ) or whose bearing has no forward component (bv_z <= kReprojMinZ) contributes nothing, and does not count.
+constexpr double kReprojMinZ = 1e-6;
+template <class V>
+__device__ __forceinline__ void reproj_rows(V px, V py, V pz, V n1, V n2, V bz, V w, V w_count, V (&s)[29]) {
+  const V ipz = LaneOps<V>::rcp(pz);
+  const V inv = ipz * LaneOps<V>::rcp(bz);           // 1 / (p_z bv_z)
+  const V r1 = n1 * inv, r2 = n2 * inv;
+  const V g1 = -(px * ipz) * ipz, g2 = -(py * ipz) * ipz;    // third components of a_1, a_2
+  // J = [a ; p x a] with a_1 = (ipz, 0, g1), a_2 = (0, ipz, g2)
+  const V J1[6] = {ipz, V(0), g1, py * g1, __builtin_elementwise_fma(pz, ipz, -(px * g1)), -(py * ipz)};
+  const V J2[6] = {V(0), ipz, g2, __builtin_elementwise_fma(py, g2, -(pz * ipz)), -(px * g2), px * ipz};
+  add_row2<V>(J1, r1, w, s);
+  add_row2<V>(J2, r2, w, s);
+  s[28] += w_count;
+}
+// one correspondence: the fp64 part (numerators of the two quotients) and the validity test; a switched-off correspondence gets the
+// harmless geometry p = (0, 0, 1), bv_z = 1 so that everything stays finite at weight 0
+template <class C>
+__device__ __forceinline__ void reproj_prepare(double pxd, double pyd, double pzd, C bx, C by, C bz, C& w, C& px, C& py, C& pz, C& n1,
+                                               C& n2, C& bzs) {
+  const bool ok = pzd > kReprojMinZ && (double)bz > kReprojMinZ;
+  w = ok ? w : C(0);
+  n1 = ok ? (C)fma(pxd, (double)bz, -(double)bx * pzd) : C(0);
+  n2 = ok ? (C)fma(pyd, (double)bz, -(double)by * pzd) : C(0);
+  px = ok ? (C)pxd : C(0); py = ok ? (C)pyd : C(0); pz = ok ? (C)pzd : C(1);
+  bzs = ok ? bz : C(1);
+}
+template <class C>
+__device__ __forceinline__ void reproj_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&bx)[2],
+                                            const C (&by)[2], const C (&bz)[2], const C (&w)[2], C __attribute__((ext_vector_type(2))) (&s)[29]) {
+  typedef C V __attribute__((ext_vector_type(2)));
+  C px[2], py[2], pz[2], n1[2], n2[2], bzs[2], wi[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    double pxd, pyd, pzd;
+    transform<C>(T, x[e], y[e], z[e], pxd, pyd, pzd);
+    wi[e] = w[e];
+    reproj_prepare<C>(pxd, pyd, pzd, bx[e], by[e], bz[e], wi[e], px[e], py[e], pz[e], n1[e], n2[e], bzs[e]);
+  }
+  reproj_rows<V>(V{px[0], px[1]}, V{py[0], py[1]}, V{pz[0], pz[1]}, V{n1[0], n1[1]}, V{n2[0], n2[1]}, V{bzs[0], bzs[1]},
+                 V{wi[0], wi[1]}, V{wi[0], wi[1]}, s);
+}
+// one correspondence, scalar lanes (the joint kernel's reprojection term); w: scaled weight of the rows, w_count: what the weight sum gets
+template <class C>
+__device__ __forceinline__ void reproj_point(double pxd, double pyd, double pzd, C bx, C by, C bz, C w, C w_count, C (&s)[29]) {
+  C px, py, pz, n1, n2, bzs, wc = w_count;
+  reproj_prepare<C>(pxd, pyd, pzd, bx, by, bz, wc, px, py, pz, n1, n2, bzs);
+  reproj_rows<C>(px, py, pz, n1, n2, bzs, wc == C(0) ? C(0) : w, wc, s);
+}
+// |r| of one correspondence (the robust weights' argument); 0 where the correspondence does not count
+template <class C>
+__device__ __forceinline__ C reproj_residual_norm(double pxd, double pyd, double pzd, C bx, C by, C bz) {
+  if (!(pzd > kReprojMinZ && (double)bz > kReprojMinZ)) return C(0);
+  const double r1 = pxd / pzd - (double)bx / (double)bz, r2 = pyd / pzd - (double)by / (double)bz;
+  return (C)sqrt(r1 * r1 + r2 * r2);
+}
 // a pair of correspondences as 2-vectors
 template <class C>
 __device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2],
@@ -216,6 +280,7 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&
                                            int npresent, T __attribute__((ext_vector_type(2))) (&s2)[NS]) {
   constexpr int P = Pk<T>::P;
   static_assert(NS == (KIND == KIND_P2P ? 17 : 29), "sums per kind");
+  static_assert(KIND == KIND_P2P || KIND == KIND_P2PLANE || KIND == KIND_BEARING || KIND == KIND_REPROJ, "residual kinds");
 #pragma unroll
   for (int j = 0; j < P / 2; j++) {
     T x[2], y[2], z[2], bx[2], by[2], bz[2], nx[2], ny[2], nz[2], wi[2];
@@ -234,7 +299,8 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&
         const bool off = w == T(0);
         // keeps NaN / inf of skipped columns out of the sums (selects, not branches); bearing: p = t + R (0, 0, 1) != 0 keeps 1 / |p|
         // finite
-        x[e] = off ? T(0) : vw[3 * i]; y[e] = off ? T(0) : vw[3 * i + 1]; z[e] = off ? (KIND == KIND_BEARING ? T(1) : T(0)) : vw[3 * i + 2];
+        x[e] = off ? T(0) : vw[3 * i]; y[e] = off ? T(0) : vw[3 * i + 1];
+        z[e] = off ? ((KIND == KIND_BEARING || KIND == KIND_REPROJ) ? T(1) : T(0)) : vw[3 * i + 2];
         bx[e] = off ? T(0) : bx[e]; by[e] = off ? T(0) : by[e]; bz[e] = off ? T(1) : bz[e];
         if (KIND == KIND_P2PLANE) { nx[e] = off ? T(0) : vc[3 * i]; ny[e] = off ? T(0) : vc[3 * i + 1];
             nz[e] = off ? T(0) : vc[3 * i + 2]; }
@@ -245,7 +311,8 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&
     // 35 of the ~50 operations per point are the accumulation
     else if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
     // two rows per point: 70 of ~100
-    else bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
+    else if constexpr (KIND == KIND_BEARING) bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
+    else reproj_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
   }
 }
 // widen the pair sums into the fp64 accumulators and clear them.  A widening costs three instructions per sum (add the halves,

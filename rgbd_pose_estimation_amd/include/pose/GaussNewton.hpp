@@ -5,6 +5,8 @@
 //   gn_refine_p2p      r = R Xw + t - Xc               same objective as shinji() (AbsoluteOrientation.hpp:47-99)   K1
 //   gn_refine_p2plane  r = Nc . (R Xw + t - Xc)        point-to-plane, no reference counterpart                     K2
 //   gn_refine_bearing  r = normalize(R Xw + t) x bv    the residual of lsq_pnp / getError (P3P.hpp:482-485)         K3
+//   gn_refine_reproj   r = f (p_x/p_z - bv_x/bv_z, p_y/p_z - bv_y/bv_z)   pixel reprojection (the conversion of
+//                      TestMain.cpp:35-36 with the adapter's focal length, principal point at the origin)           K3'
 //   gn_refine_joint    scale_33 * p2p + scale_23 * bearing over both inlier sets of an AOPoseAdapter      K1+K3 fused
 //   gn_refine_full     3D-3D (point-to-point or point-to-plane) + 2D-3D + normal-normal terms of a NormalAOPoseAdapter in
 //                      ONE fused pass per iteration, optional robust (Huber / Cauchy) weights and the adapter's weights:
@@ -66,6 +68,18 @@ int gn_refine_bearing(PnPPoseAdapter<Tp>& adapter, int max_iter = 20, double tol
   if (use_inliers) adapter.pushMask23();
   const int kind = RPE_RES_BEARING;
   return rpe::gn_run<Tp>(adapter, 1, &kind, nullptr, use_inliers, max_iter, tol);
+}
+// 2D-3D refinement on the PIXEL reprojection residual: the cost is in pixels^2 of the adapter's focal length (getFocal()); the step
+// itself does not depend on the focal length
+template <typename Tp>
+int gn_refine_reproj(PnPPoseAdapter<Tp>& adapter, int max_iter = 20, double tol = 1e-9, bool use_inliers = true) {
+  const int N = adapter.getNumberCorrespondences();
+  adapter.device().template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
+  adapter.device().template ensure<Tp>(RPE_BV, adapter.bearingData(), N);
+  if (use_inliers) adapter.pushMask23();
+  const int kind = RPE_RES_REPROJ;
+  const double f = (double)adapter.getFocal(), scale = f * f;
+  return rpe::gn_run<Tp>(adapter, 1, &kind, &scale, use_inliers, max_iter, tol);
 }
 template <typename Tp>
 int gn_refine_joint(AOPoseAdapter<Tp>& adapter, double scale_33 = 1.0, double scale_23 = 1.0, int max_iter = 20, double tol = 1e-9,

@@ -132,6 +132,8 @@ def residuals(kind, R, t, a, b, c):
         return (p - b).reshape(-1)
     if kind == 1:
         return np.einsum("ij,ij->i", c, p - b)
+    if kind == 4:   # pixel reprojection in normalised image coordinates (SURVEY.md Appendix B row 4 with f = 1)
+        return (p[:, :2] / p[:, 2:3] - b[:, :2] / b[:, 2:3]).reshape(-1)
     ph = p / np.linalg.norm(p, axis=1, keepdims=True)
     return np.cross(ph, b).reshape(-1)
 
@@ -364,10 +366,10 @@ def main():
     sub = slice(0, 200)
     vq = valid[sub]
     gn = {}
-    for kind, (a, b, c) in {0: (sc.Q, P, None), 1: (sc.Q, P, sc.N), 2: (sc.Q, sc.U, None)}.items():
+    for kind, (a, b, c) in {0: (sc.Q, P, None), 1: (sc.Q, P, sc.N), 2: (sc.Q, sc.U, None), 4: (sc.Q, sc.U, None)}.items():
         aa, bb = a[sub], b[sub]
         cc = None if c is None else c[sub]
-        if kind != 2:
+        if kind not in (2, 4):
             aa, bb = aa[vq], bb[vq]
             cc = None if cc is None else cc[vq]
         H, gvec, cost = normal_eq_numeric(kind, Rg, tg, aa, bb, cc)

@@ -17,7 +17,7 @@ M_SHINJI_RANSAC, M_SHINJI_RANSAC2, M_SHINJI_PROSAC, M_KNEIP_RANSAC, M_KNEIP_PROS
 M_SK_RANSAC, M_SK_PROSAC, M_NL_KNEIP_RANSAC, M_NL_SHINJI_RANSAC, M_NL_SK_RANSAC, M_NONE = 5, 6, 7, 8, 9, 10
 LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL = 0, 1, 2, 3, 4
 V_33, V_23, V_33_23, V_NN_23, V_NN_33, V_NN_33_23, V_23_MATRIX = 0, 1, 2, 3, 4, 5, 6
-GN_P2P, GN_P2PLANE, GN_BEARING, GN_NORMAL = 0, 1, 2, 3
+GN_P2P, GN_P2PLANE, GN_BEARING, GN_NORMAL, GN_REPROJ = 0, 1, 2, 3, 4
 ROBUST_NONE, ROBUST_HUBER, ROBUST_CAUCHY = 0, 1, 2
 
 

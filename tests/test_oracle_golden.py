@@ -135,7 +135,8 @@ def test_gn_normal_equations_match_numerical_jacobians(oracle, G):
     a = G["arr"]
     pose = oracle.pose12(G["gn_pose"]["R"], G["gn_pose"]["t"])
     sl = slice(0, 200)
-    for kind, (x, b, c) in {0: ("full_Q", "full_P", None), 1: ("full_Q", "full_P", "full_N"), 2: ("full_Q", "full_U", None)}.items():
+    for kind, (x, b, c) in {0: ("full_Q", "full_P", None), 1: ("full_Q", "full_P", "full_N"), 2: ("full_Q", "full_U", None),
+                            4: ("full_Q", "full_U", None)}.items():
         rec = oracle.gn_normal_eq(kind, a[x][sl], a[b][sl], None if c is None else a[c][sl], pose=pose, in_f64=True)
         H, g, cost, cnt = util.unpack_ne(rec)
         ref = G["gn_numeric_first200"][str(kind)]
