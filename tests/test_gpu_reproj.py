@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 F = 585.0
 
 
-def _scene(seed, n, dt, n2d=2.0, outliers=0.0, nan_frac=0.0, behind=True):
+def _scene(seed, n, dt, n2d=2.0, outliers=0.0, nan_frac=0.0, behind=True, on_plane=False):
     sc = util.scene_full(seed, n, np.float64, n2d=n2d, n3d=0.03, outliers=outliers)
     U = sc.U.copy()
     rng = np.random.default_rng(seed)
@@ -24,7 +24,8 @@ def _scene(seed, n, dt, n2d=2.0, outliers=0.0, nan_frac=0.0, behind=True):
         # a few world points that land BEHIND the camera at the true pose, one exactly on the z = 0 plane, and bearings without a
         # forward component: they must contribute nothing and must not be counted
         idx = rng.permutation(n)[:6]
-        pc = np.array([[0.3, -0.2, -1.5], [0.1, 0.1, 0.0], [1.0, 2.0, -0.2]])
+        # (on_plane: the middle one exactly ON the plane z = 0 -- for single evaluations only: a perturbed camera would see it in front)
+        pc = np.array([[0.3, -0.2, -1.5], [0.1, 0.1, 0.0 if on_plane else -0.7], [1.0, 2.0, -0.2]])
         Q[idx[:3]] = (pc - sc.t) @ sc.R
         U[idx[3]] = [0.6, 0.8, 0.0]
         U[idx[4]] = [0.0, 0.6, -0.8]
@@ -37,7 +38,7 @@ def _scene(seed, n, dt, n2d=2.0, outliers=0.0, nan_frac=0.0, behind=True):
 @pytest.mark.parametrize("n", [1, 5, 1000, 4099, 307200])
 def test_normal_equations_match_the_oracle(gpu_ctx_factory, oracle, n, flags, f64):
     dt = np.float64 if f64 else np.float32
-    sc = _scene(120 + n, n, dt, nan_frac=0.03 if n >= 100 else 0.0)
+    sc = _scene(120 + n, n, dt, nan_frac=0.03 if n >= 100 else 0.0, on_plane=True)
     rng = np.random.default_rng(n)
     pose = api.pose12(*util.perturbed_pose(rng, sc.R, sc.t))
     mask = (rng.uniform(size=n) < 0.7).astype(np.int16) if flags else None
@@ -94,7 +95,7 @@ def test_refinement_matches_the_oracles_on_every_path(oracle, n, f64):
         finally:
             ctx.close()
     # noise-free pixels: the minimiser is the true pose
-    sc0 = _scene(7, 2000, dt, n2d=0.0)
+    sc0 = _scene(7, 2000, dt, n2d=0.0, behind=False)   # (a point ON the z = 0 plane would swing in front of a perturbed camera)
     ctx = api.Context(0).load(L.F64 if f64 else L.F32, xw=sc0.Q, bv=sc0.U)
     p, it, _, _ = ctx.gn_refine([L.RES_REPROJ], api.pose12(*util.perturbed_pose(np.random.default_rng(1), sc0.R, sc0.t, 0.03, 0.05)), max_iter=30, tol=1e-9)
     ctx.close()
