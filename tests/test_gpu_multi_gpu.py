@@ -1,0 +1,93 @@
+"""-m gpu, boxes with TWO OR MORE GPUs (skipped on the single-GPU boxes of the build pool): the north star's collective on real
+hardware -- one process per GPU, the library's RCCL communicator (rpe_comm_init), one all-reduce of the 32-double record per
+Gauss-Newton iteration (BASELINE.json configs[4]).  Asserted: ncclCommCount == world on every rank, distinct
+PCI bus ids, the all-reduced record == the sum of the shards' records, the vote counters likewise, the refined pose == the single-GPU
+pose and the oracle's closed form, every rank bit-identical; and bench.py --gpus 2 from a bare shell with its RCCL headline.
+The worker script itself (tests/multigpu_worker.py) also runs with ONE rank on any box, so that it cannot rot unnoticed."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from rgbd_pose_estimation_amd import _lib as L, api
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NGPU = L.device_count()
+many = pytest.mark.skipif(NGPU < 2, reason="needs two or more GPUs (rpe_device_count() = %d)" % NGPU)
+
+
+def _run_world(world, n=400000, seed=12):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multigpu_worker.py"), str(r), str(world), d, str(n), str(seed)],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, so[-1000:] + se[-3000:]
+        return [json.load(open(os.path.join(d, "rank%d.json" % r))) for r in range(world)], n, seed
+
+
+def _check(ranks, n, seed, oracle):
+    world = len(ranks)
+    assert all(r["comm_count"] == world for r in ranks)
+    assert len({r["bus_id"] for r in ranks}) == world                                        # one GPU per rank
+    assert sorted(tuple(r["range"]) for r in ranks) == [((k * n) // world, ((k + 1) * n) // world) for k in range(world)]
+    total = np.sum([np.array(r["local_record"]) for r in ranks], axis=0)
+    for r in ranks:
+        got = np.array(r["allreduced_record"])
+        assert np.max(np.abs(got[:29] - total[:29])) <= 1e-12 * np.max(np.abs(total[:29]))  # the all-reduce adds the shards' records
+        assert np.array_equal(got, np.array(ranks[0]["allreduced_record"]))                  # bitwise the same on every rank
+        assert r["pose_after_8_steps"] == ranks[0]["pose_after_8_steps"] and r["pose_after_one_step"] == ranks[0]["pose_after_one_step"]
+        assert r["allreduced_votes"] == np.sum([q["local_votes"] for q in ranks], axis=0).tolist()
+    # against the single-GPU path and the oracle, on the whole set
+    sc = util.scene_full(seed, n, np.float32, n2d=2.0, n3d=0.03, outliers=0.0)
+    p0 = api.pose12(*util.perturbed_pose(np.random.default_rng(seed), sc.R, sc.t, 0.01, 0.03))
+    one = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P)
+    rec1, _ = one.normal_eq(L.RES_P2P, p0)
+    assert np.max(np.abs(total[:29] - rec1[:29])) <= 1e-12 * np.max(np.abs(rec1[:29]))      # shards add up to the whole
+    p = p0.copy()
+    for _ in range(8):
+        one.gn_step(L.RES_P2P, p)
+    one.close()
+    pd = np.array(ranks[0]["pose_after_8_steps"])
+    assert np.max(np.abs(pd - p)) < 1e-10
+    Ro, to, _ = oracle.shinji_f32in_f64(sc.Q, sc.P)
+    assert util.rot_err(pd[:9].reshape(3, 3), Ro) < 1e-7 and np.linalg.norm(pd[9:] - to) / np.linalg.norm(to) < 1e-7
+    assert ranks[0]["last_step"] < 1e-9
+
+
+def test_worker_with_one_rank_on_any_box(oracle):
+    ranks, n, seed = _run_world(1, n=100000)
+    _check(ranks, n, seed, oracle)
+
+
+@many
+def test_two_ranks_two_gpus(oracle):
+    _check(*_run_world(2), oracle)
+
+
+@many
+def test_all_visible_gpus(oracle):
+    _check(*_run_world(NGPU, n=125000 * NGPU), oracle)
+
+
+@many
+def test_bench_two_gpus_from_a_bare_shell_runs_rccl():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_PREWARM_STEPS="300")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RPE_BENCH_SHARE_GPU", "RPE_BENCH_COLLECTIVE", "RPE_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["config"]["rccl_ranks"] == 2 and j["config"]["rccl_verified"] is True
+    assert "rccl" in j["config"]["collective"] and len(set(j["config"]["pci_bus_ids"])) == 2
+    assert j["config"]["collective_step_us"]["rccl_us"] > 0 and j["value"] > 1e9
