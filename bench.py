@@ -697,39 +697,16 @@ def worker(args, affinity):
             t_pre = time.perf_counter()
             while time.perf_counter() - t_pre < float(os.environ.get("RPE_BENCH_PREWARM_S", "1.5")):
                 pose = run_steps(pose12(R0, t0), args.steps)
-        # which host CPU polls fastest differs from box to box (GPU-local cores usually, the other socket's on some boxes, by 5-10 %):
-        # try a few of both kinds with a short refinement each and keep the best one (one GPU, resident loop, pinned runs only)
-        if not dist_path and resident and affinity.get("pinned") and not args.no_extras and os.environ.get("RPE_BENCH_NO_CALIBRATE") != "1":   # (--no-extras: profiled runs hold the timed launches only)
+        # which host CPU polls fastest differs from box to box (GPU-local cores usually, the other socket's on some boxes, by 5-10 %).
+        # The choice is the LIBRARY's (rpe_tune_host_thread: a few candidates of both kinds, a short refinement each, the calling
+        # thread left pinned to the fastest) -- any C++ caller of rpe_gn_refine gets the same with one call or RPE_HOST_CPU=auto.
+        if not dist_path and resident and not args.no_extras and os.environ.get("RPE_BENCH_NO_CALIBRATE") != "1":   # (--no-extras: profiled runs hold the timed launches only)
             try:
-                allowed = sorted(ORIG_AFFINITY) if ORIG_AFFINITY else sorted(os.sched_getaffinity(0))
-                mine = affinity["cpu"] if isinstance(affinity["cpu"], int) else affinity["cpu"][0]
-                local = set(affinity.get("gpu_local_cpu_ids", []))
-                near = [c for c in allowed if c in local and c != mine]
-                far = [c for c in allowed if c not in local]
-                # measured (scripts/core_sweep.py): the cores of one socket are alike to 1 %, except its first ones (CPU 0 / 1 take the
-                # interrupts: 3-4 % slower), and the sockets differ by 10 % -- in either direction, whatever sysfs calls GPU-local.
-                # So: the default core, three cores spread over the local socket, two over the other one and one SMT sibling there.
-                half = (os.cpu_count() or 2) // 2
-                near_phys = [c for c in near if c < half] or near
-                far_phys = [c for c in far if c < half] or far
-                spread = lambda v, fr: [v[min(len(v) - 1, int(len(v) * f))] for f in fr] if v else []
-                cands = [mine] + spread(near_phys, (0.5, 0.75, 0.9)) + spread(far_phys, (0.02, 0.5)) + ([far[len(far) // 2]] if far else [])
-                trial = {}
-                reps_c = max(3, min(12, 6000 // args.steps))
-                for cpu in dict.fromkeys(cands):   # each trial has the shape of the timed region: synchronize, K steps, synchronize
-                    os.sched_setaffinity(0, {cpu})
-                    run_steps(pose12(R0, t0), args.steps)
-                    ts_c = []
-                    for _ in range(reps_c):
-                        torch.cuda.synchronize()
-                        t_c = time.perf_counter()
-                        run_steps(pose12(R0, t0), args.steps)
-                        torch.cuda.synchronize()
-                        ts_c.append((time.perf_counter() - t_c) / args.steps)
-                    trial[cpu] = percentile(ts_c, 0.5) * 1e6
-                pick = min(trial, key=trial.get)
-                os.sched_setaffinity(0, {pick})
-                affinity = dict(affinity, cpu=pick, calibration_us_per_step={str(k): round(v, 3) for k, v in trial.items()})
+                if ORIG_AFFINITY:
+                    os.sched_setaffinity(0, ORIG_AFFINITY)   # every CPU the process may use is a candidate again
+                tune = ctx.tune_host_thread(L.RES_P2P, pose12(R0, t0), flags=L.USE_MASK, steps=args.steps, reps=max(3, min(12, 6000 // args.steps)))
+                affinity = dict(affinity, pinned=True, cpu=tune["cpu"], tuned_by="rpe_tune_host_thread (library call; RPE_HOST_CPU=auto does the same for any caller)",
+                                calibration_us_per_step={str(k): round(v, 3) for k, v in tune["trials"].items()})
             except Exception as e:  # noqa: BLE001
                 affinity = dict(affinity, calibration_error=repr(e))
         run_steps(pose12(R0, t0), args.warmup)
@@ -884,6 +861,7 @@ def worker(args, affinity):
         out = {
             "metric": "correspondence-residuals/sec", "value": float(inl_total) * args.steps / elapsed, "unit": "correspondence-residuals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med,
+            "ms_per_step_untuned": (UNTUNED or {}).get("ms_per_step"), "untuned": UNTUNED,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
                        "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
@@ -1107,11 +1085,52 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
         out["config3_pipeline"] = {"error": repr(e)}
 
 
+def untuned_probe(args):
+    """What a caller gets WITHOUT any host-side tuning: default CPU placement (no pinning, no calibration), default environment
+    (HSA_ENABLE_INTERRUPT untouched), the same K-step regions bracketed by synchronisations.  Runs in a process of its own -- the
+    runtime knobs are read when it initialises -- before the parent touches the GPU; prints one JSON object."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from rgbd_pose_estimation_amd import _lib as L, api
+    from rgbd_pose_estimation_amd.api import pose12, pose7_from_Rt
+    n = args.n_per_gpu
+    sc = make_shard(0, n)
+    ctx = api.Context(0)
+    ctx.load(L.F32, xw=sc.Q, xc=sc.P)
+    R0, t0 = initial_pose(sc)
+    ctx.inlier_mask(L.VOTE_33, pose7_from_Rt(R0, t0, L.F32), thre_3d=THRE_3D)
+
+    def run(k):
+        return ctx.gn_refine([L.RES_P2P], pose12(R0, t0), None, L.USE_MASK, k, 0.0)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 1.0:
+        run(args.steps)
+    ts = []
+    for _ in range(args.repeats):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0_) / args.steps)
+    ctx.close()
+    print(json.dumps({"ms_per_step": percentile(ts, 0.5) * 1e3, "ms_per_step_p10": percentile(ts, 0.1) * 1e3, "ms_per_step_p90": percentile(ts, 0.9) * 1e3,
+                      "steps": args.steps, "repeats": args.repeats, "cpu": sorted(os.sched_getaffinity(0))[:4], "cpus_allowed": len(os.sched_getaffinity(0)),
+                      "hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"),
+                      "note": "no pinning, no CPU calibration, default environment: what a C++ caller of rpe_gn_refine sees before rpe_tune_host_thread / RPE_HOST_CPU"}))
+
+
+UNTUNED = None
+
+
 def main():
+    global UNTUNED
     # Completion signals polled by the waiting thread instead of interrupt-driven (ROCm runtime knob, this process only, must be in the
     # environment before the runtime initialises): the closing synchronisation of a 20-step region returns ~5 us sooner (A/B:
     # profiles/r03_hsa_interrupt_ab.txt).  Left alone if the caller set it; reported in timing.hsa_enable_interrupt.
-    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+    caller_set_interrupt = "HSA_ENABLE_INTERRUPT" in os.environ
+    if "--untuned-probe" not in sys.argv:
+        os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -1123,10 +1142,27 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs reported beside the headline (profiling runs: only the headline's launches)")
+    ap.add_argument("--untuned-probe", action="store_true", help="internal: print the K-step figure of a process with NO host-side tuning (no pinning, default environment) and exit")
     ap.add_argument("--no-hbm", action="store_true", help="skip the live bandwidth-bound block (roofline_hbm: 1 M point-to-plane steady / cold, 10 M / 20 M point-to-point)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
         sys.exit("bench.py: --gpus, --steps and --repeats must be positive")
+    if args.untuned_probe:
+        untuned_probe(args)
+        return
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_extras and os.environ.get("RPE_BENCH_NO_UNTUNED") != "1":
+        # the untuned figure beside the headline: a child process with the caller's own environment and no pinning, run BEFORE this
+        # process initialises the GPU (the two never use it at the same time)
+        try:
+            env = dict(os.environ)
+            if not caller_set_interrupt:
+                env.pop("HSA_ENABLE_INTERRUPT", None)
+            env.pop("RPE_HOST_CPU", None)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--untuned-probe", "--steps", str(args.steps), "--repeats", str(min(args.repeats, 30)),
+                                "--n-per-gpu", str(args.n_per_gpu)], env=env, capture_output=True, text=True, timeout=600)
+            UNTUNED = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:  # noqa: BLE001
+            UNTUNED = {"error": repr(e)}
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_children(sys.argv[1:], args.gpus))   # this process never initialises HIP
     world = int(os.environ.get("WORLD_SIZE", "1"))

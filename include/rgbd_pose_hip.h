@@ -239,6 +239,18 @@ int rpe_debug_resident_state(rpe_context* ctx, int* enabled, int* lost, int* cap
  * a fault from the environment. */
 int rpe_debug_inject_resident_fault(rpe_context* ctx, int iteration, double pose_wait_s);
 
+/* Which CPU should the thread that drives the resident Gauss-Newton loop sit on?  (It spins on every iteration's records and writes
+ * every pose through the PCIe BAR: the choice is worth 5-10 % of a step.)  Measures a handful of candidates -- the current CPU, three
+ * spread over the GPU-local CPUs (sysfs local_cpulist of the device), two over the others, one SMT sibling -- with `reps` refinements of
+ * `steps` iterations each over the context's OWN arrays (kind / flags as rpe_gn_refine, tol = 0, from pose12, which is not modified),
+ * then leaves the CALLING THREAD pinned to the fastest (sched_setaffinity, this thread only) and reports it: best_cpu / best_us (us per
+ * iteration), and up to `cap` (cpu, us) trials.  Opt-in; the environment RPE_HOST_CPU=auto makes the first host-driven resident
+ * refinement of every context do this by itself (200 iterations x 5 per candidate), RPE_HOST_CPU=<cpu> pins without measuring.
+ * HSA_ENABLE_INTERRUPT=0 in the process environment (a ROCm runtime knob: completion signals polled instead of interrupt-driven,
+ * -0.25 us per step of a short refinement) is the caller's choice: it must be set before the runtime initialises. */
+int rpe_tune_host_thread(rpe_context* ctx, int kind, int flags, const double* pose12, int steps, int reps, int* best_cpu, double* best_us,
+                         int* trial_cpus, double* trial_us, int cap, int* ntrials);
+
 /* HIP-event timing of the one-launch reduction kernels (rpe_normal_eq*, rpe_p2p_moments, rpe_nl_round, rpe_inlier_mask), on the
  * context's stream: after enable(max_records, stride) every stride-th such call launches its kernel with an event pair that receives the dispatch's own begin / end
  * timestamps (hipExtLaunchKernelGGL: what rocprofv3 reports for the kernel, no marker packets); collect() synchronises,

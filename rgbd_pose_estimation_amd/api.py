@@ -293,6 +293,15 @@ class Context:
     def hostex_destroy(self):
         L.check(L.lib().rpe_hostex_destroy(self._h))
 
+    def tune_host_thread(self, kind: int, pose, flags: int = 0, steps: int = 200, reps: int = 5):
+        """rpe_tune_host_thread: measure candidate CPUs for the thread that drives the resident loop, leave THIS thread pinned to the
+        fastest.  Returns dict(cpu, us_per_step, trials={cpu: us})."""
+        p = np.ascontiguousarray(pose, np.float64).reshape(12)
+        best, us, n = C.c_int(-1), C.c_double(0), C.c_int(0)
+        cpus, tus = np.zeros(16, np.int32), np.zeros(16, np.float64)
+        L.check(L.lib().rpe_tune_host_thread(self._h, kind, flags, _p(p), steps, reps, C.byref(best), C.byref(us), _p(cpus), _p(tus), 16, C.byref(n)))
+        return {"cpu": best.value, "us_per_step": us.value, "trials": {int(cpus[i]): float(tus[i]) for i in range(n.value)}}
+
     def timing_enable(self, max_records: int, stride: int = 1):
         L.check(L.lib().rpe_timing_enable(self._h, max_records, stride))
 

@@ -117,7 +117,7 @@ def build_stamps(level: int = 1, verbose: bool = False) -> str:
     return out
 
 
-EXAMPLES = ["simple_main", "test_main", "icp_main", "engine_profile"]
+EXAMPLES = ["simple_main", "test_main", "icp_main", "engine_profile", "gn_refine_main"]
 
 
 def build_examples(verbose: bool = False) -> list[str]:

@@ -17,6 +17,10 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <cctype>
+#include <sched.h>
+#include <unistd.h>
 
 namespace {
 
@@ -109,6 +113,8 @@ struct rpe_context {
   unsigned char arr_state[RPE_NUM_ARRAYS] = {0, 0, 0, 0, 0};
   bool arr_bound[RPE_NUM_ARRAYS] = {false, false, false, false, false};   // caller-owned device memory: may change between calls
   bool guard_always = false;     // RPE_GUARD_ALWAYS=1: never launch the CLEAN flavour (experiments, A/B)
+  int host_cpu_request = -2;     // RPE_HOST_CPU at rpe_create: -2 none, -1 auto (rpe_tune_host_thread at the first resident refinement), >= 0 that CPU
+  bool host_cpu_done = false;
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
   double* d_out = nullptr;       // 64 doubles
   double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
@@ -595,6 +601,34 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
   return status;
 }
 
+// ---- which CPUs, and pinning the calling thread (rpe_tune_host_thread, RPE_HOST_CPU)
+namespace {
+std::vector<int> parse_cpulist(const char* path) {
+  std::vector<int> out;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return out;
+  char buf[4096];
+  if (std::fgets(buf, sizeof buf, f)) {
+    for (char* p = buf; *p;) {
+      while (*p && !std::isdigit((unsigned char)*p)) p++;
+      if (!*p) break;
+      const long lo = std::strtol(p, &p, 10);
+      long hi = lo;
+      if (*p == '-') hi = std::strtol(p + 1, &p, 10);
+      for (long v = lo; v <= hi && v < 4096; v++) out.push_back((int)v);
+    }
+  }
+  std::fclose(f);
+  return out;
+}
+bool pin_calling_thread(int cpu) {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET(cpu, &set);
+  return sched_setaffinity(0, sizeof set, &set) == 0;   // pid 0: the calling thread
+}
+}  // namespace
+
 extern "C" {
 
 int rpe_abi_version(void) { return 1; }
@@ -622,6 +656,7 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
   if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
   if (const char* f = getenv("RPE_GUARD_ALWAYS")) c->guard_always = atoi(f) != 0;
+  if (const char* f = getenv("RPE_HOST_CPU")) c->host_cpu_request = std::strcmp(f, "auto") == 0 ? -1 : (std::isdigit((unsigned char)f[0]) ? atoi(f) : -2);
   hipError_t e = hipSuccess;
   // scratch of the cross-workgroup stages, whichever layout a launch uses: (4096 + 8 shard) records of kNlLd doubles, or 16-byte
   // granules [workgroup <= 4096][sums <= 44] followed by the autonomous loop's run records [2 parities][<= kAutoMaxRunSums = 1024]
@@ -1234,6 +1269,11 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     if (rc) return rc;
     if ((rc = check_flags(c, kinds[0], flags))) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->host_cpu_request != -2 && !c->host_cpu_done) {   // RPE_HOST_CPU: pin / tune the thread that spins here, once per context
+      c->host_cpu_done = true;
+      if (c->host_cpu_request >= 0) (void)pin_calling_thread(c->host_cpu_request);
+      else (void)rpe_tune_host_thread(c, kinds[0], flags, pose12, 200, 5, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    }
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
     const int kind = kinds[0];
@@ -1280,6 +1320,81 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   if (iters_out) *iters_out = it;
   if (last_step) *last_step = step;
   if (final_cost) *final_cost = cost;
+  return RPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- host thread of the resident loops
+// The thread that calls rpe_gn_refine spins on the records of every iteration and writes every pose through the PCIe BAR: which CPU
+// it sits on is worth 5-10 % of a step (the cores of one socket are alike to about 1 %, the sockets differ by up to 10 % -- in either
+// direction, whatever sysfs calls GPU-local; the first cores of a socket take the interrupts and are 3-4 % slower).  This call
+// MEASURES it: a handful of candidate CPUs -- the current one, three spread over the GPU-local CPUs, two over the others and one SMT
+// sibling -- each pinned in turn and timed with `reps` refinements of `steps` iterations over the context's own arrays (tol = 0, from
+// pose12, which is left unchanged); the calling thread then stays pinned to the fastest (sched_setaffinity on the calling thread
+// only).  Opt-in: nothing pins a thread unless this is called, or RPE_HOST_CPU=auto | <cpu> is in the environment (then the first
+// host-driven resident refinement of a context does it with its own arguments).  Costs candidates x (reps + 1) x steps iterations.
+
+int rpe_tune_host_thread(rpe_context* c, int kind, int flags, const double* pose12, int steps, int reps, int* best_cpu, double* best_us,
+                         int* trial_cpus, double* trial_us, int cap, int* ntrials) {
+  if (!c || !pose12 || steps < 2 || reps < 1 || cap < 0 || (cap > 0 && (!trial_cpus || !trial_us)))
+    return fail(RPE_ERR_ARG, "rpe_tune_host_thread: bad argument");
+  if (!(c->resident && c->host_resident)) return fail(RPE_ERR_STATE, "rpe_tune_host_thread: this context runs no host-driven resident loop");
+  cpu_set_t original;
+  CPU_ZERO(&original);
+  if (sched_getaffinity(0, sizeof original, &original) != 0) return fail(RPE_ERR_STATE, "sched_getaffinity failed");
+  // GPU-local CPUs from sysfs (by PCI bus id), the rest of the online CPUs as "far"
+  char bus[64] = {0};
+  std::vector<int> local, online = parse_cpulist("/sys/devices/system/cpu/online");
+  if (hipDeviceGetPCIBusId(bus, sizeof bus, c->device) == hipSuccess) {
+    for (char* p = bus; *p; p++) *p = (char)std::tolower((unsigned char)*p);
+    local = parse_cpulist((std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist").c_str());
+  } else (void)hipGetLastError();
+  const int here = sched_getcpu();
+  const int half = (int)online.size() / 2;   // SMT siblings are numbered in the upper half on the hosts this was measured on
+  auto is_local = [&](int v) { return std::find(local.begin(), local.end(), v) != local.end(); };
+  std::vector<int> near_phys, far_phys, far_all;
+  for (int v : online) {
+    if (v == here) continue;
+    if (is_local(v)) { if (v < half || half == 0) near_phys.push_back(v); }
+    else { far_all.push_back(v); if (v < half || half == 0) far_phys.push_back(v); }
+  }
+  std::vector<int> cand;
+  auto add = [&](int v) { if (v >= 0 && std::find(cand.begin(), cand.end(), v) == cand.end()) cand.push_back(v); };
+  auto spread = [&](const std::vector<int>& v, double f) { return v.empty() ? -1 : v[std::min(v.size() - 1, (size_t)(v.size() * f))]; };
+  add(here);
+  add(spread(near_phys, 0.5)); add(spread(near_phys, 0.75)); add(spread(near_phys, 0.9));
+  add(spread(far_phys, 0.02)); add(spread(far_phys, 0.5));
+  add(spread(far_all, 0.5));
+  int tried = 0, pick = -1;
+  double pick_us = 1e300;
+  std::vector<double> ts((size_t)reps);
+  int rc = RPE_OK;
+  for (int cpu : cand) {
+    if (!pin_calling_thread(cpu)) continue;   // outside the process's cpuset: not a candidate
+    double p[12];
+    int its = 0;
+    double st = 0, co = 0;
+    std::memcpy(p, pose12, sizeof p);
+    if ((rc = rpe_gn_refine(c, 1, &kind, nullptr, flags, p, steps, 0.0, &its, &st, &co))) break;
+    for (int r = 0; r < reps; r++) {
+      std::memcpy(p, pose12, sizeof p);
+      if ((rc = rpe_synchronize(c))) break;
+      const double t0 = clock_us();
+      if ((rc = rpe_gn_refine(c, 1, &kind, nullptr, flags, p, steps, 0.0, &its, &st, &co))) break;
+      if ((rc = rpe_synchronize(c))) break;
+      ts[(size_t)r] = (clock_us() - t0) / steps;
+    }
+    if (rc) break;
+    std::sort(ts.begin(), ts.end());
+    const double med = ts[(size_t)reps / 2];
+    if (tried < cap) { trial_cpus[tried] = cpu; trial_us[tried] = med; }
+    tried++;
+    if (med < pick_us) { pick_us = med; pick = cpu; }
+  }
+  if (rc || pick < 0) { (void)sched_setaffinity(0, sizeof original, &original); return rc ? rc : fail(RPE_ERR_STATE, "no candidate CPU could be pinned"); }
+  pin_calling_thread(pick);
+  if (best_cpu) *best_cpu = pick;
+  if (best_us) *best_us = pick_us;
+  if (ntrials) *ntrials = tried < cap ? tried : cap;
   return RPE_OK;
 }
 
