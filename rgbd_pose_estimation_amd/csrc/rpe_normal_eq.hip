@@ -83,6 +83,8 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     if (KIND == KIND_P2PLANE) { c0 = c4[3 * g]; c1 = c4[3 * g + 1]; c2 = c4[3 * g + 2]; }
     if (MASK) load_mask_full(mask, g, m);
     if (WEIGHT) load_weight_full(weight, g, wv);
+    pin16(a0); pin16(a1); pin16(a2); pin16(b0); pin16(b1); pin16(b2);
+    if (KIND == KIND_P2PLANE) { pin16(c0); pin16(c1); pin16(c2); }
   }
 #if defined(RPE_STAMPS) && RPE_STAMPS >= 2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build 2: when have the first loads landed?
@@ -99,10 +101,12 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     T nwv[P];
     if (MASK) load_mask_full(mask, gl, nm);
     if (WEIGHT) load_weight_full(weight, gl, nwv);
-    // the current group's vectors as opaque 16-byte values at their point of use: without this the optimiser narrows and re-splits
-    // the loads of the CLEAN bearing flavour into 12- and 8-byte pieces at odd offsets (three times the launch time)
-    pin16(a0); pin16(a1); pin16(a2); pin16(b0); pin16(b1); pin16(b2);
-    if (KIND == KIND_P2PLANE) { pin16(c0); pin16(c1); pin16(c2); }
+    // The pipeline is pinned down at both ends: nothing below may move above this point and the loads above may not sink below it
+    // (scheduling barrier), and the next group's vectors become opaque 16-byte values only AFTER the current group's arithmetic
+    // (pin16 below) -- without the first the optimiser rotates the loop of the point-to-point flavour into "load, wait, compute" (no
+    // load in flight during the arithmetic: 92 instead of 80 us at 20 M), without the second it narrows and re-splits the loads of the
+    // CLEAN bearing flavour into 12- and 8-byte pieces at odd offsets (three times the launch time).
+    __builtin_amdgcn_sched_barrier(0);
     T vw[3 * P], vb[3 * P], vc[3 * P];
     unpack3(a0, a1, a2, vw);
     unpack3(b0, b1, b2, vb);
@@ -111,6 +115,9 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
     if (++carried == kShare) { flush_pairs<T, NACC>(carry, acc); carried = 0; }
     a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
     if (KIND == KIND_P2PLANE) { c0 = nc0; c1 = nc1; c2 = nc2; }
+    __builtin_amdgcn_sched_barrier(0);
+    pin16(a0); pin16(a1); pin16(a2); pin16(b0); pin16(b1); pin16(b2);
+    if (KIND == KIND_P2PLANE) { pin16(c0); pin16(c1); pin16(c2); }
 #pragma unroll
     for (int i = 0; i < P; i++) { if (MASK) m[i] = nm[i]; if (WEIGHT) wv[i] = nwv[i]; }
     g = gn;
