@@ -52,6 +52,21 @@ struct Settings {
   // 3D-3D RANSAC (shinji_ransac / shinji_ransac2): sample + 3-point fit on the device too (rpe_ransac33_batch), bitwise the host's
   // hypotheses; false = host generation (RPE_HOST_HYPOTHESES=1 sets that default)
   bool device_hypotheses = std::getenv("RPE_HOST_HYPOTHESES") == nullptr;
+  // How a solver run decides whether the HBM copy of a caller's matrix is still that matrix (the adapters hold REFERENCES and the
+  // reference re-reads them on every call: pose/AOOnlyPoseAdapter.hpp:93-95, :147-152):
+  //   FP_SAMPLED (default)  length + 32 cache lines at even spacing: about a microsecond per array; a refilled buffer is always caught,
+  //                         an edit confined to lines that are not sampled -- NaN-marking a few columns in place -- is NOT
+  //   FP_FULL               every byte hashed (RPE_FINGERPRINT=full): any in-place edit is caught; one pass over the host array per
+  //                         array and solver run (3.7 MB at 640 x 480: ~0.15 ms per array on one host core, several times a solver run
+  //                         on resident arrays, which is why it is opt-in)
+  //   FP_OFF                address only (RPE_FINGERPRINT=off): the caller calls invalidateDevice() after every change
+  enum { FP_OFF = 0, FP_SAMPLED = 1, FP_FULL = 2 };
+  int fingerprint = fingerprint_from_env();
+  static int fingerprint_from_env() {
+    const char* e = std::getenv("RPE_FINGERPRINT");
+    if (!e) return FP_SAMPLED;
+    return std::strcmp(e, "full") == 0 ? FP_FULL : (std::strcmp(e, "off") == 0 ? FP_OFF : FP_SAMPLED);
+  }
   // Hypothesis streams made explicit (parity tests, SURVEY.md section 8d "both sides consume the same sample list"):
   //   capture != null: the RANSAC / PROSAC engines only GENERATE -- the hypotheses of `Iter` iterations are appended to *capture,
   //                    nothing is scored and no device is touched (rpe_host_hypotheses);
@@ -106,12 +121,30 @@ inline ContextPool& pool() { static ContextPool p; return p; }
 // The adapters hold REFERENCES to the caller's matrices and the reference library re-reads them on every call
 // (pose/AOOnlyPoseAdapter.hpp:93-95,147-152); the HBM copy is keyed by the host address, so a caller that refills the same buffer
 // with the next frame must not be served the previous frame's upload.  About a microsecond per array and solver run.  A refill
-// changes (nearly) every line and is always caught; an edit confined to lines that are not sampled is not -- invalidateDevice()
-// remains the explicit way to say "the matrices changed".
-inline unsigned long long host_fingerprint(const void* p, size_t bytes) {
+// changes (nearly) every line and is always caught; an edit confined to lines that are not sampled -- NaN-marking a few columns in
+// place, the reference's "invalid measurement" idiom -- is not: Settings::fingerprint = FP_FULL (RPE_FINGERPRINT=full) hashes every
+// byte instead, and invalidateDevice() remains the explicit, free way to say "the matrices changed".
+// full = true: EVERY byte enters (four independent multiply-rotate lanes over 8-byte words, folded at the end): about 25 GB/s on one
+// host core, so that a sparse in-place edit is seen too (Settings::FP_FULL).
+inline unsigned long long host_fingerprint(const void* p, size_t bytes, bool full = false) {
   unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)bytes;
   if (!p || bytes == 0) return h;
   const unsigned char* b = static_cast<const unsigned char*>(p);
+  if (full) {
+    unsigned long long a[4] = {h, h ^ 0xC2B2AE3D27D4EB4Full, h ^ 0x165667B19E3779F9ull, h ^ 0x27D4EB2F165667C5ull};
+    const size_t words = bytes / 8, blocks = words / 4;
+    for (size_t k = 0; k < blocks; k++) {
+      unsigned long long w[4];
+      std::memcpy(w, b + 32 * k, 32);
+      for (int i = 0; i < 4; i++) { a[i] = (a[i] ^ w[i]) * 0x9E3779B97F4A7C15ull; a[i] = (a[i] << 31) | (a[i] >> 33); }
+    }
+    unsigned long long tail[4] = {0, 0, 0, 0};
+    std::memcpy(tail, b + 32 * blocks, bytes - 32 * blocks);
+    for (int i = 0; i < 4; i++) { a[i] = (a[i] ^ tail[i]) * 0x9E3779B97F4A7C15ull; a[i] = (a[i] << 31) | (a[i] >> 33); }
+    unsigned long long r = a[0];
+    for (int i = 1; i < 4; i++) { r = (r ^ a[i]) * 0xFF51AFD7ED558CCDull; r ^= r >> 29; }
+    return r ^ 0x1ull;   // (never the sampled value of the same content: the modes are not mixed up when the setting changes)
+  }
   const size_t lines = (bytes + 63) / 64, samples = lines < 32 ? lines : 32;
   for (size_t k = 0; k < samples; k++) {
     const size_t line = samples > 1 ? k * (lines - 1) / (samples - 1) : 0;
@@ -163,14 +196,16 @@ class DeviceSet {
       for (int i = 0; i < 3; i++) { _mask_fresh[i] = false; _weight_fresh[i] = false; }
     }
     // same address as the resident copy's source: still the same CONTENT?  (arrays adopted from the device have no host content)
-    const bool check_content = !_borrowed || _fp_known[slot];
-    const unsigned long long fp = check_content ? host_fingerprint(host, (size_t)n * 3 * sizeof(Tp)) : 0;
+    const int fpmode = Settings::get().fingerprint;
+    const bool fp_full = fpmode == Settings::FP_FULL;
+    const bool check_content = fpmode != Settings::FP_OFF && (!_borrowed || _fp_known[slot]);
+    const unsigned long long fp = check_content ? host_fingerprint(host, (size_t)n * 3 * sizeof(Tp), fp_full) : 0;
     if (_src[slot] != (const void*)host || (check_content && _fp_known[slot] && fp != _fp[slot])) {
       const double t0 = Settings::get().profile ? now_us() : 0;
       check(rpe_upload(ctx(), slot, host), "rpe_upload");
       _src[slot] = host;
-      _fp[slot] = check_content ? fp : host_fingerprint(host, (size_t)n * 3 * sizeof(Tp));
-      _fp_known[slot] = true;
+      _fp[slot] = check_content ? fp : host_fingerprint(host, (size_t)n * 3 * sizeof(Tp), fp_full);
+      _fp_known[slot] = fpmode != Settings::FP_OFF;
       if (Settings::get().profile) { check(rpe_synchronize(ctx()), "rpe_synchronize"); Settings::get().prof.upload += now_us() - t0; }
     }
   }

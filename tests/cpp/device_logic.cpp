@@ -138,6 +138,42 @@ int main() {
       const rpe::Point3<T> dt = b.gettw() - tB;
       CHECK(dt.norm() < 0.01f);
     }
+    // ---- a SPARSE in-place edit on a full frame: three camera points are gross outliers; the caller then NaN-marks exactly those
+    // columns in its own matrix (AOPoseAdapter.hpp:147-152 "invalid measurement") and refines again.  The sampled fingerprint (32 of
+    // 57 600 cache lines) does not see three columns change; Settings::FP_FULL (RPE_FINGERPRINT=full) does, and invalidateDevice() is
+    // the explicit way.
+    {
+      const int NB = 307200;
+      rpe::sim_seed(21);
+      const rpe::Point3<T> tC = generate_random_translation_uniform<T>(5.0);
+      const rpe::SO3<T> RC = generate_random_rotation<T>(M_PI / 2, false);
+      rpe::MatrixX<T> QC, PC;
+      simulate_3d_3d_correspondences<T>(RC, tC, NB, 0.01f, 0.0f, 0.4f, 8.0f, 585.0f, true, &QC, &PC, nullptr);
+      const int bad[3] = {12345, 150001, 290000};
+      for (int c : bad) PC.setCol(c, PC.col(c) + rpe::Point3<T>(T(300), T(-200), T(250)));
+      auto refine_err = [&](AOOnlyPoseAdapter<T>& ad) {
+        ad.setRcw(RC); ad.sett(tC + rpe::Point3<T>(T(0.01), T(0.01), T(-0.01)));
+        gn_refine_p2p<T>(ad, 20, 1e-9, /*use_inliers=*/false);
+        return (double)(ad.gettw() - tC).norm();
+      };
+      const int saved = rpe::Settings::get().fingerprint;
+      for (int mode : {(int)rpe::Settings::FP_SAMPLED, (int)rpe::Settings::FP_FULL}) {
+        rpe::Settings::get().fingerprint = mode;
+        rpe::MatrixX<T> P2 = PC;                              // a fresh matrix per mode (its own address)
+        AOOnlyPoseAdapter<T> ad(P2, QC);
+        const double e_out = refine_err(ad);
+        CHECK(e_out > 1e-3);                                  // three points 440 m off pull the translation by millimetres
+        for (int c : bad) P2.setCol(c, rpe::Point3<T>(T(NAN), T(NAN), T(NAN)));   // in place, three columns of 307 200
+        const double e_marked = refine_err(ad);
+        if (mode == rpe::Settings::FP_FULL) CHECK(e_marked < 2e-4);             // seen: the frame was uploaded again, the columns are skipped
+        else {
+          CHECK(e_marked > 1e-3);                             // NOT seen (documented limit of the sampled fingerprint) ...
+          ad.invalidateDevice();
+          CHECK(refine_err(ad) < 2e-4);                       // ... until the caller says so
+        }
+      }
+      rpe::Settings::get().fingerprint = saved;
+    }
     std::printf(fails ? "device_logic: %d FAILURES\n" : "device_logic: ok\n", fails);
     return fails ? 1 : 0;
   } catch (const rpe::DeviceError& e) {

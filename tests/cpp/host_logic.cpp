@@ -1,6 +1,7 @@
 // Host-side logic of the drop-in headers that needs no GPU (compiled and run by tests/test_host_cpp.py):
 // partial PROSAC order == prefix of the full order (ties included), lazy extension, cvtInlier snapshot semantics,
 // sparse RandomElements == the reference's re-initialised Fisher-Yates table.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include "AOOnlyPoseAdapter.hpp"
@@ -27,6 +28,20 @@ int main() {
     for (float& x : b) x += 0.5f;                                           // a refilled buffer (every line changes) is always caught
     CHECK(f0 != rpe::host_fingerprint(b.data(), bytes));
     CHECK(rpe::host_fingerprint(nullptr, 0) == rpe::host_fingerprint(a.data(), 0));
+    {  // FULL mode: every byte enters -- a sparse in-place edit (three columns NaN-marked, the reference's idiom) changes the value
+      std::vector<float> c(a);
+      const unsigned long long s0 = rpe::host_fingerprint(c.data(), bytes), g0 = rpe::host_fingerprint(c.data(), bytes, true);
+      CHECK(g0 == rpe::host_fingerprint(a.data(), bytes, true) && g0 != s0);
+      for (int col : {1234, 100001, 250000}) for (int k = 0; k < 3; k++) c[3 * (size_t)col + k] = NAN;
+      CHECK(rpe::host_fingerprint(c.data(), bytes) == s0);                  // the sampled mode does not see it (documented)
+      CHECK(rpe::host_fingerprint(c.data(), bytes, true) != g0);            // the full mode does
+      for (size_t off : {(size_t)0, (size_t)7, bytes / 2 + 3, bytes - 1}) {  // any single byte, wherever it sits (tails included)
+        std::vector<float> d(a);
+        reinterpret_cast<unsigned char*>(d.data())[off] ^= 0x40;
+        CHECK(rpe::host_fingerprint(d.data(), bytes, true) != g0);
+        CHECK(rpe::host_fingerprint(d.data(), bytes - 5, true) != rpe::host_fingerprint(a.data(), bytes - 5, true) || off >= bytes - 5);
+      }
+    }
     float tiny[3] = {1.f, 2.f, 3.f};                                        // arrays shorter than a cache line
     const unsigned long long ft = rpe::host_fingerprint(tiny, sizeof tiny);
     tiny[2] = 4.f;
