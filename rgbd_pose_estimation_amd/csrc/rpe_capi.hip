@@ -1135,7 +1135,6 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
     std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
     if (single) rt.clean = take_clean(c, terms[0].kind, false);   // no host in this loop: CLEAN only over verified arrays
-    { static const bool flat = getenv("RPE_AUTO_FLAT") && atoi(getenv("RPE_AUTO_FLAT")) != 0; rt.auto_flat = flat ? 1 : 0; }   // experiment
     if (single) HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0,
         e1));
     else HIP_TRY(rpe::launch_normal_eq_joint_resident(c->arrays(), bits, flags, scale, robust, rk, nullptr, base, max_iter, rt,

@@ -61,9 +61,6 @@ struct ReduceTarget {
   // resident kernels: wait for the host's next pose at most this long (100 MHz ticks; 2 s)
   unsigned long long pose_wait_ticks = 200000000ull;
   unsigned long long fault_tag = 0;                    // test hook: see Finish
-  // EXPERIMENT (RPE_AUTO_FLAT=1, round-3 review item 9): the autonomous resident loop with ONE hop -- every workgroup reads every
-  // workgroup's granules itself instead of granule -> collecting workgroup -> run record -> every workgroup
-  int auto_flat = 0;
   double pivot_floor = 1e-12;  // device-side 6x6 solves: relative pivot floor (rpe::pivot_floor of the arrays' dtype, rpe/linalg.hpp)
   // > 0: collecting workgroups + host-side final sum -- runs of up to `rows` workgroups are added by the first workgroup of
   int rows = 0;

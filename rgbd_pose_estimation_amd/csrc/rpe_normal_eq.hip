@@ -204,10 +204,6 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     const bool stamp_it = false;
 #endif
     if (autonomous) {
-      if (KIND == KIND_P2P && fin.auto_flat) {   // experiment: one hop (RPE_AUTO_FLAT=1)
-        if (resident_auto_stage_flat<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose) != 0) return;
-        continue;
-      }
       if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose,
           stamp_it) != 0) return;
       continue;

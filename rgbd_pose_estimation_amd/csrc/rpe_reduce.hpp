@@ -293,7 +293,6 @@ struct Finish {
   // resident kernels: how long a workgroup waits for the host's next pose (100 MHz ticks) before it gives up
   unsigned long long pose_wait_ticks;
   unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
-  int auto_flat;                        // experiment: one-hop autonomous stage (resident_auto_stage_flat)
   double pivot_floor;                   // device-side 6x6 solves: relative pivot floor (rpe::pivot_floor, rpe/linalg.hpp)
 };
 // what a collecting workgroup sends to the host in place of its run's sums when a granule of the run never arrived: a quiet NaN with a
@@ -902,7 +901,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.tail = rt.tail >= 0 ? rt.tail : env_tail;
   f.rows = rt.rows > 0 ? rt.rows : 0;
   f.stride = rt.stride > 1 ? rt.stride : 0;
-  f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag; f.pivot_floor = rt.pivot_floor; f.auto_flat = rt.auto_flat;
+  f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag; f.pivot_floor = rt.pivot_floor;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

@@ -514,6 +514,9 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 // it has finished reading i.  Granules need no second buffer: a workgroup writes iteration i + 1's after it has read run records
 // that its collector published after reading iteration i's.  Returns 0 = next iteration, 1 = finished (workgroup 0 published pose |
 // step | cost | iterations | status | weight sum to the host), 2 = a granule never arrived (2 s).
+// Tried and rejected in round 4 (profiles/r04_auto_flat_ab.jsonl): ONE hop -- every workgroup reads all G x NACC granules itself (40 KB per
+// workgroup and iteration at 150 x 17) instead of collecting per run: 6.74 against 6.0-6.06 us per iteration at 307 200 correspondences,
+// 10.0 against 8.0 at 1 M (three alternations on one box): eighteen times the bytes cross the fabric, and that costs more than the hop.
 template <int NACC, int BLK>
 __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it,
     int max_iters,
@@ -608,89 +611,6 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
     __hip_atomic_store(fin.out_host + 14, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (lost ? 2.0 : 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : record_entry<MODE>(a_tot, 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  return lost ? 2 : (done ? 1 : 0);
-}
-
-// EXPERIMENT (round-3 review, item 9; RPE_AUTO_FLAT=1): the autonomous iteration with ONE hop.  Every workgroup stores its NACC sums
-// as granules (double-buffered by iteration parity: a fast workgroup's next iteration must not overwrite what a slow one still reads)
-// and then reads ALL G x NACC granules itself -- 40 KB per workgroup and iteration at 150 x 17 -- adds them in a fixed two-level order
-// (blocks of rows, then the blocks), and solves.  No collecting workgroup, no run record.  Measured against the two-hop stage in
-// profiles/r04_auto_flat_ab.jsonl; the two-hop stage stays the default.
-constexpr int kAutoFlatMaxSums = 256 * 29;
-template <int NACC, int BLK>
-__device__ __forceinline__ int resident_auto_stage_flat(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it,
-                                                        int max_iters, double tol, double* __restrict__ s_pose) {
-  constexpr int NW = BLK / 64;
-  constexpr int MODE = NACC == 17 ? 1 : 0;
-  constexpr int RGN = BLK / NACC;                        // row blocks of the first summation level
-  __shared__ double f_red[NW][NACC];
-  __shared__ double f_all[kAutoFlatMaxSums];
-  __shared__ double f_part[RGN][NACC];
-  __shared__ double f_tot[32];
-  __shared__ double f_step;
-  __shared__ int f_ok;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int G = (int)gridDim.x, total = G * NACC;
-  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials) + 2 * (size_t)(it & 1) * (size_t)kAutoFlatMaxSums;
-  wave_reduce_to<NACC>(acc, f_red[wave], lane);
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    double own = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) own += f_red[w][threadIdx.x];
-    store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
-  }
-  bool lost = total > kAutoFlatMaxSums;
-  if (!lost) {
-    for (int i = threadIdx.x; i < total; i += BLK) {
-      const unsigned long long t0 = wall_clock64();
-      granule_t q;
-      for (unsigned int spins = 1;; spins++) {
-        q = load_granule16(gran + 2 * (size_t)i);
-        if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
-        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }
-      }
-      f_all[i] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
-    }
-  }
-  lost = __syncthreads_or(lost);
-  if (!lost) {
-    const int j = threadIdx.x % NACC, b = threadIdx.x / NACC, per = (G + RGN - 1) / RGN;
-    if (b < RGN) {
-      double t = 0.0;
-      for (int r = b * per; r < (b + 1) * per && r < G; r++) t += f_all[r * NACC + j];
-      f_part[b][j] = t;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    if (!lost) {
-      double t = 0.0;
-      if (threadIdx.x < NACC) for (int b = 0; b < RGN; b++) t += f_part[b][threadIdx.x];
-      if (threadIdx.x < 32) f_tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (threadIdx.x == 0) {
-      double step = 0.0;
-      f_ok = !lost && gn_solve_update<MODE>(f_tot, s_pose, &step, fin.pivot_floor) ? 1 : 0;
-      f_step = step;
-    }
-  }
-  __syncthreads();
-  const bool ok = f_ok != 0;
-  const bool done = !ok || f_step < tol || it >= max_iters;
-  if (done && blockIdx.x == 0 && threadIdx.x == 0 && fin.out_host) {
-    for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, s_pose[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 12, f_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 13, lost ? 0.0 : record_entry<MODE>(f_tot, 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 14, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (lost ? 2.0 : 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : record_entry<MODE>(f_tot, 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
