@@ -38,7 +38,7 @@ N_SHARDED = 10_000_000       # configs[4]
 BYTES_PER_CORR = 24 + 2      # Xw 12 + Xc 12 + short inlier mask 2 (p2p fp32 + mask)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 THRE_3D = 0.2                # Parameters.yml thre_3d
-PROFILE_INDEX = "profiles/r03_bench_profiles.json"   # rocprofv3 / PMC summaries of THIS command, one entry per steps-per-launch
+PROFILE_INDEX = "profiles/r04_bench_profiles.json"   # rocprofv3 / PMC summaries of THIS command, one entry per steps-per-launch
 
 
 # ------------------------------------------------------------------------------------------------ launcher (no GPU, no torch)
@@ -267,7 +267,7 @@ def collective_plan(world: int, want: str, share_gpu: bool) -> dict:
 
 
 def profile_entries():
-    """profiles/r03_bench_profiles.json: what rocprofv3 --kernel-trace --stats and the two --pmc passes recorded for bench.py's own
+    """profiles/r04_bench_profiles.json: what rocprofv3 --kernel-trace --stats and the two --pmc passes recorded for bench.py's own
     command, keyed by the steps one launch of the resident kernel served.  File-derived numbers enter the JSON line only next to the
     steps_per_launch they were recorded with."""
     try:
@@ -337,7 +337,7 @@ def hbm_roofline(local_rank):
         if case in out and isinstance(out[case], dict):
             out[case]["traffic"] = e.get("traffic_bytes_per_launch")
             out[case]["traffic_over_algorithmic"] = e.get("traffic_over_algorithmic")
-            out[case]["traffic_source"] = "profiles/r03_hbm_stream_pmc.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes over scripts/hbm_stream_probe.py)"
+            out[case]["traffic_source"] = PROFILE_INDEX + " hbm_stream (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes over scripts/hbm_stream_probe.py)"
     return out
 
 
@@ -388,6 +388,15 @@ def reference_api_roofline(local_rank, sizes=(307200, 1_000_000, 10_000_000), la
                                                           min_launch_us=mn_ms * 1e3, achieved_GBs=bpc * n / avg / 1e9, frac_of_peak=bpc * n / avg / 1e9 / HBM_PEAK_GBS)
         ctx.close()
     evictor.close()
+    prof = profile_entries().get("reference_api_kernels", {})
+    for key, e in out.items():
+        if isinstance(e, dict) and "kernel" in e and key.endswith("_steady"):
+            pe = prof.get(key[: -len("_steady")])
+            if pe:
+                e["traffic"] = pe.get("traffic_bytes_per_launch")
+                e["traffic_over_algorithmic"] = pe.get("traffic_over_algorithmic")
+                e["rocprofv3_avg_launch_us"] = pe.get("rocprofv3_avg_launch_us")
+                e["traffic_source"] = PROFILE_INDEX + " reference_api_kernels (separate --pmc passes over scripts/reference_api_probe.py)"
     out["note"] = ("K1' is timed with the 3D-3D inlier mask (shinji_ls / shinji_ls1: 24 B + 2 B); K4b re-writes the mask it reads next, so its masks are "
                    "restored by nothing -- the masked kernels run before it at every size")
     return out

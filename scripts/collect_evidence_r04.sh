@@ -1,0 +1,56 @@
+#!/bin/bash
+# Round-4 evidence on one MI355X box (through gpurun):   gpurun --timeout 3000 -- 'bash scripts/collect_evidence_r04.sh r04e'
+# GPU tests, the bench line (default and the DRIVER'S command), rocprofv3 --kernel-trace --stats and the two --pmc passes (separate
+# runs, counters only) on the driver's command / the 2000-step default / the bandwidth-bound launches / the reference-API kernels, the
+# step budget from the stamps build, the SQ counters of the streaming kernels, a fuzz campaign.  Summarised by profile_summary_r04.py.
+tag=${1:-r04e}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+drv="--gpus 1 --steps 20 --warmup 5"
+RPE_TEST_MULTIPROC=1 timeout 1800 python3 -m pytest $root/tests -m gpu -q > $out/pytest_gpu.txt 2>&1
+tail -4 $out/pytest_gpu.txt
+timeout 900 python3 $root/bench.py $drv > $out/bench_driver_cmd.json 2> $out/bench_stderr.txt
+tail -c 300 $out/bench_driver_cmd.json; echo
+timeout 900 python3 $root/bench.py > $out/bench_default_2000steps.json 2>> $out/bench_stderr.txt
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_driver -- python3 $root/bench.py $drv > $out/bench_driver_under_rocprof.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_driver_noextras -- python3 $root/bench.py $drv --no-extras --no-cpu-baseline --no-hbm > $out/bench_driver_noextras_under_rocprof.txt 2>&1
+RPE_BENCH_PREWARM_S=0.1 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_20 -- python3 $root/bench.py $drv --repeats 20 --no-extras --no-cpu-baseline --no-hbm > /dev/null 2>&1
+RPE_BENCH_PREWARM_S=0.1 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_20 -- python3 $root/bench.py $drv --repeats 20 --no-extras --no-cpu-baseline --no-hbm > /dev/null 2>&1
+RPE_BENCH_PREWARM_S=0.1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_2000 -- python3 $root/bench.py --steps 2000 --warmup 2000 --no-extras --no-cpu-baseline --no-hbm > $out/bench_2000_under_rocprof.txt 2>&1
+RPE_BENCH_PREWARM_S=0.1 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_2000 -- python3 $root/bench.py --steps 2000 --warmup 2000 --repeats 5 --no-extras --no-cpu-baseline --no-hbm > /dev/null 2>&1
+RPE_BENCH_PREWARM_S=0.1 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_2000 -- python3 $root/bench.py --steps 2000 --warmup 2000 --repeats 5 --no-extras --no-cpu-baseline --no-hbm > /dev/null 2>&1
+for d in prof_driver prof_driver_noextras prof_2000; do f=$(ls $out/$d/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/${d}_kernel_stats.csv; done
+for d in pmc_fetch_20 pmc_write_20 pmc_fetch_2000 pmc_write_2000; do f=$(ls $out/$d/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && (head -1 $f; grep normal_eq_resident $f) > $out/${d}_counters.csv; done
+rm -rf $out/prof_driver $out/prof_driver_noextras $out/prof_2000 $out/pmc_fetch_20 $out/pmc_write_20 $out/pmc_fetch_2000 $out/pmc_write_2000
+# the bandwidth-bound launches of roofline_hbm (normal_eq_kernel: 20 M / 10 M point-to-point, 1 M point-to-plane)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_hbm -- python3 $root/scripts/hbm_stream_probe.py > $out/hbm_stream_probe.json 2>/dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_hbm -- python3 $root/scripts/hbm_stream_probe.py > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_hbm -- python3 $root/scripts/hbm_stream_probe.py > /dev/null 2>&1
+f=$(ls $out/prof_hbm/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/prof_hbm_kernel_stats.csv
+f=$(ls $out/prof_hbm/*/*_kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && (head -1 $f; grep normal_eq_kernel $f) > $out/prof_hbm_kernel_trace.csv
+for d in pmc_fetch_hbm pmc_write_hbm; do f=$(ls $out/$d/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && (head -1 $f; grep normal_eq_kernel $f) > $out/${d}_counters.csv; done
+rm -rf $out/prof_hbm $out/pmc_fetch_hbm $out/pmc_write_hbm
+# the reference-API kernels (K1' moments, K5 nl_round, K4b mask), one size per process
+for n in 307200 1000000 10000000; do
+  RPE_PROBE_N=$n timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_api_$n -- python3 $root/scripts/reference_api_probe.py > $out/reference_api_probe_$n.json 2>/dev/null
+  RPE_PROBE_N=$n timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_api_$n -- python3 $root/scripts/reference_api_probe.py > /dev/null 2>&1
+  RPE_PROBE_N=$n timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_api_$n -- python3 $root/scripts/reference_api_probe.py > /dev/null 2>&1
+  f=$(ls $out/prof_api_$n/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/prof_api_${n}_kernel_stats.csv
+  for d in pmc_fetch_api_$n pmc_write_api_$n; do f=$(ls $out/$d/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && (head -1 $f; grep -E "moments_kernel|nl_round|mask_kernel" $f) > $out/${d}_counters.csv; done
+  rm -rf $out/prof_api_$n $out/pmc_fetch_api_$n $out/pmc_write_api_$n
+done
+# where a step's time goes on this tree (stamps build of the resident kernels; built here, never shipped)
+timeout 900 python3 $root/scripts/resident_timeline.py > $out/resident_timeline.jsonl 2> $out/resident_timeline.err
+rm -f $root/rgbd_pose_estimation_amd/lib/*stamps*
+# SQ counters of the streaming kernels at 1 M
+bash $root/scripts/r03_sq_pmc.sh $tag/sq > /dev/null 2>&1
+# streaming kernels by flavour, and the examples' tuned / untuned loop
+bash $root/scripts/r04_streaming_ab.sh $tag/streaming_ab > $out/streaming_ab.txt 2>&1
+$root/examples/gn_refine_main 20 50 > $out/gn_refine_main_20.txt 2>&1
+$root/examples/gn_refine_main 2000 10 > $out/gn_refine_main_2000.txt 2>&1
+# randomised campaign against the oracle on this tree
+RPE_FUZZ_SEEDS=${RPE_FUZZ_SEEDS:-1200} timeout 2400 python3 -m pytest $root/tests/test_gpu_fuzz.py -q > $out/fuzz_campaign.txt 2>&1
+tail -3 $out/fuzz_campaign.txt
+ls $out | head -80
