@@ -719,6 +719,8 @@ def worker(args, affinity):
             except Exception as e:  # noqa: BLE001
                 affinity = dict(affinity, calibration_error=repr(e))
         run_steps(pose12(R0, t0), args.warmup)
+        if os.environ.get("RPE_BENCH_INJECT_LOST_GRID"):   # tests: a workgroup withholds its sums in the timed region's refinements
+            ctx.inject_resident_fault(int(os.environ["RPE_BENCH_INJECT_LOST_GRID"]), 0.0)
 
         # ---- timed: `repeats` repetitions of EXACTLY `steps` steps, each bracketed by barrier + synchronize, MAX over ranks
         launches_per_rep = 1 if resident else args.steps

@@ -108,54 +108,66 @@ template <class T> __device__ __forceinline__ NlConst<T> nl_const(const NlParams
   for (int i = 0; i < 9; i++) k.Rwc[i] = (T)p.Rwc[i];
   return k;
 }
+// The three modality blocks of one correspondence.  Every slot of the record belongs to exactly one block (2D-3D: 0-10 and 32-40,
+// 3D-3D: 11-20, normals: 21-31), so the blocks of a group can run one after the other without changing any slot's summation order.
+template <class T>
+__device__ __forceinline__ void nl_term23(const NlConst<T>& prm, T x, T y, T z, bool on, T w23v, T bx_, T by_, T bz_, T (&acc)[44]) {
+  // 2D-3D inliers: M23 and the find_opt_cc sums.  w = 0 switches the term off.
+  const T w = on ? w23v : T(0);
+  T ax = x - prm.c_opt[0], ay = y - prm.c_opt[1], az = z - prm.c_opt[2];
+  const T n2 = ax * ax + ay * ay + az * az;
+  const T inv = T(1) / sqrt(n2);
+  ax = on ? ax * inv : T(0); ay = on ? ay * inv : T(0); az = on ? az * inv : T(0);  // selects: NaN * 0 must not reach the sums
+  const T bx = on ? bx_ : T(0), by = on ? by_ : T(0), bz = on ? bz_ : T(0);
+  acc[0] = fma(w * bx, ax, acc[0]); acc[1] = fma(w * bx, ay, acc[1]); acc[2] = fma(w * bx, az, acc[2]);
+  acc[3] = fma(w * by, ax, acc[3]); acc[4] = fma(w * by, ay, acc[4]); acc[5] = fma(w * by, az, acc[5]);
+  acc[6] = fma(w * bz, ax, acc[6]); acc[7] = fma(w * bz, ay, acc[7]); acc[8] = fma(w * bz, az, acc[8]);
+  acc[9] += w; acc[10] += on ? T(1) : T(0);
+  // find_opt_cc: v = Rwc * bv ; A = I - v v^T ; AA += A ; bb += A * Xw
+  const T vx = prm.Rwc[0] * bx + prm.Rwc[1] * by + prm.Rwc[2] * bz;
+  const T vy = prm.Rwc[3] * bx + prm.Rwc[4] * by + prm.Rwc[5] * bz;
+  const T vz = prm.Rwc[6] * bx + prm.Rwc[7] * by + prm.Rwc[8] * bz;
+  const T o = on ? T(1) : T(0);
+  const T xo = on ? x : T(0), yo = on ? y : T(0), zo = on ? z : T(0);
+  const T Axx = o - vx * vx, Axy = -vx * vy, Axz = -vx * vz, Ayy = o - vy * vy, Ayz = -vy * vz, Azz = o - vz * vz;
+  acc[32] += Axx; acc[33] += Axy; acc[34] += Axz; acc[35] += Ayy; acc[36] += Ayz; acc[37] += Azz;
+  acc[38] += Axx * xo + Axy * yo + Axz * zo;
+  acc[39] += Axy * xo + Ayy * yo + Ayz * zo;
+  acc[40] += Axz * xo + Ayz * yo + Azz * zo;
+}
+template <class T>
+__device__ __forceinline__ void nl_term33(const NlConst<T>& prm, T x, T y, T z, bool on, T w33v, T cx_, T cy_, T cz_, T (&acc)[44]) {
+  // 3D-3D inliers: centred covariance and sigma
+  const T v = on ? w33v : T(0);
+  const T ax = on ? x - prm.Cw[0] : T(0), ay = on ? y - prm.Cw[1] : T(0), az = on ? z - prm.Cw[2] : T(0);
+  const T cx = on ? cx_ - prm.Cc[0] : T(0), cy = on ? cy_ - prm.Cc[1] : T(0), cz = on ? cz_ - prm.Cc[2] : T(0);
+  acc[20] += v * (cx * cx + cy * cy + cz * cz);
+  acc[11] = fma(v * cx, ax, acc[11]); acc[12] = fma(v * cx, ay, acc[12]); acc[13] = fma(v * cx, az, acc[13]);
+  acc[14] = fma(v * cy, ax, acc[14]); acc[15] = fma(v * cy, ay, acc[15]); acc[16] = fma(v * cy, az, acc[16]);
+  acc[17] = fma(v * cz, ax, acc[17]); acc[18] = fma(v * cz, ay, acc[18]); acc[19] = fma(v * cz, az, acc[19]);
+}
+template <class T>
+__device__ __forceinline__ void nl_termnn(bool on, T wnnv, T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T (&acc)[44]) {
+  // normal-normal inliers
+  const T l = on ? wnnv : T(0);
+  const T ax = on ? nwx : T(0), ay = on ? nwy : T(0), az = on ? nwz : T(0);
+  const T cx = on ? ncx : T(0), cy = on ? ncy : T(0), cz = on ? ncz : T(0);
+  acc[21] = fma(l * cx, ax, acc[21]); acc[22] = fma(l * cx, ay, acc[22]); acc[23] = fma(l * cx, az, acc[23]);
+  acc[24] = fma(l * cy, ax, acc[24]); acc[25] = fma(l * cy, ay, acc[25]); acc[26] = fma(l * cy, az, acc[26]);
+  acc[27] = fma(l * cz, ax, acc[27]); acc[28] = fma(l * cz, ay, acc[28]); acc[29] = fma(l * cz, az, acc[29]);
+  acc[30] += l; acc[31] += on ? T(1) : T(0);
+}
 template <class T>
 __device__ __forceinline__ void nl_point(const NlConst<T>& prm, T x, T y, T z, bool on23, T w23v, T bx_, T by_, T bz_, bool on33,
     T w33v, T cx_, T cy_,
                                          T cz_, bool onnn, T wnnv, T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T (&acc)[44]) {
-  {  // 2D-3D inliers: M23 and the find_opt_cc sums.  w = 0 switches the term off.
-    const bool on = on23;
-    const T w = on ? w23v : T(0);
-    T ax = x - prm.c_opt[0], ay = y - prm.c_opt[1], az = z - prm.c_opt[2];
-    const T n2 = ax * ax + ay * ay + az * az;
-    const T inv = T(1) / sqrt(n2);
-    ax = on ? ax * inv : T(0); ay = on ? ay * inv : T(0); az = on ? az * inv : T(0);  // selects: NaN * 0 must not reach the sums
-    const T bx = on ? bx_ : T(0), by = on ? by_ : T(0), bz = on ? bz_ : T(0);
-    acc[0] = fma(w * bx, ax, acc[0]); acc[1] = fma(w * bx, ay, acc[1]); acc[2] = fma(w * bx, az, acc[2]);
-    acc[3] = fma(w * by, ax, acc[3]); acc[4] = fma(w * by, ay, acc[4]); acc[5] = fma(w * by, az, acc[5]);
-    acc[6] = fma(w * bz, ax, acc[6]); acc[7] = fma(w * bz, ay, acc[7]); acc[8] = fma(w * bz, az, acc[8]);
-    acc[9] += w; acc[10] += on ? T(1) : T(0);
-    // find_opt_cc: v = Rwc * bv ; A = I - v v^T ; AA += A ; bb += A * Xw
-    const T vx = prm.Rwc[0] * bx + prm.Rwc[1] * by + prm.Rwc[2] * bz;
-    const T vy = prm.Rwc[3] * bx + prm.Rwc[4] * by + prm.Rwc[5] * bz;
-    const T vz = prm.Rwc[6] * bx + prm.Rwc[7] * by + prm.Rwc[8] * bz;
-    const T o = on ? T(1) : T(0);
-    const T xo = on ? x : T(0), yo = on ? y : T(0), zo = on ? z : T(0);
-    const T Axx = o - vx * vx, Axy = -vx * vy, Axz = -vx * vz, Ayy = o - vy * vy, Ayz = -vy * vz, Azz = o - vz * vz;
-    acc[32] += Axx; acc[33] += Axy; acc[34] += Axz; acc[35] += Ayy; acc[36] += Ayz; acc[37] += Azz;
-    acc[38] += Axx * xo + Axy * yo + Axz * zo;
-    acc[39] += Axy * xo + Ayy * yo + Ayz * zo;
-    acc[40] += Axz * xo + Ayz * yo + Azz * zo;
-  }
-  {  // 3D-3D inliers: centred covariance and sigma
-    const bool on = on33;
-    const T v = on ? w33v : T(0);
-    const T ax = on ? x - prm.Cw[0] : T(0), ay = on ? y - prm.Cw[1] : T(0), az = on ? z - prm.Cw[2] : T(0);
-    const T cx = on ? cx_ - prm.Cc[0] : T(0), cy = on ? cy_ - prm.Cc[1] : T(0), cz = on ? cz_ - prm.Cc[2] : T(0);
-    acc[20] += v * (cx * cx + cy * cy + cz * cz);
-    acc[11] = fma(v * cx, ax, acc[11]); acc[12] = fma(v * cx, ay, acc[12]); acc[13] = fma(v * cx, az, acc[13]);
-    acc[14] = fma(v * cy, ax, acc[14]); acc[15] = fma(v * cy, ay, acc[15]); acc[16] = fma(v * cy, az, acc[16]);
-    acc[17] = fma(v * cz, ax, acc[17]); acc[18] = fma(v * cz, ay, acc[18]); acc[19] = fma(v * cz, az, acc[19]);
-  }
-  {  // normal-normal inliers
-    const bool on = onnn;
-    const T l = on ? wnnv : T(0);
-    const T ax = on ? nwx : T(0), ay = on ? nwy : T(0), az = on ? nwz : T(0);
-    const T cx = on ? ncx : T(0), cy = on ? ncy : T(0), cz = on ? ncz : T(0);
-    acc[21] = fma(l * cx, ax, acc[21]); acc[22] = fma(l * cx, ay, acc[22]); acc[23] = fma(l * cx, az, acc[23]);
-    acc[24] = fma(l * cy, ax, acc[24]); acc[25] = fma(l * cy, ay, acc[25]); acc[26] = fma(l * cy, az, acc[26]);
-    acc[27] = fma(l * cz, ax, acc[27]); acc[28] = fma(l * cz, ay, acc[28]); acc[29] = fma(l * cz, az, acc[29]);
-    acc[30] += l; acc[31] += on ? T(1) : T(0);
-  }
+  nl_term23<T>(prm, x, y, z, on23, w23v, bx_, by_, bz_, acc);
+  nl_term33<T>(prm, x, y, z, on33, w33v, cx_, cy_, cz_, acc);
+  nl_termnn<T>(onnn, wnnv, nwx, nwy, nwz, ncx, ncy, ncz, acc);
+}
+template <int A, int B, class T> __device__ __forceinline__ void nl_flush(double (&acc)[44], const T (&sg)[44]) {
+#pragma unroll
+  for (int k = A; k < B; k++) acc[k] += (double)sg[k];
 }
 
 // generic form: any subset of the arrays / masks / weights, bounds-checked loads
@@ -204,97 +216,135 @@ __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw,
   reduce_and_finish<44, kNlLd, 0, BLK>(acc, fin);
 }
 
-// the common case -- all five arrays and all three masks present, weights all or none -- without bounds checks or pointer tests in
-// the loop, and with the next group's 15 vector loads in flight while the current group is reduced (as normal_eq_kernel does)
+// a 16-byte vector in registers made opaque to the optimiser AT THIS POINT of the program (no instruction is emitted; volatile, so
+// it keeps its place between the scheduling barriers)
+template <class V> __device__ __forceinline__ void pin16_here(V& v) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  u4 t = __builtin_bit_cast(u4, v);
+  asm volatile("" : "+v"(t));
+  v = __builtin_bit_cast(V, t);
+}
+template <class T> __device__ __forceinline__ void pin_weights(T (&u)[Pk<T>::P]) {
+  typedef typename Pk<T>::V V;
+  V t;
+  __builtin_memcpy(&t, u, 16);
+  pin16_here(t);
+  __builtin_memcpy(u, &t, 16);
+}
 template <class T, int BLK, bool WEIGHT>
-__global__ __launch_bounds__(BLK) void nl_round_full_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
-    const T* __restrict__ bv,
-                                                            const T* __restrict__ nw, const T* __restrict__ nc,
-                                                            const short* __restrict__ k23, const short* __restrict__ k33,
-                                                            const short* __restrict__ knn, const T* __restrict__ w23,
-                                                            const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n, NlParams prm,
-                                                            Finish fin) {
+__global__ __launch_bounds__(BLK, 512 / BLK) void nl_round_full_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
+                                                           const T* __restrict__ bv, const T* __restrict__ nw, const T* __restrict__ nc,
+                                                           const short* __restrict__ k23, const short* __restrict__ k33,
+                                                           const short* __restrict__ knn, const T* __restrict__ w23,
+                                                           const T* __restrict__ w33, const T* __restrict__ wnn, int64_t n, NlParams prm,
+                                                           Finish fin) {
   constexpr int P = Pk<T>::P;
   typedef typename Pk<T>::V V;
-  // software pipeline depth is bounded by registers (88 for the fp64 accumulators alone): without weights all five arrays of the
-  // NEXT group are in flight during the arithmetic; with weights only the three arrays consumed first are, the normals (consumed
-  // last) and the weights are loaded at the top of the iteration that uses them
-  constexpr int NPRE = WEIGHT ? 3 : 5;
   const NlConst<T> kc = nl_const<T>(prm);
   double acc[44];
 #pragma unroll
   for (int k = 0; k < 44; k++) acc[k] = 0.0;
   const int64_t full = n / P;
   const int64_t stride = (int64_t)gridDim.x * BLK;
-  const V* __restrict__ a4[5] = {reinterpret_cast<const V*>(xw), reinterpret_cast<const V*>(xc), reinterpret_cast<const V*>(bv),
-                                 reinterpret_cast<const V*>(nw), reinterpret_cast<const V*>(nc)};
+  const V* __restrict__ pw = reinterpret_cast<const V*>(xw);
+  const V* __restrict__ pc = reinterpret_cast<const V*>(xc);
+  const V* __restrict__ pb = reinterpret_cast<const V*>(bv);
+  const V* __restrict__ pnw = reinterpret_cast<const V*>(nw);
+  const V* __restrict__ pnc = reinterpret_cast<const V*>(nc);
   int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  V cur[5][3];
-  short m[3][P];
-  if (g < full) {
+  V w0 = {}, w1 = {}, w2 = {}, b0 = {}, b1 = {}, b2 = {}, c0 = {}, c1 = {}, c2 = {}, p0 = {}, p1 = {}, p2 = {}, q0 = {}, q1 = {}, q2 = {};
+  short m23[P], m33[P], mnn[P];
+  T u23[P], u33[P], unn[P];
 #pragma unroll
-    for (int a = 0; a < NPRE; a++) { cur[a][0] = a4[a][3 * g]; cur[a][1] = a4[a][3 * g + 1]; cur[a][2] = a4[a][3 * g + 2]; }
-    load_mask_full(k23, g, m[0]); load_mask_full(k33, g, m[1]); load_mask_full(knn, g, m[2]);
+  for (int i = 0; i < P; i++) { m23[i] = m33[i] = mnn[i] = 0; u23[i] = u33[i] = unn[i] = T(1); }
+  if (g < full) {
+    w0 = pw[3 * g]; w1 = pw[3 * g + 1]; w2 = pw[3 * g + 2];
+    b0 = pb[3 * g]; b1 = pb[3 * g + 1]; b2 = pb[3 * g + 2];
+    load_mask_full(k23, g, m23);
+    if (WEIGHT) load_weight_full(w23, g, u23);
+    c0 = pc[3 * g]; c1 = pc[3 * g + 1]; c2 = pc[3 * g + 2];
+    load_mask_full(k33, g, m33);
+    if (WEIGHT) load_weight_full(w33, g, u33);
+    p0 = pnw[3 * g]; p1 = pnw[3 * g + 1]; p2 = pnw[3 * g + 2];
+    q0 = pnc[3 * g]; q1 = pnc[3 * g + 1]; q2 = pnc[3 * g + 2];
+    load_mask_full(knn, g, mnn);
+    if (WEIGHT) load_weight_full(wnn, g, unn);
   }
   while (g < full) {
     const int64_t gn = g + stride;
-    const int64_t gl = gn < full ? gn : g;  // clamp: the last iteration re-reads its own (cached) group instead of branching
-    V nxt[NPRE][3];
-    short nm[3][P];
-    T wv[3][P];
-#pragma unroll
-    for (int a = NPRE; a < 5; a++) { cur[a][0] = a4[a][3 * g]; cur[a][1] = a4[a][3 * g + 1]; cur[a][2] = a4[a][3 * g + 2]; }
-    if (WEIGHT) { load_weight_full(w23, g, wv[0]); load_weight_full(w33, g, wv[1]); load_weight_full(wnn, g, wv[2]); }
-#pragma unroll
-    for (int a = 0; a < NPRE; a++) { nxt[a][0] = a4[a][3 * gl]; nxt[a][1] = a4[a][3 * gl + 1]; nxt[a][2] = a4[a][3 * gl + 2]; }
-    load_mask_full(k23, gl, nm[0]); load_mask_full(k33, gl, nm[1]); load_mask_full(knn, gl, nm[2]);
-    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
-    unpack3(cur[0][0], cur[0][1], cur[0][2], vw);
-    unpack3(cur[1][0], cur[1][1], cur[1][2], vc);
-    unpack3(cur[2][0], cur[2][1], cur[2][2], vb);
-    unpack3(cur[3][0], cur[3][1], cur[3][2], vnw);
-    unpack3(cur[4][0], cur[4][1], cur[4][2], vnc);
+    const int64_t gl = gn < full ? gn : g;  // clamp: the last trip re-reads its own (cached) group instead of branching
+    const V x0 = pw[3 * gl], x1 = pw[3 * gl + 1], x2 = pw[3 * gl + 2];   // the world points are read by two blocks: double-buffered
+    __builtin_amdgcn_sched_barrier(0);
+    T vw[3 * P], va[3 * P], vb[3 * P];
     T sg[44];
 #pragma unroll
     for (int k = 0; k < 44; k++) sg[k] = T(0);
+    // the vectors a block consumes become opaque 16-byte values HERE: any repacking the optimiser wants for its packed arithmetic
+    // happens after this point, not right behind the loads (where it would wait for them with everything else still in flight)
+    pin16_here(w0); pin16_here(w1); pin16_here(w2); pin16_here(b0); pin16_here(b1); pin16_here(b2);
+    if (WEIGHT) pin_weights<T>(u23);
+    unpack3(w0, w1, w2, vw);
+    unpack3(b0, b1, b2, va);
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], m[0][i] == 1, WEIGHT ? wv[0][i] : T(1), vb[3 * i], vb[3 * i + 1],
-          vb[3 * i + 2],
-                  m[1][i] == 1, WEIGHT ? wv[1][i] : T(1), vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], m[2][i] == 1, WEIGHT ? wv[2][i] : T(1),
-                  vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], sg);
+      nl_term23<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], m23[i] == 1, WEIGHT ? u23[i] : T(1), va[3 * i], va[3 * i + 1], va[3 * i + 2], sg);
     }
+    nl_flush<0, 11>(acc, sg); nl_flush<32, 41>(acc, sg);
+    __builtin_amdgcn_sched_barrier(0);
+    b0 = pb[3 * gl]; b1 = pb[3 * gl + 1]; b2 = pb[3 * gl + 2];
+    load_mask_full(k23, gl, m23);
+    if (WEIGHT) load_weight_full(w23, gl, u23);
+    __builtin_amdgcn_sched_barrier(0);
+    pin16_here(c0); pin16_here(c1); pin16_here(c2);
+    if (WEIGHT) pin_weights<T>(u33);
+    unpack3(c0, c1, c2, va);
 #pragma unroll
-    for (int k = 0; k < 44; k++) acc[k] += (double)sg[k];
-#pragma unroll
-    for (int a = 0; a < NPRE; a++) { cur[a][0] = nxt[a][0]; cur[a][1] = nxt[a][1]; cur[a][2] = nxt[a][2]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-#pragma unroll
-      for (int i = 0; i < P; i++) m[k][i] = nm[k][i];
+    for (int i = 0; i < P; i++) {
+      nl_term33<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], m33[i] == 1, WEIGHT ? u33[i] : T(1), va[3 * i], va[3 * i + 1], va[3 * i + 2], sg);
     }
+    nl_flush<11, 21>(acc, sg);
+    __builtin_amdgcn_sched_barrier(0);
+    c0 = pc[3 * gl]; c1 = pc[3 * gl + 1]; c2 = pc[3 * gl + 2];
+    load_mask_full(k33, gl, m33);
+    if (WEIGHT) load_weight_full(w33, gl, u33);
+    __builtin_amdgcn_sched_barrier(0);
+    pin16_here(p0); pin16_here(p1); pin16_here(p2); pin16_here(q0); pin16_here(q1); pin16_here(q2);
+    if (WEIGHT) pin_weights<T>(unn);
+    unpack3(p0, p1, p2, va);
+    unpack3(q0, q1, q2, vb);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      nl_termnn<T>(mnn[i] == 1, WEIGHT ? unn[i] : T(1), va[3 * i], va[3 * i + 1], va[3 * i + 2], vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], sg);
+    }
+    nl_flush<21, 32>(acc, sg);
+    __builtin_amdgcn_sched_barrier(0);
+    p0 = pnw[3 * gl]; p1 = pnw[3 * gl + 1]; p2 = pnw[3 * gl + 2];
+    q0 = pnc[3 * gl]; q1 = pnc[3 * gl + 1]; q2 = pnc[3 * gl + 2];
+    load_mask_full(knn, gl, mnn);
+    if (WEIGHT) load_weight_full(wnn, gl, unn);
+    __builtin_amdgcn_sched_barrier(0);
+    w0 = x0; w1 = x1; w2 = x2;
     g = gn;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences through the bounds-checked loaders
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
     short a23[P], a33[P], ann[P];
-    T u23[P], u33[P], unn[P];
+    T t23[P], t33[P], tnn[P];
     load_group<T>(xw, full, n, vw); load_group<T>(xc, full, n, vc); load_group<T>(bv, full, n, vb);
     load_group<T>(nw, full, n, vnw); load_group<T>(nc, full, n, vnc);
     load_mask_group(k23, full, n, a23); load_mask_group(k33, full, n, a33); load_mask_group(knn, full, n, ann);
-    if (WEIGHT) { load_weight_group(w23, full, n, u23); load_weight_group(w33, full, n, u33); load_weight_group(wnn, full, n, unn); }
+    if (WEIGHT) { load_weight_group(w23, full, n, t23); load_weight_group(w33, full, n, t33); load_weight_group(wnn, full, n, tnn); }
     T sg[44];
 #pragma unroll
     for (int k = 0; k < 44; k++) sg[k] = T(0);
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], a23[i] == 1, WEIGHT ? u23[i] : T(1), vb[3 * i], vb[3 * i + 1],
-          vb[3 * i + 2],
-                  a33[i] == 1, WEIGHT ? u33[i] : T(1), vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], ann[i] == 1, WEIGHT ? unn[i] : T(1),
-                  vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], sg);
+      nl_point<T>(kc, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], a23[i] == 1, WEIGHT ? t23[i] : T(1), vb[3 * i], vb[3 * i + 1],
+                  vb[3 * i + 2], a33[i] == 1, WEIGHT ? t33[i] : T(1), vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], ann[i] == 1,
+                  WEIGHT ? tnn[i] : T(1), vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], sg);
     }
-#pragma unroll
-    for (int k = 0; k < 44; k++) acc[k] += (double)sg[k];
+    nl_flush<0, 44>(acc, sg);
   }
   reduce_and_finish<44, kNlLd, 0, BLK>(acc, fin);
 }
@@ -431,8 +481,8 @@ static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, cons
   NlParams prm;
   for (int i = 0; i < 3; i++) { prm.c_opt[i] = params24[i]; prm.Cw[i] = params24[3 + i]; prm.Cc[i] = params24[6 + i]; }
   for (int i = 0; i < 9; i++) prm.Rwc[i] = params24[9 + i];
-  // 44 fp64 accumulators + a software-pipelined group need ~250 VGPRs: 256-thread workgroups (one wave per SIMD, no spills) beat
-  // 512-thread ones here (10 M correspondences: 135 us vs 137 us unweighted, 158 us vs 172 us weighted; 307 200: 29 us vs 31 us)
+  // 44 fp64 accumulators + one group of streamed data need ~240 VGPRs (two waves per SIMD, no spills): 256-thread workgroups unless
+  // the caller's reduce target asks for 512 (the same two waves per SIMD in half as many workgroups)
   if (rt.block == 512) nl_round_launch<T, 512>(A, prm, rt, s, e0, e1);
   else nl_round_launch<T, 256>(A, prm, rt, s, e0, e1);
   return hipGetLastError();
