@@ -349,65 +349,162 @@ __global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict
 
 // P flags of one group as ONE store (8 bytes for fp32 / P = 4, 4 bytes for fp64 / P = 2): a thread owns P consecutive
 // correspondences, so its shorts are contiguous; 2-byte scattered stores cost an order of magnitude more per byte.
+// the masks are written once and not read by this kernel: nontemporal stores (2-3 % of the launch at 10 M correspondences)
 __device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[4]) {
-  uint2 u;
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  u2 u;
   u.x = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
   u.y = (unsigned int)v[2] | ((unsigned int)v[3] << 16);
-  *reinterpret_cast<uint2*>(m + 4 * g) = u;
+  __builtin_nontemporal_store(u, reinterpret_cast<u2*>(m + 4 * g));
 }
 __device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g, const bool (&v)[2]) {
-  *reinterpret_cast<unsigned int*>(m + 2 * g) = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+  __builtin_nontemporal_store((unsigned int)v[0] | ((unsigned int)v[1] << 16), reinterpret_cast<unsigned int*>(m + 2 * g));
 }
 
 template <class T> struct PoseArg { T v[12]; };  // one hypothesis by value (kernel argument): no H2D copy for a single pose
 
+// a 16-byte vector in registers made opaque to the optimiser at this point of the program (no instruction is emitted)
+template <class V> __device__ __forceinline__ void pin16_here(V& v) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  u4 t = __builtin_bit_cast(u4, v);
+  asm("" : "+v"(t));
+  v = __builtin_bit_cast(V, t);
+}
+// the inlier flags of ONE hypothesis over one full group: the predicates of count_group_votes (EXACT: pairs of correspondences as
+// 2-vectors, one rotation of the world point for the 3D and the 2D test, the 2D test behind its wave-uniform filter), kept as flags
 template <class T, int KIND, bool EXACT>
-__global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
-                                                      const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
-                                                      PoseArg<T> pose, T thr33, T cthr, T cnl, short* __restrict__ m23,
-                                                      short* __restrict__ m33, short* __restrict__ mnn, Finish fin) {
+__device__ __forceinline__ void group_flags(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
+                                            const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
+                                            T thr33, T cthr, T cnl, bool (&f23)[Pk<T>::P], bool (&f33)[Pk<T>::P], bool (&fnn)[Pk<T>::P]) {
   constexpr int P = Pk<T>::P;
   typedef VoteMods<KIND> MD;
+  bool valid[P];
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    valid[i] = !MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]);
+    f23[i] = f33[i] = fnn[i] = false;
+  }
+  if constexpr (EXACT) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    static_assert(P % 2 == 0, "pairs");
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+      const int a = 2 * j, b = 2 * j + 1;
+      const V2 x = {vw[3 * a], vw[3 * b]}, y = {vw[3 * a + 1], vw[3 * b + 1]}, z = {vw[3 * a + 2], vw[3 * b + 2]};
+      if (MD::mnn) {
+        const V2 nwx = {vnw[3 * a], vnw[3 * b]}, nwy = {vnw[3 * a + 1], vnw[3 * b + 1]}, nwz = {vnw[3 * a + 2], vnw[3 * b + 2]};
+        const V2 ncx = {vnc[3 * a], vnc[3 * b]}, ncy = {vnc[3 * a + 1], vnc[3 * b + 1]}, ncz = {vnc[3 * a + 2], vnc[3 * b + 2]};
+        bool va, vb2;
+        hyp.innnx2(nwx, nwy, nwz, ncx, ncy, ncz, cnl, va, vb2);
+        fnn[a] = valid[a] & va; fnn[b] = valid[b] & vb2;
+      }
+      V2 rx, ry, rz;
+      if (KIND == VOTE_23_MATRIX) hyp.rotm2(x, y, z, rx, ry, rz); else hyp.rot2(x, y, z, rx, ry, rz);
+      if (MD::m33) {
+        const V2 cx = {vc[3 * a], vc[3 * b]}, cy = {vc[3 * a + 1], vc[3 * b + 1]}, cz = {vc[3 * a + 2], vc[3 * b + 2]};
+        bool va, vb2;
+        hyp.in33_rot_x2(rx, ry, rz, cx, cy, cz, thr33, va, vb2);
+        f33[a] = valid[a] & va; f33[b] = valid[b] & vb2;
+      }
+      if (MD::m23) {
+        const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
+        hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, f23[a], f23[b]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+      if (MD::mnn) fnn[i] = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
+      if (MD::m33) f33[i] = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
+      if (MD::m23) f23[i] = hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
+    }
+  }
+}
+// K4b: the winner's inlier masks.  The next group's vector loads are in flight while the current group's predicates are evaluated and
+// its masks stored (the software pipeline of normal_eq_kernel, pinned down the same way).  What keeps the kinds with two or three
+// masks at 0.66 of the HBM peak at 10 M correspondences is the STORES: with the stores compiled out the same loops run at 0.81-0.88
+// (36.8 / 61.0 / 101.9 us against 41.2 / 76.0 / 125.4 for one / two / three masks, profiles/r04_k4b_stores_ab.jsonl) -- 20 MB of
+// mask cost 4 / 15 / 23 us, far more than their share of the bytes; writes interleaved with a read stream are what the memory
+// system likes least.
+template <class T, int KIND, bool EXACT>
+__global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                           const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                           PoseArg<T> pose, T thr33, T cthr, T cnl, short* __restrict__ m23,
+                                                           short* __restrict__ m33, short* __restrict__ mnn, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  typedef typename Pk<T>::V V;
+  typedef VoteMods<KIND> MD;
+  constexpr bool need[5] = {true, MD::need_xc, MD::m23, MD::mnn, MD::mnn};
   Hyp<T, EXACT> hyp;
   hyp.load(pose.v, KIND == VOTE_23_MATRIX);
   int cnt = 0;
-  const int64_t groups = (n + P - 1) / P, full = n / P;
+  const int64_t full = n / P;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+  const V* __restrict__ a4[5] = {reinterpret_cast<const V*>(xw), reinterpret_cast<const V*>(xc), reinterpret_cast<const V*>(bv),
+                                 reinterpret_cast<const V*>(nw), reinterpret_cast<const V*>(nc)};
+  int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  V cur[5][3];
+#pragma unroll
+  for (int a = 0; a < 5; a++) { cur[a][0] = V{}; cur[a][1] = V{}; cur[a][2] = V{}; }
+  if (g < full) {
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+      if (need[a]) { cur[a][0] = a4[a][3 * g]; cur[a][1] = a4[a][3 * g + 1]; cur[a][2] = a4[a][3 * g + 2]; }
+  }
+  while (g < full) {
+    const int64_t gn = g + stride;
+    const int64_t gl = gn < full ? gn : g;  // clamp: the last trip re-reads its own (cached) group instead of branching
+    V nxt[5][3];
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+      if (need[a]) { nxt[a][0] = a4[a][3 * gl]; nxt[a][1] = a4[a][3 * gl + 1]; nxt[a][2] = a4[a][3 * gl + 2]; }
+    __builtin_amdgcn_sched_barrier(0);
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
-    load_group<T>(xw, g, n, vw);
-    if (MD::need_xc) load_group<T>(xc, g, n, vc);
-    if (MD::m23) load_group<T>(bv, g, n, vb);
-    if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+    unpack3(cur[0][0], cur[0][1], cur[0][2], vw);
+    if (MD::need_xc) unpack3(cur[1][0], cur[1][1], cur[1][2], vc);
+    if (MD::m23) unpack3(cur[2][0], cur[2][1], cur[2][2], vb);
+    if (MD::mnn) { unpack3(cur[3][0], cur[3][1], cur[3][2], vnw); unpack3(cur[4][0], cur[4][1], cur[4][2], vnc); }
     bool f23[P], f33[P], fnn[P];
+    group_flags<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, thr33, cthr, cnl, f23, f33, fnn);
+#pragma unroll
+    for (int i = 0; i < P; i++) cnt += (int)fnn[i] + (int)f33[i] + (int)f23[i];
+    if (MD::mnn) store_mask_full(mnn, g, fnn);
+    if (MD::m33) store_mask_full(m33, g, f33);
+    if (MD::m23) store_mask_full(m23, g, f23);
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+      if (need[a]) { cur[a][0] = nxt[a][0]; cur[a][1] = nxt[a][1]; cur[a][2] = nxt[a][2]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+      if (need[a]) { pin16_here(cur[a][0]); pin16_here(cur[a][1]); pin16_here(cur[a][2]); }
+    g = gn;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences through the bounds-checked loaders
+    T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+    load_group<T>(xw, full, n, vw);
+    if (MD::need_xc) load_group<T>(xc, full, n, vc);
+    if (MD::m23) load_group<T>(bv, full, n, vb);
+    if (MD::mnn) { load_group<T>(nw, full, n, vnw); load_group<T>(nc, full, n, vnc); }
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      const bool present = (g * P + i) < n;
-      const bool valid = present & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
-      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
-      fnn[i] = MD::mnn ? (valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2],
-          cnl)) : false;
-      f33[i] = MD::m33 ? (valid & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33)) : false;
-      f23[i] = MD::m23 ? (present & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX)) : false;
-      cnt += (int)fnn[i] + (int)f33[i] + (int)f23[i];
-    }
-    if (g < full) {
-      if (MD::mnn) store_mask_full(mnn, g, fnn);
-      if (MD::m33) store_mask_full(m33, g, f33);
-      if (MD::m23) store_mask_full(m23, g, f23);
-    } else {
-#pragma unroll
-      for (int i = 0; i < P; i++) {
-        const int64_t idx = g * P + i;
-        if (idx < n) {
-          if (MD::mnn) mnn[idx] = fnn[i];
-          if (MD::m33) m33[idx] = f33[i];
-          if (MD::m23) m23[idx] = f23[i];
-        }
+      const int64_t idx = full * P + i;
+      if (idx < n) {
+        const bool valid = !MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]);
+        const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+        const bool fn = MD::mnn ? (valid & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2],
+            cnl)) : false;
+        const bool f3 = MD::m33 ? (valid & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33)) : false;
+        const bool f2 = MD::m23 ? hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX) : false;
+        cnt += (int)fn + (int)f3 + (int)f2;
+        if (MD::mnn) mnn[idx] = fn;
+        if (MD::m33) m33[idx] = f3;
+        if (MD::m23) m23[idx] = f2;
       }
     }
   }
-  // the vote total rides the same in-launch reduction + pinned-host publish as the normal equations (exact: integers < 2^53)
   double acc[1] = {(double)cnt};
   reduce_and_finish<1, kNeLd, 0, kBlock>(acc, fin);
 }
@@ -428,10 +525,28 @@ static void score_launch(const DeviceArrays& A, const void* d_poses, int H, cons
                      (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, hchunk, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
 }
 template <class T, int KIND, bool EXACT>
-static void mask_launch(const DeviceArrays& A, const double* pose12, const double* thr, const ReduceTarget& rt, int G, hipStream_t s,
+static void mask_launch(const DeviceArrays& A, const double* pose12, const double* thr, const ReduceTarget& rt, hipStream_t s,
     hipEvent_t e0, hipEvent_t e1) {
   PoseArg<T> pa;
   for (int i = 0; i < 12; i++) pa.v[i] = (T)pose12[i];
+  // As many workgroups as are RESIDENT at once, no more: the kernel needs 136-147 VGPRs, so three 256-thread workgroups fit a CU, and
+  // a fourth per CU (the round-3 grid of 1024) ran as a second, one-third-full pass: 81-84 against 75-76 us at 10 M correspondences
+  // for the 3D + 2D masks (profiles/r04_k4b_pipeline_ab.jsonl tag pipe1 = 1024 workgroups, r04_k4b_stores_ab.jsonl tag store1 = 768).
+  // Asked of the runtime once per instantiation.
+  static const int resident = [] {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)mask_kernel<T, KIND, EXACT>, kBlock, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 3;
+    }
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    return per_cu * cus;
+  }();
+  const int cap = resident > 4096 ? 4096 : resident;   // one partial record per workgroup: the scratch holds 4096
+  const int G = grid_for(A.n, Pk<T>::P, cap);
   RPE_LAUNCH_EV((mask_kernel<T, KIND, EXACT>), dim3(G), dim3(kBlock), 0, s, e0, e1, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
                      (const T*)A.a[3], (const T*)A.a[4], A.n, pa, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2],
                      make_finish(rt));
@@ -509,15 +624,12 @@ hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const 
 }
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
                        hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  const int cap = rt.max_blocks < 1024 ? 1024 : rt.max_blocks;  // streaming + stores: 4 workgroups of 256 per CU
   if (A.dtype) {
-    const int G = grid_for(A.n, 2, cap);
-    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, pose12, thr3, rt, G, s, e0, e1) }
-    else { RPE_KIND_SWITCH(mask_launch, double, false, A, pose12, thr3, rt, G, s, e0, e1) }
+    if (exact) { RPE_KIND_SWITCH(mask_launch, double, true, A, pose12, thr3, rt, s, e0, e1) }
+    else { RPE_KIND_SWITCH(mask_launch, double, false, A, pose12, thr3, rt, s, e0, e1) }
   } else {
-    const int G = grid_for(A.n, 4, cap);
-    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, pose12, thr3, rt, G, s, e0, e1) }
-    else { RPE_KIND_SWITCH(mask_launch, float, false, A, pose12, thr3, rt, G, s, e0, e1) }
+    if (exact) { RPE_KIND_SWITCH(mask_launch, float, true, A, pose12, thr3, rt, s, e0, e1) }
+    else { RPE_KIND_SWITCH(mask_launch, float, false, A, pose12, thr3, rt, s, e0, e1) }
   }
   return hipGetLastError();
 }
