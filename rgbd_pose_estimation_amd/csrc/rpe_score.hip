@@ -531,7 +531,7 @@ static void mask_launch(const DeviceArrays& A, const double* pose12, const doubl
   for (int i = 0; i < 12; i++) pa.v[i] = (T)pose12[i];
   // As many workgroups as are RESIDENT at once, no more: the kernel needs 136-147 VGPRs, so three 256-thread workgroups fit a CU, and
   // a fourth per CU (the round-3 grid of 1024) ran as a second, one-third-full pass: 81-84 against 75-76 us at 10 M correspondences
-  // for the 3D + 2D masks (profiles/r04_k4b_pipeline_ab.jsonl tag pipe1 = 1024 workgroups, r04_k4b_stores_ab.jsonl tag store1 = 768).
+  // for the 3D + 2D masks (profiles/r04_grid_sweep.txt).
   // Asked of the runtime once per instantiation.
   static const int resident = [] {
     int per_cu = 0, dev = 0, cus = 0;
