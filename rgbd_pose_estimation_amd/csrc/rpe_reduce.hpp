@@ -370,6 +370,13 @@ template <int MODE> __device__ __forceinline__ double record_entry(const double*
 //    closed forms.
 // Fully unrolled so that every matrix entry is a register.  Results agree with the host's LDL^T + rpe::se3_exp to rounding (checked
 // against the golden to 1e-13: tests/test_gpu_joint.py, rpe_debug_device_gn_update).
+// Tried and rejected in round 4: the same solve spread over ONE WAVE (lane 8 i + j holds U[i][j] or b[i]; pivot by v_readlane, row k
+// gathered by ds_bpermute, one fma per elimination step; pose update one entry per lane).  An instruction costs a wave its four
+// cycles whether one lane is active or all, and of the ~600 instructions of this function only ~120 are the elimination: the wave
+// form executes about as many (selects, gathers and their waits replace the multiply-adds).  Per iteration of the autonomous loop
+// (scripts/device_loop_time.py, profiles/r04_device_solve_wave_ab.jsonl; wave form against this one): point-to-point at 307 200
+// correspondences 6.14-6.18 against 5.78 us, point-to-plane 6.32-6.35 against 6.54, joint 9.11-9.15 against 9.19; one workgroup
+// (1 000 correspondences) 4.31-4.38 / 4.41-4.49 / 5.83-5.89 against 4.02 / 4.60 / 6.01 -- no gain beyond the noise between boxes.
 static __device__ __forceinline__ double rcp_newton(double d) {
   double y = __builtin_amdgcn_rcp(d);
   double e = fma(-d, y, 1.0);
