@@ -30,10 +30,13 @@ template <class T> struct Hyp<T, false> {
     oz = fma(R[6], x, fma(R[7], y, R[8] * z));
   }
   // fast forms: squared distance / squared cosine compares (no sqrt, no divide)
+  // (the transformed point is formed exactly as in23 forms it: a kind with both tests transforms once -- the common subexpression --
+  // instead of twice; 9 of 33 multiply-adds per correspondence and hypothesis)
   __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T thr_sq) const {
-    const T ex = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0] - cx)));
-    const T ey = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1] - cy)));
-    const T ez = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2] - cz)));
+    const T px = fma(R[0], x, fma(R[1], y, fma(R[2], z, t[0])));
+    const T py = fma(R[3], x, fma(R[4], y, fma(R[5], z, t[1])));
+    const T pz = fma(R[6], x, fma(R[7], y, fma(R[8], z, t[2])));
+    const T ex = px - cx, ey = py - cy, ez = pz - cz;
     return fma(ex, ex, fma(ey, ey, ez * ez)) < thr_sq;
   }
   __device__ __forceinline__ bool in23(T x, T y, T z, T bx, T by, T bz, T c, bool) const {
@@ -185,13 +188,23 @@ template <class T> struct Hyp<T, true> {
   }
 };
 
+// votes of a predicate over the wave, among the lanes of `mask`: the compare's lane mask IS the ballot (__builtin_amdgcn_ballot_w64 on
+// the compare itself), the hypothesis-independent part of the predicate (present / valid) is a wave mask taken once per group and
+// applied with one scalar AND, one s_bcnt1 counts.  __ballot(valid & pred) made the compiler materialise the combined predicate as
+// a 0 / 1 VGPR and compare it with zero again: two vector instructions per predicate, 8 of the 46 per hypothesis and group in the 3D
+// fast loop (profiles/r04_score_sq_counters.json).
+typedef unsigned long long wave_mask_t;
+__device__ __forceinline__ int votes_of(wave_mask_t mask, bool pred) {
+  return __builtin_popcountll(__builtin_amdgcn_ballot_w64(pred) & mask);
+}
+
 // votes of ONE hypothesis over one group of P correspondences, summed over the wave (every lane gets the wave's count).  Predicates are
 // evaluated unconditionally and masked with '&': no divergent branches; the compare IS the ballot.  EXACT: the 3D and normal tests run
 // on pairs of correspondences as 2-vectors (packed fp32 instructions), the 2D test (a square root and three divisions) stays scalar.
 template <class T, int KIND, bool EXACT>
 __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
                                                  const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
-                                                 const bool (&present)[Pk<T>::P], const bool (&valid)[Pk<T>::P], T thr33, T cthr, T cnl) {
+                                                 const wave_mask_t (&present)[Pk<T>::P], const wave_mask_t (&valid)[Pk<T>::P], T thr33, T cthr, T cnl) {
   constexpr int P = Pk<T>::P;
   typedef VoteMods<KIND> MD;
   int cnt = 0;
@@ -207,7 +220,7 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
         const V2 ncx = {vnc[3 * a], vnc[3 * b]}, ncy = {vnc[3 * a + 1], vnc[3 * b + 1]}, ncz = {vnc[3 * a + 2], vnc[3 * b + 2]};
         bool va, vb2;
         hyp.innnx2(nwx, nwy, nwz, ncx, ncy, ncz, cnl, va, vb2);
-        cnt += __popcll(__ballot(valid[a] & va)) + __popcll(__ballot(valid[b] & vb2));
+        cnt += votes_of(valid[a], va) + votes_of(valid[b], vb2);
       }
       V2 rx, ry, rz;
       if (KIND == VOTE_23_MATRIX) hyp.rotm2(x, y, z, rx, ry, rz); else hyp.rot2(x, y, z, rx, ry, rz);
@@ -215,13 +228,13 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
         const V2 cx = {vc[3 * a], vc[3 * b]}, cy = {vc[3 * a + 1], vc[3 * b + 1]}, cz = {vc[3 * a + 2], vc[3 * b + 2]};
         bool va, vb2;
         hyp.in33_rot_x2(rx, ry, rz, cx, cy, cz, thr33, va, vb2);
-        cnt += __popcll(__ballot(valid[a] & va)) + __popcll(__ballot(valid[b] & vb2));
+        cnt += votes_of(valid[a], va) + votes_of(valid[b], vb2);
       }
       if (MD::m23) {
         const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
         bool va, vb2;
         hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, va, vb2);
-        cnt += __popcll(__ballot(present[a] & va)) + __popcll(__ballot(present[b] & vb2));
+        cnt += votes_of(present[a], va) + votes_of(present[b], vb2);
       }
     }
   } else {
@@ -229,16 +242,13 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
     for (int i = 0; i < P; i++) {
       const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
       if (MD::mnn) {
-        const bool v = valid[i] & hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl);
-        cnt += __popcll(__ballot(v));
+        cnt += votes_of(valid[i], hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl));
       }
       if (MD::m33) {
-        const bool v = valid[i] & hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33);
-        cnt += __popcll(__ballot(v));
+        cnt += votes_of(valid[i], hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33));
       }
       if (MD::m23) {
-        const bool v = present[i] & hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX);
-        cnt += __popcll(__ballot(v));
+        cnt += votes_of(present[i], hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX));
       }
     }
   }
@@ -267,24 +277,36 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
   for (int64_t gb = (int64_t)blockIdx.x * kBlock; gb < groups; gb += stride) {
     const int64_t g = gb + threadIdx.x;
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
-    bool present[P], valid[P];
+    wave_mask_t present[P], valid[P];   // hypothesis-independent: lane masks, once per group
     load_group<T>(xw, g, n, vw);
     if (MD::need_xc) load_group<T>(xc, g, n, vc);
     if (MD::m23) load_group<T>(bv, g, n, vb);
     if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      present[i] = (g * P + i) < n;
-      valid[i] = present[i] & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+      const bool here = (g * P + i) < n;
+      present[i] = __builtin_amdgcn_ballot_w64(here);
+      valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
     }
     for (int h0 = 0; h0 < hcnt; h0 += 64) {
       const int hmax = min(64, hcnt - h0);
       int mine = 0;
-      for (int hl = 0; hl < hmax; hl++) {
-        Hyp<T, EXACT> hyp;
-        hyp.load(poses + (size_t)(hbeg + h0 + hl) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
-        const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
-        mine += (lane == hl) ? cnt : 0;
+      // HU hypotheses per trip: their scalar loads are issued together and waited for once -- with one hypothesis per trip a wave of the
+      // 3D fast kind spent 47 % of its life in that wait (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r04_score_sq_counters.json; a prefetch
+      // of the next hypothesis is sunk back to its use by the compiler, so the wait is shared instead of hidden).  Four where the
+      // registers allow, two for the exact 2D test (profiles/r04_score_hypotheses_per_trip_ab.txt).
+      constexpr int HU = (MD::m23 && EXACT) ? 2 : 4;
+      const T* hp = poses + (size_t)(hbeg + h0) * Hyp<T, EXACT>::STRIDE;
+      for (int hl = 0; hl < hmax; hl += HU) {
+        Hyp<T, EXACT> hyp[HU];
+#pragma unroll
+        for (int u = 0; u < HU; u++)   // past the end of the list: the last hypothesis again (its count is dropped below)
+          hyp[u].load(hp + (size_t)(hl + u < hmax ? hl + u : hmax - 1) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
+#pragma unroll
+        for (int u = 0; u < HU; u++) {
+          const int cnt = count_group_votes<T, KIND, EXACT>(hyp[u], vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
+          mine = (lane == hl + u) ? cnt : mine;   // every hypothesis once per block of 64, `mine` starts at 0: a select, not an add
+        }
       }
       if (lane < hmax && mine != 0) atomicAdd(&lds_votes[h0 + lane], mine);
     }
@@ -323,15 +345,16 @@ __global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict
   for (int64_t gb = (int64_t)blockIdx.x * tile; gb < groups; gb += stride) {
     const int64_t g = gb + (wave % per_copy) * 64 + lane;
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
-    bool present[P], valid[P];
+    wave_mask_t present[P], valid[P];   // hypothesis-independent: lane masks, once per group
     load_group<T>(xw, g, n, vw);
     if (MD::need_xc) load_group<T>(xc, g, n, vc);
     if (MD::m23) load_group<T>(bv, g, n, vb);
     if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      present[i] = (g * P + i) < n;
-      valid[i] = present[i] & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2]));
+      const bool here = (g * P + i) < n;
+      present[i] = __builtin_amdgcn_ballot_w64(here);
+      valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
     }
     for (int hl = copy; hl < H; hl += hs) {
       Hyp<T, EXACT> hyp;
