@@ -89,3 +89,58 @@ def test_non_unit_bearings_keep_the_oracles_votes(gpu_ctx_factory, oracle, scale
         assert len(set(v.tolist())) >= 3               # points do sit on the threshold
         tot = ctx.inlier_mask(kind, poses[0], 0.05, cos_thr, 0.999, mode=L.SCORE_EXACT)
         assert tot == vo[0]
+
+
+# ---- the 3D vote of long lists (the table kernel): correspondences ON the 3D threshold, for scenes far from the origin, large scenes and
+# hypotheses with non-unit quaternions.  Written for a matrix-form filter of the exact 3D test that was measured and removed
+# (profiles/r04_score_3d_filter_rejected.txt); kept because they pin the exact-mode 3D vote where rounding decides it.
+def _near_3d_threshold_scene(n, dt, seed, thre_3d, offset=0.0, coord_scale=1.0):
+    """camera points constructed so that |Xc - (R Xw + t)| lands within a few hundred ulps of thre_3d for the TRUE pose"""
+    rng = np.random.default_rng(seed)
+    sc = util.scene_full(seed, n, np.float64, n2d=0.0, n3d=0.01, nnl_deg=1.0, outliers=0.0)
+    sc.Q = sc.Q * coord_scale
+    sc.t = sc.t * coord_scale + offset
+    p = sc.Q @ sc.R.T + sc.t
+    d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a third of the points ON the threshold (+- 300 ulps of the COORDINATES' magnitude, which is what the rounding scales with), a third
+    # well inside, a third well outside
+    mag = np.abs(p).max(axis=1) + thre_3d
+    eps = np.finfo(dt).eps
+    r = np.where(np.arange(n) % 3 == 0, thre_3d + rng.integers(-300, 301, n) * eps * mag, np.where(np.arange(n) % 3 == 1, 0.3 * thre_3d, 3.0 * thre_3d))
+    sc.P = p + d * r[:, None]
+    sc.P[0] = np.nan          # NaN-marked: invalid, must not vote and must not force anything
+    sc.Q[1] = np.nan
+    sc.Q[2] = 1e25
+    sc.P[3] = np.inf
+    return sc.astype(dt)
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("kind", [L.VOTE_33, L.VOTE_NN_33])
+@pytest.mark.parametrize("case", ["plain", "far_from_origin", "large_scene", "non_unit_quaternion"])
+def test_3d_votes_on_the_threshold_are_the_oracles_long_lists(gpu_ctx_factory, oracle, kind, f64, case):
+    dt = np.float64 if f64 else np.float32
+    n, thre_3d = 20000, 0.2
+    sc = _near_3d_threshold_scene(n, dt, 91, thre_3d, offset=500.0 if case == "far_from_origin" else 0.0, coord_scale=40.0 if case == "large_scene" else 1.0)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    rng = np.random.default_rng(2)
+    q_true = oracle.pose7_from_Rt(sc.R, sc.t, f64)
+    H = 80                                                       # > 32: the table kernel
+    poses = np.tile(q_true, (H, 1))
+    poses[1:, :4] += 3e-8 * rng.standard_normal((H - 1, 4))      # rotations a few ulps apart: residuals move across the threshold
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    poses[40:, 4:] += 1e-7 * np.abs(poses[40:, 4:]).max() * rng.standard_normal((H - 40, 3))
+    if case == "non_unit_quaternion":
+        poses[::2, :4] *= 1.37                                   # the API does not renormalise: Eigen's sequence scales the rotation by |q|^2
+        poses[1::4, :4] *= 0.6
+    poses[5, 4:] = np.nan                                        # a NaN hypothesis: zero votes, as the oracle
+    poses = np.ascontiguousarray(poses.astype(dt).astype(np.float64))
+    v = ctx.score(kind, poses, thre_3d, 2.0, 0.999, mode=L.SCORE_EXACT)
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    okind = {L.VOTE_33: oracle.V_33, L.VOTE_NN_33: oracle.V_NN_33}[kind]
+    vo = oracle.votes(prob, okind, poses, thre_3d=thre_3d, cos_thr=2.0, cos_nl=0.999)
+    assert np.array_equal(v, vo), (v[:8], vo[:8])
+    if case != "non_unit_quaternion":
+        assert len(set(v.tolist())) >= 3   # points do sit on the threshold: hypotheses a few ulps apart get different counts
+    # the short-list kernel agrees hypothesis by hypothesis
+    assert np.array_equal(ctx.score(kind, poses[:16], thre_3d, 2.0, 0.999, mode=L.SCORE_EXACT), vo[:16])
