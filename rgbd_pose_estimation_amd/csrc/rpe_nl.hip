@@ -216,15 +216,6 @@ __global__ __launch_bounds__(BLK) void nl_round_kernel(const T* __restrict__ xw,
   reduce_and_finish<44, kNlLd, 0, BLK>(acc, fin);
 }
 
-// a 16-byte vector in registers made opaque to the optimiser AT THIS POINT of the program (no instruction is emitted; volatile, so
-// it keeps its place between the scheduling barriers)
-template <class V> __device__ __forceinline__ void pin16_here(V& v) {
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  static_assert(sizeof(V) == 16, "16-byte vectors");
-  u4 t = __builtin_bit_cast(u4, v);
-  asm volatile("" : "+v"(t));
-  v = __builtin_bit_cast(V, t);
-}
 template <class T> __device__ __forceinline__ void pin_weights(T (&u)[Pk<T>::P]) {
   typedef typename Pk<T>::V V;
   V t;

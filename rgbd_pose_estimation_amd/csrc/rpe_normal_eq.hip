@@ -25,14 +25,6 @@ hipError_t launch_gn_update_probe(const double* d_rec, double* d_pose, double* d
   return hipGetLastError();
 }
 
-// a 16-byte vector in registers made opaque to the optimiser (no instruction is emitted)
-template <class V> __device__ __forceinline__ void pin16(V& v) {
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  static_assert(sizeof(V) == 16, "16-byte vectors");
-  u4 t = __builtin_bit_cast(u4, v);
-  asm("" : "+v"(t));
-  v = __builtin_bit_cast(V, t);
-}
 // The streaming loop is bound by the bytes the memory system delivers, not by instruction issue: at 1 M correspondences the CLEAN
 // flavour executes 24 % fewer vector instructions per wave than the guarded one and takes the same time, and loading two groups
 // ahead instead of one changes nothing either (profiles/r04_streaming_ab.jsonl) -- only the bearing kind, with two

@@ -62,6 +62,25 @@ __device__ __forceinline__ void unpack3(const double2& a, const double2& b, cons
   v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
 }
 
+// A 16-byte vector in registers made opaque to the optimiser (no instruction is emitted): what is loaded as one 16-byte vector stays one
+// -- no narrowing or re-splitting of the load, no repacking behind it -- up to this point.  pin16 is a data dependence only (it may
+// move between the definition and the first use; the streaming loops put a scheduling barrier in front of it); pin16_here is
+// volatile and keeps its place in program order (between the scheduling barriers of the rotating K5 pipeline).
+template <class V> __device__ __forceinline__ void pin16(V& v) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  u4 t = __builtin_bit_cast(u4, v);
+  asm("" : "+v"(t));
+  v = __builtin_bit_cast(V, t);
+}
+template <class V> __device__ __forceinline__ void pin16_here(V& v) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  u4 t = __builtin_bit_cast(u4, v);
+  asm volatile("" : "+v"(t));
+  v = __builtin_bit_cast(V, t);
+}
+
 // group g = correspondences [P*g, P*g + P).  Entries past n read as zero.
 template <class T>
 __device__ __forceinline__ void load_group(const T* __restrict__ a, int64_t g, int64_t n, T (&v)[3 * Pk<T>::P]) {

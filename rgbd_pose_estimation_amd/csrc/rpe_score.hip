@@ -386,14 +386,6 @@ __device__ __forceinline__ void store_mask_full(short* __restrict__ m, int64_t g
 
 template <class T> struct PoseArg { T v[12]; };  // one hypothesis by value (kernel argument): no H2D copy for a single pose
 
-// a 16-byte vector in registers made opaque to the optimiser at this point of the program (no instruction is emitted)
-template <class V> __device__ __forceinline__ void pin16_here(V& v) {
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  static_assert(sizeof(V) == 16, "16-byte vectors");
-  u4 t = __builtin_bit_cast(u4, v);
-  asm("" : "+v"(t));
-  v = __builtin_bit_cast(V, t);
-}
 // the inlier flags of ONE hypothesis over one full group: the predicates of count_group_votes (EXACT: pairs of correspondences as
 // 2-vectors, one rotation of the world point for the 3D and the 2D test, the 2D test behind its wave-uniform filter), kept as flags
 template <class T, int KIND, bool EXACT>
@@ -502,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int a = 0; a < 5; a++)
-      if (need[a]) { pin16_here(cur[a][0]); pin16_here(cur[a][1]); pin16_here(cur[a][2]); }
+      if (need[a]) { pin16(cur[a][0]); pin16(cur[a][1]); pin16(cur[a][2]); }
     g = gn;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {  // leftover correspondences through the bounds-checked loaders
