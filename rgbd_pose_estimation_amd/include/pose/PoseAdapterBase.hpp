@@ -82,21 +82,29 @@ inline void indices_of_ones(const std::vector<short>& mask, std::vector<int>& ou
 // stages read the device masks.  So the host copy is fetched on first access instead of after every solver run (0.15 ms per
 // modality at 307200 rows, half of a whole RANSAC run).  read(): host access; edit(): host access that will modify;
 // replace(): the whole content is about to be overwritten; device_is_newer(): a kernel just wrote the device copy.
+// assign() is LAZY too: an adapter is constructed over every frame, and filling N shorts per modality up front (a fresh 600 KB
+// allocation at 640 x 480: page faults and all, ~50 us each) is wasted on the calls that never look at a mask on the host -- ao()
+// spends a fifth of its wall time there.  The vector is materialised by the first access that needs it.
 class HostMask {
  public:
-  void assign(size_t n, short v) { _v.assign(n, v); _stale = false; }
-  size_t size() const { return _v.size(); }
+  void assign(size_t n, short v) { _n = n; _fill = v; _lazy = true; _stale = false; }
+  size_t size() const { return _lazy ? _n : _v.size(); }
   const std::vector<short>& read(DeviceSet& dev, int mod) const {
+    materialise();
     if (_stale) { dev.download_mask(mod, _v.data()); _stale = false; }
     return _v;
   }
   std::vector<short>& edit(DeviceSet& dev, int mod) { read(dev, mod); dev.mask_changed_on_host(mod); return _v; }
-  std::vector<short>& replace(DeviceSet& dev, int mod) { _stale = false; dev.mask_changed_on_host(mod); return _v; }
+  std::vector<short>& replace(DeviceSet& dev, int mod) { materialise(); _stale = false; dev.mask_changed_on_host(mod); return _v; }
   void device_is_newer(DeviceSet& dev, int mod) { _stale = true; dev.mask_written_on_device(mod); }
   // make the device copy current (no-op when it already is, in particular when it is the newer one)
-  void push(DeviceSet& dev, int mod) const { if (!dev.mask_fresh(mod)) dev.upload_mask(mod, _v); }
+  void push(DeviceSet& dev, int mod) const { if (!dev.mask_fresh(mod)) { materialise(); dev.upload_mask(mod, _v); } }
  private:
+  void materialise() const { if (_lazy) { _v.assign(_n, _fill); _lazy = false; } }
   mutable std::vector<short> _v;
+  mutable size_t _n = 0;
+  mutable short _fill = 0;
+  mutable bool _lazy = false;
   mutable bool _stale = false;
 };
 
