@@ -407,9 +407,10 @@ LS_NONE, LS_SHINJI_INLIERS, LS_NL_BUGCOMPAT, LS_NL_FIXED, LS_SHINJI_ALL, LS_GN_P
 
 
 def run(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weights=None, f=585.0, thre_3d=0.0, thre_2d=0.0, thre_nl=0.0,
-        iters=0, confidence=0.99, seed=1, ls=LS_NONE, score_mode=L.SCORE_EXACT, mask_in=None, pose_in=None, max_votes_in=1):
+        iters=0, confidence=0.99, seed=1, ls=LS_NONE, score_mode=L.SCORE_EXACT, mask_in=None, pose_in=None, max_votes_in=1, want_masks=True):
     """Run one solver of pose/*.hpp on a freshly built adapter (AOOnly / PnP / AO / NormalAO chosen like the
-    reference's demos do).  Returns dict(R, t, iters, max_votes, masks[3, n])."""
+    reference's demos do).  Returns dict(R, t, iters, max_votes, masks[3, n]); want_masks=False leaves the masks on the device
+    (mask_out = NULL: no read-back), masks is then None."""
     dt = _np_dtype(dtype)
     arrs = {k: (None if a is None else np.ascontiguousarray(a, dtype=dt)) for k, a in dict(xw=xw, xc=xc, bv=bv, nw=nw, nc=nc).items()}
     n = len(arrs["xw"])
@@ -424,7 +425,7 @@ def run(method, dtype=L.F32, xw=None, xc=None, bv=None, nw=None, nc=None, weight
         R[:] = np.eye(3).reshape(9)
     it, mv = C.c_int(iters), C.c_int(max_votes_in)
     mi = None if mask_in is None else np.ascontiguousarray(mask_in, dtype=np.int16)
-    mo = np.zeros((3, n), np.int16)
+    mo = np.zeros((3, n), np.int16) if want_masks else None
     L.check(L.lib().rpe_run(method, C.byref(prob), thre_3d, thre_2d, thre_nl, C.byref(it), confidence, seed, ls, score_mode, _p(mi), _p(R),
                             _p(t), C.byref(mv), _p(mo)))
     return dict(R=R.reshape(3, 3), t=t, iters=it.value, max_votes=mv.value, masks=mo)

@@ -6,6 +6,7 @@
 #include "../include/pose/GaussNewton.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 namespace rpe { int set_error(int code, const char* msg); }
@@ -65,12 +66,9 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
   HostMat<Tp> bv{(const Tp*)p->bv, n}, xc{(const Tp*)p->xc, n}, nc{(const Tp*)p->nc, n}, xw{(const Tp*)p->xw, n}, nw{(const Tp*)p->nw, n};
   HostWeights<Tp> w{(const Tp*)p->weights, n, p->wcols};
   int Iter = iter_io ? *iter_io : 0;
-  auto masks_out = [&](const std::vector<short>* m23, const std::vector<short>* m33, const std::vector<short>* mnn) {
-    if (!mask_out) return;
-    for (int i = 0; i < n; i++) {
-      mask_out[i] = m23 ? (*m23)[i] : 0; mask_out[n + i] = m33 ? (*m33)[i] : 0; mask_out[2 * n + i] = mnn ? (*mnn)[i] : 0;
-    }
-  };
+  // mask_out: rows 23 | 33 | NN of n shorts each; a modality the adapter does not have reads as zero.  Written straight from the device
+  // copy where that is the current one (copyInlierMask*).
+  auto zero_row = [&](int row) { if (mask_out) std::memset(mask_out + (size_t)row * n, 0, (size_t)n * sizeof(short)); };
   const bool has_n = p->nc && p->nw, has_bv = p->bv != nullptr, has_xc = p->xc != nullptr;
   const bool aoonly = method == M_SHINJI_RANSAC2 || method == M_SHINJI_PROSAC || (method == M_NONE && !has_bv);
   const bool pnp = method == M_KNEIP_RANSAC || method == M_KNEIP_PROSAC || (method == M_NONE && has_bv && !has_xc);
@@ -92,7 +90,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
     // host copies are fetched only when asked for
-    if (mask_out) { const auto& cad = ad; masks_out(nullptr, &cad.inlierMask33(), nullptr); }
+    if (mask_out) { zero_row(0); ad.copyInlierMask33(mask_out + (size_t)n); zero_row(2); }
   } else if (pnp) {
     PnPPoseAdapter<Tp> ad(bv, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -107,7 +105,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_REPROJ) Iter = gn_refine_reproj<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), nullptr, nullptr); }
+    if (mask_out) { ad.copyInlierMask23(mask_out); zero_row(1); zero_row(2); }
   } else if (ao) {
     AOPoseAdapter<Tp> ad(bv, xc, xw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -129,7 +127,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_REPROJ) Iter = gn_refine_reproj<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), &cad.inlierMask33(), nullptr); }
+    if (mask_out) { ad.copyInlierMask23(mask_out); ad.copyInlierMask33(mask_out + (size_t)n); zero_row(2); }
   } else {
     NormalAOPoseAdapter<Tp> ad(bv, xc, nc, xw, nw);
     ad.setFocal((Tp)p->fx, (Tp)p->fy);
@@ -154,7 +152,7 @@ int run_t(int method, const rpe_problem* p, double thre_3d, double thre_2d, doub
     if (ls == LS_GN_JOINT) Iter = gn_refine_joint<Tp>(ad);
     write_pose<Tp>(ad, R9, t3);
     if (max_votes) *max_votes = ad.getMaxVotes();
-    if (mask_out) { const auto& cad = ad; masks_out(&cad.inlierMask23(), &cad.inlierMask33(), &cad.inlierMaskNN()); }
+    if (mask_out) { ad.copyInlierMask23(mask_out); ad.copyInlierMask33(mask_out + (size_t)n); ad.copyInlierMaskNN(mask_out + 2 * (size_t)n); }
   }
   if (iter_io) *iter_io = Iter;
   return RPE_OK;

@@ -61,7 +61,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
     if (cols != 1) {
       flushInlierIdx();
       if (device_cols & 2u) _inliers_3d.device_is_newer(this->device(), RPE_MOD_33);
-      else { std::vector<short>& m = _inliers_3d.replace(this->device(), RPE_MOD_33); std::fill(m.begin(), m.end(), (short)0); }
+      else _inliers_3d.set_all(this->device(), RPE_MOD_33, (short)0);
     }
   }
   // N x 3 weights: column 1 (reference :200-212 tests rows() == 1)
@@ -97,6 +97,7 @@ class AOOnlyPoseAdapter : public PoseAdapterBase<Tp> {
   std::vector<short>& inlierMask33() { flushInlierIdx(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }
   // host copy, read only
   const std::vector<short>& inlierMask33() const { return mask33(); }
+  void copyInlierMask33(short* dst) const { _inliers_3d.copy_to(this->device(), RPE_MOD_33, dst); }   // additive: n shorts, no host copy kept
   // device copy current
   void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }
   virtual void syncHostMasks() const { (void)mask33(); }

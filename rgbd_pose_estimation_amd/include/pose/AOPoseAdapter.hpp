@@ -46,7 +46,7 @@ class AOPoseAdapter : public PnPPoseAdapter<Tp> {
     if (cols != 1) {
       flushInlierIdx33();
       if (device_cols & 2u) _inliers_3d.device_is_newer(this->device(), RPE_MOD_33);
-      else { std::vector<short>& m = _inliers_3d.replace(this->device(), RPE_MOD_33); std::fill(m.begin(), m.end(), (short)0); }
+      else _inliers_3d.set_all(this->device(), RPE_MOD_33, (short)0);
     }
   }
   template <class M> void setWeights(const M& weights) {  // reference :186-199
@@ -66,6 +66,7 @@ class AOPoseAdapter : public PnPPoseAdapter<Tp> {
   const Tp* pointsCurrData() const { return _points_c.p; }
   std::vector<short>& inlierMask33() { flushInlierIdx33(); return _inliers_3d.edit(this->device(), RPE_MOD_33); }
   const std::vector<short>& inlierMask33() const { return mask33(); }
+  void copyInlierMask33(short* dst) const { _inliers_3d.copy_to(this->device(), RPE_MOD_33, dst); }   // additive: n shorts, no host copy kept
   void pushMask33() const { _inliers_3d.push(this->device(), RPE_MOD_33); }
   virtual void syncHostMasks() const { PnPPoseAdapter<Tp>::syncHostMasks(); (void)mask33(); }
   const std::vector<Tp>& weights33() const { return _weights_3d; }

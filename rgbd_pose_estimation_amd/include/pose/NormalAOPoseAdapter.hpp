@@ -55,7 +55,7 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
       AOPoseAdapter<Tp>::setInlierFromDevice(cols, device_cols);
       flushInlierIdxNN();
       if (device_cols & 4u) _inliers_nl.device_is_newer(this->device(), RPE_MOD_NN);
-      else { std::vector<short>& m = _inliers_nl.replace(this->device(), RPE_MOD_NN); std::fill(m.begin(), m.end(), (short)0); }
+      else _inliers_nl.set_all(this->device(), RPE_MOD_NN, (short)0);
     }
   }
   template <class M> void setWeights(const M& weights) {  // reference :197-212 dispatches on cols()
@@ -82,6 +82,7 @@ class NormalAOPoseAdapter : public AOPoseAdapter<Tp> {
   const Tp* normalGlobData() const { return _normal_g.p; }
   std::vector<short>& inlierMaskNN() { flushInlierIdxNN(); return _inliers_nl.edit(this->device(), RPE_MOD_NN); }
   const std::vector<short>& inlierMaskNN() const { return maskNN(); }
+  void copyInlierMaskNN(short* dst) const { _inliers_nl.copy_to(this->device(), RPE_MOD_NN, dst); }   // additive: n shorts, no host copy kept
   void pushMaskNN() const { _inliers_nl.push(this->device(), RPE_MOD_NN); }
   virtual void syncHostMasks() const { AOPoseAdapter<Tp>::syncHostMasks(); (void)maskNN(); }
   const std::vector<Tp>& weightsNN() const { return _weights_nl; }

@@ -42,7 +42,7 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
     (void)cols;
     flushInlierIdx23();
     if (device_cols & 1u) _inliers.device_is_newer(this->device(), RPE_MOD_23);
-    else { std::vector<short>& m = _inliers.replace(this->device(), RPE_MOD_23); std::fill(m.begin(), m.end(), (short)0); }
+    else _inliers.set_all(this->device(), RPE_MOD_23, (short)0);
   }
   template <class M> void setWeights(const M& weights) { setWeights23(weights); }
   virtual void printInlier() const { for (short v : mask23()) std::cout << v << " "; std::cout << std::endl; }
@@ -75,6 +75,7 @@ class PnPPoseAdapter : public PoseAdapterBase<Tp> {
   const Tp* pointsGlobData() const { return _points_g.p; }
   std::vector<short>& inlierMask23() { flushInlierIdx23(); return _inliers.edit(this->device(), RPE_MOD_23); }
   const std::vector<short>& inlierMask23() const { return mask23(); }
+  void copyInlierMask23(short* dst) const { _inliers.copy_to(this->device(), RPE_MOD_23, dst); }   // additive: n shorts, no host copy kept
   void pushMask23() const { _inliers.push(this->device(), RPE_MOD_23); }
   virtual void syncHostMasks() const { (void)mask23(); }
   const std::vector<Tp>& weights23() const { return _weights; }
