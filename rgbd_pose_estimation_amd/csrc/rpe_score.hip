@@ -526,16 +526,18 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
 
 template <class T, int KIND, bool EXACT>
 static void score_launch(const DeviceArrays& A, const void* d_poses, int H, const double* thr, int* d_votes, int G, hipStream_t s) {
-  // enough workgroups for ~16 per CU: split the hypothesis list (in multiples of 64) over blockIdx.y when one sweep is too few.  The
-  // loop is a chain of dependent vector and scalar instructions per wave, so more (shorter) waves per SIMD hide more of it: 4096
-  // against the 2048 of round 3 is 4-5 % faster for every kind and mode at 512 hypotheses x 307 200 (profiles/r04_score_grid_ab.txt)
+  // Split the hypothesis list over blockIdx.y (chunks of a multiple of 16 hypotheses) until there are ~8192 workgroups: the loop is a
+  // chain of dependent vector and scalar instructions per wave, so many short waves per SIMD hide more of it than few long ones, and
+  // a problem that is small for the machine (few tiles, or few hypotheses) fills it only through the split.  Against round 3 (chunks of
+  // 64, 2048 workgroups): 512 hypotheses x 307 200 correspondences -9 %, 128 x 307 200 -19 %, 512 x 50 000 -25 %, 2048 x 307 200 and
+  // 512 x 1 M unchanged (profiles/r04_score_grid_ab.txt).
   int gy = 1, hchunk = H;
-  constexpr int target = 4096;
-  if (G < target && H > 64) {
-    const int chunks64 = (H + 63) / 64;
+  constexpr int target = 8192, gran = 16;
+  if (G < target && H > gran) {
+    const int chunks = (H + gran - 1) / gran;
     gy = (target + G - 1) / G;
-    if (gy > chunks64) gy = chunks64;
-    hchunk = ((chunks64 + gy - 1) / gy) * 64;
+    if (gy > chunks) gy = chunks;
+    hchunk = ((chunks + gy - 1) / gy) * gran;
     gy = (H + hchunk - 1) / hchunk;
   }
   hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G, gy), dim3(kBlock), (size_t)hchunk * sizeof(int), s, (const T*)A.a[0],
