@@ -227,6 +227,7 @@ def cpu_baseline(sc, seconds: float):
             o0 = None
         return {"value": n / ao1, "unit": "correspondence-residuals/s", "cores": 1, "kind": "port", "statistic": "median of the timed runs (one warm-up run before)",
                 "runs": ao1_runs, "no_O_flag_value": o0,
+                "sample_short": f"{ao1_runs} calls of oracle shinji_ls2<float> (= Library.cpp ao()) on the same {n}-corr scene, g++ -O2, 1 thread, {ao1_spent:.1f} s; median",
                 "sample": f"{ao1_runs} calls of the oracle's shinji_ls2<float> (AOOnlyPoseAdapter virtual getters, gather + centroid + covariance "
                           f"passes + 3x3 SVD = Library.cpp ao()) on the same {n}-correspondence scene, g++ -O2, 1 thread, {ao1_spent:.1f} s",
                 "all_cores": {"value": n / aoN, "threads": threads, "runs": aoN_runs,
@@ -500,12 +501,14 @@ def worker(args, affinity):
         n = hi - lo
         workload = (f"configs[4]: {total_n} 3D-3D correspondences sharded over {world} GPUs (contiguous ranges, {n} on rank 0), point-to-point "
                     "Gauss-Newton step over the RANSAC inlier mask, ONE all-reduce(sum) of the 32-double record per iteration")
+        workload_short = f"configs[4]: {total_n} 3D-3D corr sharded over {world} GPUs, p2p GN step over inlier mask, one all-reduce of the 32-double record per iteration"
         scaling = "strong"
     else:
         n = args.n_per_gpu
         total_n = n
         workload = (f"configs[1]: 640x480 dense depth, {n} 3D-3D correspondences, point-to-point absolute orientation, Gauss-Newton "
                     "step (K1 normal equations + host 6x6 solve + SE3 exp-map update) over the RANSAC inlier mask")
+        workload_short = f"configs[1]: 640x480 dense depth, {n} 3D-3D corr, point-to-point GN step (K1 normal eq + host 6x6 solve + SE3 exp) over inlier mask"
         scaling = "weak"
     sc = make_shard(rank, n)
     # the collective needs the kernel on the stream torch orders the all-reduce after; one GPU uses the library's own stream
@@ -874,7 +877,7 @@ def worker(args, affinity):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med,
             "ms_per_step_untuned": (UNTUNED or {}).get("ms_per_step"), "untuned": UNTUNED,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
+            "config": {"workload": workload, "workload_short": workload_short, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
                        "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
                        "streamed_corr_per_s": float(total_n) * args.steps / elapsed, "accumulate": "fp64", "collective": collective,
                        "collective_step_us": ({"rccl_us": coll_times.get("rccl_us"), "host_us": coll_times.get("host_us"), "p2p_us": coll_times.get("p2p_us")} if dist_path else None),
@@ -977,9 +980,93 @@ def worker(args, affinity):
             out["valid"] = False
             out["invalid_reason"] = invalid
             print("bench.py: INVALID RUN: " + invalid, file=sys.stderr, flush=True)
-        print(json.dumps(out), flush=True)
+        write_extras(out)
+        print(contract_line(out), flush=True)
         if invalid:
             sys.exit(3)
+
+
+LINE_LIMIT = 4096            # the driver keeps the last 8 KB of stdout; the round-4 line (21.9 KB) could not be parsed
+EXTRAS_FILE = "bench_extras.json"
+
+
+def _num(x, digits=6):
+    """floats rounded to `digits` significant digits (the line is for reading and parsing, the full values are in the extras file)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def contract_line(full: dict) -> str:
+    """The ONE line the driver parses: the contract's keys and nothing else (each object flat, strings short), at most LINE_LIMIT bytes.
+    Everything else this run measured is in EXTRAS_FILE (write_extras) -- never in the line."""
+    cfg, roof, cpu, tim = (full.get(k) or {} for k in ("config", "roofline", "cpu_baseline", "timing"))
+    resident = (roof.get("steps_per_launch") or 1) > 1
+    line = {
+        "metric": full.get("metric"), "value": _num(full.get("value"), 9), "unit": full.get("unit"), "n_gpus": full.get("n_gpus"),
+        "steps": full.get("steps"), "warmup": full.get("warmup"), "ms_per_step": _num(full.get("ms_per_step"), 9),
+        "higher_is_better": True, "scaling": full.get("scaling"), "vs_baseline": None, "dtype": full.get("dtype"), "data": full.get("data"),
+        "config": {"workload": cfg.get("workload_short") or (cfg.get("workload") or "")[:200], "corr_rank0": cfg.get("corr_rank0"),
+                   "global_corr": cfg.get("global_corr"), "valid_corr_per_step": cfg.get("valid_corr_per_step"),
+                   "collective": (cfg.get("collective") or "none")[:40], "rccl_ranks": cfg.get("rccl_ranks"), "rccl_verified": cfg.get("rccl_verified"),
+                   "host_loop": "resident kernel, host exp-map" if resident else "launch per step, host exp-map",
+                   "repeats": tim.get("repeats"), "ms_per_step_p10": _num(tim.get("ms_per_step_p10")), "ms_per_step_p90": _num(tim.get("ms_per_step_p90"))},
+        "roofline": {"bound": roof.get("bound"), "achieved": _num(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
+                     "frac": _num(roof.get("frac")), "traffic": _num(roof.get("traffic"), 9),
+                     "traffic_over_algorithmic": _num(roof.get("traffic_over_algorithmic")), "kernel": (roof.get("kernel") or "")[:96],
+                     "avg_launch_us": _num(roof.get("avg_launch_us")), "steps_per_launch": roof.get("steps_per_launch"),
+                     "bytes_per_launch": roof.get("algorithmic_bytes_per_launch"), "launches_timed": roof.get("launches_timed")},
+        "cpu_baseline": None if not cpu else {
+            "value": _num(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+            "sample": (cpu.get("sample_short") or cpu.get("sample") or "")[:160], "cpu_model": (cpu.get("cpu_model") or "")[:48],
+            "host_cpus": cpu.get("host_cpus"), "all_cores_value": _num(_get(cpu, "all_cores", "value")), "all_cores_threads": _get(cpu, "all_cores", "threads")},
+    }
+    pe = full.get("pose_error_vs_cpu") or {}
+    if "rot_rad" in pe:
+        line["pose_error_vs_cpu"] = {"rot_rad": _num(pe.get("rot_rad"), 3), "trans_rel": _num(pe.get("trans_rel"), 3), "tol_rot_rad": 1e-5, "tol_trans_rel": 1e-4}
+    # at most three scalar extras: configs[3] (the HBM-bound run) steady / cold, and K4 scoring against the fp32 vector peak
+    for key, val in (("config3_frac_steady", _get(full, "roofline_hbm", "config3_p2plane_1M_steady", "frac_of_peak")),
+                     ("config3_frac_cold", _get(full, "roofline_hbm", "config3_p2plane_1M_cold", "frac_of_peak")),
+                     ("k4_exact_33_valu_frac", _get(full, "ransac_scoring", "roofline", "exact_33", "valu_frac"))):
+        if val is not None:
+            line[key] = _num(val, 4)
+    if full.get("valid") is False:
+        line["valid"] = False
+        line["invalid_reason"] = (full.get("invalid_reason") or "")[:160]
+    line["extras_file"] = EXTRAS_FILE
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT or "\n" in text:
+        raise RuntimeError(f"bench.py: the contract line is {len(text)} bytes (limit {LINE_LIMIT}): something long was added to it")
+    return text
+
+
+def write_extras(full: dict):
+    """Everything beside the headline (bandwidth-bound figures, the reference-API kernels, fp64, untuned, configs[2] pipeline, notes) goes to
+    bench_extras.json next to bench.py -- and to gpurun_out/ when that directory exists, so that it comes back from the GPU box."""
+    text = json.dumps(full, indent=1, default=repr)
+    paths = [os.path.join(d, EXTRAS_FILE) for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    if os.environ.get("RPE_BENCH_EXTRAS"):   # tests: a path of their own
+        paths = [os.environ["RPE_BENCH_EXTRAS"]]
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
 
 
 def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):

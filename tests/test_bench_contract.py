@@ -1,38 +1,79 @@
-"""CPU: the committed bench line (profiles/r02_bench_n1.json, produced by `python bench.py` on an MI355X) carries every field of
-the driver's contract, with BASELINE.json's metric, and its roofline / cpu_baseline objects are well formed."""
+"""CPU: the emitter of the CURRENT bench.py (contract_line) run on a canned full record -- the round-4 record (21.9 KB as one line, which
+the driver could not parse) -- must give one JSON line under 4 KB with exactly the contract's keys, flat objects and BASELINE.json's metric;
+whatever else a run measured belongs in bench_extras.json (write_extras), never in the line."""
 import json
 import os
+import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (imports nothing heavy at module level: no torch, no HIP library)
+from bench_util import check_line  # noqa: E402
 
 
-def test_committed_bench_line_matches_the_contract():
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")).read().strip().splitlines()[-1]
-    j = json.loads(line)
+def canned():
+    return json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_driver_cmd.json")).read().strip().splitlines()[-1])
+
+
+def test_line_of_the_current_emitter_is_small_flat_and_complete():
+    full = canned()
+    assert len(json.dumps(full)) > 20000                     # the record that broke the driver's parser
+    text = bench.contract_line(full)
+    j = check_line(text)                                     # one line, < 4096 bytes, contract keys, flat config / roofline / cpu_baseline
+    assert len(text) < 2500
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline", "cpu_baseline"):
-        assert key in j, key
     assert j["metric"].split("/")[0].replace("-", " ") in base["metric"].replace("-", " ")
     assert j["n_gpus"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
-    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
-    # value counts VALID correspondences (rows passing the RANSAC inlier mask), per median step time
-    assert abs(j["value"] - j["config"]["valid_corr_per_step"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
-    assert 0.8 * j["config"]["global_corr"] < j["config"]["valid_corr_per_step"] <= j["config"]["global_corr"] == 307200
-    assert j["timing"]["repeats"] >= 50 and j["timing"]["ms_per_step_p10"] <= j["ms_per_step"] <= j["timing"]["ms_per_step_p90"]
-    assert j["value"] >= 1e9                                   # the north star's target on one MI355X at 307k points
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "configs[1]" in j["config"]["workload"]
+    assert abs(j["value"] - j["config"]["valid_corr_per_step"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"] and j["value"] >= 1e9
+    assert j["config"]["ms_per_step_p10"] <= j["ms_per_step"] <= j["config"]["ms_per_step_p90"]
     r = j["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
-    assert r["launches_timed"] >= 16 and r["steps_per_launch"] >= 1   # bench.py --event-reps
-    assert (r["traffic"] is None) == (r["traffic_source"] is None)       # a counter figure always names the profiles/ file it was read from
-    assert (r["rocprofv3_avg_launch_us"] is None) == (r["rocprofv3_source"] is None)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-4 * r["achieved"]
+    assert r["bytes_per_launch"] == 26 * 307200 * r["steps_per_launch"] and r["steps_per_launch"] == 20
+    assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["bytes_per_launch"]) < 1e-5
     c = j["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and "sample" in c
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"] and c["all_cores_value"] > 0
     e = j["pose_error_vs_cpu"]
-    assert e["rot_rad"] <= e["tolerance"]["rot_rad"] == 1e-5 and e["trans_rel"] <= e["tolerance"]["trans_rel"] == 1e-4
-    cv = j["convergence"]                                      # iterations to |delta| < 1e-9
-    for name in ("all_points", "inliers_only"):
-        assert 1 <= cv[name]["iterations"] < 50 and cv[name]["last_step"] < 1e-9
-        assert cv[name]["rot_rad_vs_cpu_closed_form"] <= 1e-5 and cv[name]["trans_rel_vs_cpu_closed_form"] <= 1e-4
+    assert e["rot_rad"] <= e["tol_rot_rad"] == 1e-5 and e["trans_rel"] <= e["tol_trans_rel"] == 1e-4
+    extra = set(j) - {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                      "config", "roofline", "cpu_baseline", "pose_error_vs_cpu", "extras_file"}
+    assert extra <= {"config3_frac_steady", "config3_frac_cold", "k4_exact_33_valu_frac"}            # at most three scalar extras
+    assert all(isinstance(j[k], float) for k in extra)
+
+
+def test_growth_of_the_full_record_never_reaches_the_line():
+    full = canned()
+    full["roofline_hbm"]["reference_api_kernels"].update({f"more_{i}": {"note": "x" * 500} for i in range(100)})
+    full["roofline"]["note"] = "y" * 10000
+    full["anything_new"] = {"z": list(range(5000))}
+    assert len(bench.contract_line(full)) < 2500
+
+
+def test_missing_legs_and_odd_values_still_give_a_valid_line():
+    full = canned()
+    for k in ("cpu_baseline", "roofline_hbm", "pose_error_vs_cpu", "ransac_scoring", "timing"):
+        full.pop(k, None)
+    full["cpu_baseline"] = None
+    full["roofline"]["traffic"] = None
+    full["roofline"]["traffic_over_algorithmic"] = float("nan")
+    j = json.loads(bench.contract_line(full))
+    assert j["cpu_baseline"] is None and j["roofline"]["traffic"] is None and j["roofline"]["traffic_over_algorithmic"] is None
+    full["valid"], full["invalid_reason"] = False, "3 resident grid(s) lost during the run " * 20
+    j = json.loads(bench.contract_line(full))
+    assert j["valid"] is False and len(j["invalid_reason"]) <= 160
+
+
+def test_a_line_over_the_limit_is_refused(monkeypatch):
+    monkeypatch.setattr(bench, "LINE_LIMIT", 500)
+    with pytest.raises(RuntimeError):
+        bench.contract_line(canned())
+
+
+def test_extras_file_holds_the_full_record(tmp_path, monkeypatch):
+    monkeypatch.setenv("RPE_BENCH_EXTRAS", str(tmp_path / "x.json"))
+    full = canned()
+    bench.write_extras(full)
+    assert json.load(open(tmp_path / "x.json")) == full

@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from bench_util import run_bench
+
 # Several processes share the ONE GPU of the test box here and wait for each other inside kernels: on request only
 # (RPE_TEST_MULTIPROC=1); the smallest peer-to-peer exchange case is part of the default suite (tests/test_gpu_p2p.py).
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1",
@@ -21,10 +23,8 @@ def test_bench_two_ranks_one_gpu_from_a_bare_shell():
                RPE_BENCH_STRICT_COLLECTIVE="1", RPE_BENCH_SHARE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--n-total", "614400",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    r, line, j = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--n-total", "614400",
+                        "--no-cpu-baseline"], env, timeout=900)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 20 and j["value"] > 1e9
     assert j["config"]["global_corr"] == 614400 and j["config"]["corr_rank0"] == 307200
     assert 0.8 * 614400 < j["config"]["valid_corr_per_step"] < 614400

@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from bench_util import run_bench
+
 pytestmark = [pytest.mark.gpu]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -17,10 +19,8 @@ def test_bench_two_ranks_host_exchange_from_a_bare_shell():
                RPE_BENCH_SHARE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--n-total", "614400",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    r, line, j = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--n-total", "614400",
+                        "--no-cpu-baseline"], env, timeout=900)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 20 and j["value"] > 1e9
     assert j["config"]["global_corr"] == 614400 and j["config"]["corr_rank0"] == 307200
     assert "configs[4]" in j["config"]["workload"] and "host-side exchange" in j["config"]["collective"]
@@ -37,10 +37,8 @@ def test_bench_falls_back_together_when_one_rank_loses_the_exchange():
                RPE_BENCH_SHARE_GPU="1", RPE_BENCH_INJECT_HOSTEX_FAIL="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "5", "--n-total", "614400",
-                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
+    r, line, j = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "5", "--n-total", "614400",
+                        "--no-cpu-baseline", "--no-extras"], env, timeout=900)
     assert "host-side exchange dropped" in r.stderr
-    j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == 2 and j["value"] > 1e8 and "host-side exchange" not in j["config"]["collective"]
     assert j["pose_error_vs_truth"]["rot_rad"] < 1e-2

@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from bench_util import run_bench
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -17,11 +19,9 @@ def test_lost_grid_makes_the_line_invalid():
     env = dict(os.environ, RPE_BENCH_INJECT_LOST_GRID="3", RPE_BENCH_PREWARM_S="0.2", RPE_BENCH_NO_UNTUNED="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "4", "--no-extras",
-                        "--no-cpu-baseline", "--no-hbm"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    r, line, j = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "4", "--no-extras",
+                        "--no-cpu-baseline", "--no-hbm"], env, timeout=900, expect_rc=3)
     assert "INVALID RUN" in r.stderr
-    j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["valid"] is False and "lost" in j["invalid_reason"]
     st = j["config"]["resident_state"]
     assert st["lost_in_run"] >= 1 and st["resident_loop_ran"] is False and st["before"]["lost"] == 0
@@ -32,9 +32,7 @@ def test_an_undisturbed_run_is_valid():
     env = dict(os.environ, RPE_BENCH_PREWARM_S="0.2", RPE_BENCH_NO_UNTUNED="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RPE_BENCH_INJECT_LOST_GRID"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "4", "--no-extras",
-                        "--no-cpu-baseline", "--no-hbm"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    r, line, j = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "4", "--no-extras",
+                        "--no-cpu-baseline", "--no-hbm"], env, timeout=900)
     assert "valid" not in j and j["config"]["resident_state"]["resident_loop_ran"] is True and j["roofline"]["steps_per_launch"] == 20
     assert j["roofline"]["traffic"] and 0.03 < j["roofline"]["traffic_over_algorithmic"] < 0.2     # the committed PMC profile of this command

@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from bench_util import run_bench
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -15,10 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_collective_path_on_rccl_with_one_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_FORCE_DIST="1", RPE_BENCH_PREWARM_STEPS="300", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "10", "--no-cpu-baseline",
-                        "--no-extras", "--no-hbm"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
-    j = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    r, line, j = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "10", "--no-cpu-baseline",
+                        "--no-extras", "--no-hbm"], env, timeout=900)
     cfg = j["config"]
     assert j["n_gpus"] == 1 and j["value"] > 1e9
     assert cfg["collective"].startswith("rccl:") and "library-owned communicator" in cfg["collective"]

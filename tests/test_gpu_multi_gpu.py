@@ -13,6 +13,8 @@ import tempfile
 import numpy as np
 import pytest
 
+from bench_util import run_bench
+
 from rgbd_pose_estimation_amd import _lib as L, api
 import util
 
@@ -84,10 +86,7 @@ def test_bench_two_gpus_from_a_bare_shell_runs_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RPE_BENCH_PREWARM_STEPS="300")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RPE_BENCH_SHARE_GPU", "RPE_BENCH_COLLECTIVE", "RPE_BENCH_BACKEND"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-2500:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    r, line, j = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--repeats", "10", "--no-cpu-baseline"], env, timeout=1200)
     assert j["n_gpus"] == 2 and j["config"]["rccl_ranks"] == 2 and j["config"]["rccl_verified"] is True
     assert "rccl" in j["config"]["collective"] and len(set(j["config"]["pci_bus_ids"])) == 2
     assert j["config"]["collective_step_us"]["rccl_us"] > 0 and j["value"] > 1e9
