@@ -535,7 +535,7 @@ template <class Launch>
 static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale,
     double* pose12, int max_iter,
                        double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what,
-                       bool clean = false) {
+                       bool clean = false, bool* first_record_finite = nullptr) {
   const unsigned long long base = c->seq;
   auto hand_over = [&](const double* p, unsigned long long tag) {
     if (p) for (int k = 0; k < 12; k++) { unsigned long long w; std::memcpy(&w, &p[k], 8); c->ctl[1 + k] = w; }   // words 1..7 | 8..12
@@ -571,6 +571,7 @@ static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc,
     // CLEAN flavour: a NaN or an infinity anywhere in the arrays shows in the very first record (before any pose update could
     // produce one): stop the grid; the caller repeats the refinement with the guarded flavour, from the same start pose
     if (clean && received == 0 && !record_finite(ne, 29)) { status = kResidentDirty; received++; break; }
+    if (clean && received == 0 && first_record_finite) *first_record_finite = true;   // only THIS vouches for the arrays' content
     if (c->hostex && (rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) { status = rc; received++; break; }
     received++;
     if (c->loop_prof) { const double t = clock_us(); if (received > 1) { c->prof_wait_us += t - tp; c->prof_steps++; } tp = t; }
@@ -1272,7 +1273,10 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     if (c->host_cpu_request != -2 && !c->host_cpu_done) {   // RPE_HOST_CPU: pin / tune the thread that spins here, once per context
       c->host_cpu_done = true;
       if (c->host_cpu_request >= 0) (void)pin_calling_thread(c->host_cpu_request);
-      else (void)rpe_tune_host_thread(c, kinds[0], flags, pose12, 200, 5, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+      // (auto-tuning runs trial refinements; on a sharded context each of them would take part in the ranks' exchange, and the number
+      // of trials is a per-rank matter -- cpusets, local_cpulist -- so the ranks would fall out of step: single-GPU contexts only)
+      else if (!c->hostex && !c->comm && c->p2p_world < 1 && c->p2p_world_saved < 1)
+        (void)rpe_tune_host_thread(c, kinds[0], flags, pose12, 200, 5, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
     }
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), kinds[0], c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
@@ -1287,10 +1291,14 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     };
     for (int attempt = 0; attempt < 2; attempt++) {
       const bool clean = take_clean(c, kind, true);   // CLEAN flavour first; its first record is checked
+      bool verified = false;
       { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
         rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight,
-            "normal equations", clean); }
-      if (clean) note_clean_launch(c, kind, rc != kResidentDirty);
+            "normal equations", clean, &verified); }
+      // promoted to "verified finite" only by a first record that was received and finite: a launch error, a wait that timed out or a
+      // grid lost before the first record say nothing about the arrays (their state stays as it was)
+      if (clean && rc == kResidentDirty) note_clean_launch(c, kind, false);
+      else if (clean && verified) note_clean_launch(c, kind, true);
       if (rc != kResidentDirty) break;   // else: NaN-marked arrays -- once more, guarded, from the untouched start pose
       it = 0;
     }
@@ -1558,6 +1566,7 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
     int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
     if (rc) return rc;
     if ((rc = rpe_host_exchange_allreduce_f64(c->hostex, ne, 32))) return rc;
+    ne[29] = rpe::pivot_floor(c->dtype == RPE_F64);   // slot 29 is not a sum: after the exchange it held world x floor
     if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
         ne[28]);
     rpe::se3_left_update(d, pose12);
@@ -1593,6 +1602,7 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
   for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
   if (c->p2p_world >= 1 && ne[31] != 0.0) return fail(RPE_ERR_HIP,
       "peer-to-peer exchange timed out at step %llu (a peer did not deliver its record)", c->p2p_step - 1);
+  ne[29] = rpe::pivot_floor(c->dtype == RPE_F64);   // the record handed out carries the floor rpe_gn_solve reads, as rpe_normal_eq's does
   if (!rpe::solve_normal_eq6(ne, d, rpe::pivot_floor(c->dtype == RPE_F64))) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite (weight sum %g)",
       ne[28]);
   rpe::se3_left_update(d, pose12);

@@ -312,7 +312,18 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&
     else if constexpr (KIND == KIND_P2PLANE) p2plane_pair<T>(pose, x, y, z, bx, by, bz, nx, ny, nz, wi, s2);
     // two rows per point: 70 of ~100
     else if constexpr (KIND == KIND_BEARING) bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
-    else reproj_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
+    else {
+      reproj_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
+      // CLEAN promises "a NaN or an infinity anywhere in the arrays makes at least one sum non-finite" (rpe_capi.hip clean-first protocol).
+      // reproj_prepare switches a correspondence with p_z or bv_z not above kReprojMinZ off -- which a NaN is -- and hands harmless
+      // geometry on, so the inputs are multiplied into the cost slot by hand: 0 x finite = +0 (the sum of squares keeps its bits),
+      // 0 x NaN = 0 x inf = NaN
+      if (CLEAN) {
+        typedef T V __attribute__((ext_vector_type(2)));
+        const V all = ((V{x[0], x[1]} + V{y[0], y[1]}) + (V{z[0], z[1]} + V{bx[0], bx[1]})) + (V{by[0], by[1]} + V{bz[0], bz[1]});
+        s2[27] = __builtin_elementwise_fma(V{T(0), T(0)}, all, s2[27]);
+      }
+    }
   }
 }
 // widen the pair sums into the fp64 accumulators and clear them.  A widening costs three instructions per sum (add the halves,

@@ -77,3 +77,21 @@ def test_extras_file_holds_the_full_record(tmp_path, monkeypatch):
     full = canned()
     bench.write_extras(full)
     assert json.load(open(tmp_path / "x.json")) == full
+
+
+def test_sharded_record_check_judges_every_entry_on_its_own_scale():
+    import numpy as np
+    rng = np.random.default_rng(0)
+    J = rng.standard_normal((500, 6)) * np.array([1, 1, 1, 30, 30, 30])     # rotation columns ~ |p|: H spans three orders of magnitude
+    r = 0.05 * rng.standard_normal(500)
+    H, g = J.T @ J, J.T @ r
+    rec = np.zeros(32); k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            rec[k] = H[i, j]; k += 1
+    rec[21:27], rec[27], rec[28] = g, r @ r, 500
+    assert bench.record_close(rec * (1 + 1e-7), rec, 2e-6)
+    bad = rec.copy(); bad[21] *= 1.5                  # a wrong gradient entry: tiny against max |H|, caught on its own scale
+    assert np.max(np.abs(bad[:29] - rec[:29])) <= 2e-6 * np.max(np.abs(rec[:29])) and not bench.record_close(bad, rec, 2e-6)
+    half = rec * 0.5                                   # a missing shard
+    assert not bench.record_close(half, rec, 2e-6)
