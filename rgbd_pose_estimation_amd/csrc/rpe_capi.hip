@@ -426,6 +426,7 @@ unsigned kind_slot_bits(int kind) {
     case RPE_RES_P2P: return (1u << RPE_XW) | (1u << RPE_XC);
     case RPE_RES_P2PLANE: return (1u << RPE_XW) | (1u << RPE_XC) | (1u << RPE_NC);
     case RPE_RES_BEARING: case RPE_RES_REPROJ: return (1u << RPE_XW) | (1u << RPE_BV);
+    case RPE_RES_NORMAL: return (1u << RPE_NW) | (1u << RPE_NC);
   }
   return 0;
 }
@@ -452,6 +453,15 @@ void note_clean_launch(rpe_context* c, int kind, bool finite) {
     if (!finite) c->arr_state[s] = kArrDirty;
     else if (!c->arr_bound[s]) c->arr_state[s] = kArrClean;
   }
+}
+// ... for a SET of residual kinds (the joint kernels; bits = 1 << kind): CLEAN only if every kind of the set may take it
+bool take_clean_terms(const rpe_context* c, int bits, bool host_verifies) {
+  if (c->dtype == RPE_F64) return false;   // the joint kernels' CLEAN flavour exists for fp32 arrays
+  for (int k = 0; k <= 4; k++) if ((bits & (1 << k)) && !take_clean(c, k, host_verifies)) return false;
+  return bits != 0;
+}
+void note_clean_terms(rpe_context* c, int bits, bool finite) {
+  for (int k = 0; k <= 4; k++) if (bits & (1 << k)) note_clean_launch(c, k, finite);
 }
 void arrays_changed(rpe_context* c, int slot, bool bound) { c->arr_state[slot] = kArrUnknown; c->arr_bound[slot] = bound; }
 
@@ -883,11 +893,11 @@ int rpe_pose_from_moments(const double* m, double* R9, double* t3) {
 }
 
 // ---------------------------------------------------------------------------------------------- K1/K2/K3
-static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12);
+static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, bool clean, int* bits_out);
 static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32, bool clean) {
   if (kind == RPE_RES_NORMAL && !d_out32) {
     const rpe_term t = {RPE_RES_NORMAL, 1.0, RPE_ROBUST_NONE, 1.0};
-    return joint_launch_checked(c, 1, &t, flags, pose12);
+    return joint_launch_checked(c, 1, &t, flags, pose12, false, nullptr);   // (guarded: this caller does not look at the record's finiteness)
   }
   if (kind == RPE_RES_NORMAL) return fail(RPE_ERR_ARG, "RPE_RES_NORMAL is served by rpe_normal_eq / rpe_normal_eq_joint (host record)");
   int rc = kind_arrays(c, kind);
@@ -1013,20 +1023,37 @@ static int joint_spec(rpe_context* c, int nterms, const rpe_term* terms, int fla
   if ((bits & 4) && (bits & 16)) return fail(RPE_ERR_ARG, "bearing and reprojection are alternatives for the 2D-3D term");
   return RPE_OK;
 }
-static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12) {
+static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, bool clean, int* bits_out) {
   JointSpec sp;
   int rc = joint_spec(c, nterms, terms, flags, pose12, &sp);
   if (rc) return rc;
+  if (bits_out) *bits_out = sp.bits;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), sp.bits, flags, pose12, sp.scale, sp.robust, sp.rk, collect_target(c), c->stream));
-  return RPE_OK;
+  rpe::ReduceTarget rt = collect_target(c);
+  rt.clean = clean && take_clean_terms(c, sp.bits, true);
+  hipEvent_t e0, e1;
+  timing_pair(c, &e0, &e1);
+  HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), sp.bits, flags, pose12, sp.scale, sp.robust, sp.rk, rt, c->stream, e0, e1));
+  return rt.clean ? 1 : RPE_OK;   // 1 = launched in the CLEAN flavour: the caller looks at the record
 }
 
 int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, double* out32) {
   if (!out32) return fail(RPE_ERR_ARG, "null out32");
-  int rc = joint_launch_checked(c, nterms, terms, flags, pose12);
-  if (rc) return rc;
+  // CLEAN flavour first (fp32 arrays): this record is looked at right here -- a NaN or an infinity in the arrays shows in it, the
+  // launch is repeated guarded and the arrays are remembered as needing the guards (clean-first protocol, as rpe_normal_eq)
+  int bits = 0;
+  int rc = joint_launch_checked(c, nterms, terms, flags, pose12, true, &bits);
+  if (rc != RPE_OK && rc != 1) return rc;
+  const bool clean = rc == 1;
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  if (clean) {
+    const bool finite = record_finite(c->h_out, 29);
+    note_clean_terms(c, bits, finite);
+    if (!finite) {
+      if ((rc = joint_launch_checked(c, nterms, terms, flags, pose12, false, nullptr))) return rc;
+      if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+    }
+  }
   for (int i = 0; i < 32; i++) out32[i] = c->h_out[i];
   out32[29] = rpe::pivot_floor(c->dtype == RPE_F64);
   return RPE_OK;
@@ -1039,22 +1066,34 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
   double step = 0, cost = 0;
   if (c && c->resident && c->host_resident && max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
     // ONE launch for the whole refinement, as rpe_gn_refine: the grid of the joint kernel stays resident, the host hands every pose
-    // over through the control block, adds the run records, solves and updates
+    // over through the control block, adds the run records, solves and updates.  Frame-sized problems only (one group per thread,
+    // staged in LDS: rpe_joint.hip joint_resident_fits); larger ones take the loop below, one launch per iteration.
     JointSpec sp;
     int rc = joint_spec(c, nterms, terms, flags, pose12, &sp);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
-    rpe::resident_geometry(c->arrays(), RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);   // the 29-sum geometry
-    double weight = 0;
-    auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
-      return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk,
-          (const unsigned long long*)c->ctl, base,
-                                                  max_iter, rt, c->stream);
-    };
-    { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
-      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight,
-          "normal equations"); }
+    double start[12];
+    std::memcpy(start, pose12, sizeof(start));
+    for (int attempt = 0; attempt < 2; attempt++) {
+      const bool clean = take_clean_terms(c, sp.bits, true);   // CLEAN flavour first; its first record is checked
+      if (!rpe::joint_resident_fits(c->arrays(), sp.bits, flags, c->max_blocks, false, clean)) { rc = kResidentLost; it = 0; break; }
+      int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
+      rpe::resident_geometry(c->arrays(), RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);   // the 29-sum geometry
+      double weight = 0;
+      bool verified = false;
+      auto launch = [&](const rpe::ReduceTarget& rt, unsigned long long base) -> hipError_t {
+        return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk,
+                                                    (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream);
+      };
+      { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+        rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight,
+            "normal equations", clean, &verified); }
+      if (clean && rc == kResidentDirty) note_clean_terms(c, sp.bits, false);
+      else if (clean && verified) note_clean_terms(c, sp.bits, true);
+      if (rc != kResidentDirty) break;   // else: NaN-marked arrays -- once more, guarded, from the untouched start pose
+      std::memcpy(pose12, start, sizeof(start));
+      it = 0;
+    }
     if (rc != kResidentLost) {
       if (iters_out) *iters_out = it;
       if (rc != RPE_OK) return rc;
@@ -1122,7 +1161,9 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
   double pose_in[12];
   std::memcpy(pose_in, pose12, sizeof(pose_in));
-  if (auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2) {
+  const bool joint_clean = !single && take_clean_terms(c, bits, false);   // no host in these loops: CLEAN only over verified arrays
+  if (auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2 &&
+      (single || rpe::joint_resident_fits(c->arrays(), bits, flags, c->max_blocks, true, joint_clean))) {
     // a single plain kind: the dedicated kernel (17 structured sums for point-to-point); anything else: the joint kernel (29 sums)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
@@ -1135,7 +1176,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
     std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
-    if (single) rt.clean = take_clean(c, terms[0].kind, false);   // no host in this loop: CLEAN only over verified arrays
+    rt.clean = single ? take_clean(c, terms[0].kind, false) : joint_clean;   // no host in this loop: CLEAN only over verified arrays
     if (single) HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0,
         e1));
     else HIP_TRY(rpe::launch_normal_eq_joint_resident(c->arrays(), bits, flags, scale, robust, rk, nullptr, base, max_iter, rt,
@@ -1161,7 +1202,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   }
   for (int it = 0; it < max_iter; it++) {
     if (sharded) { rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++; }
-    if (single) rt.clean = take_clean(c, terms[0].kind, false);
+    rt.clean = single ? take_clean(c, terms[0].kind, false) : joint_clean;
     if (single) HIP_TRY(rpe::launch_normal_eq(c->arrays(), terms[0].kind, flags, pose_in, rt, c->stream));
     else HIP_TRY(rpe::launch_normal_eq_joint(c->arrays(), bits, flags, pose_in, scale, robust, rk, rt, c->stream));
   }

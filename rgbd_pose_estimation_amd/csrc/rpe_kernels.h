@@ -110,10 +110,13 @@ hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& 
                           hipEvent_t ev_end = nullptr);
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
 hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4,
-    const int* robust4,
-                                  const double* robust_k4, const ReduceTarget& rt, hipStream_t s);
+                                  const int* robust4, const double* robust_k4, const ReduceTarget& rt, hipStream_t s,
+                                  hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 // RESIDENT form of the joint kernel (one launch per refinement; control block, tags and run records as launch_normal_eq_resident;
 // geometry = resident_geometry of a 29-sum kind)
+// the resident form serves frame-sized problems only (one group per thread, the workgroup's slice staged in its LDS): true if this
+// term set / size / mask-and-weight use fits; otherwise the refinement runs one launch of the joint kernel per iteration
+bool joint_resident_fits(const DeviceArrays& A, int terms, int flags, int max_blocks, bool autonomous, bool clean);
 hipError_t launch_normal_eq_joint_resident(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4,
                                            const double* robust_k4, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
                                            const ReduceTarget& rt, hipStream_t s);

@@ -80,9 +80,15 @@ def main():
             "K1_p2p_mask": (lambda: ctx.normal_eq(L.RES_P2P, pose, L.USE_MASK), 26),
             "K2_p2plane": (lambda: ctx.normal_eq(L.RES_P2PLANE, pose), 36),
             "K3_bearing": (lambda: ctx.normal_eq(L.RES_BEARING, pose), 24),
+            # the fused joint kernel (rpe_joint.hip): bytes = the arrays its terms read
+            "J_p2p_bearing": (lambda: ctx.normal_eq_joint([(L.RES_P2P, 1.0), (L.RES_BEARING, 1.0)], pose), 36),
+            "J_p2plane_bearing": (lambda: ctx.normal_eq_joint([(L.RES_P2PLANE, 1.0), (L.RES_BEARING, 1.0)], pose), 48),
+            "J_p2p_bearing_normal": (lambda: ctx.normal_eq_joint([(L.RES_P2P, 1.0), (L.RES_BEARING, 1.0), (L.RES_NORMAL, 1.0)], pose), 60),
+            "J_p2p_bearing_mask": (lambda: ctx.normal_eq_joint([(L.RES_P2P, 1.0), (L.RES_BEARING, 1.0)], pose, L.USE_MASK), 40),
         }
         # masks written by K4b would change what the masked kernels read: K4b cases run last, and the masks are restored after them
         order = ["K1p_moments", "K1p_moments_mask", "K5_nl_round", "K1_p2p", "K1_p2p_mask", "K2_p2plane", "K3_bearing",
+                 "J_p2p_bearing", "J_p2plane_bearing", "J_p2p_bearing_normal", "J_p2p_bearing_mask",
                  "K4b_mask_33", "K4b_mask_33_23", "K4b_mask_nn_33_23"]
         weighted_done = False
         for name in order + ["K5_nl_round_weighted"]:
