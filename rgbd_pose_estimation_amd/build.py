@@ -79,7 +79,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # without contraction -- the minimal solvers in pose/*.hpp evaluate the reference's expressions operation by operation
             cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+            # --offload-compress: the gfx950 code objects are stored compressed in the fat binary (a third of the size; the runtime
+            # unpacks a unit once, when its first kernel is looked up -- rpe_create touches every unit)
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress",
                    "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if not force and os.path.exists(obj) and all(os.path.getmtime(p) <= os.path.getmtime(obj) for p in _deps()):
             objs.append(obj)   # this unit is newer than every source and header: keep it
@@ -107,7 +109,7 @@ def build_stamps(level: int = 1, verbose: bool = False) -> str:
     obj = os.path.join(LIBDIR, f"rpe_normal_eq_stamps{level}.o")
     if os.path.exists(out) and all(os.path.getmtime(p) <= os.path.getmtime(out) for p in _deps()):
         return out
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", f"-DRPE_STAMPS={level}",
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress", f"-DRPE_STAMPS={level}",
            "-x", "hip", "-c", os.path.join(CSRC, "rpe_normal_eq.hip"), "-o", obj]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -89,6 +89,9 @@ int set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; 
 struct rpe_context {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // the solving workgroup of the autonomous resident loops runs beside its workers (created on first use)
+  hipEvent_t ev_stream2 = nullptr; // ... behind the uploads of the start pose / loop state on `stream`
+  bool auto_solver = true;         // ... until the two kernels once failed to meet (a platform that serialises them)
   bool own_stream = false;
   int64_t n = 0;
   int dtype = RPE_F32;
@@ -289,6 +292,8 @@ int wait_host(rpe_context* c, int ld) {
       hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail(RPE_ERR_HIP, "stream error while waiting for a kernel result: %s",
           hipGetErrorString(q));
+      // (an autonomous loop's result comes from its solving workgroup on the second stream: the workers' kernel ends before it does)
+      if (q == hipSuccess && c->stream2) { const hipError_t q2 = hipStreamQuery(c->stream2); if (q2 == hipErrorNotReady) continue; if (q2 != hipSuccess) (void)hipGetLastError(); }
       if (q == hipSuccess && __atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != want)
         return fail(RPE_ERR_HIP, "kernel finished without publishing its result (sequence %llu)", want);
     }
@@ -432,7 +437,7 @@ unsigned kind_slot_bits(int kind) {
 }
 bool take_clean(const rpe_context* c, int kind, bool host_verifies) {
   const unsigned bits = kind_slot_bits(kind);
-  if (c->guard_always || bits == 0) return false;
+  if (c->guard_always || bits == 0 || c->dtype == RPE_F64) return false;   // (the CLEAN flavours exist for fp32 arrays)
   bool all_verified = true;
   for (int s = 0; s < RPE_NUM_ARRAYS; s++) if (bits & (1u << s)) {
     if (c->arr_state[s] == kArrDirty) return false;
@@ -456,7 +461,7 @@ void note_clean_launch(rpe_context* c, int kind, bool finite) {
 }
 // ... for a SET of residual kinds (the joint kernels; bits = 1 << kind): CLEAN only if every kind of the set may take it
 bool take_clean_terms(const rpe_context* c, int bits, bool host_verifies) {
-  if (c->dtype == RPE_F64) return false;   // the joint kernels' CLEAN flavour exists for fp32 arrays
+  if (!rpe::joint_has_clean_flavour(c->dtype == RPE_F64 ? 1 : 0, bits)) return false;   // (the launch would run guarded: its finite record says nothing about the arrays)
   for (int k = 0; k <= 4; k++) if ((bits & (1 << k)) && !take_clean(c, k, host_verifies)) return false;
   return bits != 0;
 }
@@ -665,7 +670,7 @@ int rpe_create(rpe_context** out, int device, void* stream) {
       return fail(RPE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
   if (const char* mb = getenv("RPE_MAX_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 4096) c->max_blocks = v; }
   if (const char* mb = getenv("RPE_SCORE_BLOCKS")) { int v = atoi(mb); if (v >= 1 && v <= 65535) c->score_blocks = v; }
-  if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512 || v == 1024) c->block = v; }
+  if (const char* mb = getenv("RPE_BLOCK")) { int v = atoi(mb); if (v == 256 || v == 512) c->block = v; }
   if (const char* f = getenv("RPE_GUARD_ALWAYS")) c->guard_always = atoi(f) != 0;
   if (const char* f = getenv("RPE_HOST_CPU")) c->host_cpu_request = std::strcmp(f, "auto") == 0 ? -1 : (std::isdigit((unsigned char)f[0]) ? atoi(f) : -2);
   hipError_t e = hipSuccess;
@@ -767,6 +772,8 @@ void rpe_destroy(rpe_context* c) {
   if (c->comm && rccl().ok) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
+  if (c->ev_stream2) (void)hipEventDestroy(c->ev_stream2);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1162,11 +1169,30 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
   double pose_in[12];
   std::memcpy(pose_in, pose12, sizeof(pose_in));
   const bool joint_clean = !single && take_clean_terms(c, bits, false);   // no host in these loops: CLEAN only over verified arrays
+  // A SOLVING WORKGROUP beside the grid (rpe_residuals.hpp solver_loop): a one-workgroup kernel on a second stream that sums the
+  // workers' granules, solves, and hands the poses out -- one hop in and one out instead of two hops in front of `grid` identical
+  // solves.  It needs a compute unit of its own, so the workers' grid is capped one below the co-residency cap.  The two kernels must
+  // run together; a platform that serialises them ends in the bounded waits (a lost grid, below) and the context never tries again.
+  // Single kinds on fewer than 8 workgroups keep the form in which every workgroup solves (one workgroup: no hop at all); the joint
+  // kernels have only the solving-workgroup form.
+  bool use_solver = false;
+  int auto_blocks = c->max_blocks;
+  if (auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2 && c->auto_solver) {
+    const int capped = std::min(c->max_blocks, rpe::auto_solver_cap());
+    int g = 0, na = 0, mr = 1, ra = 1;
+    if (capped >= 1) rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, capped, &g, &na, &mr, &ra);
+    if (g >= 1 && (rpe::auto_solver_workers(g) > 0 || !single)) {
+      if (!c->stream2) { hipStream_t s2 = nullptr; if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) c->stream2 = s2; else (void)hipGetLastError(); }
+      if (c->stream2) { use_solver = true; auto_blocks = capped; }
+    }
+  }
   if (auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2 &&
-      (single || rpe::joint_resident_fits(c->arrays(), bits, flags, c->max_blocks, true, joint_clean))) {
+      (single ? rpe::normal_eq_resident_fits(c->arrays(), terms[0].kind, auto_blocks, !use_solver)
+              : (use_solver && rpe::joint_resident_fits(c->arrays(), bits, flags, auto_blocks, true, joint_clean)))) {
     // a single plain kind: the dedicated kernel (17 structured sums for point-to-point); anything else: the joint kernel (29 sums)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
-    rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
+    rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, auto_blocks, &grid, &nacc, &max_rows, &rows_auto);
+    rt.max_blocks = auto_blocks;
     const unsigned long long base = c->seq;          // granule / run-record tags base + 1 ... base + max_iter
     // as the host-driven loop: the run records are the ones its host would add
     (void)resident_run_shape(grid, nacc, max_rows, rows_auto, &rt);
@@ -1177,6 +1203,14 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
     std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
     rt.clean = single ? take_clean(c, terms[0].kind, false) : joint_clean;   // no host in this loop: CLEAN only over verified arrays
+    if (use_solver) {
+      rt.solver = 1;
+      // the solving workgroup reads the start pose and the loop state too: its stream waits for their upload on `stream`
+      if (!c->ev_stream2) HIP_TRY(hipEventCreateWithFlags(&c->ev_stream2, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(c->ev_stream2, c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_stream2, 0));
+      HIP_TRY(rpe::launch_auto_solver(nacc, grid, base, max_iter, rt, c->stream2));
+    }
     if (single) HIP_TRY(rpe::launch_normal_eq_resident(c->arrays(), terms[0].kind, flags, nullptr, base, max_iter, rt, c->stream, e0,
         e1));
     else HIP_TRY(rpe::launch_normal_eq_joint_resident(c->arrays(), bits, flags, scale, robust, rk, nullptr, base, max_iter, rt,
@@ -1193,7 +1227,9 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
       return RPE_OK;
     }
     // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per iteration
-    note_lost_grid(c);
+    if (rt.solver) { c->auto_solver = false; (void)hipStreamSynchronize(c->stream2); }   // (the solving workgroup and its workers did not meet)
+    else note_lost_grid(c);
+    rt.solver = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose_in, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
@@ -1304,7 +1340,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
   // sharded contexts: only with the host-side exchange (every rank's host thread adds the peers' records to its own each iteration);
   // RCCL / in-kernel peer-to-peer contexts take rpe_gn_steps_dist
   const bool sharded_ok = c->hostex ? !c->hostex_shared_gpu : (!c->comm && c->p2p_world_saved < 1);
-  if (c->resident && c->host_resident && max_iter >= 2 && sharded_ok) {
+  if (c->resident && c->host_resident && max_iter >= 2 && sharded_ok && rpe::normal_eq_resident_fits(c->arrays(), kinds[0], c->max_blocks)) {
     // ONE launch for the whole loop: the grid stays resident, the host hands every new pose to it through the control block in
     // device memory (two stores' worth of PCIe latency instead of a kernel launch per iteration) and solves / updates as before.
     int rc = kind_arrays(c, kinds[0]);

@@ -176,7 +176,7 @@ hipError_t launch_icp_fused(const float* vmap, const float* nmap, int64_t n, con
   // workgroups a streaming reduction of this size uses; measured, scripts/icp_sweep.sh); RPE_ICP_BLOCK / RPE_ICP_GRID override
   static const int env_blk = getenv("RPE_ICP_BLOCK") ? atoi(getenv("RPE_ICP_BLOCK")) : 0;
   static const int env_grid = getenv("RPE_ICP_GRID") ? atoi(getenv("RPE_ICP_GRID")) : 0;
-  const int blk = env_blk == 256 || env_blk == 512 ? env_blk : pick_block(rt, false);
+  const int blk = env_blk == 256 || env_blk == 512 ? env_blk : pick_block(rt);
   const int64_t groups = (n + 3) / 4;
   int G = env_grid > 0 ? env_grid : rt.max_blocks;
   if ((int64_t)G > (groups + blk - 1) / blk) G = (int)((groups + blk - 1) / blk);

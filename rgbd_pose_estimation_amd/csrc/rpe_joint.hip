@@ -348,7 +348,12 @@ template <int TERMS> struct JointNeeds {
   static constexpr bool HASNN = (TERMS & TERM_NORMAL) != 0;
   static constexpr bool XW = HAS33 || HAS23;                       // the normal-normal term alone never reads the world points
   static constexpr bool NC_WITH_33 = (TERMS & TERM_P2PLANE) != 0 && !HASNN;   // camera normals: reloaded behind the last term that reads them
+  static constexpr bool NC_SHARED = (TERMS & TERM_P2PLANE) != 0 && HASNN;     // ... read by the point-to-plane AND the normal-normal term
   static constexpr bool FIRST_IS_P2P = (TERMS & TERM_P2P) != 0;    // then the group's TermSums start as the expansion of its sums
+  // sets with another term beside the normal-normal one: the normal arrays are NOT part of the rotating set -- they are asked for right before their term (of the current
+  // group) and waited for there: with the accumulators, the fp64 points, the group's sums and three other arrays in flight the 256
+  // registers of a wave have no room to hold them through the two heavier terms
+  static constexpr bool LATE_NN = HASNN && (HAS33 || HAS23);
 };
 // a value every lane holds (read from LDS) moved into scalar registers: the pose of a resident iteration -- 24 vector registers otherwise
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -395,17 +400,20 @@ template <class T> struct JointSet {
     load_mask(A.m23, A.bv, g, k23);
     load_weight(A.w23, A.bv, g, u23);
   }
-  __device__ __forceinline__ void load_nn(const JointArrays<T>& A, int64_t g) {
+  // (with_nc = false: the camera normals are shared with the point-to-plane term and rotate by themselves -- load_nc)
+  __device__ __forceinline__ void load_nn(const JointArrays<T>& A, int64_t g, bool with_nc = true) {
     load3(A.nw, g, nw);
-    load3(A.nc, g, nc);
+    if (with_nc) load3(A.nc, g, nc);
     load_mask(A.mnn, A.nw, g, knn);
     load_weight(A.wnn, A.nw, g, unn);
   }
+  __device__ __forceinline__ void load_nc(const JointArrays<T>& A, int64_t g) { load3(A.nc, g, nc); }
   template <int TERMS> __device__ __forceinline__ void load_all(const JointArrays<T>& A, int64_t g) {
     if (JointNeeds<TERMS>::XW) load_xw(A, g);
     if (JointNeeds<TERMS>::HAS33) load_33<TERMS>(A, g);
     if (JointNeeds<TERMS>::HAS23) load_23(A, g);
-    if (JointNeeds<TERMS>::HASNN) load_nn(A, g);
+    if (JointNeeds<TERMS>::NC_SHARED) load_nc(A, g);
+    if (JointNeeds<TERMS>::HASNN && !JointNeeds<TERMS>::LATE_NN) load_nn(A, g);
   }
   // ---- the same through the workgroup's LDS (LdsPlan): plane k of an xyz array = vector k of every thread's group
   template <int BLK> static __device__ __forceinline__ void lds_put3(unsigned char* lds, int off, const V (&v)[3]) {
@@ -478,7 +486,7 @@ template <class V> __device__ __forceinline__ void pin3_here(V (&v)[3]) { pin16_
 // the next trip's use (load, wait, compute).
 template <class T, int TERMS, bool CLEAN>
 __device__ __forceinline__ void joint_trip(const PoseK<double>& pose, const JointK<T>& prm, const JointArrays<T>& A, JointSet<T>& q,
-                                           int64_t gl, double (&acc)[29]) {
+                                           int64_t g, int64_t gl, double (&acc)[29]) {
   constexpr int P = Pk<T>::P;
   typedef JointNeeds<TERMS> N;
   double pd[P][3];
@@ -511,12 +519,14 @@ __device__ __forceinline__ void joint_trip(const PoseK<double>& pose, const Join
     __builtin_amdgcn_sched_barrier(0);
   }
   if (N::HASNN) {
+    if (N::LATE_NN) { q.load_nn(A, g, !N::NC_SHARED); __builtin_amdgcn_sched_barrier(0); }
     pin3_here(q.nw); pin3_here(q.nc);
     unpack3(q.nw[0], q.nw[1], q.nw[2], va);
     unpack3(q.nc[0], q.nc[1], q.nc[2], vn);
     joint_groupnn<T, CLEAN>(pose, prm, va, vn, q.knn, A.mnn != nullptr, q.unn, A.wnn != nullptr, rs);
     __builtin_amdgcn_sched_barrier(0);
-    q.load_nn(A, gl);
+    if (!N::LATE_NN) q.load_nn(A, gl);
+    if (N::NC_SHARED) q.load_nc(A, gl);   // (the next group's, behind the last term that reads this group's)
     __builtin_amdgcn_sched_barrier(0);
   }
   rs.flush(acc);
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(BLK, sizeof(T) == 4 ? 512 / BLK : 1) void normal_eq
   if (g < full) q.template load_all<TERMS>(A, g);
   while (g < full) {
     const int64_t gn = g + stride;
-    joint_trip<T, TERMS, CLEAN>(pose, prm, A, q, gn < full ? gn : g, acc);
+    joint_trip<T, TERMS, CLEAN>(pose, prm, A, q, g, gn < full ? gn : g, acc);
     g = gn;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) joint_leftover<T, TERMS, CLEAN>(pose, prm, A, full, n, acc);
@@ -644,8 +654,8 @@ __global__ __launch_bounds__(BLK, sizeof(T) == 4 ? 512 / BLK : 1) void normal_eq
 // beyond the LDS) the slice is streamed from memory every iteration with the rotating trips of the one-launch kernel, the last trip
 // asking for the first group again; this form exists for the two-term fp32 sets (the three-term ones spill in it by 2-37 registers:
 // those refinements run one launch per iteration -- joint_resident_fits tells the caller).
-// AUTO (rpe_gn_refine_device): no host in the loop -- the first pose from HBM, every later one from the workgroup's own solve
-// (resident_auto_stage), exactly as the single-kind resident kernel's autonomous form.
+// AUTO (rpe_gn_refine_device): no host in the loop -- the first pose from HBM, every later one from the SOLVING WORKGROUP that the
+// caller launches beside this grid (launch_auto_solver; rpe_residuals.hpp solver_loop).
 template <class T, int TERMS, int BLK, bool AUTO, bool CLEAN, bool STAGED>
 __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArrays<T> A, int64_t n, JointK<T> prm, LdsPlan pl,
                                                                        const unsigned long long* __restrict__ ctl,
@@ -655,23 +665,27 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
   __shared__ double s_pose[12];
   __shared__ int s_go;
   const int64_t full = n / P;
+  // AUTO: the autonomous loop -- a solving workgroup (auto_solver_kernel, launched beside this grid) plays the host: the workers send
+  // their sums as granules and wait for its pose record (rpe_residuals.hpp solver_loop)
+  constexpr bool with_solver = AUTO;
+  const int workers = (int)gridDim.x;
   const int64_t g0 = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  const bool mine = g0 < full;     // (STAGED: the launcher guarantees full <= gridDim.x * BLK: one group per thread)
+  const bool mine = g0 < full;     // (STAGED: the launcher guarantees full <= workers * BLK: one group per thread)
   JointSet<T> q;
   if (mine) {
     q.template load_all<TERMS>(A, g0);
+    if (STAGED && JointNeeds<TERMS>::LATE_NN) q.load_nn(A, g0, !JointNeeds<TERMS>::NC_SHARED);   // (not part of the rotating set: asked for here, for the staging)
     if (STAGED) q.template stage_all<TERMS, BLK>(j_lds, pl, A);   // every thread reads back only what it wrote itself: no barrier
   }
-  double tol = 0.0;
   if (AUTO) {
     if (threadIdx.x < 12) s_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
-    tol = fin.gn->tol;
     __syncthreads();
   }
   for (int it = 1; it <= max_iters; it++) {
     if (STAGED) q.template get_first<TERMS, BLK>(j_lds, pl);   // in flight while the workgroup waits for its pose (a thread without a group reads its own unused slot)
     // stop requested or no host
     if (!AUTO && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;
+    if (with_solver && it > 1 && solver_wait_pose<BLK>(solver_pose_area(fin, workers, 29), first_tag + (unsigned long long)it, s_pose, &s_go) != 0) return;
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = uniform_f64(s_pose[k]);
@@ -682,18 +696,15 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
     for (int k = 0; k < 29; k++) acc[k] = 0.0;
     if (STAGED) { if (mine) joint_trip_lds<T, TERMS, BLK, CLEAN>(pose, prm, A, q, j_lds, pl, acc); }
     else {
-      const int64_t stride = (int64_t)gridDim.x * BLK;
+      const int64_t stride = (int64_t)workers * BLK;
       for (int64_t g = g0; g < full;) {
         const int64_t gn = g + stride;
-        joint_trip<T, TERMS, CLEAN>(pose, prm, A, q, gn < full ? gn : g0, acc);   // (the last trip asks for the FIRST group: the next iteration's)
+        joint_trip<T, TERMS, CLEAN>(pose, prm, A, q, g, gn < full ? gn : g0, acc);   // (the last trip asks for the FIRST group: the next iteration's)
         g = gn;
       }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) joint_leftover<T, TERMS, CLEAN>(pose, prm, A, full, n, acc);
-    if (AUTO) {
-      if (resident_auto_stage<29, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose) != 0) return;
-      continue;
-    }
+    if (with_solver) { solver_send_sums<29, BLK>(acc, fin, first_tag + (unsigned long long)it); continue; }
     if (!resident_cross_stage<29, BLK>(acc, fin, first_tag + (unsigned long long)it, fin.seq + (unsigned long long)it, false)) return;
   }
 }
@@ -705,14 +716,16 @@ template <class T> static JointArrays<T> joint_arrays(const DeviceArrays& A, boo
   J.w23 = uw ? (const T*)A.weight[0] : nullptr; J.w33 = uw ? (const T*)A.weight[1] : nullptr; J.wnn = uw ? (const T*)A.weight[2] : nullptr;
   return J;
 }
-// The CLEAN flavour exists for fp32 arrays (the dense-depth path); fp64 arrays always take the guarded one.
-template <class T> constexpr bool joint_has_clean() { return sizeof(T) == 4; }
+// The CLEAN flavour exists for fp32 arrays (the dense-depth path) -- fp64 arrays always take the guarded one -- and not for the sets
+// in which the point-to-plane and the normal-normal term share the camera normals (its instances are 2-14 registers short).
+// joint_has_clean_flavour tells the C-ABI shim, whose clean-first protocol must know which flavour a launch really took.
+template <class T, int TERMS> constexpr bool joint_has_clean() { return sizeof(T) == 4 && !JointNeeds<TERMS>::NC_SHARED; }
 // The resident form exists for every fp32 term set and for the single-term fp64 sets: the multi-term fp64 instances would spill (term
 // sums of 64 registers beside 58 accumulator registers in the 256 a wave of a 512-thread workgroup gets); those refinements run one
 // launch per iteration.
 // ... and its CLEAN flavour for all of those but the autonomous three-term instances (1-4 registers short: they run guarded)
 template <class T, int TERMS, bool AUTO> constexpr bool joint_has_clean_resident() {
-  return sizeof(T) == 4 && !(AUTO && JointNeeds<TERMS>::HAS33 && JointNeeds<TERMS>::HAS23 && JointNeeds<TERMS>::HASNN);
+  return joint_has_clean<T, TERMS>() && !(AUTO && JointNeeds<TERMS>::HAS33 && JointNeeds<TERMS>::HAS23 && JointNeeds<TERMS>::HASNN);
 }
 template <class T, int TERMS> constexpr bool joint_has_resident() { return sizeof(T) == 4 || (TERMS & (TERMS - 1)) == 0; }
 
@@ -726,7 +739,7 @@ static void joint_launch(const DeviceArrays& A, int flags, const PoseK<double>& 
   const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
   const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
   const JointArrays<T> J = joint_arrays<T>(A, um, uw);
-  if constexpr (joint_has_clean<T>()) {
+  if constexpr (joint_has_clean<T, TERMS>()) {
     if (rt.clean) { RPE_LAUNCH_EV((normal_eq_joint_kernel<T, TERMS, BLK, true>), dim3(G), dim3(BLK), 0, s, e0, e1, J, A.n, pose, prm, make_finish(rt)); return; }
   }
   RPE_LAUNCH_EV((normal_eq_joint_kernel<T, TERMS, BLK, false>), dim3(G), dim3(BLK), 0, s, e0, e1, J, A.n, pose, prm, make_finish(rt));
@@ -780,7 +793,7 @@ template <class T, int TERMS> constexpr bool joint_has_stream_resident() {
   return sizeof(T) == 4 && ((int)N::HAS33 + (int)N::HAS23 + (int)N::HASNN) == 2;
 }
 template <class T, int TERMS, bool AUTO> constexpr bool joint_has_clean_stream_resident() {
-  return joint_has_stream_resident<T, TERMS>() && !(AUTO && (TERMS & TERM_P2PLANE) != 0);
+  return joint_has_stream_resident<T, TERMS>() && joint_has_clean<T, TERMS>() && !(AUTO && (TERMS & TERM_P2PLANE) != 0);
 }
 template <class T, int TERMS, bool AUTO, bool CLEAN> static int joint_resident_lds() {
   static int left[64];
@@ -824,8 +837,8 @@ static void joint_resident_launch_k(const JointArrays<T>& J, int64_t n, int G, c
   LdsPlan pl = joint_lds_plan<T, TERMS, BLK>(J);
   if (STAGED) (void)joint_resident_lds<T, TERMS, AUTO, CLEAN>();   // (sets the instance's dynamic-LDS limit)
   else pl.bytes = 0;
-  hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, AUTO, CLEAN, STAGED>), dim3(G), dim3(BLK), (size_t)pl.bytes, s, J, n, prm, pl,
-                     ctl, first_tag, max_iters, fin);
+  hipLaunchKernelGGL((normal_eq_joint_resident_kernel<T, TERMS, BLK, AUTO, CLEAN, STAGED>), dim3(G), dim3(BLK), (size_t)pl.bytes, s, J, n, prm, pl, ctl,
+                     first_tag, max_iters, fin);
 }
 template <class T, int TERMS>
 static void joint_resident_launch(const DeviceArrays& A, int flags, const JointParams& prm64, const unsigned long long* ctl,
@@ -884,6 +897,15 @@ static bool joint_fits_t(const DeviceArrays& A, int terms, int flags, int max_bl
   const JointArrays<T> J = joint_arrays<T>(A, (flags & F_USE_MASK) != 0, (flags & F_USE_WEIGHT) != 0);
   switch (terms) {
 #define RPE_JOINT_CASE(M) case M: return (autonomous ? joint_resident_form<T, M, true>(J, A.n, G, clean) : joint_resident_form<T, M, false>(J, A.n, G, clean)) != 0;
+    RPE_JOINT_TERM_SETS(RPE_JOINT_CASE)
+#undef RPE_JOINT_CASE
+  }
+  return false;
+}
+bool joint_has_clean_flavour(int dtype, int terms) {
+  if (dtype) return false;
+  switch (terms) {
+#define RPE_JOINT_CASE(M) case M: return joint_has_clean<float, M>();
     RPE_JOINT_TERM_SETS(RPE_JOINT_CASE)
 #undef RPE_JOINT_CASE
   }

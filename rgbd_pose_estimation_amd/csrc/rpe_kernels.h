@@ -68,6 +68,7 @@ struct ReduceTarget {
   // to hold finite values: the shim launches it first and repeats the launch in the guarded flavour if the record comes back
   // non-finite (rpe_capi.hip clean_first); results nobody on the host inspects use it only for arrays already verified
   bool clean = false;
+  int solver = 0;              // autonomous resident loops: 1 = launch_auto_solver's workgroup sums, solves and hands the poses out
   int stride = 0;              // resident kernels: > 1 = strided runs (see Finish)
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out
                                // must hold
@@ -101,6 +102,15 @@ int resident_cap_device();
 void preload_normal_eq(); void preload_icp(); void preload_joint(); void preload_score(); void preload_nl();
 void preload_frontend(); void preload_hypotheses(); void preload_prosac();
 void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* grid, int* nacc, int* max_rows, int* rows_auto);
+// The solving workgroup of an autonomous resident loop (rpe_residuals.hpp solver_loop): ONE workgroup, launched on a stream of its own
+// BEFORE the workers' kernel (launch_normal_eq_resident / launch_normal_eq_joint_resident with rt.solver = 1, same rt otherwise); nacc =
+// 17 (point-to-point) or 29; workers = the grid of the workers' kernel (resident_geometry).  auto_solver_workers: that grid if the
+// solving workgroup applies to it (enough workers, one compute unit to spare, RPE_AUTO_SOLVER != 0), else 0.
+int auto_solver_workers(int grid);
+int auto_solver_cap();   // the largest workers' grid that leaves the solving workgroup its compute unit
+hipError_t launch_auto_solver(int nacc, int workers, unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s);
+// false: no resident instance serves this problem (fp64 arrays, 2D-3D kinds, more than one group per thread): one launch per iteration
+bool normal_eq_resident_fits(const DeviceArrays& A, int kind, int max_blocks, bool autonomous_no_solver = false);
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl,
     unsigned long long first_tag,
                                      int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
@@ -117,6 +127,8 @@ hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, c
 // the resident form serves frame-sized problems only (one group per thread, the workgroup's slice staged in its LDS): true if this
 // term set / size / mask-and-weight use fits; otherwise the refinement runs one launch of the joint kernel per iteration
 bool joint_resident_fits(const DeviceArrays& A, int terms, int flags, int max_blocks, bool autonomous, bool clean);
+// does the joint kernel of this term set have a CLEAN flavour (no NaN guards)?  rt.clean is ignored where it has none
+bool joint_has_clean_flavour(int dtype, int terms);
 hipError_t launch_normal_eq_joint_resident(const DeviceArrays& A, int terms, int flags, const double* scale4, const int* robust4,
                                            const double* robust_k4, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
                                            const ReduceTarget& rt, hipStream_t s);

@@ -442,9 +442,8 @@ static void moments_launch(const DeviceArrays& A, int flags, const ReduceTarget&
 }
 template <class T>
 static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  const int blk = pick_block(rt, true);
-  if (blk == 1024) moments_launch<T, 1024>(A, flags, rt, s, e0, e1);
-  else if (blk == 512) moments_launch<T, 512>(A, flags, rt, s, e0, e1);
+  const int blk = pick_block(rt);
+  if (blk == 512) moments_launch<T, 512>(A, flags, rt, s, e0, e1);
   else moments_launch<T, 256>(A, flags, rt, s, e0, e1);
   return hipGetLastError();
 }
@@ -474,7 +473,8 @@ static hipError_t nl_round_t(const DeviceArrays& A, const double* params24, cons
   for (int i = 0; i < 9; i++) prm.Rwc[i] = params24[9 + i];
   // 44 fp64 accumulators + one group of streamed data need ~240 VGPRs (two waves per SIMD, no spills): 256-thread workgroups unless
   // the caller's reduce target asks for 512 (the same two waves per SIMD in half as many workgroups)
-  if (rt.block == 512) nl_round_launch<T, 512>(A, prm, rt, s, e0, e1);
+  // (fp64 arrays: 256 only -- the generic form's 512-thread instance is 3 registers short)
+  if (rt.block == 512 && sizeof(T) == 4) { if constexpr (sizeof(T) == 4) nl_round_launch<T, 512>(A, prm, rt, s, e0, e1); }
   else nl_round_launch<T, 256>(A, prm, rt, s, e0, e1);
   return hipGetLastError();
 }

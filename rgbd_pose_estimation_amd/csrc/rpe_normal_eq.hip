@@ -133,7 +133,9 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
 
 // IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
 // loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, bool AUTO, bool CLEAN>
+// AUTO: 0 = host-driven; 1 = autonomous, every workgroup adds the run records and solves (resident_auto_stage: grids too small for
+// 2, always one group per thread); 2 = autonomous with a solving workgroup beside the grid (auto_solver_kernel, solver_loop)
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, int AUTO, bool CLEAN>
 __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b,
     const T* __restrict__ c,
                                                                  const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
@@ -144,7 +146,10 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
   __shared__ double s_pose[12];
   __shared__ int s_go;
   const int64_t full = n / P, groups = (n + P - 1) / P;
-  const int64_t stride = (int64_t)gridDim.x * BLK;
+  // autonomous loop with a solving workgroup (auto_solver_kernel below, launched beside this grid): the workers send sums and wait
+  constexpr bool with_solver = AUTO == 2;
+  const int workers = (int)gridDim.x;
+  const int64_t stride = (int64_t)workers * BLK;
   const int64_t g0 = (int64_t)blockIdx.x * BLK + threadIdx.x;
   T rw[3 * P], rb[3 * P], rc[3 * P];
   short rm[P];
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     rpresent = g0 < full ? P : (int)(n - full * P);
   }
   // autonomous form (fin.gn set): the first pose comes from HBM, every later one from this workgroup's own solve (resident_auto_stage)
-  constexpr bool autonomous = AUTO;   // a template parameter: the host-driven instances carry no call to the solve (registers, scratch)
+  constexpr bool autonomous = AUTO != 0;   // a template parameter: the host-driven instances carry no call to the solve (registers, scratch)
   double tol = 0.0;
   if (autonomous) {
     if (threadIdx.x < 12) s_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     // stop requested or no host: uniform for the workgroup
     if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go,
         fin.pose_wait_ticks) != 1) return;
+    if (with_solver && it > 1 && solver_wait_pose<BLK>(solver_pose_area(fin, workers, NACC), first_tag + (unsigned long long)it, s_pose, &s_go) != 0) return;
 #ifdef RPE_STAMPS
     const bool stamp_it = it == 1000;
     if (stamp_it) RPE_STAMP(0);
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #ifndef RPE_STAMPS
     const bool stamp_it = false;
 #endif
+    if (with_solver) { solver_send_sums<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it); continue; }
     if (autonomous) {
       if (resident_auto_stage<NACC, BLK>(acc, fin, first_tag + (unsigned long long)it, it, max_iters, tol, s_pose,
           stamp_it) != 0) return;
@@ -233,7 +240,8 @@ static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<doubl
   // timed launches (bench.py's roofline leg) go through hipExtLaunchKernelGGL: the two events then carry the dispatch's own begin / end
   // timestamps -- what rocprofv3 reports for the kernel -- instead of bracketing it with two marker packets (which adds their latency)
 #define RPE_NE_LAUNCH2(M, W, C) RPE_LAUNCH_EV((normal_eq_kernel<T, KIND, BLK, M, W, C>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, pose, fin)
-#define RPE_NE_LAUNCH(M, W) do { if (rt.clean) RPE_NE_LAUNCH2(M, W, true); else RPE_NE_LAUNCH2(M, W, false); } while (0)
+  // (the CLEAN flavour exists for fp32 arrays -- the dense-depth path; fp64 arrays always take the guarded one)
+#define RPE_NE_LAUNCH(M, W) do { if constexpr (sizeof(T) == 4) { if (rt.clean) { RPE_NE_LAUNCH2(M, W, true); break; } } RPE_NE_LAUNCH2(M, W, false); } while (0)
   if (mask && weight) RPE_NE_LAUNCH(true, true);
   else if (mask) RPE_NE_LAUNCH(true, false);
   else if (weight) RPE_NE_LAUNCH(false, true);
@@ -245,19 +253,20 @@ template <class T>
 static hipError_t normal_eq_t(const DeviceArrays& A, int kind, int flags, const double* pose12, const ReduceTarget& rt, hipStream_t s,
                               hipEvent_t ev0, hipEvent_t ev1) {
   const PoseK<double> pose = make_pose<double>(pose12);
-  const int blk = pick_block(rt, kind == KIND_P2P);
+  // fp64 arrays, the 29-sum kinds: 256-thread workgroups only (one wave per SIMD with the whole register file; their 512-thread
+  // instances spilled 2-183 registers)
+  const int blk = (sizeof(T) == 8 && kind != KIND_P2P) ? 256 : pick_block(rt);
   if (kind == KIND_P2P) {
-    if (blk == 1024) normal_eq_launch<T, KIND_P2P, 1024>(A, flags, pose, rt, s, ev0, ev1);
-    else if (blk == 512) normal_eq_launch<T, KIND_P2P, 512>(A, flags, pose, rt, s, ev0, ev1);
+    if (blk == 512) normal_eq_launch<T, KIND_P2P, 512>(A, flags, pose, rt, s, ev0, ev1);
     else normal_eq_launch<T, KIND_P2P, 256>(A, flags, pose, rt, s, ev0, ev1);
   } else if (kind == KIND_P2PLANE) {
-    if (blk == 512) normal_eq_launch<T, KIND_P2PLANE, 512>(A, flags, pose, rt, s, ev0, ev1);
+    if (blk == 512) { if constexpr (sizeof(T) == 4) normal_eq_launch<T, KIND_P2PLANE, 512>(A, flags, pose, rt, s, ev0, ev1); }
     else normal_eq_launch<T, KIND_P2PLANE, 256>(A, flags, pose, rt, s, ev0, ev1);
   } else if (kind == KIND_BEARING) {
-    if (blk == 512) normal_eq_launch<T, KIND_BEARING, 512>(A, flags, pose, rt, s, ev0, ev1);
+    if (blk == 512) { if constexpr (sizeof(T) == 4) normal_eq_launch<T, KIND_BEARING, 512>(A, flags, pose, rt, s, ev0, ev1); }
     else normal_eq_launch<T, KIND_BEARING, 256>(A, flags, pose, rt, s, ev0, ev1);
   } else if (kind == KIND_REPROJ) {
-    if (blk == 512) normal_eq_launch<T, KIND_REPROJ, 512>(A, flags, pose, rt, s, ev0, ev1);
+    if (blk == 512) { if constexpr (sizeof(T) == 4) normal_eq_launch<T, KIND_REPROJ, 512>(A, flags, pose, rt, s, ev0, ev1); }
     else normal_eq_launch<T, KIND_REPROJ, 256>(A, flags, pose, rt, s, ev0, ev1);
   } else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -268,6 +277,7 @@ hipError_t launch_normal_eq(const DeviceArrays& A, int kind, int flags, const do
       ev0, ev1);
 }
 
+template <class T, int KIND> constexpr bool resident_streams() { return !(sizeof(T) == 8 && (KIND == KIND_BEARING || KIND == KIND_REPROJ)); }
 // resident form: ONE launch for up to max_iters iterations; ctl = the control block in fine-grained device memory, first_tag + i =
 // tag of pose i (i = 1 ...), rt.seq + i = sequence value published with record i
 template <class T, int KIND, int BLK>
@@ -289,10 +299,15 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   constexpr int kMaxRows = 4 * (BLK / (KIND == KIND_P2P ? 17 : 29));   // up to 4 granules per collecting thread
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
   if (fin.rows < 1) fin.rows = 1;
+  if (fin.gn == nullptr) fin.solver = 0;
 #define RPE_RES_LAUNCH4(M, W, R, AU, C) RPE_LAUNCH_EV((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU, C>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin)
-#define RPE_RES_LAUNCH3(M, W, R, AU) do { if (rt.clean) RPE_RES_LAUNCH4(M, W, R, AU, true); else RPE_RES_LAUNCH4(M, W, R, AU, false); } while (0)
-#define RPE_RES_LAUNCH2(M, W, R) do { if (fin.gn != nullptr) RPE_RES_LAUNCH3(M, W, R, true); else RPE_RES_LAUNCH3(M, W, R, false); } while (0)
-#define RPE_RES_LAUNCH(M, W) do { if (in_regs) RPE_RES_LAUNCH2(M, W, true); else RPE_RES_LAUNCH2(M, W, false); } while (0)
+#define RPE_RES_LAUNCH3(M, W, R, AU) do { if constexpr (sizeof(T) == 4) { if (rt.clean) { RPE_RES_LAUNCH4(M, W, R, AU, true); break; } } RPE_RES_LAUNCH4(M, W, R, AU, false); } while (0)
+  // (autonomous without a solving workgroup: only grids of fewer than 8 workgroups -- always one group per thread)
+#define RPE_RES_LAUNCH2(M, W, R) do { if (fin.gn != nullptr) { if (fin.solver) RPE_RES_LAUNCH3(M, W, R, 2); else if constexpr (R) RPE_RES_LAUNCH3(M, W, R, 1); } \
+                                      else RPE_RES_LAUNCH3(M, W, R, 0); } while (0)
+  // (fp64 arrays, the two-row 2D-3D kinds, more than one group per thread: no instance -- it spilled 7-45 registers; the callers ask
+  // normal_eq_resident_fits first and run those refinements one launch per iteration)
+#define RPE_RES_LAUNCH(M, W) do { if (in_regs) RPE_RES_LAUNCH2(M, W, true); else if constexpr (resident_streams<T, KIND>()) RPE_RES_LAUNCH2(M, W, false); } while (0)
   if (mask && weight) RPE_RES_LAUNCH(true, true);
   else if (mask) RPE_RES_LAUNCH(true, false);
   else if (weight) RPE_RES_LAUNCH(false, true);
@@ -328,9 +343,9 @@ int resident_cap_device() {
   int cus = 0, c = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
   int per_cu = 1;
-  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, false, false, false>,
-                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, 512, true, false, true, true, false>,
-                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, 512, true, true, false, false, false>};
+  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, false, 0, false>,
+                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, 512, true, false, true, 1, false>,
+                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, 512, true, true, true, 0, false>};
   for (const void* k : heavy) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 512, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
@@ -357,6 +372,29 @@ void resident_geometry(const DeviceArrays& A, int kind, int max_blocks, int* gri
   if (mult > 4) mult = 4;
   if (mult < 1) mult = 1;
   *rows_auto = rgn * mult;
+}
+// ---- the solving workgroup of the autonomous loops, as a kernel of its own (rpe_residuals.hpp solver_loop)
+template <int NACC>
+__global__ __launch_bounds__(512) void auto_solver_kernel(int workers, unsigned long long first_tag, int max_iters, Finish fin) {
+  solver_loop<NACC, 512>(fin, workers, first_tag, max_iters);
+}
+int auto_solver_workers(int grid) { return auto_solver_grid(grid, std::max(1, resident_cap_device())) ? grid : 0; }
+int auto_solver_cap() { return std::max(1, resident_cap_device()) - 1; }
+hipError_t launch_auto_solver(int nacc, int workers, unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s) {
+  const Finish fin = make_finish(rt);
+  if (nacc == 17) hipLaunchKernelGGL((auto_solver_kernel<17>), dim3(1), dim3(512), 0, s, workers, first_tag, max_iters, fin);
+  else hipLaunchKernelGGL((auto_solver_kernel<29>), dim3(1), dim3(512), 0, s, workers, first_tag, max_iters, fin);
+  return hipGetLastError();
+}
+// has the resident kernel an instance for this problem?  Everything but (a) fp64 arrays of the 2D-3D kinds beyond one group per thread,
+// (b) autonomous loops WITHOUT a solving workgroup beyond one group per thread (that form exists for small grids only).
+bool normal_eq_resident_fits(const DeviceArrays& A, int kind, int max_blocks, bool autonomous_no_solver) {
+  const bool narrow = A.dtype && (kind == KIND_BEARING || kind == KIND_REPROJ);
+  if (!narrow && !autonomous_no_solver) return true;
+  const int P = A.dtype ? 2 : 4;
+  const int blk = resident_block(), cap = std::max(1, resident_cap_device());
+  const int G = reduce_grid(A.n, P, max_blocks < cap ? max_blocks : cap, blk);
+  return (int64_t)G * blk >= (A.n + P - 1) / P;
 }
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl,
     unsigned long long first_tag,

@@ -313,6 +313,7 @@ struct Finish {
   unsigned long long pose_wait_ticks;
   unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
   double pivot_floor;                   // device-side 6x6 solves: relative pivot floor (rpe::pivot_floor, rpe/linalg.hpp)
+  int solver;                           // autonomous resident loops: 1 = a solving workgroup (auto_solver_kernel, its own launch) plays the host
 };
 // what a collecting workgroup sends to the host in place of its run's sums when a granule of the run never arrived: a quiet NaN with a
 // payload no arithmetic produces; the host then releases the grid and finishes the refinement with one launch per iteration
@@ -928,19 +929,19 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.rows = rt.rows > 0 ? rt.rows : 0;
   f.stride = rt.stride > 1 ? rt.stride : 0;
   f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag; f.pivot_floor = rt.pivot_floor;
+  f.solver = rt.solver;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)
 // costs latency proportional to the number of workgroups, the body wants every CU busy: 512-thread workgroups, at
 // most 2 per CU (512 records), is the measured sweet spot on MI355X from 307 200 correspondences up; rt.block /
 // rt.max_blocks (RPE_BLOCK / RPE_MAX_BLOCKS) override it for experiments.
-static inline int pick_block(const ReduceTarget& rt, bool allow_1024) {
+static inline int pick_block(const ReduceTarget& rt) {
   // with the collecting stage the cross-workgroup cost no longer grows with the number of workgroups, and 256-thread workgroups (one
-  // wave per SIMD on a frame, two workgroups per CU beyond) win: 5.7 vs 6.3 us at 307 200 points, configs[3] cold 11.8 vs 13.0 us
-  int b = rt.block > 0 ? rt.block : (rt.rows > 0 ? 256 : 512);
-  if (b >= 1024 && allow_1024) return 1024;
-  if (b >= 512) return 512;
-  return 256;
+  // wave per SIMD on a frame, two workgroups per CU beyond) win: 5.7 vs 6.3 us at 307 200 points, configs[3] cold 11.8 vs 13.0 us.
+  // (1024-thread workgroups existed until round 4: 128 registers per wave, every instance spilled 7-87 of them -- removed.)
+  const int b = rt.block > 0 ? rt.block : (rt.rows > 0 ? 256 : 512);
+  return b >= 512 ? 512 : 256;
 }
 
 }  // namespace rpe

@@ -565,13 +565,14 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
     lost = __syncthreads_or(collect_rows<NACC, BLK>(gran, G, leader, rows, tag, a_part, rs.step));
     if (!lost) {   // uniform over the workgroup
       const double t = sum_rows<NACC, BLK>(a_part, rows < RGN ? rows : RGN);
-      if (threadIdx.x < NACC) store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag);
+      // (ONE workgroup: its sums are the record -- no run record through device memory, no poll: 1 us of a 4 us iteration)
+      if (threadIdx.x < NACC) { if (G == 1) a_runs[threadIdx.x] = t; else store_granule16(rrec + 2 * ((size_t)run * NACC + threadIdx.x), t, tag); }
     }
   }
 #ifdef RPE_STAMPS
   if (stamp_it) RPE_STAMP(3);
 #endif
-  if (!lost) {
+  if (!lost && G > 1) {
     const int total = runs * NACC;
     for (int i = threadIdx.x; i < total; i += BLK) {
       const unsigned long long t0 = wall_clock64();
@@ -626,6 +627,136 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   return lost ? 2 : (done ? 1 : 0);
+}
+
+// ---- AUTONOMOUS loop with a SOLVING WORKGROUP (round 5).  resident_auto_stage above makes every workgroup a reader of all run records
+// and a solver: two cross-workgroup hops (granules -> per-XCD collectors -> run records -> everybody) in front of 150 identical solves,
+// 6.0 us per iteration at 307 200 correspondences of which 2.8 us are the hops.  A frame-sized problem leaves a hundred compute units
+// idle, so ONE extra workgroup plays the part the host plays in the host-driven loop: the workers store their sums as granules and wait
+// for the next pose; the solving workgroup -- a ONE-WORKGROUP KERNEL OF ITS OWN on a second stream (auto_solver_kernel; inside the
+// workers' kernel, inlined or as a call, it cost the main path 16-50 spilled registers or a 160-byte stack) -- polls ALL G x NACC
+// granules itself (up to four
+// in flight per thread: collect_rows), adds them in workgroup order, solves, applies the exp-map and publishes the pose as 14 granules
+// {value, tag} that the first wave of every worker polls.  One hop in, one hop out, one solve.
+// Pose record: granules 0..11 = pose, 12 = |delta|, 13 = code (0 go on, 1 finished, 2 failed / lost), all tagged first_tag + iteration
+// of the iteration that is to USE the pose.  Single-buffered like the granules: the solver writes pose i + 1 after it has read every
+// worker's sums of iteration i, i.e. after every worker has read pose i; a worker overwrites its granules of iteration i after it has
+// read pose i + 1, which was written after they were read.
+constexpr int kSolverPoseGranules = 14;
+__device__ __forceinline__ unsigned long long* solver_pose_area(const Finish& fin, int workers, int nacc) {
+  return reinterpret_cast<unsigned long long*>(fin.partials) + 2 * ((size_t)(workers + 8) * nacc);
+}
+// worker: wait for the pose record tagged `want`; returns the code (0 go on -- pose in s_pose --, 1 / 2 leave, 3 timed out)
+template <int BLK>
+__device__ __forceinline__ int solver_wait_pose(const unsigned long long* __restrict__ area, unsigned long long want, double* __restrict__ s_pose,
+                                                int* __restrict__ s_go) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    granule_t q = {};
+    int go = -1;
+    for (unsigned int spins = 1;; spins++) {
+      bool have = true;
+      if (lane < kSolverPoseGranules) {
+        q = load_granule16(area + 2 * (size_t)lane);
+        have = (((unsigned long long)q.w << 32) | q.z) == want;
+      }
+      if (__builtin_amdgcn_ballot_w64(!have) == 0) { go = 0; break; }
+      if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // 2 s: the solving workgroup went away
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const double v = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
+    if (lane < 12) s_pose[lane] = v;
+    if (lane == 13) *s_go = go == 3 ? 3 : (int)v;
+  }
+  __syncthreads();
+  return *s_go;
+}
+// worker: this workgroup's NACC sums of the iteration as granules (every worker, no collecting workgroup)
+template <int NACC, int BLK>
+__device__ __forceinline__ void solver_send_sums(const double (&acc)[NACC], const Finish& fin, unsigned long long tag) {
+  constexpr int NW = BLK / 64;
+  __shared__ double w_red[NW][NACC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);
+  wave_reduce_to<NACC>(acc, w_red[wave], lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double own = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) own += w_red[w][threadIdx.x];
+    store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+  }
+  __syncthreads();   // w_red is reused by the next iteration
+}
+// the solving workgroup's whole life: iterations 1 .. max_iters
+template <int NACC, int BLK>
+__device__ __forceinline__ void solver_loop(const Finish& fin, int workers, unsigned long long first_tag, int max_iters) {
+  constexpr int RGN = BLK / NACC;
+  constexpr int MODE = NACC == 17 ? 1 : 0;
+  __shared__ double v_part[RGN][NACC];
+  __shared__ double v_tot[32];
+  __shared__ double v_pose[12];
+  __shared__ double v_step;
+  __shared__ int v_code;
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);
+  unsigned long long* area = solver_pose_area(fin, workers, NACC);
+  if (threadIdx.x < 12) v_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
+  const double tol = fin.gn->tol;
+  __syncthreads();
+  for (int it = 1; it <= max_iters; it++) {
+    const unsigned long long tag = first_tag + (unsigned long long)it;
+    if (threadIdx.x < NACC) v_part[0][threadIdx.x] = 0.0;   // "row 0" of collect_rows is the collector's own record: none here
+    __syncthreads();
+    bool lost = collect_rows<NACC, BLK, 12>(gran, workers, -1, workers + 1, tag, v_part, 1);   // rows 1 .. workers = workgroups 0 .. workers - 1 (up to twelve granules in flight per thread: ONE sweep for a frame-sized grid of either record size)
+    lost = __syncthreads_or(lost);
+    const double t = sum_rows<NACC, BLK>(v_part, workers + 1 < RGN ? workers + 1 : RGN);
+    if (threadIdx.x < 64) {
+      if (threadIdx.x < 32) v_tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (threadIdx.x == 0) {
+        double step = 0.0;
+        const bool ok = !lost && gn_solve_update<MODE>(v_tot, v_pose, &step, fin.pivot_floor);
+        v_step = step;
+        v_code = !ok ? 2 : ((step < tol || it >= max_iters) ? 1 : 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int lane = threadIdx.x;
+      // finished: the result to the host FIRST (as resident_auto_stage publishes it), the pose record -- on whose code the workers leave
+      // -- after it: the host takes "the workers' kernel has ended" for "the result is there"
+      if (lane == 0 && v_code != 0 && fin.out_host) {
+        const bool ok = v_code == 1;
+        for (int k = 0; k < 12; k++) __hip_atomic_store(fin.out_host + k, v_pose[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 12, v_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 13, lost ? 0.0 : record_entry<MODE>(v_tot, 27), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 14, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 15, ok ? 0.0 : (lost ? 2.0 : 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 16, lost ? 0.0 : record_entry<MODE>(v_tot, 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(fin.out_host + 32), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < kSolverPoseGranules) {
+        const double v = lane < 12 ? v_pose[lane] : (lane == 12 ? v_step : (double)v_code);
+        store_granule16(area + 2 * (size_t)lane, v, tag + 1);
+      }
+    }
+    __syncthreads();
+    if (v_code != 0) return;
+  }
+}
+// Grids for which the solving workgroup pays: enough workers that the two hops of resident_auto_stage hurt, and one compute unit to spare
+// (the two kernels must be on the compute units together: the workers' grid is capped at one workgroup per compute unit)
+static inline bool auto_solver_grid(int workers, int cap) {
+  static const int env = getenv("RPE_AUTO_SOLVER") ? atoi(getenv("RPE_AUTO_SOLVER")) : 1;
+  static const int env_min = getenv("RPE_AUTO_SOLVER_MIN") ? atoi(getenv("RPE_AUTO_SOLVER_MIN")) : 32;   // (measured: no gain at 10 workgroups, 5-9 % at 150, 25 % at 255)
+  return env != 0 && workers >= env_min && workers + 1 <= cap;
 }
 
 // workgroup size of the resident kernels.  256-thread workgroups (two per CU) were measured and lose here -- 6.95-7.3 vs 6.0-6.7 us

@@ -8,6 +8,22 @@ import tempfile
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def code_object(obj_path, tmp):
+    """Path of the gfx950 code object of a hipcc -c object, extracted into `tmp` (None for a unit without device code).  Through the
+    offload bundler, so that compressed fat binaries (--offload-compress, what the build ships) are handled like plain ones."""
+    fat, co = os.path.join(tmp, "unit.fatbin"), os.path.join(tmp, "unit.gfx950.co")
+    subprocess.run([OBJCOPY, "-O", "binary", "--only-section=.hip_fatbin", obj_path, fat], check=True, capture_output=True)
+    if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+        return None
+    subprocess.run([BUNDLER, "--unbundle", "--type=o", "--targets=" + TARGET, "--input=" + fat, "--output=" + co], check=True, capture_output=True)
+    return co if os.path.exists(co) and os.path.getsize(co) > 0 else None
+
+
 class Ins:
     __slots__ = ("addr", "text", "target")
 
@@ -18,13 +34,9 @@ class Ins:
 def disassemble(obj_path):
     """{mangled kernel name: [Ins]} of the gfx950 code object bundled in a hipcc -c object file."""
     with tempfile.TemporaryDirectory() as tmp:
-        local = os.path.join(tmp, os.path.basename(obj_path))
-        with open(obj_path, "rb") as src, open(local, "wb") as dst:
-            dst.write(src.read())
-        subprocess.run([OBJDUMP, "--offloading", local], cwd=tmp, check=True, capture_output=True)
-        co = [f for f in os.listdir(tmp) if "amdgcn" in f and "gfx950" in f]
-        assert len(co) == 1, co
-        out = subprocess.run([OBJDUMP, "-d", "--symbolize-operands", os.path.join(tmp, co[0])], check=True, capture_output=True, text=True).stdout
+        co = code_object(obj_path, tmp)
+        assert co is not None, obj_path
+        out = subprocess.run([OBJDUMP, "-d", "--symbolize-operands", co], check=True, capture_output=True, text=True).stdout
     funcs, labels, cur, pending = {}, {}, None, []
     for line in out.splitlines():
         m = re.match(r"^([0-9a-f]{8,16}) <(.+)>:$", line)
@@ -64,3 +76,25 @@ def in_loop(ins, spans):
 def between(body, a, b):
     """instructions with a.addr < addr < b.addr in address order"""
     return [i for i in body if a.addr < i.addr < b.addr]
+
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def kernel_resources(obj_path):
+    """[{name (demangled), vgpr, agpr, vgpr_spill, sgpr_spill, scratch}] of every kernel in the gfx950 code object of a hipcc -c object
+    (the metadata notes of the code object: what the loader goes by).  [] for a unit without device code."""
+    with tempfile.TemporaryDirectory() as tmp:
+        co = code_object(obj_path, tmp)
+        if co is None:
+            return []
+        txt = subprocess.run([READELF, "--notes", co], check=True, capture_output=True, text=True).stdout
+    rows = []
+    for blk in txt.split("- .agpr_count:")[1:]:
+        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
+        rows.append(dict(mangled=re.search(r"\.name:\s+(\S+)", blk).group(1), agpr=int(blk.split()[0]), vgpr=g("vgpr_count"), vgpr_spill=g("vgpr_spill_count"),
+                         sgpr_spill=g("sgpr_spill_count"), scratch=g("private_segment_fixed_size"), lds=g("group_segment_fixed_size")))
+    names = demangle([r["mangled"] for r in rows])
+    for r in rows:
+        r["name"] = re.sub(r"\(.*", "", names[r["mangled"]]).replace("void ", "")
+    return rows

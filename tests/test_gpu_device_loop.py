@@ -46,11 +46,15 @@ def test_one_launch_loop_follows_the_host_driven_loop(gpu_ctx_factory, n, kind, 
             continue
         pd, itd, stepd, costd = ctx.gn_refine_device([(kind, 1.0)], p0, flags, 25, 1e-9)
         assert itd == ith and 0 < itd <= 25
-        assert np.max(np.abs(pd - ph)) < 1e-9     # same records; the device solve rounds differently (one reciprocal per pivot, sincos)
-        assert abs(costd - costh) <= 1e-9 * max(abs(costh), 1e-30) and abs(stepd - steph) <= 1e-9 * steph + 1e-11   # the last step is at rounding level
+        # same records; the device solve rounds differently (one reciprocal per pivot, sincos).  Beyond one group per thread the two
+        # loops run on different grids (the autonomous one leaves a compute unit to its solving workgroup: 255 workgroups against 256), so
+        # their fp32 group sums are widened in different company: equal to the rounding of fp32 products, not of fp64 sums
+        ptol = 1e-9 if n <= 500000 else 5e-8
+        assert np.max(np.abs(pd - ph)) < ptol
+        assert abs(costd - costh) <= (1e-9 if n <= 500000 else 1e-7) * max(abs(costh), 1e-30) and abs(stepd - steph) <= 1e-9 * steph + (1e-11 if n <= 500000 else 1e-9)   # the last step is at rounding level
         p2, it2, *_ = ctx.gn_refine_device([(kind, 1.0)], p0, flags, 2, 0.0)     # the iteration cap
         h2, *_ = ctx.gn_refine([kind], p0, None, flags, 2, 0.0)
-        assert it2 == 2 and np.max(np.abs(p2 - h2)) < 1e-9
+        assert it2 == 2 and np.max(np.abs(p2 - h2)) < ptol
 
 
 def test_back_to_back_loops_are_bitwise_reproducible(gpu_ctx_factory):

@@ -107,3 +107,29 @@ def test_k4_score_loop_counts_votes_from_the_compare_masks():
     # four hypotheses per trip (two scalar loads each) behind at most two waits (one per hypothesis before)
     assert sum(i.text.startswith("s_load_dword") for i in loop) == 8 and sum(i.text.startswith("s_waitcnt lgkmcnt") for i in loop) <= 2
     assert sum(i.text.startswith("s_bcnt1_i32_b64") for i in loop) == 16
+
+
+@pytest.mark.parametrize("sig,arrays", [("<float, 5, 256, false>", 3), ("<float, 5, 256, true>", 3), ("<float, 13, 256, true>", 5), ("<double, 5, 256, false>", 3)])
+def test_joint_rotating_pipeline_keeps_its_loads_in_flight(sig, arrays):
+    """rpe_joint.hip, one-launch kernel: one register set, each array's next-group loads issued right behind the term that consumed it.
+    Every trip issues the same loads (clamped index, dummy address for absent masks / weights), so the waits count exactly: no
+    vmcnt(0) and never fewer than five loads outstanding at a wait inside the streaming loop (round 5, first form: conditional reloads
+    made the compiler wait for everything before the 2D-3D term)."""
+    ks = {n: b for n, b in kernels("rpe_joint").items() if "normal_eq_joint_kernel" + sig in n}
+    assert len(ks) == 1, [n for n in kernels("rpe_joint") if "joint_kernel" in n][:5]
+    body = next(iter(ks.values()))
+    spans = T.loops(body)
+    count = lambda s: sum(1 for i in body if s[0] <= i.addr <= s[1] and i.text.startswith("global_load_dwordx4"))
+    best = max(count(s) for s in spans)
+    assert best >= 3 * arrays, best
+    a, b = max((s for s in spans if count(s) == best), key=lambda s: s[1] - s[0])   # the widest loop with all of a trip's loads
+    loop = [i for i in body if a <= i.addr <= b]
+    assert not any(i.text.startswith("scratch_") for i in loop)
+    waits = [vmcnt(i) for i in loop if vmcnt(i) is not None]
+    if arrays == 5:
+        # sets with another term beside the normal-normal one ask for the normal arrays right before their term (JointNeeds::LATE_NN:
+        # no room to hold them through the heavier terms): that wait drains the queue, and so does the first wait of the next trip;
+        # the other waits still leave the prefetched arrays in flight
+        assert waits and sum(1 for w in waits if w == 0) <= 2 and max(waits) >= 5, waits
+    else:
+        assert waits and min(waits) >= 5, waits
