@@ -119,6 +119,22 @@ def build_stamps(level: int = 1, verbose: bool = False) -> str:
     return out
 
 
+def build_score_stats(verbose: bool = False) -> str:
+    """DIAGNOSTIC build (never loaded by the product): the library with -DRPE_SCORE_STATS, whose exact 2D vote counts how often a wave
+    falls through its band filter (scripts/score_filter_stats.py).  Only rpe_score.hip is recompiled; scratch, like the stamps builds."""
+    build()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out, obj = os.path.join(LIBDIR, "librgbdpose_hip_scorestats.so"), os.path.join(LIBDIR, "rpe_score_stats.o")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress", "-DRPE_SCORE_STATS",
+           "-x", "hip", "-c", os.path.join(CSRC, "rpe_score.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    objs = [obj] + [os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o") for src in SOURCES if src != "rpe_score.hip"]
+    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", LINK_RT, "-o", out] + objs)
+    return out
+
+
 EXAMPLES = ["simple_main", "test_main", "icp_main", "engine_profile", "gn_refine_main"]
 
 

@@ -6,6 +6,15 @@ namespace rpe {
 // ================================================================================================
 // K4 : batched hypothesis scoring (vote loops V1..V8) and K4b : winner mask
 // ================================================================================================
+// ---- diagnostic build only (-DRPE_SCORE_STATS, rgbd_pose_estimation_amd/build.py build_score_stats; scripts/score_filter_stats.py):
+// how often a wave of the EXACT 2D test falls through its band filter into the reference's square root + three divisions.
+// [0] = wave evaluations of a pair, [1] = fall-throughs.  No counter exists in the product build.
+#ifdef RPE_SCORE_STATS
+static __device__ unsigned long long g_score_stats[4];
+#define RPE_SCORE_STAT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_score_stats[k], 1ull); } while (0)
+#else
+#define RPE_SCORE_STAT(k) do {} while (0)
+#endif
 enum { VOTE_33 = 0, VOTE_23 = 1, VOTE_33_23 = 2, VOTE_NN_23 = 3, VOTE_NN_33 = 4, VOTE_NN_33_23 = 5, VOTE_23_MATRIX = 6 };
 template <int KIND> struct VoteMods {
   static constexpr bool m33 = KIND == VOTE_33 || KIND == VOTE_33_23 || KIND == VOTE_NN_33 || KIND == VOTE_NN_33_23;
@@ -128,6 +137,7 @@ template <class T> struct Hyp<T, true> {
 #pragma clang fp contract(off)
     V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
     const V2 n2 = px * px + py * py + pz * pz;
+    RPE_SCORE_STAT(0);
 #ifndef RPE_NO_23_FILTER
     {
       const V2 dt = px * bx + py * by + pz * bz;
@@ -147,10 +157,40 @@ template <class T> struct Hyp<T, true> {
       if (__builtin_amdgcn_ballot_w64(!(sure0 & sure1)) == 0) { a = in0; b = in1; return; }
     }
 #endif
+    RPE_SCORE_STAT(1);
     const V2 len = {sqrt(n2.x), sqrt(n2.y)};
     px = px / len; py = py / len; pz = pz / len;
     const V2 d = px * bx + py * by + pz * bz;
     a = d.x > c; b = d.y > c;
+  }
+  // The same filter, DECIDING ONLY (the batched scoring kernel): a = b = the decided votes, need_a / need_b = this element is inside the
+  // band (or not a unit bearing, or |p|^2 out of range) and must be given the reference's own sequence -- by the caller, LATER: with
+  // realistic bearing noise 0.8 % of the elements sit inside the band, i.e. two waves in three hold one, and a wave that runs the square
+  // root and the six divisions for one lane pays them for all 128 elements (counted: profiles/r05_score_filter_stats.jsonl, 69 % of the
+  // wave evaluations fell through).  The caller queues those elements in LDS and evaluates them densely (score_kernel, DeferQ).
+  __device__ __forceinline__ void in23_rot_x2_decide(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b, bool& need_a, bool& need_b) const {
+#pragma clang fp contract(off)
+    const V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+    const V2 n2 = px * px + py * py + pz * pz;
+    const V2 dt = px * bx + py * by + pz * bz;
+    const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
+    const T band = T(24) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 24 u
+    const T hi = c + band, lo = c - band;
+    const T tiny = T(1e-30), huge = T(1e30);
+    a = ct.x > hi; b = ct.y > hi;
+    const V2 b2 = bx * bx + by * by + bz * bz;
+    const bool unit0 = (b2.x > T(0.999)) & (b2.x < T(1.001)), unit1 = (b2.y > T(0.999)) & (b2.y < T(1.001));
+    need_a = !((a | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge) & unit0);
+    need_b = !((b | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge) & unit1);
+    a = a & !need_a; b = b & !need_b;
+  }
+  // ... and the reference's sequence on ONE rotated point (what in23_rot_x2 runs behind its filter, element by element: the same bits)
+  static __device__ __forceinline__ bool in23_reference(T rx, T ry, T rz, T t0, T t1, T t2, T bx, T by, T bz, T c) {
+#pragma clang fp contract(off)
+    T px = rx + t0, py = ry + t1, pz = rz + t2;
+    const T len = sqrt(px * px + py * py + pz * pz);
+    px = px / len; py = py / len; pz = pz / len;
+    return (px * bx + py * by + pz * bz) > c;
   }
   static __device__ __forceinline__ float rsqrt_est(float x) { return __builtin_amdgcn_rsqf(x); }
   static __device__ __forceinline__ double rsqrt_est(double x) {
@@ -198,13 +238,60 @@ __device__ __forceinline__ int votes_of(wave_mask_t mask, bool pred) {
   return __builtin_popcountll(__builtin_amdgcn_ballot_w64(pred) & mask);
 }
 
+// ---- deferred exact 2D votes (score_kernel, fp32 EXACT kinds with a 2D test): elements the band filter cannot decide are queued --
+// rotated point, bearing, hypothesis slot: 8 values -- and given the reference's sequence DENSELY, 64 at a time, one element per lane.
+// Every wave has a queue of its own in LDS (no atomics, no workgroup barriers: the count is a wave-uniform register) and drains it
+// whenever 64 entries have gathered, and at the end of its tile.
+constexpr int kDeferEntries = 192;   // per wave: fewer than 64 left by the last drain + at most 128 new ones from one pair
+template <class T> struct DeferQ {
+  T* entry;              // this wave's kDeferEntries x 8 values of LDS
+  const T* poses;        // the chunk's hypotheses (exact layout: qw qx qy qz tx ty tz pad)
+  int* votes;            // the workgroup's vote table (LDS)
+  int n;                 // entries queued (wave-uniform)
+  // the reference's sequence for entries [0, n): the votes go to the table by LDS atomics
+  __device__ __forceinline__ void drain(T cthr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < n; e += 64) {
+      const T* en = entry + 8 * e;
+      const int slot = (int)en[6];
+      const T* hq = poses + (size_t)slot * 8;
+      if (Hyp<T, true>::in23_reference(en[0], en[1], en[2], hq[4], hq[5], hq[6], en[3], en[4], en[5], cthr)) atomicAdd(&votes[slot], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    n = 0;
+  }
+  // the undecided elements of a PAIR (element a: *.x, element b: *.y)
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ void append(bool need_a, bool need_b, V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, int slot, T cthr) {
+    const wave_mask_t ma = __builtin_amdgcn_ballot_w64(need_a), mb = __builtin_amdgcn_ballot_w64(need_b);
+    if ((ma | mb) == 0) return;
+    const int lane = threadIdx.x & 63;
+    const wave_mask_t below = (1ull << lane) - 1ull;
+    const int ca = __builtin_popcountll(ma);
+    if (need_a) { T* e = entry + 8 * (n + __builtin_popcountll(ma & below)); e[0] = rx.x; e[1] = ry.x; e[2] = rz.x; e[3] = bx.x; e[4] = by.x; e[5] = bz.x; e[6] = (T)slot; }
+    if (need_b) { T* e = entry + 8 * (n + ca + __builtin_popcountll(mb & below)); e[0] = rx.y; e[1] = ry.y; e[2] = rz.y; e[3] = bx.y; e[4] = by.y; e[5] = bz.y; e[6] = (T)slot; }
+    n += ca + __builtin_popcountll(mb);
+    if (n >= 64) drain(cthr);
+  }
+};
+
 // votes of ONE hypothesis over one group of P correspondences, summed over the wave (every lane gets the wave's count).  Predicates are
 // evaluated unconditionally and masked with '&': no divergent branches; the compare IS the ballot.  EXACT: the 3D and normal tests run
 // on pairs of correspondences as 2-vectors (packed fp32 instructions), the 2D test (a square root and three divisions) stays scalar.
-template <class T, int KIND, bool EXACT>
+// DEFER: queue the undecided 2D votes in `defer` (score_kernel's deferred-exact queue; the other callers pass a dummy and DEFER = false);
+// slot = where the hypothesis' deferred votes go (< 0: a padding hypothesis whose count is dropped -- nothing is queued for it)
+template <class T, int KIND, bool EXACT, bool DEFER = false>
 __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
                                                  const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
-                                                 const wave_mask_t (&present)[Pk<T>::P], const wave_mask_t (&valid)[Pk<T>::P], T thr33, T cthr, T cnl) {
+                                                 const wave_mask_t (&present)[Pk<T>::P], const wave_mask_t (&valid)[Pk<T>::P], T thr33, T cthr, T cnl,
+                                                 DeferQ<T>& defer, int slot = -1) {
+  // (present[] for the 2D test: lanes whose correspondence exists AND whose bearing holds no NaN -- a NaN bearing makes the reference's
+  // comparison false whatever the hypothesis, so such a lane never votes, and a wave without any bearing at all -- configs[2] has 2 000
+  // of them among 307 200 correspondences -- skips the test: the callers build the masks that way, once per group)
   constexpr int P = Pk<T>::P;
   typedef VoteMods<KIND> MD;
   int cnt = 0;
@@ -230,10 +317,19 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
         hyp.in33_rot_x2(rx, ry, rz, cx, cy, cz, thr33, va, vb2);
         cnt += votes_of(valid[a], va) + votes_of(valid[b], vb2);
       }
-      if (MD::m23) {
+      if (MD::m23 && (present[a] | present[b]) != 0) {
         const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
         bool va, vb2;
-        hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, va, vb2);
+        if constexpr (DEFER) {
+          bool na, nb;
+          hyp.in23_rot_x2_decide(rx, ry, rz, bx, by, bz, cthr, va, vb2, na, nb);
+          const int lane = threadIdx.x & 63;
+          na = na & (((present[a] >> lane) & 1ull) != 0) & (slot >= 0);
+          nb = nb & (((present[b] >> lane) & 1ull) != 0) & (slot >= 0);
+          defer.append(na, nb, rx, ry, rz, bx, by, bz, slot, cthr);
+        } else {
+          hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, va, vb2);
+        }
         cnt += votes_of(present[a], va) + votes_of(present[b], vb2);
       }
     }
@@ -247,7 +343,7 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
       if (MD::m33) {
         cnt += votes_of(valid[i], hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33));
       }
-      if (MD::m23) {
+      if (MD::m23 && present[i] != 0) {
         cnt += votes_of(present[i], hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX));
       }
     }
@@ -269,6 +365,13 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
   const int hbeg = blockIdx.y * hchunk;
   const int hcnt = min(hchunk, H - hbeg);
   for (int i = threadIdx.x; i < hcnt; i += kBlock) lds_votes[i] = 0;
+  // deferred exact 2D votes (DeferQ): every wave's queue sits behind the vote table in the dynamic LDS (score_launch sizes it)
+  constexpr bool DEFER = sizeof(T) == 4 && EXACT && MD::m23 && KIND != VOTE_23_MATRIX;
+  DeferQ<T> dq;
+  dq.entry = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(lds_votes) + (((size_t)hchunk * sizeof(int) + 15) & ~(size_t)15)) + (size_t)(threadIdx.x >> 6) * kDeferEntries * 8;
+  dq.poses = poses + (size_t)hbeg * Hyp<T, EXACT>::STRIDE;
+  dq.votes = lds_votes;
+  dq.n = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t groups = (n + P - 1) / P;
@@ -285,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
 #pragma unroll
     for (int i = 0; i < P; i++) {
       const bool here = (g * P + i) < n;
-      present[i] = __builtin_amdgcn_ballot_w64(here);
+      // (only the 2D test reads present[]: lanes with a NaN in their bearing are left out -- see count_group_votes)
+      present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
       valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
     }
     for (int h0 = 0; h0 < hcnt; h0 += 64) {
@@ -304,12 +408,14 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
           hyp[u].load(hp + (size_t)(hl + u < hmax ? hl + u : hmax - 1) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
 #pragma unroll
         for (int u = 0; u < HU; u++) {
-          const int cnt = count_group_votes<T, KIND, EXACT>(hyp[u], vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
+          const int cnt = count_group_votes<T, KIND, EXACT, DEFER>(hyp[u], vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, dq,
+                                                                   hl + u < hmax ? h0 + hl + u : -1);
           mine = (lane == hl + u) ? cnt : mine;   // every hypothesis once per block of 64, `mine` starts at 0: a select, not an add
         }
       }
       if (lane < hmax && mine != 0) atomicAdd(&lds_votes[h0 + lane], mine);
     }
+    if (DEFER && dq.n > 0) dq.drain(cthr);   // what is left of the tile's undecided 2D votes
   }
   __syncthreads();
   for (int i = threadIdx.x; i < hcnt; i += kBlock) {
@@ -353,14 +459,16 @@ __global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict
 #pragma unroll
     for (int i = 0; i < P; i++) {
       const bool here = (g * P + i) < n;
-      present[i] = __builtin_amdgcn_ballot_w64(here);
+      // (only the 2D test reads present[]: lanes with a NaN in their bearing are left out -- see count_group_votes)
+      present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
       valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
     }
     for (int hl = copy; hl < H; hl += hs) {
       Hyp<T, EXACT> hyp;
       if (dposes) hyp.load(dposes + (size_t)hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);   // a list generated on the device
       else hyp.load(sp.v + hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
-      const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl);
+      DeferQ<T> none;   // (no queue here: the in-place filter)
+      const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none);
       mine += (lane == hl) ? cnt : 0;
     }
   }
@@ -540,7 +648,10 @@ static void score_launch(const DeviceArrays& A, const void* d_poses, int H, cons
     hchunk = ((chunks + gy - 1) / gy) * gran;
     gy = (H + hchunk - 1) / hchunk;
   }
-  hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G, gy), dim3(kBlock), (size_t)hchunk * sizeof(int), s, (const T*)A.a[0],
+  // (vote table, and behind it the deferred-exact queues of the fp32 exact kinds with a 2D test: one per wave)
+  const bool queues = sizeof(T) == 4 && EXACT && VoteMods<KIND>::m23 && KIND != VOTE_23_MATRIX;
+  const size_t lds = (((size_t)hchunk * sizeof(int) + 15) & ~(size_t)15) + (queues ? (size_t)(kBlock / 64) * kDeferEntries * 8 * sizeof(T) : 0);
+  hipLaunchKernelGGL((score_kernel<T, KIND, EXACT>), dim3(G, gy), dim3(kBlock), lds, s, (const T*)A.a[0],
       (const T*)A.a[1],
                      (const T*)A.a[2], (const T*)A.a[3], (const T*)A.a[4], A.n, (const T*)d_poses, H, hchunk, (T)thr[0], (T)thr[1], (T)thr[2], d_votes);
 }
@@ -654,6 +765,16 @@ hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double*
   return hipGetLastError();
 }
 
+#ifdef RPE_SCORE_STATS
+}  // namespace rpe
+extern "C" int rpe_debug_read_score_stats(unsigned long long* out4) {   // diagnostic build only: read and clear the counters
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rpe::g_score_stats), 32) != hipSuccess) return -1;
+  static unsigned long long zeros[4];
+  return hipMemcpyToSymbol(HIP_SYMBOL(rpe::g_score_stats), zeros, 32) == hipSuccess ? 0 : -1;
+}
+namespace rpe {
+#endif
 void preload_score() {
   hipFuncAttributes a;
   if (hipFuncGetAttributes(&a, (const void*)mask_kernel<float, VOTE_33, true>) != hipSuccess) (void)hipGetLastError();
