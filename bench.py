@@ -1154,7 +1154,9 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
         fctx.close()
     except Exception as e:  # noqa: BLE001
         out["icp_frame_loop"] = {"error": repr(e)}
-    # (4) the other half of the hot path: batched RANSAC hypothesis scoring (vote loops V1/V2, kernel K4), 512 hypotheses per pass
+    # (4) the other half of the hot path: batched RANSAC hypothesis scoring (vote loops V1/V2/V4, kernel K4), 512 hypotheses per pass,
+    # against BOTH ceilings SURVEY 8(d) names: the fp32 vector rate (157.3 TFLOP/s; flops per correspondence x hypothesis counted from
+    # the predicates, stated below) and HBM amortised over the hypotheses of a pass (the arrays are read once per pass)
     try:
         rng_s = np.random.default_rng(3)
         H = 512
@@ -1163,22 +1165,33 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
         poses = base7[None, :] + dq
         poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
         poses = np.ascontiguousarray(poses.astype(np.float32).astype(np.float64))
-        res = {}
-        v_exact = None
-        for mode, name in ((L.SCORE_FAST, "fast"), (L.SCORE_EXACT, "exact")):
-            t_w = time.perf_counter()
-            while time.perf_counter() - t_w < 0.2:
-                ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
-            reps, per_call = 30, []
-            for _ in range(reps):   # every call timed by itself: the median is not moved by one stalled call (a mean of 20 once was: 588 us)
-                t0s = time.perf_counter()
-                v = ctx.score(L.VOTE_33, poses, THRE_3D, mode=mode)
-                per_call.append(time.perf_counter() - t0s)
-            per_call.sort()
-            dts = per_call[len(per_call) // 2]
-            res[name] = {"corr_hyp_per_s": n * H / dts, "us_per_pass": dts * 1e6, "us_per_pass_min": per_call[0] * 1e6, "statistic": "median of 30 calls"}
-            if mode == L.SCORE_EXACT:
-                v_exact = v
+        # a bearing for every correspondence (camera point direction + ~4.5 px of noise at f = 585): the 2D test at full load
+        bv = sc.P / np.linalg.norm(sc.P, axis=1, keepdims=True) + (0.3 * 15.0 / 585.0) * rng_s.standard_normal(sc.P.shape)
+        bv = (bv / np.linalg.norm(bv, axis=1, keepdims=True)).astype(np.float32)
+        sctx = api.Context(local_rank).load(L.F32, xw=sc.Q, xc=sc.P, bv=bv)
+        cthr = math.cos(math.atan(8.0 / 585.0))
+        FLOPS = {"33": {"fast": 32, "exact": 41}, "33_23": {"fast": 46, "exact": 58}}   # per correspondence x hypothesis: transform / quaternion
+        # rotation 18 / 30, 3D test 11-14, 2D test (dot, |p|^2, compare form; exact: + reciprocal square root estimate) 14-17
+        BYTES = {"33": 24, "33_23": 36}
+        res, roof, v_exact = {}, {}, None
+        for kname, kind in (("33", L.VOTE_33), ("33_23", L.VOTE_33_23)):
+            for mode, name in ((L.SCORE_FAST, "fast"), (L.SCORE_EXACT, "exact")):
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 0.15:
+                    sctx.score(kind, poses, THRE_3D, cthr, mode=mode)
+                per_call = []
+                for _ in range(30):   # every call timed by itself: the median is not moved by one stalled call
+                    t0s = time.perf_counter()
+                    v = sctx.score(kind, poses, THRE_3D, cthr, mode=mode)
+                    per_call.append(time.perf_counter() - t0s)
+                per_call.sort()
+                dts = per_call[len(per_call) // 2]
+                res[kname + "_" + name] = {"corr_hyp_per_s": n * H / dts, "us_per_pass": dts * 1e6, "us_per_pass_min": per_call[0] * 1e6}
+                roof[name + "_" + kname] = {"valu_frac": n * H * FLOPS[kname][name] / dts / 157.3e12, "flops_per_corr_hyp": FLOPS[kname][name],
+                                            "hbm_amortised_frac": BYTES[kname] * n / dts / 1e9 / HBM_PEAK_GBS, "bytes_per_pass": BYTES[kname] * n}
+                if mode == L.SCORE_EXACT and kname == "33":
+                    v_exact = v
+        sctx.close()
         cpu = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -1191,8 +1204,9 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
                                             C.c_float(THRE_3D), votes_cpu.ctypes.data_as(C.c_void_p))
             cpu = {"corr_hyp_per_s": n * 8 / dtc, "cores": 1, "sample": "8 hypotheses through the oracle's vote loop",
                    "votes_equal_exact_mode": bool(np.array_equal(votes_cpu, v_exact[:8]))}
-        out["ransac_scoring"] = {"hypotheses": H, "kind": "3D-3D (V1/V2)", "fast": res["fast"], "exact": res["exact"], "cpu_port": cpu,
-                                 "note": "wall time per rpe_score call incl. pose upload and vote read-out; beside, not instead of, the headline"}
+        out["ransac_scoring"] = {"hypotheses": H, "kinds": "3D-3D (V1/V2) and 3D-3D + 2D-3D (V4), a bearing for every correspondence", "passes": res, "roofline": roof,
+                                 "cpu_port": cpu, "peaks": {"fp32_vector_TFLOPs": 157.3, "hbm_GBs": HBM_PEAK_GBS},
+                                 "note": "wall time per rpe_score call incl. pose upload and vote read-out (median of 30); beside, not instead of, the headline"}
     except Exception as e:  # noqa: BLE001
         out["ransac_scoring"] = {"error": repr(e)}
     # (5) configs[2] exactly as SURVEY 8d states it: 307 200 3D-3D + 2 000 bearings, 300 RANSAC iterations of shinji + kneip from a

@@ -304,6 +304,16 @@ int rpe_ransac_p3p_batch(rpe_context* ctx, int solver, uint64_t rng_state, uint6
  * untouched) -- what setInlier() stores; returns the vote total. */
 int rpe_inlier_mask(rpe_context* ctx, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,
                     int* votes_out);
+/* K4r -- resident scoring session: between _begin and _end, rpe_score calls of at most 128 hypotheses and rpe_inlier_mask calls with
+ * exactly these parameters are served by ONE resident launch (the hypotheses travel through the context's control block, the vote
+ * counts return as run records): a whole RANSAC run of the reference (pose/AbsoluteOrientation.hpp:169-209: sample, score, keep the
+ * best, shrink Iter, finally the winner's mask) costs one kernel launch instead of one per batch and one for the masks.  Results are
+ * those of the calls outside a session, bit for bit.  RPE_ERR_STATE when the context cannot hold one (resident kernels unavailable,
+ * a sharded context, more correspondences than one group per thread of a co-resident grid): the caller goes on without.  Any other
+ * call on the context -- and a longer hypothesis list, or other parameters -- ends the session implicitly; _end is idempotent.  One
+ * session per host thread; while it is open, resident loops of other contexts on the same GPU wait for it. */
+int rpe_score_session_begin(rpe_context* ctx, int kind, int mode, double thre_3d, double cos_thr, double cos_nl);
+int rpe_score_session_end(rpe_context* ctx);
 
 /* ---- PROSAC order: the first top_k (<= 4096) entries of "indices sorted by weight, descending" (pose/Utility.hpp:107-118 sortIndexes as
  * PROSAC consumes it through getSortedIdx, pose/AOOnlyPoseAdapter.hpp:233-254) for n float weights (host pointer), computed on the GPU:

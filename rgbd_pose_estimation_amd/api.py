@@ -348,6 +348,18 @@ class Context:
         L.check(L.lib().rpe_inlier_mask(self._h, kind, mode, _p(q), thre_3d, cos_thr, cos_nl, C.byref(v)))
         return v.value
 
+    def score_session_begin(self, kind: int, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mode=L.SCORE_EXACT) -> bool:
+        """Open a resident scoring session (rpe_score_session_begin): score() calls of <= 128 hypotheses and inlier_mask() calls with
+        these parameters are then served by one resident launch.  False if the context cannot hold one (RPE_ERR_STATE)."""
+        rc = L.lib().rpe_score_session_begin(self._h, kind, mode, thre_3d, cos_thr, cos_nl)
+        if rc == L.RPE_ERR_STATE:
+            return False
+        L.check(rc)
+        return True
+
+    def score_session_end(self):
+        L.check(L.lib().rpe_score_session_end(self._h))
+
     def nl_round(self, c_opt, Cw, Cc, Rwc) -> np.ndarray:
         a = [np.ascontiguousarray(x, np.float64) for x in (c_opt, Cw, Cc, Rwc)]
         out = np.zeros(44)

@@ -89,6 +89,9 @@ int set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; 
 struct rpe_context {
   int device = 0;
   hipStream_t stream = nullptr;
+  // resident scoring session (rpe_score_session_begin ... _end): the grid of score_resident_kernel waits for batches in c->ctl
+  struct { bool active = false; int kind = 0, mode = 0, grid = 0, runs = 0, batches = 0; double thre_3d = 0, cos_thr = 0, cos_nl = 0;
+           unsigned long long base = 0; } sess;
   hipStream_t stream2 = nullptr;   // the solving workgroup of the autonomous resident loops runs beside its workers (created on first use)
   hipEvent_t ev_stream2 = nullptr; // ... behind the uploads of the start pose / loop state on `stream`
   bool auto_solver = true;         // ... until the two kernels once failed to meet (a platform that serialises them)
@@ -645,6 +648,48 @@ bool pin_calling_thread(int cpu) {
 }
 }  // namespace
 
+// ---- resident scoring session (K4r, rpe_score.hip): ONE launch serves the batches of a RANSAC run and the winner's masks.
+// Ends a session that is open (idempotent): the stop tag releases the grid, the per-device resident mutex is given back.  Every entry
+// point that would queue work behind the resident kernel on the context's stream calls this first.
+static thread_local rpe_context* t_session = nullptr;   // the context whose session this thread holds open (at most one per thread)
+static void session_end(rpe_context* c) {
+  // (a session of ANOTHER context of this thread on the same GPU holds the device's resident slot: a resident loop of `c` would wait
+  // for it forever)
+  if (c && t_session && t_session != c && t_session->device == c->device) session_end(t_session);
+  if (!c || !c->sess.active) return;
+  if (t_session == c) t_session = nullptr;
+  c->sess.active = false;
+  const unsigned long long stop = (c->sess.base + (unsigned long long)c->sess.batches + 1) | rpe::kResidentStopBit;
+  store_fence();
+  c->ctl[0] = stop; c->ctl[rpe::kSessionCtlWordsMax - 1] = stop;
+  store_fence();
+  c->seq = c->sess.base + (unsigned long long)c->sess.batches + 2;   // stays ahead of every tag / sequence value the launch could use
+  resident_mutex(c->device).unlock();
+}
+// one batch through the open session: op 0 = score `count` hypotheses (staged: the kernel's layout, values of the array dtype), op 1 =
+// the masks of one; totals = the 32 sums of the batch.  On a failure the session is closed and the caller takes the launch path.
+static int session_batch(rpe_context* c, int op, const void* staged, int count, size_t bytes, double* totals) {
+  const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
+  const size_t words = (bytes + 7) / 8;
+  unsigned long long buf[rpe::kSessionCtlWordsMax];
+  std::memset(buf, 0, words * 8);
+  std::memcpy(buf, staged, bytes);
+  for (size_t k = 0; k < words; k++) c->ctl[2 + k] = buf[k];
+  c->ctl[1] = (unsigned long long)(unsigned int)count | ((unsigned long long)op << 32);
+  store_fence();
+  c->ctl[0] = tag; c->ctl[rpe::kSessionCtlWordsMax - 1] = tag;
+  store_fence();
+  c->sess.batches++;
+  c->seq = tag;
+  const int rc = wait_host_partials(c, c->sess.runs, rpe::kSessionHypsMax, totals, 0, true);
+  if (rc != RPE_OK) { session_end(c); return rc == kResidentLost ? RPE_ERR_HIP : rc; }
+  return RPE_OK;
+}
+static bool session_matches(const rpe_context* c, int kind, int mode, double thre_3d, double cos_thr, double cos_nl) {
+  return c->sess.active && c->sess.kind == kind && c->sess.mode == mode && c->sess.thre_3d == thre_3d && c->sess.cos_thr == cos_thr &&
+         c->sess.cos_nl == cos_nl;
+}
+
 extern "C" {
 
 int rpe_abi_version(void) { return 1; }
@@ -740,6 +785,7 @@ int rpe_create(rpe_context** out, int device, void* stream) {
 }
 
 void rpe_destroy(rpe_context* c) {
+  session_end(c);
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -779,12 +825,14 @@ void rpe_destroy(rpe_context* c) {
 }
 
 int rpe_synchronize(rpe_context* c) {
+  session_end(c);
   if (!c) return fail(RPE_ERR_ARG, "null context");
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RPE_OK;
 }
 
 int rpe_set_problem(rpe_context* c, int64_t n, int dtype) {
+  session_end(c);
   if (!c) return fail(RPE_ERR_ARG, "null context");
   if (n < 0 || (dtype != RPE_F32 && dtype != RPE_F64)) return fail(RPE_ERR_ARG, "bad n (%lld) or dtype (%d)", (long long)n, dtype);
   HIP_TRY(hipSetDevice(c->device));
@@ -797,6 +845,7 @@ int rpe_set_problem(rpe_context* c, int64_t n, int dtype) {
 }
 
 int rpe_upload(rpe_context* c, int slot, const void* host) {
+  session_end(c);
   if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS || !host) return fail(RPE_ERR_ARG, "rpe_upload: bad argument");
   if (c->n <= 0) return fail(RPE_ERR_STATE, "rpe_set_problem first");
   HIP_TRY(hipSetDevice(c->device));
@@ -814,6 +863,7 @@ int rpe_upload(rpe_context* c, int slot, const void* host) {
 }
 
 int rpe_download(rpe_context* c, int slot, void* host) {
+  session_end(c);
   if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS || !host) return fail(RPE_ERR_ARG, "rpe_download: bad argument");
   if (!c->arr[slot]) return fail(RPE_ERR_STATE, "array slot %d was never uploaded, bound or produced", slot);
   HIP_TRY(hipSetDevice(c->device));
@@ -821,6 +871,7 @@ int rpe_download(rpe_context* c, int slot, void* host) {
 }
 
 int rpe_bind(rpe_context* c, int slot, const void* device_ptr) {
+  session_end(c);
   if (!c || slot < 0 || slot >= RPE_NUM_ARRAYS) return fail(RPE_ERR_ARG, "rpe_bind: bad argument");
   if (device_ptr && ((uintptr_t)device_ptr & 15u)) return fail(RPE_ERR_ALIGN, "device pointer %p is not 16-byte aligned", device_ptr);
   c->arr[slot] = const_cast<void*>(device_ptr);  // not owned; the context's own storage for this slot stays allocated but idle
@@ -829,6 +880,7 @@ int rpe_bind(rpe_context* c, int slot, const void* device_ptr) {
 }
 
 int rpe_upload_mask(rpe_context* c, int mod, const short* host_mask) {
+  session_end(c);
   if (!c || mod < 0 || mod > 2) return fail(RPE_ERR_ARG, "rpe_upload_mask: bad argument");
   HIP_TRY(hipSetDevice(c->device));
   if (!host_mask) { c->mask[mod] = nullptr; return RPE_OK; }
@@ -840,6 +892,7 @@ int rpe_upload_mask(rpe_context* c, int mod, const short* host_mask) {
 }
 
 int rpe_upload_weight(rpe_context* c, int mod, const void* host_weight) {
+  session_end(c);
   if (!c || mod < 0 || mod > 2) return fail(RPE_ERR_ARG, "rpe_upload_weight: bad argument");
   HIP_TRY(hipSetDevice(c->device));
   if (!host_weight) { c->weight[mod] = nullptr; return RPE_OK; }
@@ -857,6 +910,7 @@ int rpe_upload_weight(rpe_context* c, int mod, const void* host_weight) {
 }
 
 int rpe_download_mask(rpe_context* c, int mod, short* host_mask) {
+  session_end(c);
   if (!c || mod < 0 || mod > 2 || !host_mask) return fail(RPE_ERR_ARG, "rpe_download_mask: bad argument");
   if (!c->mask[mod]) return fail(RPE_ERR_STATE, "no mask for modality %d", mod);
   HIP_TRY(hipSetDevice(c->device));
@@ -872,6 +926,7 @@ static void timing_pair(rpe_context* c, hipEvent_t* e0, hipEvent_t* e1) {
 }
 
 int rpe_p2p_moments(rpe_context* c, int flags, double* out18) {
+  session_end(c);
   int rc = need_arrays(c, {RPE_XW, RPE_XC});
   if (rc) return rc;
   if (!out18) return fail(RPE_ERR_ARG, "null out18");
@@ -921,6 +976,7 @@ static int normal_eq_launch(rpe_context* c, int kind, int flags, const double* p
 }
 
 int rpe_normal_eq_device(rpe_context* c, int kind, int flags, const double* pose12, double* d_out32) {
+  session_end(c);
   if (!d_out32) return fail(RPE_ERR_ARG, "null d_out32");
   return normal_eq_launch(c, kind, flags, pose12, d_out32, c && take_clean(c, kind, false));   // nobody on the host sees this record
 }
@@ -957,6 +1013,7 @@ int rpe_timing_collect(rpe_context* c, int* count, double* total_ms, double* min
 }
 
 int rpe_timing_calibrate(rpe_context* c, int pairs, double* avg_ms, double* min_ms) {
+  session_end(c);
   if (!c || pairs < 1 || pairs > 4096) return fail(RPE_ERR_ARG, "rpe_timing_calibrate: bad argument");
   HIP_TRY(hipSetDevice(c->device));
   hipEvent_t a, b;
@@ -979,6 +1036,7 @@ int rpe_timing_calibrate(rpe_context* c, int pairs, double* avg_ms, double* min_
 
 // One Gauss-Newton step on one GPU: normal equations (device) -> solve -> pose <- exp(delta) * pose (host).
 int rpe_gn_step(rpe_context* c, int kind, int flags, double* pose12, double* ne32_out, double* step_norm) {
+  session_end(c);
   double ne[32], d[6];
   int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
   if (rc) return rc;
@@ -991,6 +1049,7 @@ int rpe_gn_step(rpe_context* c, int kind, int flags, double* pose12, double* ne3
 }
 
 int rpe_normal_eq(rpe_context* c, int kind, int flags, const double* pose12, double* out32) {
+  session_end(c);
   if (!out32) return fail(RPE_ERR_ARG, "null out32");
   const bool clean = c && take_clean(c, kind, true);   // CLEAN flavour first: this record is looked at right here
   int rc = normal_eq_launch(c, kind, flags, pose12, nullptr, clean);  // null device target = publish to pinned host memory
@@ -1045,6 +1104,7 @@ static int joint_launch_checked(rpe_context* c, int nterms, const rpe_term* term
 }
 
 int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, const double* pose12, double* out32) {
+  session_end(c);
   if (!out32) return fail(RPE_ERR_ARG, "null out32");
   // CLEAN flavour first (fp32 arrays): this record is looked at right here -- a NaN or an infinity in the arrays shows in it, the
   // launch is repeated guarded and the arrays are remembered as needing the guards (clean-first protocol, as rpe_normal_eq)
@@ -1069,6 +1129,7 @@ int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
 int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
     int* iters_out,
                         double* last_step, double* final_cost) {
+  session_end(c);
   int it = 0;
   double step = 0, cost = 0;
   if (c && c->resident && c->host_resident && max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world_saved < 1) {
@@ -1134,6 +1195,7 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
 int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
     int* iters_out,
                          double* last_step, double* final_cost) {
+  session_end(c);
   if (!c || !terms || nterms < 1 || nterms > 4 || !pose12 || max_iter < 1) return fail(RPE_ERR_ARG,
       "rpe_gn_refine_device: bad argument");
   int bits = 0, robust[5] = {0, 0, 0, 0, 0};
@@ -1259,6 +1321,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
 // apply pose <- exp(delta) pose by the kernel's own exponential map (sophus/se3.hpp:321-342) -- on the GPU, for a record and pose of
 // the caller's.  Returns RPE_ERR_DEGENERATE where the device solve refuses the system.
 int rpe_debug_device_gn_update(rpe_context* c, const double* ne32, double* pose12, double* step_norm) {
+  session_end(c);
   if (!c || !ne32 || !pose12) return fail(RPE_ERR_ARG, "rpe_debug_device_gn_update: bad argument");
   HIP_TRY(hipSetDevice(c->device));
   double buf[48];
@@ -1327,6 +1390,7 @@ int rpe_debug_loop_profile(rpe_context* c, int enable, double* wait_us, double* 
 int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
     double tol,
                   int* iters_out, double* last_step, double* final_cost) {
+  session_end(c);
   if (!c || nterms < 1 || nterms > 4 || !kinds || !pose12) return fail(RPE_ERR_ARG, "rpe_gn_refine: bad argument");
   if (nterms > 1 || kinds[0] == RPE_RES_NORMAL) {  // several residual kinds: ONE fused pass per iteration
     rpe_term terms[4];
@@ -1420,6 +1484,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
 
 int rpe_tune_host_thread(rpe_context* c, int kind, int flags, const double* pose12, int steps, int reps, int* best_cpu, double* best_us,
                          int* trial_cpus, double* trial_us, int cap, int* ntrials) {
+  session_end(c);
   if (!c || !pose12 || steps < 2 || reps < 1 || cap < 0 || (cap > 0 && (!trial_cpus || !trial_us)))
     return fail(RPE_ERR_ARG, "rpe_tune_host_thread: bad argument");
   if (!(c->resident && c->host_resident)) return fail(RPE_ERR_STATE, "rpe_tune_host_thread: this context runs no host-driven resident loop");
@@ -1496,6 +1561,7 @@ int rpe_comm_unique_id(void* id128) {
 }
 
 int rpe_comm_init(rpe_context* c, int world, int rank, const void* id128) {
+  session_end(c);
   if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(RPE_ERR_ARG, "rpe_comm_init: bad argument");
   if (!rccl().ok) return fail(RPE_ERR_STATE, "librccl.so.1 could not be loaded");
   HIP_TRY(hipSetDevice(c->device));
@@ -1524,6 +1590,7 @@ int rpe_device_bus_id(rpe_context* c, char* buf, int len) {
 }
 
 int rpe_comm_destroy(rpe_context* c) {
+  session_end(c);
   if (!c) return fail(RPE_ERR_ARG, "null context");
   if (c->comm) { (void)hipStreamSynchronize(c->stream); NCCL_TRY(rccl().CommDestroy(c->comm)); c->comm = nullptr; c->comm_world = 1; }
   return RPE_OK;
@@ -1531,6 +1598,7 @@ int rpe_comm_destroy(rpe_context* c) {
 
 // ---- peer-to-peer exchange over xGMI (one process per GPU, one node, <= 8 ranks)
 int rpe_p2p_export(rpe_context* c, void* handle64) {
+  session_end(c);
   if (!c || !handle64) return fail(RPE_ERR_ARG, "rpe_p2p_export: bad argument");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   HIP_TRY(hipSetDevice(c->device));
@@ -1550,6 +1618,7 @@ int rpe_p2p_export(rpe_context* c, void* handle64) {
 }
 
 int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
+  session_end(c);
   if (!c || !handles || world < 1 || world > rpe::kP2PMaxWorld || rank < 0 || rank >= world) return fail(RPE_ERR_ARG,
       "rpe_p2p_init: bad argument (1 <= world <= 8)");
   if (!c->p2p_box) return fail(RPE_ERR_STATE, "rpe_p2p_export first");
@@ -1589,6 +1658,7 @@ int rpe_p2p_init(rpe_context* c, int world, int rank, const void* handles) {
 // pause = 1: keep the mailboxes mapped but let rpe_gn_step_dist / rpe_score use the RCCL communicator (or nothing); 0 resumes.  Every
 // rank must switch at the same point of its call sequence.
 int rpe_p2p_pause(rpe_context* c, int pause) {
+  session_end(c);
   if (!c) return fail(RPE_ERR_ARG, "null context");
   if (!c->d_p2p || c->p2p_world_saved < 1) return fail(RPE_ERR_STATE, "rpe_p2p_init was not called");
   c->p2p_world = pause ? 0 : c->p2p_world_saved;
@@ -1596,6 +1666,7 @@ int rpe_p2p_pause(rpe_context* c, int pause) {
 }
 
 int rpe_p2p_destroy(rpe_context* c) {
+  session_end(c);
   if (!c) return fail(RPE_ERR_ARG, "null context");
   if (!c->p2p_box && !c->d_p2p) return RPE_OK;
   (void)hipSetDevice(c->device);
@@ -1612,6 +1683,7 @@ int rpe_p2p_destroy(rpe_context* c) {
 // context's stream -> publish to pinned host memory -> (every rank, identically) solve + exp-map update.
 // ---- host-side exchange between the rank processes of one node (csrc/rpe_hostex.cpp)
 int rpe_hostex_init(rpe_context* c, int world, int rank, const char* name, int create) {
+  session_end(c);
   if (!c || !name) return fail(RPE_ERR_ARG, "rpe_hostex_init: bad argument");
   if (c->hostex) return fail(RPE_ERR_STATE, "rpe_hostex_init: an exchange is already set (rpe_hostex_destroy first)");
   rpe_host_exchange* h = nullptr;
@@ -1632,12 +1704,14 @@ int rpe_hostex_init(rpe_context* c, int world, int rank, const char* name, int c
   return RPE_OK;
 }
 int rpe_hostex_destroy(rpe_context* c) {
+  session_end(c);
   if (!c) return fail(RPE_ERR_ARG, "null context");
   if (c->hostex) { rpe_host_exchange_close(c->hostex); c->hostex = nullptr; c->hostex_world = 1; c->hostex_shared_gpu = false; }
   return RPE_OK;
 }
 
 int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double* ne32_out, double* step_norm) {
+  session_end(c);
   if (c && c->hostex) {   // ONE launch with the single-GPU collecting stage; the shards' records meet on the hosts
     double ne[32], d[6];
     int rc = rpe_normal_eq(c, kind, flags, pose12, ne);
@@ -1690,6 +1764,7 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
 
 // `steps` sharded steps in one call (the host loop stays inside the library, as rpe_gn_refine keeps it for one GPU)
 int rpe_gn_steps_dist(rpe_context* c, int kind, int flags, double* pose12, int steps, double* last_step_norm) {
+  session_end(c);
   if (steps < 0) return fail(RPE_ERR_ARG, "rpe_gn_steps_dist: negative step count");
   double sn = 0;
   for (int k = 0; k < steps; k++) {
@@ -1759,6 +1834,20 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
   if (!poses7 || !votes_out || H < 0) return fail(RPE_ERR_ARG, "rpe_score: bad argument");
   HIP_TRY(hipSetDevice(c->device));
   const int exact = mode == RPE_SCORE_EXACT;
+  if (c->sess.active) {   // a resident scoring session is open: short lists with its parameters go through its grid
+    if (H >= 1 && H <= 4 * rpe::kSessionHypsMax && session_matches(c, kind, mode, thre_3d, cos_thr, cos_nl)) {
+      const size_t per = (size_t)(exact ? 8 : 12) * elem_size(c->dtype);
+      stage_poses(c->dtype, exact, poses7, H, c->h_poses);
+      int h0 = 0;
+      for (; h0 < H; h0 += rpe::kSessionHypsMax) {
+        const int hn = std::min(rpe::kSessionHypsMax, H - h0);
+        double tot[rpe::kSessionHypsMax];
+        if (session_batch(c, 0, (const char*)c->h_poses + (size_t)h0 * per, hn, (size_t)hn * per, tot) != RPE_OK) break;   // (closed: launch)
+        for (int i = 0; i < hn; i++) votes_out[h0 + i] = (int)tot[i];
+      }
+      if (h0 >= H) return RPE_OK;
+    } else session_end(c);
+  }
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   const size_t per = (exact ? 8 : 12) * elem_size(c->dtype);
@@ -1805,6 +1894,7 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
 // Device-side generation + scoring of one batch of 3D-3D RANSAC iterations (the vote loop V1/V2 with its hypothesis generator H1)
 int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int iters, int mode, double thre_3d, int* votes_out,
                        double* q7_out, unsigned char* valid_out) {
+  session_end(c);
   int rc = need_arrays(c, {RPE_XW, RPE_XC});
   if (rc) return rc;
   if (!votes_out || !q7_out || !valid_out || iters < 1 || iters > rpe::kMaxScoreH) return fail(RPE_ERR_ARG,
@@ -1850,6 +1940,7 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
 int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr,
     double cos_nl,
                          int* votes_out, double* q7_out, unsigned char* valid_out) {
+  session_end(c);
   const int per = rpe::gen_p3p_slots(solver);
   if (per == 0) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: solver must be 0 .. 4");
   static const int kinds[5] = {RPE_VOTE_23, RPE_VOTE_33_23, RPE_VOTE_NN_23, RPE_VOTE_NN_33, RPE_VOTE_NN_33_23};
@@ -1896,6 +1987,18 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   if (m33 && (rc = ensure_mask(c, RPE_MOD_33, true))) return rc;
   if (mnn && (rc = ensure_mask(c, RPE_MOD_NN, true))) return rc;
   const int exact = mode == RPE_SCORE_EXACT;
+  if (c->sess.active) {   // the winner's masks by the session's grid (it was launched with the mask arrays of this kind)
+    if (session_matches(c, kind, mode, thre_3d, cos_thr, cos_nl)) {
+      double one[12];
+      stage_poses(c->dtype, exact, pose7, 1, one);
+      double tot[rpe::kSessionHypsMax];
+      if (session_batch(c, 1, one, 1, (size_t)(exact ? 8 : 12) * elem_size(c->dtype), tot) == RPE_OK) {
+        c->h_votes[0] = (int)tot[0];
+        if (votes_out) *votes_out = c->h_votes[0];
+        return RPE_OK;
+      }
+    } else session_end(c);
+  }
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   double staged[12];
@@ -1909,8 +2012,58 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   return RPE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- resident scoring session
+// Resident scoring session: the batches of ONE RANSAC run (rpe_score with at most 32 hypotheses and exactly these parameters) and the
+// winner's masks (rpe_inlier_mask) are served by one resident launch instead of a launch each.  RPE_ERR_STATE if the context cannot
+// run one (no large-BAR control block, a sharded context, a problem beyond one group per thread of the co-resident grid): the caller
+// simply goes on -- rpe_score / rpe_inlier_mask then launch as always.  Any other call on the context closes the session.
+int rpe_score_session_begin(rpe_context* c, int kind, int mode, double thre_3d, double cos_thr, double cos_nl) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  session_end(c);
+  if (t_session) session_end(t_session);   // one session per thread
+  int rc = vote_arrays(c, kind);
+  if (rc) return rc;
+  static const bool off = getenv("RPE_SCORE_SESSION") && atoi(getenv("RPE_SCORE_SESSION")) == 0;
+  if (off || !c->resident || !c->host_resident || c->hostex || c->comm || c->p2p_world >= 1 || c->p2p_world_saved >= 1)
+    return fail(RPE_ERR_STATE, "no resident scoring session on this context");
+  HIP_TRY(hipSetDevice(c->device));
+  const int grid = rpe::score_resident_grid(c->arrays(), c->max_blocks);
+  if (grid < 1) return fail(RPE_ERR_STATE, "the problem is not frame-sized: no resident scoring session");
+  const bool m33 = kind == RPE_VOTE_33 || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
+  const bool m23 = kind == RPE_VOTE_23 || kind == RPE_VOTE_23_MATRIX || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33_23;
+  const bool mnn = kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
+  if (m23 && (rc = ensure_mask(c, RPE_MOD_23, true))) return rc;
+  if (m33 && (rc = ensure_mask(c, RPE_MOD_33, true))) return rc;
+  if (mnn && (rc = ensure_mask(c, RPE_MOD_NN, true))) return rc;
+  const int exact = mode == RPE_SCORE_EXACT;
+  double thr[3];
+  stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
+  resident_mutex(c->device).lock();
+  const unsigned long long base = c->seq;
+  rpe::ReduceTarget rt = host_target(c);
+  rt.seq = base;
+  rt.h_out = c->h_big;
+  const int nacc = rpe::kSessionHypsMax, rgn = 512 / nacc;
+  int mult = (grid + rgn * 8 - 1) / (rgn * 8);
+  mult = mult < 1 ? 1 : (mult > 4 ? 4 : mult);
+  const int runs = resident_run_shape(grid, nacc, 4 * rgn, rgn * mult, &rt);
+  c->seq = base;
+  const hipError_t e = rpe::launch_score_resident(c->arrays(), kind, exact, (const unsigned long long*)c->ctl, base, thr, grid, rt, c->stream);
+  if (e != hipSuccess) { resident_mutex(c->device).unlock(); return fail(RPE_ERR_HIP, "resident scoring launch: %s", hipGetErrorString(e)); }
+  c->sess.active = true; c->sess.kind = kind; c->sess.mode = mode; c->sess.grid = grid; c->sess.runs = runs; c->sess.batches = 0;
+  c->sess.thre_3d = thre_3d; c->sess.cos_thr = cos_thr; c->sess.cos_nl = cos_nl; c->sess.base = base;
+  t_session = c;
+  return RPE_OK;
+}
+int rpe_score_session_end(rpe_context* c) {
+  if (!c) return fail(RPE_ERR_ARG, "null context");
+  session_end(c);
+  return RPE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- PROSAC order
 int rpe_prosac_order(rpe_context* c, const float* weights, int n, int top_k, int* order_out) {
+  session_end(c);
   if (!c || !weights || !order_out || n < 1 || top_k < 1) return fail(RPE_ERR_ARG, "rpe_prosac_order: bad argument");
   if (top_k > n) top_k = n;
   if (top_k > rpe::kProsacMaxTopK) return fail(RPE_ERR_ARG,
@@ -1937,6 +2090,7 @@ int rpe_prosac_order(rpe_context* c, const float* weights, int n, int top_k, int
 
 // ---------------------------------------------------------------------------------------------- K5
 int rpe_nl_round(rpe_context* c, const double* c_opt3, const double* Cw3, const double* Cc3, const double* Rwc9, double* out44) {
+  session_end(c);
   int rc = need_arrays(c, {RPE_XW});
   if (rc) return rc;
   // the kernel reads the normal arrays as a PAIR (one without the other would dereference a null pointer on the device)
@@ -2031,6 +2185,7 @@ int associate_ready(rpe_context* c) {
 int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const rpe_camera* cam, double depth_scale, double dmin,
     double dmax,
                         double max_jump) {
+  session_end(c);
   if (!c || !depth || (depth_type != RPE_DEPTH_U16 && depth_type != RPE_DEPTH_F32)) return fail(RPE_ERR_ARG,
       "rpe_frame_set_depth: bad argument");
   rpe::Camera k;
@@ -2057,6 +2212,7 @@ int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const
 }
 
 int rpe_frame_download(rpe_context* c, int which, float* out) {
+  session_end(c);
   if (!c || !out || which < 0 || which > RPE_MAP_MODEL_NORMAL) return fail(RPE_ERR_ARG, "rpe_frame_download: bad argument");
   auto& F = c->fe;
   const bool model = which >= RPE_MAP_MODEL_VERTEX;
@@ -2070,6 +2226,7 @@ int rpe_frame_download(rpe_context* c, int which, float* out) {
 }
 
 int rpe_model_from_frame(rpe_context* c, const double* pose12) {
+  session_end(c);
   if (!c || !pose12) return fail(RPE_ERR_ARG, "rpe_model_from_frame: bad argument");
   auto& F = c->fe;
   if (!F.have_frame) return fail(RPE_ERR_STATE, "no frame: call rpe_frame_set_depth first");
@@ -2085,6 +2242,7 @@ int rpe_model_from_frame(rpe_context* c, const double* pose12) {
 }
 
 int rpe_model_upload(rpe_context* c, const float* vertex_w, const float* normal_w, const rpe_camera* cam, const double* pose12) {
+  session_end(c);
   if (!c || !vertex_w || !normal_w || !pose12) return fail(RPE_ERR_ARG, "rpe_model_upload: bad argument");
   rpe::Camera k;
   int rc = camera_of(cam, &k);
@@ -2103,6 +2261,7 @@ int rpe_model_upload(rpe_context* c, const float* vertex_w, const float* normal_
 }
 
 int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double cos_thr, int use_normals, int64_t* matched) {
+  session_end(c);
   int rc = associate_ready(c);
   if (rc) return rc;
   if (!pose12 || !(dist_thr >= 0)) return fail(RPE_ERR_ARG, "rpe_associate: bad argument");
@@ -2122,6 +2281,7 @@ int rpe_associate(rpe_context* c, const double* pose12, double dist_thr, double 
 
 int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters_out, double* last_step, double* final_cost,
     int64_t* matched) {
+  session_end(c);
   int rc = associate_ready(c);
   if (rc) return rc;
   if (!o || !pose12 || o->max_iter < 1 || (o->kind != RPE_RES_P2P && o->kind != RPE_RES_P2PLANE) || !(o->dist_thr >= 0))

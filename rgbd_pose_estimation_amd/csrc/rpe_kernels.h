@@ -145,6 +145,14 @@ int score_small_cap(int dtype, int exact);
 hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H,
     const double* thr3,
                               const ReduceTarget& rt, hipStream_t s);
+// RESIDENT scoring (K4r): one launch serves a whole RANSAC run on resident arrays -- batches of up to kSessionHyps hypotheses (op 0) and
+// the winner's masks (op 1) handed over through the control block (layout in rpe_score.hip), the counts back as run records of
+// kSessionHyps sums each, published with sequence value rt.seq + batch number.  grid = score_resident_grid (0: not frame-sized).
+constexpr int kSessionHypsMax = 32;
+constexpr int kSessionCtlWordsMax = 512;   // = the context's 4-KB control block
+int score_resident_grid(const DeviceArrays& A, int max_blocks);
+hipError_t launch_score_resident(const DeviceArrays& A, int kind, int exact, const unsigned long long* ctl, unsigned long long first_tag,
+                                 const double* thr3, int grid, const ReduceTarget& rt, hipStream_t s);
 // pose12: fast = R row-major (9) t (3); exact = qw qx qy qz tx ty tz (rest ignored).  The vote total is record[0] of rt.
 hipError_t launch_mask(const DeviceArrays& A, int kind, int exact, const double* pose12, const double* thr3, const ReduceTarget& rt,
                        hipStream_t s, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);

@@ -465,24 +465,15 @@ __device__ __forceinline__ RunShape run_shape(const Finish& fin, int G) {
 // own record (tiny problems).  A workgroup overwrites its granules only in the next iteration, which the host starts after it has
 // received every run record, i.e. after the granules have been read.  Returns false if a granule never arrived (the kernel ends without
 // publishing; the host reports that).
+// ... from a value every thread < NACC already holds (the workgroup's sum number threadIdx.x): the resident scoring kernel's vote counts
 template <int NACC, int BLK>
-__device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag,
-    unsigned long long seq,
-                                                     bool stamp_it) {
-  constexpr int NW = BLK / 64;
+__device__ __forceinline__ bool resident_cross_own(double own, const Finish& fin, unsigned long long tag, unsigned long long seq, bool stamp_it) {
   constexpr int RGN = BLK / NACC;                       // rows a collecting workgroup takes with one granule per thread
-  __shared__ double g_red[NW][NACC];
   __shared__ double g_part[RGN][NACC];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
   const RunShape rs = run_shape(fin, (int)gridDim.x);
   const int run = rs.run, leader = rs.leader;
-  wave_reduce_to<NACC>(acc, g_red[wave], lane);
-  __syncthreads();
   if (threadIdx.x < NACC) {
-    double own = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
     // test hook: a granule that never comes
     const bool withheld = fin.fault_tag != 0 && tag == fin.fault_tag && blockIdx.x + 1 == gridDim.x;
     if ((int)blockIdx.x != leader) { if (!withheld) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag); }
@@ -510,8 +501,24 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
     if (stamp_it) RPE_STAMP(5);
 #endif
   }
-  __syncthreads();   // g_red / g_part are reused by the next iteration
+  __syncthreads();   // g_part is reused by the next iteration
   return ok;
+}
+template <int NACC, int BLK>
+__device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag,
+    unsigned long long seq,
+                                                     bool stamp_it) {
+  constexpr int NW = BLK / 64;
+  __shared__ double g_red[NW][NACC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_reduce_to<NACC>(acc, g_red[wave], lane);
+  __syncthreads();
+  double own = 0.0;
+  if (threadIdx.x < NACC) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) own += g_red[w][threadIdx.x];
+  }
+  return resident_cross_own<NACC, BLK>(own, fin, tag, seq, stamp_it);
 }
 
 // Cross-workgroup stage of one AUTONOMOUS resident iteration (rpe_gn_refine_device: solve and exp-map on the GPU, no host in the loop).

@@ -1,5 +1,5 @@
 // K4: batched RANSAC hypothesis scoring (the eight vote loops) and K4b: the winner's inlier masks.
-#include "rpe_reduce.hpp"
+#include "rpe_residuals.hpp"   // (the resident scoring kernel shares the resident loops' control block and collecting stage)
 
 namespace rpe {
 
@@ -632,6 +632,138 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
   reduce_and_finish<1, kNeLd, 0, kBlock>(acc, fin);
 }
 
+// ================================================================================================
+// K4r: RESIDENT scoring -- a whole RANSAC run on resident arrays in ONE launch (the reference's real entry points are whole runs:
+// ao_ransac, Library.cpp:47-75; shinji_ransac2, AbsoluteOrientation.hpp:159-213).  Scored batch by batch with one launch each, a run
+// at 640x480 is 2-3 launches of 8-32 hypotheses plus the mask launch: 37-75 us of which ~7.5 us per launch are fixed.  Here the grid
+// stays resident for the run, as the Gauss-Newton loops' does: every thread keeps its group of correspondences in registers, the host
+// hands every batch over through the control block in fine-grained device memory (written through the PCIe BAR), the vote counts come
+// back as run records through the collecting stage (resident_cross_own), and the best-so-far / adaptive-Iter replay stays on the host
+// exactly as before.  The winner's masks are written by the same grid (op 1).  Frame-sized problems only (one group per thread).
+// Control block (512 words of 8 bytes): [0] tag | [1] count (low 32 bits), op (high: 0 score, 1 masks) | [2 ...] count hypotheses in
+// the scoring layout of the mode, values of the array dtype | [511] tag again.  The host writes payload and header, a store fence, both
+// tags (bit 63: stop).
+// ================================================================================================
+constexpr int kSessionHyps = kSessionHypsMax;          // hypotheses per batch
+constexpr int kSessionCtlWords = kSessionCtlWordsMax;  // the context's control block: 4 KB
+template <class T, int KIND, bool EXACT>
+__global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                                                             const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
+                                                             const unsigned long long* __restrict__ ctl, unsigned long long first_tag, T thr33,
+                                                             T cthr, T cnl, short* __restrict__ m23, short* __restrict__ m33,
+                                                             short* __restrict__ mnn, Finish fin) {
+  constexpr int P = Pk<T>::P, BLK = 512, HB = kSessionHyps;
+  constexpr int STRIDE = Hyp<T, EXACT>::STRIDE;
+  constexpr int PAYLOAD_WORDS = (HB * STRIDE * (int)sizeof(T) + 7) / 8;
+  static_assert(2 + PAYLOAD_WORDS < kSessionCtlWords, "the batch fits the control block");
+  typedef VoteMods<KIND> MD;
+  __shared__ unsigned long long s_words[PAYLOAD_WORDS];
+  __shared__ unsigned long long s_hdr;
+  __shared__ int s_go;
+  __shared__ double red[BLK / 64][HB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
+  wave_mask_t present[P], valid[P];
+  load_group<T>(xw, g, n, vw);
+  if (MD::need_xc) load_group<T>(xc, g, n, vc);
+  if (MD::m23) load_group<T>(bv, g, n, vb);
+  if (MD::mnn) { load_group<T>(nw, g, n, vnw); load_group<T>(nc, g, n, vnc); }
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    const bool here = (g * P + i) < n;
+    present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
+    valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
+  }
+  for (unsigned long long b = 1;; b++) {
+    const unsigned long long want = first_tag + b;
+    // ---- wait for batch b (both tags), bounded like the Gauss-Newton loops' wait for a pose
+    if (threadIdx.x < 64) {
+      const unsigned long long t0 = wall_clock64();
+      int go = 0;
+      unsigned long long w = 0;
+      for (;;) {
+        if (lane < 3) w = __hip_atomic_load(ctl + (lane == 0 ? 0 : (lane == 1 ? kSessionCtlWords - 1 : 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned int lo = (unsigned int)w, hi = (unsigned int)(w >> 32);
+        const unsigned long long ta = ((unsigned long long)__builtin_amdgcn_readlane(hi, 0) << 32) | __builtin_amdgcn_readlane(lo, 0);
+        const unsigned long long tb = ((unsigned long long)__builtin_amdgcn_readlane(hi, 1) << 32) | __builtin_amdgcn_readlane(lo, 1);
+        if (ta == tb) {
+          const unsigned long long num = ta & ~kResidentStop;
+          if (num == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
+          if (num > want) { go = 2; break; }   // a later call's tag: this launch is over
+        }
+        if (wall_clock64() - t0 > fin.pose_wait_ticks) { go = 3; break; }   // the host went away
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (lane == 2) s_hdr = w;   // (read in the same sweep as the matching tags or a later one: the header was written before them)
+      if (lane == 0) s_go = go;
+    }
+    __syncthreads();
+    if (s_go != 1) return;
+    // the header again, now that the tags are known good (the copy above may predate them)
+    if (threadIdx.x == 0) s_hdr = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    const int count = (int)(unsigned int)s_hdr, op = (int)(s_hdr >> 32);
+    const int words = (count * STRIDE * (int)sizeof(T) + 7) / 8;
+    if ((int)threadIdx.x < words) s_words[threadIdx.x] = __hip_atomic_load(ctl + 2 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    const T* batch = reinterpret_cast<const T*>(s_words);
+    double own = 0.0;
+    if (op == 0) {
+      int mine = 0;
+      for (int h = 0; h < count; h++) {
+        Hyp<T, EXACT> hyp;
+        hyp.load(batch + h * STRIDE, KIND == VOTE_23_MATRIX);
+        DeferQ<T> none;   // (no queue here: the in-place filter)
+        const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none);
+        mine = (lane == h) ? cnt : mine;
+      }
+      if (lane < HB) red[wave][lane] = (double)mine;
+      __syncthreads();
+      if (threadIdx.x < HB) {
+#pragma unroll
+        for (int w = 0; w < BLK / 64; w++) own += red[w][threadIdx.x];
+      }
+    } else {
+      // the masks of ONE hypothesis (the run's winner; fast layout: R row-major, t -- exact: quaternion, t) for this thread's group, and
+      // the total of the votes in sum 0
+      Hyp<T, EXACT> hyp;
+      hyp.load(batch, KIND == VOTE_23_MATRIX);
+      bool f23[P], f33[P], fnn[P];
+      group_flags<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, thr33, cthr, cnl, f23, f33, fnn);
+      int cnt = 0;
+      const int64_t full = n / P;
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        const bool here = (g * P + i) < n;
+        f23[i] = f23[i] & here; f33[i] = f33[i] & here; fnn[i] = fnn[i] & here;
+        cnt += (int)fnn[i] + (int)f33[i] + (int)f23[i];
+      }
+      if (g < full) {
+        if (MD::mnn) store_mask_full(mnn, g, fnn);
+        if (MD::m33) store_mask_full(m33, g, f33);
+        if (MD::m23) store_mask_full(m23, g, f23);
+      } else {
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+          const int64_t idx = g * P + i;
+          if (idx < n) { if (MD::mnn) mnn[idx] = fnn[i]; if (MD::m33) m33[idx] = f33[i]; if (MD::m23) m23[idx] = f23[i]; }
+        }
+      }
+      const double wsum = wave_sum_to_lane63((double)cnt);
+      if (lane < HB) red[wave][lane] = 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 63) red[wave][0] = wsum;
+      __syncthreads();
+      if (threadIdx.x < HB) {
+#pragma unroll
+        for (int w = 0; w < BLK / 64; w++) own += red[w][threadIdx.x];
+      }
+    }
+    if (!resident_cross_own<HB, BLK>(own, fin, want, fin.seq + b, false)) return;
+  }
+}
 template <class T, int KIND, bool EXACT>
 static void score_launch(const DeviceArrays& A, const void* d_poses, int H, const double* thr, int* d_votes, int G, hipStream_t s) {
   // Split the hypothesis list over blockIdx.y (chunks of a multiple of 16 hypotheses) until there are ~8192 workgroups: the loop is a
@@ -693,6 +825,37 @@ static void mask_launch(const DeviceArrays& A, const double* pose12, const doubl
     case VOTE_23_MATRIX: FN<T, VOTE_23_MATRIX, EX>(__VA_ARGS__); break;    \
     default: return hipErrorInvalidValue;                                  \
   }
+
+template <class T, int KIND, bool EXACT>
+static void score_resident_launch(const DeviceArrays& A, const unsigned long long* ctl, unsigned long long first_tag, const double* thr, int G,
+                                  const ReduceTarget& rt, hipStream_t s) {
+  Finish fin = make_finish(rt);
+  constexpr int kMaxRows = 4 * (512 / kSessionHyps);
+  if (fin.rows > kMaxRows) fin.rows = kMaxRows;
+  if (fin.rows < 1) fin.rows = 1;
+  hipLaunchKernelGGL((score_resident_kernel<T, KIND, EXACT>), dim3(G), dim3(512), 0, s, (const T*)A.a[0], (const T*)A.a[1], (const T*)A.a[2],
+                     (const T*)A.a[3], (const T*)A.a[4], A.n, ctl, first_tag, (T)thr[0], (T)thr[1], (T)thr[2], A.mask[0], A.mask[1], A.mask[2], fin);
+}
+// grid of the resident scoring kernel (one group per thread), or 0 if the problem is not frame-sized for this device
+int score_resident_grid(const DeviceArrays& A, int max_blocks) {
+  const int P = A.dtype ? 2 : 4;
+  const int cap = std::max(1, resident_cap_device());
+  const int64_t groups = (A.n + P - 1) / P;
+  const int64_t G = (groups + 511) / 512;
+  return G >= 1 && G <= std::min(cap, max_blocks) ? (int)G : 0;
+}
+hipError_t launch_score_resident(const DeviceArrays& A, int kind, int exact, const unsigned long long* ctl, unsigned long long first_tag,
+                                 const double* thr3, int grid, const ReduceTarget& rt, hipStream_t s) {
+  if (grid < 1) return hipErrorInvalidValue;
+  if (A.dtype) {
+    if (exact) { RPE_KIND_SWITCH(score_resident_launch, double, true, A, ctl, first_tag, thr3, grid, rt, s) }
+    else { RPE_KIND_SWITCH(score_resident_launch, double, false, A, ctl, first_tag, thr3, grid, rt, s) }
+  } else {
+    if (exact) { RPE_KIND_SWITCH(score_resident_launch, float, true, A, ctl, first_tag, thr3, grid, rt, s) }
+    else { RPE_KIND_SWITCH(score_resident_launch, float, false, A, ctl, first_tag, thr3, grid, rt, s) }
+  }
+  return hipGetLastError();
+}
 
 hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* d_poses, int H, const double* thr3, int* d_votes,
                         int max_blocks, hipStream_t s) {

@@ -10,6 +10,9 @@
 // may have been advanced further than the reference would have advanced rand().
 // The winner's inlier mask is written once at the end (rpe_inlier_mask, kernel K4b) instead of at every improvement, and stays on
 // the device until somebody reads the adapter's host copy.
+// On a frame-sized problem the whole run -- every short batch and the masks -- is served by ONE resident launch (a scoring session,
+// rpe_score_session_begin / _end, kernel K4r): the batches travel through the context's control block, the votes come back as run
+// records, and the replay below is unchanged.
 #ifndef RPE_RANSAC_ENGINE_HEADER
 #define RPE_RANSAC_ENGINE_HEADER
 
@@ -56,6 +59,13 @@ void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce p
   auto lap = [&](double& acc) { if (prof) { const double t = now_us(); acc += t - tp; tp = t; } };
   rpe_context* ctx = adapter.device().ctx();
   adapter.setMaxVotes(-1);
+  // ONE resident launch serves the short batches and the winner's masks of this run (rpe_score_session_begin; refused -- no large-BAR
+  // control block, a sharded context, more than a frame's worth of correspondences -- the calls below launch one kernel each as before)
+  struct Session {
+    rpe_context* ctx; bool open;
+    ~Session() { if (open) rpe_score_session_end(ctx); }
+  } session = {ctx, cfg.score_session && Iter > 0 &&
+      rpe_score_session_begin(ctx, spec.kind, opt.mode(), (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl) == RPE_OK};
   bool have_best = false;
   SE3<Tp> best;
   int it = 0;
@@ -96,6 +106,7 @@ void ransac_engine_batched(Adapter& adapter, const VoteSpec<Tp>& spec, Produce p
     int total = 0;
     check(rpe_inlier_mask(ctx, spec.kind, opt.mode(), b7, (double)spec.thre_3d, (double)spec.cos_thr, (double)spec.cos_nl, &total),
           "rpe_inlier_mask");
+    if (session.open) { session.open = false; check(rpe_score_session_end(ctx), "rpe_score_session_end"); }
     const bool has23 = spec.kind == RPE_VOTE_23 || spec.kind == RPE_VOTE_23_MATRIX || spec.kind == RPE_VOTE_33_23 ||
                        spec.kind == RPE_VOTE_NN_23 || spec.kind == RPE_VOTE_NN_33_23;
     const bool has33 = spec.kind == RPE_VOTE_33 || spec.kind == RPE_VOTE_33_23 || spec.kind == RPE_VOTE_NN_33 || spec.kind == RPE_VOTE_NN_33_23;

@@ -49,6 +49,7 @@ struct Settings {
   // runs after ONE round (307 200 points, RPE_SCORE_EXACT: shinji_kneip_ransac 68 us with 8 against 291 us with 64; every run of
   // profiles/r02_engine_profile.txt ended in its first batch).  RPE_FIRST_BATCH overrides.
   int first_batch = std::getenv("RPE_FIRST_BATCH") ? std::atoi(std::getenv("RPE_FIRST_BATCH")) : 8, max_batch = 2048;
+  bool score_session = true;   // serve a run's short batches and masks by one resident launch where the context can (RPE_SCORE_SESSION=0: never)
   // 3D-3D RANSAC (shinji_ransac / shinji_ransac2): sample + 3-point fit on the device too (rpe_ransac33_batch), bitwise the host's
   // hypotheses; false = host generation (RPE_HOST_HYPOTHESES=1 sets that default)
   bool device_hypotheses = std::getenv("RPE_HOST_HYPOTHESES") == nullptr;

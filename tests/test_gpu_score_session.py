@@ -1,0 +1,154 @@
+"""-m gpu: the resident scoring session (K4r, rpe_score_session_begin / _end).  Inside a session the batches of a RANSAC run and the
+winner's masks are served by ONE resident launch; votes and masks must be the oracle's -- hence those of the same calls outside a
+session -- bit for bit, for every vote kind, both scoring modes and both dtypes, for any batch length up to 128, with NaN-marked
+points, and whatever ends the session (its end call, another entry point, a list too long for it, other parameters)."""
+import numpy as np
+import pytest
+
+from rgbd_pose_estimation_amd import _lib as L, api
+import util
+
+pytestmark = pytest.mark.gpu
+
+KINDS = [L.VOTE_33, L.VOTE_23, L.VOTE_23_MATRIX, L.VOTE_33_23, L.VOTE_NN_23, L.VOTE_NN_33, L.VOTE_NN_33_23]
+
+
+def _okind(oracle, kind):
+    return {L.VOTE_33: oracle.V_33, L.VOTE_23: oracle.V_23, L.VOTE_23_MATRIX: oracle.V_23_MATRIX, L.VOTE_33_23: oracle.V_33_23,
+            L.VOTE_NN_23: oracle.V_NN_23, L.VOTE_NN_33: oracle.V_NN_33, L.VOTE_NN_33_23: oracle.V_NN_33_23}[kind]
+
+
+def _scene(n, dt, seed):
+    sc = util.scene_full(seed, n, np.float64, n2d=1.5 / 585.0, n3d=0.02, nnl_deg=2.0, outliers=0.3)
+    sc.P[5] = np.nan          # an invalid depth pixel
+    sc.P[n - 1] = np.nan      # ... in the ragged tail
+    sc.U[7] = np.nan
+    return sc.astype(dt)
+
+
+def _poses(oracle, sc, f64, count, seed):
+    rng = np.random.default_rng(seed)
+    q = np.tile(oracle.pose7_from_Rt(sc.R, sc.t, f64), (count, 1))
+    q[1:, :4] += 0.01 * rng.standard_normal((count - 1, 4)) * rng.random((count - 1, 1))
+    q[:, :4] /= np.linalg.norm(q[:, :4], axis=1, keepdims=True)
+    q[1:, 4:] += 0.05 * rng.standard_normal((count - 1, 3)) * rng.random((count - 1, 1))
+    dt = np.float64 if f64 else np.float32
+    return np.ascontiguousarray(q.astype(dt).astype(np.float64))
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("mode", [L.SCORE_EXACT, L.SCORE_FAST])
+@pytest.mark.parametrize("kind", KINDS)
+def test_session_votes_and_masks_are_the_oracles(gpu_ctx_factory, oracle, kind, mode, f64):
+    dt = np.float64 if f64 else np.float32
+    n = 30001                                             # ragged: the last group is partial
+    sc = _scene(n, dt, 5)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=float(np.cos(np.radians(5.0))))
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    assert ctx.score_session_begin(kind, mode=mode, **thr)
+    best = None
+    for count in (8, 1, 32, 33, 100, 128):               # one batch, a single hypothesis, a full one, split lists
+        q = _poses(oracle, sc, f64, count, 100 + count)
+        v = ctx.score(kind, q, mode=mode, **thr)
+        if mode == L.SCORE_EXACT:
+            vo = oracle.votes(prob, _okind(oracle, kind), q, **thr)
+            assert np.array_equal(v, vo), (count, v[:8], vo[:8])
+        best = q[int(np.argmax(v))] if best is None else best
+    has = {L.MOD_23: kind in (L.VOTE_23, L.VOTE_23_MATRIX, L.VOTE_33_23, L.VOTE_NN_23, L.VOTE_NN_33_23),
+           L.MOD_33: kind in (L.VOTE_33, L.VOTE_33_23, L.VOTE_NN_33, L.VOTE_NN_33_23),
+           L.MOD_NN: kind in (L.VOTE_NN_23, L.VOTE_NN_33, L.VOTE_NN_33_23)}
+    mods = [m for m in (L.MOD_23, L.MOD_33, L.MOD_NN) if has[m]]
+    votes_in = ctx.inlier_mask(kind, best, mode=mode, **thr)
+    ctx.score_session_end()
+    masks_in = {m: ctx.download_mask(m) for m in mods}
+    # the same call outside a session
+    votes_out = ctx.inlier_mask(kind, best, mode=mode, **thr)
+    masks_out = {m: ctx.download_mask(m) for m in mods}
+    assert votes_in == votes_out
+    for m in mods:
+        assert np.array_equal(masks_in[m], masks_out[m]), m
+    if mode == L.SCORE_EXACT:
+        vo, mo = oracle.votes(prob, _okind(oracle, kind), best[None], mask_for=0, **thr)
+        assert votes_in == int(vo[0])
+        for m in mods:
+            assert np.array_equal(masks_in[m], mo[m]), m
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("kind", KINDS)
+def test_fast_mode_session_equals_the_launch_path(gpu_ctx_factory, oracle, kind, f64):
+    dt = np.float64 if f64 else np.float32
+    sc = _scene(20000, dt, 6)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=float(np.cos(np.radians(5.0))))
+    q = _poses(oracle, sc, f64, 96, 9)
+    plain = ctx.score(kind, q, mode=L.SCORE_FAST, **thr)
+    assert ctx.score_session_begin(kind, mode=L.SCORE_FAST, **thr)
+    inside = np.concatenate([ctx.score(kind, q[:8], mode=L.SCORE_FAST, **thr), ctx.score(kind, q[8:24], mode=L.SCORE_FAST, **thr),
+                             ctx.score(kind, q[24:], mode=L.SCORE_FAST, **thr)])
+    ctx.score_session_end()
+    assert np.array_equal(plain, inside)
+
+
+def test_whatever_ends_a_session_leaves_a_working_context(gpu_ctx_factory, oracle):
+    sc = _scene(40000, np.float32, 7)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    prob = oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=2.0)
+    q = _poses(oracle, sc, False, 200, 3)
+    vo = oracle.votes(prob, oracle.V_33_23, q, **thr)
+    pose = api.pose12(sc.R, sc.t)
+    for ender in ("end", "end_twice", "long_list", "other_threshold", "other_kind", "normal_eq", "refine", "upload", "download_mask", "none"):
+        assert ctx.score_session_begin(L.VOTE_33_23, **thr)
+        assert np.array_equal(ctx.score(L.VOTE_33_23, q[:20], **thr), vo[:20])
+        if ender == "end":
+            ctx.score_session_end()
+        elif ender == "end_twice":
+            ctx.score_session_end(); ctx.score_session_end()
+        elif ender == "long_list":
+            assert np.array_equal(ctx.score(L.VOTE_33_23, q, **thr), vo)                     # 200 > 128: the launch path
+        elif ender == "other_threshold":
+            v2 = ctx.score(L.VOTE_33_23, q[:8], thre_3d=0.1, cos_thr=thr["cos_thr"], cos_nl=2.0)
+            assert np.array_equal(v2, oracle.votes(prob, oracle.V_33_23, q[:8], thre_3d=0.1, cos_thr=thr["cos_thr"], cos_nl=2.0))
+        elif ender == "other_kind":
+            assert np.array_equal(ctx.score(L.VOTE_33, q[:8], thre_3d=0.05), oracle.votes(prob, oracle.V_33, q[:8], thre_3d=0.05))
+        elif ender == "normal_eq":
+            assert ctx.normal_eq(L.RES_P2P, pose)[0][28] > 0
+        elif ender == "refine":
+            ctx.gn_refine([L.RES_P2P], pose, max_iter=5)                                     # a resident loop of the same context
+        elif ender == "upload":
+            ctx.upload(L.XW, sc.Q)
+        elif ender == "download_mask":
+            ctx.inlier_mask(L.VOTE_33_23, q[0], **thr)
+            m = ctx.download_mask(L.MOD_33)
+            _, mo = oracle.votes(prob, oracle.V_33_23, q[:1], mask_for=0, **thr)
+            assert np.array_equal(m, mo[L.MOD_33])
+        # "none": the next begin (or close) ends it
+        assert np.array_equal(ctx.score(L.VOTE_33_23, q[:40], **thr), vo[:40])
+    st = ctx.resident_state()
+    assert st["enabled"] and st["lost"] == 0
+
+
+def test_two_contexts_of_one_thread_do_not_deadlock(gpu_ctx_factory, oracle):
+    sc = _scene(30000, np.float32, 8)
+    a = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    b = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    q = _poses(oracle, sc, False, 16, 4)
+    assert a.score_session_begin(L.VOTE_33, thre_3d=0.05)
+    va = a.score(L.VOTE_33, q, thre_3d=0.05)
+    b.gn_refine([L.RES_P2P], api.pose12(sc.R, sc.t), max_iter=3)      # needs the device's resident slot: a's session gives it up
+    assert b.score_session_begin(L.VOTE_33, thre_3d=0.05)             # one session per thread
+    vb = b.score(L.VOTE_33, q, thre_3d=0.05)
+    assert np.array_equal(va, vb) and np.array_equal(va, a.score(L.VOTE_33, q, thre_3d=0.05))
+    b.score_session_end()
+
+
+def test_a_problem_beyond_a_frame_is_refused_and_scored_by_launches(gpu_ctx_factory, oracle):
+    n = 3_000_000
+    rng = np.random.default_rng(0)
+    xw = rng.standard_normal((n, 3)).astype(np.float32)
+    ctx = gpu_ctx_factory().load(L.F32, xw=xw, xc=xw + np.float32(0.01))
+    assert not ctx.score_session_begin(L.VOTE_33, thre_3d=0.05)
+    q = np.array([[1.0, 0, 0, 0, 0.01, 0.01, 0.01]])
+    assert ctx.score(L.VOTE_33, q, thre_3d=0.05)[0] == n
