@@ -74,6 +74,20 @@ int main(int argc, char** argv) {
         std::printf("%-24s %5d %9.0f | %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f | %5d %4d %8d\n", r.name, rep, dt, p.upload, p.sort, p.generate, p.score, p.replay, p.mask,
                     p.hypotheses, p.batches, adapter.getMaxVotes());
       }
+    {  // the reference's 3D-3D entry point on the same frame (shinji_ransac2, AbsoluteOrientation.hpp:158-213): arrays resident, 8 runs
+      AOOnlyPoseAdapter<T> ao(P, Q);
+      ao.setFocal(585.0f, 585.0f);
+      for (int rep = 0; rep < 8; rep++) {
+        cfg.prof = rpe::EngineProfile();
+        int it = 1000;
+        const double t0 = rpe::now_us();
+        shinji_ransac2<T>(ao, thre_3d, it, conf);
+        const double dt = rpe::now_us() - t0;
+        const rpe::EngineProfile& p = cfg.prof;
+        std::printf("%-24s %5d %9.1f | %8.0f %8.0f %8.0f %8.0f %8.0f %8.0f | %5d %4d %8d   Iter %d\n", "shinji_ransac2", rep, dt, p.upload, p.sort, p.generate, p.score,
+                    p.replay, p.mask, p.hypotheses, p.batches, ao.getMaxVotes(), it);
+      }
+    }
     return 0;
   } catch (const rpe::DeviceError& e) {
     std::fprintf(stderr, "device error %d: %s\n", e.code, e.what());

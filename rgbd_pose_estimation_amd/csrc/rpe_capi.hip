@@ -91,7 +91,12 @@ struct rpe_context {
   hipStream_t stream = nullptr;
   // resident scoring session (rpe_score_session_begin ... _end): the grid of score_resident_kernel waits for batches in c->ctl
   struct { bool active = false; int kind = 0, mode = 0, grid = 0, runs = 0, batches = 0; double thre_3d = 0, cos_thr = 0, cos_nl = 0;
-           unsigned long long base = 0; } sess;
+           unsigned long long base = 0;
+           // every hypothesis the session has scored (pose as the caller gave it -> votes): the winner's total is known without
+           // waiting for the masks' own record
+           std::vector<double> seen_pose; std::vector<int> seen_votes;
+           // the session's LAST message was "write these masks and leave" and its record has not been looked at yet (session_verify)
+           bool pending = false; unsigned long long pend_tag = 0; int pend_votes = 0; double pend_pose[7] = {0, 0, 0, 0, 0, 0, 0}; } sess;
   hipStream_t stream2 = nullptr;   // the solving workgroup of the autonomous resident loops runs beside its workers (created on first use)
   hipEvent_t ev_stream2 = nullptr; // ... behind the uploads of the start pose / loop state on `stream`
   bool auto_solver = true;         // ... until the two kernels once failed to meet (a platform that serialises them)
@@ -649,41 +654,81 @@ bool pin_calling_thread(int cpu) {
 }  // namespace
 
 // ---- resident scoring session (K4r, rpe_score.hip): ONE launch serves the batches of a RANSAC run and the winner's masks.
-// Ends a session that is open (idempotent): the stop tag releases the grid, the per-device resident mutex is given back.  Every entry
-// point that would queue work behind the resident kernel on the context's stream calls this first.
 static thread_local rpe_context* t_session = nullptr;   // the context whose session this thread holds open (at most one per thread)
-static void session_end(rpe_context* c) {
-  // (a session of ANOTHER context of this thread on the same GPU holds the device's resident slot: a resident loop of `c` would wait
-  // for it forever)
-  if (c && t_session && t_session != c && t_session->device == c->device) session_end(t_session);
-  if (!c || !c->sess.active) return;
-  if (t_session == c) t_session = nullptr;
-  c->sess.active = false;
-  const unsigned long long stop = (c->sess.base + (unsigned long long)c->sess.batches + 1) | rpe::kResidentStopBit;
-  store_fence();
-  c->ctl[0] = stop; c->ctl[rpe::kSessionCtlWordsMax - 1] = stop;
-  store_fence();
-  c->seq = c->sess.base + (unsigned long long)c->sess.batches + 2;   // stays ahead of every tag / sequence value the launch could use
-  resident_mutex(c->device).unlock();
-}
-// one batch through the open session: op 0 = score `count` hypotheses (staged: the kernel's layout, values of the array dtype), op 1 =
-// the masks of one; totals = the 32 sums of the batch.  On a failure the session is closed and the caller takes the launch path.
-static int session_batch(rpe_context* c, int op, const void* staged, int count, size_t bytes, double* totals) {
-  const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
+static int mask_by_launch(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl, int* votes_out);
+static void session_message(rpe_context* c, int op, const void* staged, int count, size_t bytes, unsigned long long tag) {
   const size_t words = (bytes + 7) / 8;
   unsigned long long buf[rpe::kSessionCtlWordsMax];
-  std::memset(buf, 0, words * 8);
-  std::memcpy(buf, staged, bytes);
+  if (words) { buf[words - 1] = 0; std::memcpy(buf, staged, bytes); }
   for (size_t k = 0; k < words; k++) c->ctl[2 + k] = buf[k];
   c->ctl[1] = (unsigned long long)(unsigned int)count | ((unsigned long long)op << 32);
   store_fence();
   c->ctl[0] = tag; c->ctl[rpe::kSessionCtlWordsMax - 1] = tag;
   store_fence();
+}
+// Closes a session that is open (idempotent): the stop message releases the grid, the per-device resident slot is given back.
+static void session_close(rpe_context* c) {
+  if (!c || !c->sess.active) return;
+  if (t_session == c) t_session = nullptr;
+  c->sess.active = false;
+  session_message(c, 2, nullptr, 0, 0, (c->sess.base + (unsigned long long)c->sess.batches + 1) | rpe::kResidentStopBit);
+  c->seq = c->sess.base + (unsigned long long)c->sess.batches + 2;   // stays ahead of every tag / sequence value the launch could use
+  resident_mutex(c->device).unlock();
+}
+// The masks of a session's last message ("write them and leave", session_final_masks) were not waited for.  Look at their record now
+// -- it has long arrived -- and, should the grid have gone away before it consumed the message (a host stalled beyond the grid's
+// bounded wait), write the masks with the one-launch kernel: either way they are in place, in stream order, for whoever reads them.
+static void session_verify(rpe_context* c) {
+  if (!c || !c->sess.pending) return;
+  c->sess.pending = false;
+  const unsigned long long keep = c->seq;
+  c->seq = c->sess.pend_tag;
+  double tot[rpe::kSessionHypsMax];
+  const int rc = wait_host_partials(c, c->sess.runs, rpe::kSessionHypsMax, tot, 0, true);
+  c->seq = keep;
+  if (rc == RPE_OK && (int)tot[0] == c->sess.pend_votes) return;
+  if (rc == kResidentLost) note_lost_grid(c);
+  int votes = 0;
+  (void)mask_by_launch(c, c->sess.kind, c->sess.mode, c->sess.pend_pose, c->sess.thre_3d, c->sess.cos_thr, c->sess.cos_nl, &votes);
+}
+// Every entry point that queues work behind the context's stream, reads the masks or reuses the host-side record area calls this first.
+static void session_end(rpe_context* c) {
+  // (a session of ANOTHER context of this thread on the same GPU holds the device's resident slot: a resident loop of `c` would wait
+  // for it forever)
+  if (c && t_session && t_session != c && t_session->device == c->device) session_close(t_session);
+  session_close(c);
+  session_verify(c);
+}
+// one batch through the open session: op 0 = score `count` hypotheses (staged: the kernel's layout, values of the array dtype), op 1 =
+// the masks of one; totals = the 32 sums of the batch.  On a failure the session is closed and the caller takes the launch path.
+static int session_batch(rpe_context* c, int op, const void* staged, int count, size_t bytes, double* totals) {
+  const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
+  session_message(c, op, staged, count, bytes, tag);
   c->sess.batches++;
   c->seq = tag;
   const int rc = wait_host_partials(c, c->sess.runs, rpe::kSessionHypsMax, totals, 0, true);
-  if (rc != RPE_OK) { session_end(c); return rc == kResidentLost ? RPE_ERR_HIP : rc; }
+  if (rc != RPE_OK) { if (rc == kResidentLost) note_lost_grid(c); session_close(c); return rc == kResidentLost ? RPE_ERR_HIP : rc; }
   return RPE_OK;
+}
+// The session's LAST message: the masks of a hypothesis whose vote total is already known (it was scored in this session), together
+// with the stop.  Nothing is waited for: the grid writes the masks, sends their record and leaves on its own; the context's stream
+// orders every later reader behind it, and session_verify looks at the record at the next call.
+static void session_final_masks(rpe_context* c, const void* staged, size_t bytes, const double* pose7, int votes) {
+  const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
+  session_message(c, 1, staged, 1, bytes, tag | rpe::kResidentStopBit);
+  c->sess.batches++;
+  if (t_session == c) t_session = nullptr;
+  c->sess.active = false;
+  c->sess.pending = true; c->sess.pend_tag = tag; c->sess.pend_votes = votes;
+  std::memcpy(c->sess.pend_pose, pose7, sizeof c->sess.pend_pose);
+  c->seq = tag + 1;
+  resident_mutex(c->device).unlock();   // (the grid waits for nobody any more: another resident grid may start beside it)
+}
+static bool session_seen(const rpe_context* c, const double* pose7, int* votes) {
+  const size_t count = c->sess.seen_votes.size();
+  for (size_t i = count; i-- > 0;)   // (the winner is usually among the latest)
+    if (std::memcmp(&c->sess.seen_pose[7 * i], pose7, 7 * sizeof(double)) == 0) { *votes = c->sess.seen_votes[i]; return true; }
+  return false;
 }
 static bool session_matches(const rpe_context* c, int kind, int mode, double thre_3d, double cos_thr, double cos_nl) {
   return c->sess.active && c->sess.kind == kind && c->sess.mode == mode && c->sess.thre_3d == thre_3d && c->sess.cos_thr == cos_thr &&
@@ -1845,9 +1890,15 @@ int rpe_score(rpe_context* c, int kind, int mode, const double* poses7, int H, d
         if (session_batch(c, 0, (const char*)c->h_poses + (size_t)h0 * per, hn, (size_t)hn * per, tot) != RPE_OK) break;   // (closed: launch)
         for (int i = 0; i < hn; i++) votes_out[h0 + i] = (int)tot[i];
       }
-      if (h0 >= H) return RPE_OK;
+      if (h0 >= H) {
+        if (c->sess.seen_votes.size() + (size_t)H <= 1024) {
+          c->sess.seen_pose.insert(c->sess.seen_pose.end(), poses7, poses7 + (size_t)7 * H);
+          c->sess.seen_votes.insert(c->sess.seen_votes.end(), votes_out, votes_out + H);
+        }
+        return RPE_OK;
+      }
     } else session_end(c);
-  }
+  } else session_end(c);   // (a closed session's masks may still be unverified)
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   const size_t per = (exact ? 8 : 12) * elem_size(c->dtype);
@@ -1974,31 +2025,8 @@ int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_
   return RPE_OK;
 }
 
-int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,
-    int* votes_out) {
-  int rc = vote_arrays(c, kind);
-  if (rc) return rc;
-  if (!pose7) return fail(RPE_ERR_ARG, "null pose");
-  HIP_TRY(hipSetDevice(c->device));
-  const bool m33 = kind == RPE_VOTE_33 || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
-  const bool m23 = kind == RPE_VOTE_23 || kind == RPE_VOTE_23_MATRIX || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33_23;
-  const bool mnn = kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
-  if (m23 && (rc = ensure_mask(c, RPE_MOD_23, true))) return rc;
-  if (m33 && (rc = ensure_mask(c, RPE_MOD_33, true))) return rc;
-  if (mnn && (rc = ensure_mask(c, RPE_MOD_NN, true))) return rc;
+static int mask_by_launch(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl, int* votes_out) {
   const int exact = mode == RPE_SCORE_EXACT;
-  if (c->sess.active) {   // the winner's masks by the session's grid (it was launched with the mask arrays of this kind)
-    if (session_matches(c, kind, mode, thre_3d, cos_thr, cos_nl)) {
-      double one[12];
-      stage_poses(c->dtype, exact, pose7, 1, one);
-      double tot[rpe::kSessionHypsMax];
-      if (session_batch(c, 1, one, 1, (size_t)(exact ? 8 : 12) * elem_size(c->dtype), tot) == RPE_OK) {
-        c->h_votes[0] = (int)tot[0];
-        if (votes_out) *votes_out = c->h_votes[0];
-        return RPE_OK;
-      }
-    } else session_end(c);
-  }
   double thr[3];
   stage_thresholds(c->dtype, exact, thre_3d, cos_thr, cos_nl, thr);
   double staged[12];
@@ -2006,10 +2034,46 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
   hipEvent_t e0, e1;
   timing_pair(c, &e0, &e1);
   HIP_TRY(rpe::launch_mask(c->arrays(), kind, exact, staged, thr, collect_target(c), c->stream, e0, e1));
+  int rc;
   if ((rc = wait_host(c, rpe::kNeLd))) return rc;
   c->h_votes[0] = (int)c->h_out[0];
   if (votes_out) *votes_out = c->h_votes[0];
   return RPE_OK;
+}
+int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl,
+    int* votes_out) {
+  int rc = vote_arrays(c, kind);
+  if (rc) return rc;
+  if (!pose7) return fail(RPE_ERR_ARG, "null pose");
+  HIP_TRY(hipSetDevice(c->device));
+  if (session_matches(c, kind, mode, thre_3d, cos_thr, cos_nl)) {   // by the session's grid (launched with the mask arrays of this kind)
+    const int exact = mode == RPE_SCORE_EXACT;
+    double one[12];
+    stage_poses(c->dtype, exact, pose7, 1, one);
+    const size_t bytes = (size_t)(exact ? 8 : 12) * elem_size(c->dtype);
+    int known = 0;
+    static const bool lazy = !(getenv("RPE_SESSION_LAZY_MASK") && atoi(getenv("RPE_SESSION_LAZY_MASK")) == 0);
+    if (lazy && session_seen(c, pose7, &known)) {   // the run's winner: its total is known, the masks end the session
+      session_final_masks(c, one, bytes, pose7, known);
+      c->h_votes[0] = known;
+      if (votes_out) *votes_out = known;
+      return RPE_OK;
+    }
+    double tot[rpe::kSessionHypsMax];
+    if (session_batch(c, 1, one, 1, bytes, tot) == RPE_OK) {
+      c->h_votes[0] = (int)tot[0];
+      if (votes_out) *votes_out = c->h_votes[0];
+      return RPE_OK;
+    }
+  }
+  session_end(c);
+  const bool m33 = kind == RPE_VOTE_33 || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
+  const bool m23 = kind == RPE_VOTE_23 || kind == RPE_VOTE_23_MATRIX || kind == RPE_VOTE_33_23 || kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33_23;
+  const bool mnn = kind == RPE_VOTE_NN_23 || kind == RPE_VOTE_NN_33 || kind == RPE_VOTE_NN_33_23;
+  if (m23 && (rc = ensure_mask(c, RPE_MOD_23, true))) return rc;
+  if (m33 && (rc = ensure_mask(c, RPE_MOD_33, true))) return rc;
+  if (mnn && (rc = ensure_mask(c, RPE_MOD_NN, true))) return rc;
+  return mask_by_launch(c, kind, mode, pose7, thre_3d, cos_thr, cos_nl, votes_out);
 }
 
 // ---------------------------------------------------------------------------------------------- resident scoring session
@@ -2020,7 +2084,7 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
 int rpe_score_session_begin(rpe_context* c, int kind, int mode, double thre_3d, double cos_thr, double cos_nl) {
   if (!c) return fail(RPE_ERR_ARG, "null context");
   session_end(c);
-  if (t_session) session_end(t_session);   // one session per thread
+  if (t_session) session_close(t_session);   // one session per thread
   int rc = vote_arrays(c, kind);
   if (rc) return rc;
   static const bool off = getenv("RPE_SCORE_SESSION") && atoi(getenv("RPE_SCORE_SESSION")) == 0;
@@ -2052,12 +2116,13 @@ int rpe_score_session_begin(rpe_context* c, int kind, int mode, double thre_3d, 
   if (e != hipSuccess) { resident_mutex(c->device).unlock(); return fail(RPE_ERR_HIP, "resident scoring launch: %s", hipGetErrorString(e)); }
   c->sess.active = true; c->sess.kind = kind; c->sess.mode = mode; c->sess.grid = grid; c->sess.runs = runs; c->sess.batches = 0;
   c->sess.thre_3d = thre_3d; c->sess.cos_thr = cos_thr; c->sess.cos_nl = cos_nl; c->sess.base = base;
+  c->sess.seen_pose.clear(); c->sess.seen_votes.clear();
   t_session = c;
   return RPE_OK;
 }
 int rpe_score_session_end(rpe_context* c) {
   if (!c) return fail(RPE_ERR_ARG, "null context");
-  session_end(c);
+  session_close(c);   // (masks of the session are complete in stream order; their record is looked at by the next call that needs to)
   return RPE_OK;
 }
 

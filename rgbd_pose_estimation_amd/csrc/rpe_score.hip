@@ -642,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const T* __restrict__ xw, 
 // exactly as before.  The winner's masks are written by the same grid (op 1).  Frame-sized problems only (one group per thread).
 // Control block (512 words of 8 bytes): [0] tag | [1] count (low 32 bits), op (high: 0 score, 1 masks) | [2 ...] count hypotheses in
 // the scoring layout of the mode, values of the array dtype | [511] tag again.  The host writes payload and header, a store fence, both
-// tags (bit 63: stop).
+// tags (bit 63: stop -- with op 1 the masks are still written and their record sent before the grid leaves, any other op leaves at once).
 // ================================================================================================
 constexpr int kSessionHyps = kSessionHypsMax;          // hypotheses per batch
 constexpr int kSessionCtlWords = kSessionCtlWordsMax;  // the context's control block: 4 KB
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
         const unsigned long long tb = ((unsigned long long)__builtin_amdgcn_readlane(hi, 1) << 32) | __builtin_amdgcn_readlane(lo, 1);
         if (ta == tb) {
           const unsigned long long num = ta & ~kResidentStop;
-          if (num == want) { go = (ta & kResidentStop) ? 2 : 1; break; }
+          if (num == want) { go = (ta & kResidentStop) ? 4 : 1; break; }   // (4: the session's last message)
           if (num > want) { go = 2; break; }   // a later call's tag: this launch is over
         }
         if (wall_clock64() - t0 > fin.pose_wait_ticks) { go = 3; break; }   // the host went away
@@ -699,11 +699,13 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
       if (lane == 0) s_go = go;
     }
     __syncthreads();
-    if (s_go != 1) return;
+    const int go = s_go;
+    if (go != 1 && go != 4) return;
     // the header again, now that the tags are known good (the copy above may predate them)
     if (threadIdx.x == 0) s_hdr = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     const int count = (int)(unsigned int)s_hdr, op = (int)(s_hdr >> 32);
+    if (go == 4 && op != 1) return;   // a plain stop; with op 1: "write these masks, send their record, and leave"
     const int words = (count * STRIDE * (int)sizeof(T) + 7) / 8;
     if ((int)threadIdx.x < words) s_words[threadIdx.x] = __hip_atomic_load(ctl + 2 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
@@ -762,6 +764,7 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
       }
     }
     if (!resident_cross_own<HB, BLK>(own, fin, want, fin.seq + b, false)) return;
+    if (go == 4) return;
   }
 }
 template <class T, int KIND, bool EXACT>

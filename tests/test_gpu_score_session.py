@@ -62,6 +62,14 @@ def test_session_votes_and_masks_are_the_oracles(gpu_ctx_factory, oracle, kind, 
     votes_in = ctx.inlier_mask(kind, best, mode=mode, **thr)
     ctx.score_session_end()
     masks_in = {m: ctx.download_mask(m) for m in mods}
+    assert votes_in == int(ctx.score(kind, best[None], mode=mode, **thr)[0])     # the total of a lazily written mask = the hypothesis' score
+    # ... and of a pose the session has NOT scored (its masks are waited for)
+    assert ctx.score_session_begin(kind, mode=mode, **thr)
+    other = _poses(oracle, sc, f64, 3, 77)[2]
+    votes_other = ctx.inlier_mask(kind, other, mode=mode, **thr)
+    masks_other = {m: ctx.download_mask(m) for m in mods}
+    assert votes_other == int(ctx.score(kind, other[None], mode=mode, **thr)[0])
+    assert votes_other == sum(int(masks_other[m].sum()) for m in mods)
     # the same call outside a session
     votes_out = ctx.inlier_mask(kind, best, mode=mode, **thr)
     masks_out = {m: ctx.download_mask(m) for m in mods}
@@ -126,6 +134,42 @@ def test_whatever_ends_a_session_leaves_a_working_context(gpu_ctx_factory, oracl
             assert np.array_equal(m, mo[L.MOD_33])
         # "none": the next begin (or close) ends it
         assert np.array_equal(ctx.score(L.VOTE_33_23, q[:40], **thr), vo[:40])
+    st = ctx.resident_state()
+    assert st["enabled"] and st["lost"] == 0
+
+
+def test_lazily_written_masks_are_in_place_for_every_kind_of_reader(gpu_ctx_factory, oracle):
+    """The masks of a hypothesis the session has scored are not waited for (the session's last message); whoever reads them next --
+    a download, a masked Gauss-Newton launch or resident loop, a new session -- must find them complete."""
+    sc = _scene(307200, np.float32, 9)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    prob = oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=2.0)
+    q = _poses(oracle, sc, False, 24, 11)
+    vo = oracle.votes(prob, oracle.V_33_23, q, **thr)
+    pose = api.pose12(sc.R, sc.t)
+    expect = {}
+    for h in (0, 5, 23):
+        _, mo = oracle.votes(prob, oracle.V_33_23, q[h:h + 1], mask_for=0, **thr)
+        ctx.inlier_mask(L.VOTE_33_23, q[h], **thr)                                            # one launch, waited for
+        expect[h] = (mo, ctx.normal_eq(L.RES_P2P, pose, flags=L.USE_MASK)[0], ctx.gn_refine([L.RES_P2P], pose, flags=L.USE_MASK, max_iter=4)[0])
+    for reader in ("download", "normal_eq", "refine", "session", "download") * 3:
+        for h in (0, 5, 23):
+            assert ctx.score_session_begin(L.VOTE_33_23, **thr)
+            assert np.array_equal(ctx.score(L.VOTE_33_23, q[:8], **thr), vo[:8])
+            assert np.array_equal(ctx.score(L.VOTE_33_23, q[8:], **thr), vo[8:])
+            assert ctx.inlier_mask(L.VOTE_33_23, q[h], **thr) == vo[h]
+            mo, ne, refined = expect[h]
+            if reader == "download":
+                assert np.array_equal(ctx.download_mask(L.MOD_33), mo[L.MOD_33]) and np.array_equal(ctx.download_mask(L.MOD_23), mo[L.MOD_23])
+            elif reader == "normal_eq":
+                assert np.array_equal(ctx.normal_eq(L.RES_P2P, pose, flags=L.USE_MASK)[0], ne)
+            elif reader == "refine":
+                assert np.array_equal(ctx.gn_refine([L.RES_P2P], pose, flags=L.USE_MASK, max_iter=4)[0], refined)
+            else:
+                assert ctx.score_session_begin(L.VOTE_33, thre_3d=0.05)
+                ctx.score_session_end()
+                assert np.array_equal(ctx.download_mask(L.MOD_23), mo[L.MOD_23])
     st = ctx.resident_state()
     assert st["enabled"] and st["lost"] == 0
 
