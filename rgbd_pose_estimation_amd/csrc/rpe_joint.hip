@@ -737,7 +737,11 @@ static void joint_launch(const DeviceArrays& A, int flags, const PoseK<double>& 
   // points and one group of up to five arrays)
   constexpr int BLK = 256;
   const bool um = (flags & F_USE_MASK) != 0, uw = (flags & F_USE_WEIGHT) != 0;
-  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, BLK);
+  // ... and the grid is capped at TWO per compute unit (2 x max_blocks): the joint loops are bound by instruction issue (SQ counters
+  // at 10 M, point-to-point + bearing: one wave per SIMD spends 74 % of its life issuing vector instructions and the rest waiting for
+  // its loads; the second wave fills those waits -- 83.9 -> 76.8 us, three terms 126 -> 109 us; a third changes nothing,
+  // profiles/r05_joint_grid_ab.txt).  fp64 arrays keep one (their kernels hold the whole register file).
+  const int G = reduce_grid(A.n, Pk<T>::P, sizeof(T) == 4 ? std::min(2 * rt.max_blocks, 4096) : rt.max_blocks, BLK);
   const JointArrays<T> J = joint_arrays<T>(A, um, uw);
   if constexpr (joint_has_clean<T, TERMS>()) {
     if (rt.clean) { RPE_LAUNCH_EV((normal_eq_joint_kernel<T, TERMS, BLK, true>), dim3(G), dim3(BLK), 0, s, e0, e1, J, A.n, pose, prm, make_finish(rt)); return; }

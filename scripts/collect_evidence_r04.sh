@@ -45,7 +45,7 @@ done
 timeout 900 python3 $root/scripts/resident_timeline.py > $out/resident_timeline.jsonl 2> $out/resident_timeline.err
 rm -f $root/rgbd_pose_estimation_amd/lib/*stamps*
 # SQ counters of the streaming kernels at 1 M
-bash $root/scripts/r03_sq_pmc.sh $tag/sq > /dev/null 2>&1
+bash $root/scripts/sq_pmc.sh $tag/sq > /dev/null 2>&1
 # streaming kernels by flavour, and the examples' tuned / untuned loop
 bash $root/scripts/r04_streaming_ab.sh $tag/streaming_ab > $out/streaming_ab.txt 2>&1
 $root/examples/gn_refine_main 20 50 > $out/gn_refine_main_20.txt 2>&1

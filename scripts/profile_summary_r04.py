@@ -169,7 +169,7 @@ for f in glob.glob(os.path.join(src, "sq", "counters_*.csv")):
             sq.setdefault(kind, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if sq:
     out = {"what": "SQ counters of normal_eq_kernel<float, kind, 256, false, false, CLEAN> at 1 000 000 correspondences (256 workgroups x 256 threads = 1024 waves, one per SIMD); rocprofv3 --pmc, "
-                   "separate passes of three counters, medians over the dispatches; scripts/r03_sq_pmc.sh on the round-4 tree",
+                   "separate passes of three counters, medians over the dispatches; scripts/sq_pmc.sh on the round-4 tree",
            "note": "SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units of 4 cycles, summed over the waves"}
     for kind, d in sq.items():
         m = {c: statistics.median(v) for c, v in d.items()}

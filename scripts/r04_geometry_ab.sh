@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: the streaming normal-equation kernels after the instruction cuts -- time per launch by geometry (workgroup size x cap) and
-# with / without the fp32 transform, 1 M and 10 M; then the SQ counters of the default geometry at 1 M (as scripts/r03_sq_pmc.sh)
+# with / without the fp32 transform, 1 M and 10 M; then the SQ counters of the default geometry at 1 M (as scripts/sq_pmc.sh)
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/r04_geometry_ab.jsonl
 K=K1_p2p,K2_p2plane,K3_bearing,K1p_moments
@@ -17,5 +17,5 @@ for r in rows:
     if r["state"] == "steady":
         print(r["tag"], r["kernel"], r["n"], r["avg_us"], r["frac_of_peak"])
 PY
-bash $root/scripts/r03_sq_pmc.sh r04sq > /dev/null 2>&1
+bash $root/scripts/sq_pmc.sh r04sq > /dev/null 2>&1
 cat $root/gpurun_out/r04sq/counters_*.csv | cut -c1-400 | head -60
