@@ -335,8 +335,7 @@ int rpe_host_hypotheses(int method, const rpe_problem* p, int iters, uint64_t se
   return H;
 }
 
-int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d,
-    double thre_2d,
+int rpe_run_replay(int method, const rpe_problem* p, const double* poses7, const int* first, int list_iters, double thre_3d, double thre_2d,
                    double thre_nl, int* iter_io, double confidence, int ls, int score_mode, double* R9, double* t3, int* max_votes,
                    short* mask_out) {
   if (!poses7 || !first || list_iters < 0) return rpe::set_error(RPE_ERR_ARG, "rpe_run_replay: bad argument");

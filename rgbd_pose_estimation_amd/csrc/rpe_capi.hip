@@ -556,9 +556,8 @@ static void note_lost_grid(rpe_context* c) {
 
 template <class Launch>
 static int resident_host_loop(rpe_context* c, Launch launch, int grid, int nacc, int max_rows, int rows_auto, double cost_scale,
-    double* pose12, int max_iter,
-                       double tol, int* it_out, double* step_out, double* cost_out, double* weight_out, const char* what,
-                       bool clean = false, bool* first_record_finite = nullptr) {
+                              double* pose12, int max_iter, double tol, int* it_out, double* step_out, double* cost_out, double* weight_out,
+                              const char* what, bool clean = false, bool* first_record_finite = nullptr) {
   const unsigned long long base = c->seq;
   auto hand_over = [&](const double* p, unsigned long long tag) {
     if (p) for (int k = 0; k < 12; k++) { unsigned long long w; std::memcpy(&w, &p[k], 8); c->ctl[1 + k] = w; }   // words 1..7 | 8..12
@@ -1172,8 +1171,7 @@ int rpe_normal_eq_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
 }
 
 int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
-    int* iters_out,
-                        double* last_step, double* final_cost) {
+                        int* iters_out, double* last_step, double* final_cost) {
   session_end(c);
   int it = 0;
   double step = 0, cost = 0;
@@ -1238,8 +1236,7 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
 // Device-resident Gauss-Newton: the pose and the loop state live in HBM; every iteration is ONE launch whose last workgroup
 // solves the 6x6 system and applies the exp-map update; the host only enqueues the launches and waits for the final record.
 int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int flags, double* pose12, int max_iter, double tol,
-    int* iters_out,
-                         double* last_step, double* final_cost) {
+                         int* iters_out, double* last_step, double* final_cost) {
   session_end(c);
   if (!c || !terms || nterms < 1 || nterms > 4 || !pose12 || max_iter < 1) return fail(RPE_ERR_ARG,
       "rpe_gn_refine_device: bad argument");
@@ -1432,8 +1429,7 @@ int rpe_debug_loop_profile(rpe_context* c, int enable, double* wait_us, double* 
   return RPE_OK;
 }
 
-int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter,
-    double tol,
+int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* scales, int flags, double* pose12, int max_iter, double tol,
                   int* iters_out, double* last_step, double* final_cost) {
   session_end(c);
   if (!c || nterms < 1 || nterms > 4 || !kinds || !pose12) return fail(RPE_ERR_ARG, "rpe_gn_refine: bad argument");
@@ -1989,8 +1985,7 @@ int rpe_ransac33_batch(rpe_context* c, uint64_t rng_state, uint64_t rng_inc, int
 // (tolerance parity with the host's hypotheses, not bit parity): solver 0 = kneip_ransac, 1 = shinji_kneip_ransac, 2 = nl_kneip_ransac,
 // 3 = nl_shinji_ransac, 4 = nl_shinji_kneip_ransac (slots per iteration: 1, 2, 1, 2, 3)
 int rpe_ransac_p3p_batch(rpe_context* c, int solver, uint64_t rng_state, uint64_t rng_inc, int iters, double thre_3d, double cos_thr,
-    double cos_nl,
-                         int* votes_out, double* q7_out, unsigned char* valid_out) {
+                         double cos_nl, int* votes_out, double* q7_out, unsigned char* valid_out) {
   session_end(c);
   const int per = rpe::gen_p3p_slots(solver);
   if (per == 0) return fail(RPE_ERR_ARG, "rpe_ransac_p3p_batch: solver must be 0 .. 4");
@@ -2248,8 +2243,7 @@ int associate_ready(rpe_context* c) {
 }  // namespace
 
 int rpe_frame_set_depth(rpe_context* c, const void* depth, int depth_type, const rpe_camera* cam, double depth_scale, double dmin,
-    double dmax,
-                        double max_jump) {
+                        double dmax, double max_jump) {
   session_end(c);
   if (!c || !depth || (depth_type != RPE_DEPTH_U16 && depth_type != RPE_DEPTH_F32)) return fail(RPE_ERR_ARG,
       "rpe_frame_set_depth: bad argument");

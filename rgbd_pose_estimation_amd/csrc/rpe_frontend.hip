@@ -64,10 +64,8 @@ __device__ __forceinline__ void load4(const float* __restrict__ in, int64_t g, i
 
 // ---------------------------------------------------------------------------------------------- F1
 template <class D>
-__global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restrict__ depth, Camera cam, float scale, float dmin,
-    float dmax,
-                                                              float max_jump, float* __restrict__ vmap, float* __restrict__ nmap,
-                                                              float* __restrict__ bmap) {
+__global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restrict__ depth, Camera cam, float scale, float dmin, float dmax,
+                             float max_jump, float* __restrict__ vmap, float* __restrict__ nmap, float* __restrict__ bmap) {
   const int64_t n = (int64_t)cam.width * cam.height;
   const int64_t g = (int64_t)blockIdx.x * kFeBlock + threadIdx.x;
   if (g * 4 >= n) return;
@@ -115,8 +113,7 @@ __global__ __launch_bounds__(kFeBlock) void frame_maps_kernel(const D* __restric
 
 // ---------------------------------------------------------------------------------------------- F2
 __global__ __launch_bounds__(kFeBlock) void to_world_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap, int64_t n,
-    PoseF T,
-                                                            float* __restrict__ vw, float* __restrict__ nw) {
+                             PoseF T, float* __restrict__ vw, float* __restrict__ nw) {
   const int64_t g = (int64_t)blockIdx.x * kFeBlock + threadIdx.x;
   if (g * 4 >= n) return;
   float V[12], N[12], OV[12], ON[12];
@@ -184,8 +181,7 @@ int fe_grid(int64_t n) { return (int)((n + 4 * kFeBlock - 1) / (4 * kFeBlock)); 
 
 }  // namespace
 
-hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax,
-    float max_jump,
+hipError_t launch_frame_maps(const void* d_depth, int depth_type, const Camera& cam, float scale, float dmin, float dmax, float max_jump,
                              float* vmap, float* nmap, float* bmap, hipStream_t s) {
   const int64_t n = (int64_t)cam.width * cam.height;
   if (n == 0) return hipSuccess;

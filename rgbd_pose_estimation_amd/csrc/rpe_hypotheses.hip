@@ -42,10 +42,8 @@ template <> struct Eps<double> { __device__ static double value() { return 1e-10
 // out_pose: scoring layout (exact: qw qx qy qz tx ty tz 0 ; fast: R row-major 9, t 3) in T.  h_q7: 8 T per iteration in pinned host
 // memory (qw qx qy qz tx ty tz valid).
 template <class T>
-__global__ __launch_bounds__(64) void gen_shinji_kernel(const T* __restrict__ xw, const T* __restrict__ xc, int n,
-    unsigned long long state,
-                                                        unsigned long long inc, int iters, int exact, T* __restrict__ out_pose,
-                                                        T* __restrict__ h_q7) {
+__global__ __launch_bounds__(64) void gen_shinji_kernel(const T* __restrict__ xw, const T* __restrict__ xc, int n, unsigned long long state,
+                             unsigned long long inc, int iters, int exact, T* __restrict__ out_pose, T* __restrict__ h_q7) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= iters) return;
   constexpr int K = 3;
@@ -345,9 +343,8 @@ __global__ __launch_bounds__(64) void gen_p3p_kernel(const T* __restrict__ xw, c
 int gen_p3p_slots(int solver) {
   switch (solver) { case 0: case 2: return 1; case 1: case 3: return 2; case 4: return 3; default: return 0; }
 }
-hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters,
-    void* d_poses, void* h_q7,
-                          hipStream_t s) {
+hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long state, unsigned long long inc, int iters, void* d_poses,
+                          void* h_q7, hipStream_t s) {
   if (iters < 1) return hipSuccess;
   if (gen_p3p_slots(solver) == 0) return hipErrorInvalidValue;
   const int G = (iters + 63) / 64;
@@ -358,8 +355,7 @@ hipError_t launch_gen_p3p(const DeviceArrays& A, int solver, unsigned long long 
   return hipGetLastError();
 }
 
-hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact,
-    void* d_poses,
+hipError_t launch_gen_shinji(const DeviceArrays& A, unsigned long long state, unsigned long long inc, int iters, int exact, void* d_poses,
                              void* h_q7, hipStream_t s) {
   if (iters < 1) return hipSuccess;
   const int G = (iters + 63) / 64;

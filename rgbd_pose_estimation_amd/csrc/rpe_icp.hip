@@ -200,9 +200,8 @@ void icp_resident_geometry(int64_t n, int kind, int max_blocks, int* grid, int* 
   resident_geometry(A, kind, max_blocks, grid, nacc, max_rows, rows_auto);
 }
 hipError_t launch_icp_resident(const float* vmap, const float* nmap, int64_t n, const float* mv, const float* mn, const Camera& mcam,
-    const PoseF& M,
-                               float dist_sq, float cos_thr, int use_normals, int kind, const unsigned long long* ctl, unsigned long long first_tag,
-                               int max_iters, const ReduceTarget& rt, hipStream_t s) {
+                               const PoseF& M, float dist_sq, float cos_thr, int use_normals, int kind, const unsigned long long* ctl,
+                               unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s) {
   if (kind != KIND_P2P && kind != KIND_P2PLANE) return hipErrorInvalidValue;
   AssocParams P;
   P.mcam = mcam; P.M = M; P.dist_sq = dist_sq; P.cos_thr = cos_thr; P.use_normals = use_normals;

@@ -34,9 +34,8 @@ __device__ __forceinline__ void moments_group(const T (&vw)[3 * Pk<T>::P], const
 }
 
 template <class T, int BLK, bool MASK, bool WEIGHT>
-__global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
-    const short* __restrict__ mask,
-                                                      const T* __restrict__ weight, int64_t n, int skip_invalid, Finish fin) {
+__global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const short* __restrict__ mask,
+                             const T* __restrict__ weight, int64_t n, int skip_invalid, Finish fin) {
   constexpr int P = Pk<T>::P;
   typedef typename Pk<T>::V V;
   double acc[18];
@@ -158,9 +157,8 @@ __device__ __forceinline__ void nl_termnn(bool on, T wnnv, T nwx, T nwy, T nwz, 
   acc[30] += l; acc[31] += on ? T(1) : T(0);
 }
 template <class T>
-__device__ __forceinline__ void nl_point(const NlConst<T>& prm, T x, T y, T z, bool on23, T w23v, T bx_, T by_, T bz_, bool on33,
-    T w33v, T cx_, T cy_,
-                                         T cz_, bool onnn, T wnnv, T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T (&acc)[44]) {
+__device__ __forceinline__ void nl_point(const NlConst<T>& prm, T x, T y, T z, bool on23, T w23v, T bx_, T by_, T bz_, bool on33, T w33v,
+                                         T cx_, T cy_, T cz_, bool onnn, T wnnv, T nwx, T nwy, T nwz, T ncx, T ncy, T ncz, T (&acc)[44]) {
   nl_term23<T>(prm, x, y, z, on23, w23v, bx_, by_, bz_, acc);
   nl_term33<T>(prm, x, y, z, on33, w33v, cx_, cy_, cz_, acc);
   nl_termnn<T>(onnn, wnnv, nwx, nwy, nwz, ncx, ncy, ncz, acc);
@@ -362,8 +360,7 @@ hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned 
 }
 // vote counters: publish to the host AND clear them for the next scoring launch (the counters are accumulated with atomics, so
 // they must start at zero; clearing here saves a memset per launch)
-__global__ void publish_votes_kernel(int* __restrict__ votes, int count, int* __restrict__ h_dst,
-    unsigned long long* __restrict__ h_flag,
+__global__ void publish_votes_kernel(int* __restrict__ votes, int count, int* __restrict__ h_dst, unsigned long long* __restrict__ h_flag,
                                      unsigned long long seq) {
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     __hip_atomic_store(h_dst + i, votes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -136,11 +136,9 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
 // AUTO: 0 = host-driven; 1 = autonomous, every workgroup adds the run records and solves (resident_auto_stage: grids too small for
 // 2, always one group per thread); 2 = autonomous with a solving workgroup beside the grid (auto_solver_kernel, solver_loop)
 template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, int AUTO, bool CLEAN>
-__global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b,
-    const T* __restrict__ c,
-                                                                 const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
-                                                                 const unsigned long long* __restrict__ ctl, unsigned long long first_tag,
-                                                                 int max_iters, Finish fin) {
+__global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
+                             const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
+                             const unsigned long long* __restrict__ ctl, unsigned long long first_tag, int max_iters, Finish fin) {
   constexpr int P = Pk<T>::P;
   constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
   __shared__ double s_pose[12];
@@ -227,8 +225,7 @@ namespace rpe {
 
 template <class T, int KIND, int BLK>
 static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const ReduceTarget& rt, hipStream_t s,
-    hipEvent_t ev0,
-                             hipEvent_t ev1) {
+                             hipEvent_t ev0, hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
   const T* b = (const T*)((KIND == KIND_BEARING || KIND == KIND_REPROJ) ? A.a[2] : A.a[1]);
   const T* c = (const T*)A.a[4];
@@ -281,8 +278,7 @@ template <class T, int KIND> constexpr bool resident_streams() { return !(sizeof
 // resident form: ONE launch for up to max_iters iterations; ctl = the control block in fine-grained device memory, first_tag + i =
 // tag of pose i (i = 1 ...), rt.seq + i = sequence value published with record i
 template <class T, int KIND, int BLK>
-static void resident_launch(const DeviceArrays& A, int flags, const unsigned long long* ctl, unsigned long long first_tag,
-    int max_iters,
+static void resident_launch(const DeviceArrays& A, int flags, const unsigned long long* ctl, unsigned long long first_tag, int max_iters,
                             const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const T* xw = (const T*)A.a[0];
   const T* b = (const T*)((KIND == KIND_BEARING || KIND == KIND_REPROJ) ? A.a[2] : A.a[1]);
@@ -319,8 +315,7 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
 }
 template <class T>
 static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl, unsigned long long first_tag,
-    int max_iters,
-                             const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                             int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   if (kind == KIND_P2P) resident_launch<T, KIND_P2P, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else if (kind == KIND_P2PLANE) resident_launch<T, KIND_P2PLANE, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
   else if (kind == KIND_BEARING) resident_launch<T, KIND_BEARING, 512>(A, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
@@ -397,8 +392,8 @@ bool normal_eq_resident_fits(const DeviceArrays& A, int kind, int max_blocks, bo
   return (int64_t)G * blk >= (A.n + P - 1) / P;
 }
 hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags, const unsigned long long* ctl,
-    unsigned long long first_tag,
-                                     int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                                     unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev0,
+                                     hipEvent_t ev1) {
   return A.dtype ? resident_t<double>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1)
                  : resident_t<float>(A, kind, flags, ctl, first_tag, max_iters, rt, s, ev0, ev1);
 }

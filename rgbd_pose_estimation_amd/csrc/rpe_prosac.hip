@@ -28,8 +28,7 @@ __device__ __forceinline__ unsigned long long prosac_key(float w, unsigned int i
 
 // level 0: histogram of the keys' bits 63..53 over all keys; level 1: of bits 52..42 over the keys whose bits 63..53 equal ctl[0]
 __global__ __launch_bounds__(256) void prosac_hist_kernel(const float* __restrict__ w, int n, unsigned int* __restrict__ hist,
-    const unsigned int* __restrict__ ctl,
-                                                          int level) {
+                             const unsigned int* __restrict__ ctl, int level) {
   __shared__ unsigned int h[kBins];
   for (int i = threadIdx.x; i < kBins; i += 256) h[i] = 0;
   __syncthreads();
@@ -112,9 +111,8 @@ __global__ __launch_bounds__(1024) void prosac_sort_kernel(const unsigned long l
 
 // d_w: n floats in HBM.  d_hist: kBins uints (zero on entry; left zero), d_ctl: 8 uints, d_cand: kSortCap keys, d_order: top_k ints,
 // d_status: 0 ok, 1 too many candidates (ties), 2 internal count mismatch.
-hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl,
-    unsigned long long* d_cand, int* d_order,
-                               int* d_status, hipStream_t s) {
+hipError_t launch_prosac_order(const float* d_w, int n, int top_k, unsigned int* d_hist, unsigned int* d_ctl, unsigned long long* d_cand,
+                               int* d_order, int* d_status, hipStream_t s) {
   const int G = n >= 256 * 512 ? 512 : (n + 255) / 256;
   hipLaunchKernelGGL(prosac_hist_kernel, dim3(G), dim3(256), 0, s, d_w, n, d_hist, d_ctl, 0);
   hipLaunchKernelGGL(prosac_pick_kernel, dim3(1), dim3(256), 0, s, d_hist, top_k, d_ctl, 0);

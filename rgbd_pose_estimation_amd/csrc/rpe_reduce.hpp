@@ -408,8 +408,7 @@ static __device__ __forceinline__ double rcp_newton(double d) {
 // here, in registers: record_entry with compile-time indices costs a few adds, a separate expansion pass costs two barriers).
 template <int MODE>
 static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ tot /* LDS */, double* __restrict__ pose /* LDS, 12,
-    in/out */,
-                                                    double* step_out, double rel_floor) {
+                                                    in/out */, double* step_out, double rel_floor) {
   double U[6][6], b[6], inv[6], d[6];
   {
     int k = 0;

@@ -38,10 +38,9 @@ template <class V> __device__ __forceinline__ void add_row2(const V (&J)[6], V r
   s[27] = __builtin_elementwise_fma(w * r, r, s[27]);
 }
 template <class C>
-__device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2],
-    const C (&cx)[2], const C (&cy)[2],
-                                             const C (&cz)[2], const C (&nx)[2], const C (&ny)[2], const C (&nz)[2], const C (&w)[2],
-                                             C __attribute__((ext_vector_type(2))) (&s)[29]) {
+__device__ __forceinline__ void p2plane_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&cx)[2],
+                                             const C (&cy)[2], const C (&cz)[2], const C (&nx)[2], const C (&ny)[2], const C (&nz)[2],
+                                             const C (&w)[2], C __attribute__((ext_vector_type(2))) (&s)[29]) {
   typedef C V __attribute__((ext_vector_type(2)));
   C px[2], py[2], pz[2], r[2];
 #pragma unroll
@@ -213,9 +212,9 @@ __device__ __forceinline__ C reproj_residual_norm(double pxd, double pyd, double
 }
 // a pair of correspondences as 2-vectors
 template <class C>
-__device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2],
-    const C (&bx)[2], const C (&by)[2],
-                                             const C (&bz)[2], const C (&w)[2], C __attribute__((ext_vector_type(2))) (&s)[29]) {
+__device__ __forceinline__ void bearing_pair(const PoseK<double>& T, const C (&x)[2], const C (&y)[2], const C (&z)[2], const C (&bx)[2],
+                                             const C (&by)[2], const C (&bz)[2], const C (&w)[2],
+                                             C __attribute__((ext_vector_type(2))) (&s)[29]) {
   typedef C V __attribute__((ext_vector_type(2)));
   const V BX = {bx[0], bx[1]}, BY = {by[0], by[1]}, BZ = {bz[0], bz[1]};
   V e1[3], e2[3];
@@ -369,9 +368,9 @@ constexpr unsigned long long kResidentStop = 1ull << 63;
 // otherwise
 template <class T, int KIND, bool MASK, bool WEIGHT>
 __device__ __forceinline__ void load_any_group(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
-    const short* __restrict__ mask,
-                                               const T* __restrict__ weight, int64_t g, int64_t full, int64_t n, T (&vw)[3 * Pk<T>::P],
-                                               T (&vb)[3 * Pk<T>::P], T (&vc)[3 * Pk<T>::P], short (&m)[Pk<T>::P], T (&wv)[Pk<T>::P]) {
+                                               const short* __restrict__ mask, const T* __restrict__ weight, int64_t g, int64_t full,
+                                               int64_t n, T (&vw)[3 * Pk<T>::P], T (&vb)[3 * Pk<T>::P], T (&vc)[3 * Pk<T>::P],
+                                               short (&m)[Pk<T>::P], T (&wv)[Pk<T>::P]) {
   typedef typename Pk<T>::V V;
   if (g < full) {
     const V* xw4 = reinterpret_cast<const V*>(xw);
@@ -417,8 +416,8 @@ __device__ __forceinline__ int resident_judge_pose(unsigned long long w, unsigne
 // step waits for the LAST of 150 workgroups, and more pollers only add traffic on the control block.
 template <int BLK>
 __device__ __forceinline__ int resident_wait_pose(const unsigned long long* __restrict__ ctl, unsigned long long want,
-    double* __restrict__ s_pose,
-                                                  int* __restrict__ s_go, unsigned long long wait_ticks = 200000000ull) {
+                                                  double* __restrict__ s_pose, int* __restrict__ s_go,
+                                                  unsigned long long wait_ticks = 200000000ull) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -506,8 +505,7 @@ __device__ __forceinline__ bool resident_cross_own(double own, const Finish& fin
 }
 template <int NACC, int BLK>
 __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag,
-    unsigned long long seq,
-                                                     bool stamp_it) {
+                                                     unsigned long long seq, bool stamp_it) {
   constexpr int NW = BLK / 64;
   __shared__ double g_red[NW][NACC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -537,8 +535,7 @@ __device__ __forceinline__ bool resident_cross_stage(const double (&acc)[NACC], 
 // 10.0 against 8.0 at 1 M (three alternations on one box): eighteen times the bytes cross the fabric, and that costs more than the hop.
 template <int NACC, int BLK>
 __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], const Finish& fin, unsigned long long tag, int it,
-    int max_iters,
-                                                   double tol, double* __restrict__ s_pose, bool stamp_it = false) {
+                                                   int max_iters, double tol, double* __restrict__ s_pose, bool stamp_it = false) {
   constexpr int NW = BLK / 64;
   constexpr int RGN = BLK / NACC;
   constexpr int MODE = NACC == 17 ? 1 : 0;

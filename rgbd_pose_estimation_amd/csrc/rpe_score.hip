@@ -431,11 +431,9 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
 // scoring kernel + read-out kernel + flag (42 us per batch of 16 at 640 x 480) for lists of up to HB hypotheses.
 template <class T, int HB, int STRIDE> struct SmallPoses { T v[HB * STRIDE]; };
 template <class T, int KIND, bool EXACT, int HB>
-__global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict__ xw, const T* __restrict__ xc,
-    const T* __restrict__ bv,
-                                                             const T* __restrict__ nw, const T* __restrict__ nc, int64_t n,
-                                                             SmallPoses<T, HB, Hyp<T, EXACT>::STRIDE> sp, const T* __restrict__ dposes, int H, int hs,
-                                                             T thr33, T cthr, T cnl, Finish fin) {
+__global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict__ xw, const T* __restrict__ xc, const T* __restrict__ bv,
+                             const T* __restrict__ nw, const T* __restrict__ nc, int64_t n, SmallPoses<T, HB, Hyp<T, EXACT>::STRIDE> sp,
+                             const T* __restrict__ dposes, int H, int hs, T thr33, T cthr, T cnl, Finish fin) {
   constexpr int P = Pk<T>::P;
   typedef VoteMods<KIND> MD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -877,8 +875,7 @@ hipError_t launch_score(const DeviceArrays& A, int kind, int exact, const void* 
 }
 template <class T, int KIND, bool EXACT>
 static void score_small_launch(const DeviceArrays& A, const void* h_poses, const void* d_poses, int H, const double* thr,
-    const ReduceTarget& rt, int cap,
-                               hipStream_t s) {
+                               const ReduceTarget& rt, int cap, hipStream_t s) {
   constexpr int STRIDE = Hyp<T, EXACT>::STRIDE;
   const Finish fin = make_finish(rt);
   // up to a million correspondences the list is split over the 4 waves of a workgroup (RPE_SCORE_SPLIT = 1 | 2 | 4 overrides)
@@ -906,8 +903,7 @@ int score_small_cap(int dtype, int exact) {
 // argument) -- or null and d_poses: the same list in HBM (a device-generated batch).  The vote counts arrive through rt (a collecting
 // target): record[h] = votes of hypothesis h.
 hipError_t launch_score_small(const DeviceArrays& A, int kind, int exact, const void* h_poses, const void* d_poses, int H,
-    const double* thr3,
-                              const ReduceTarget& rt, hipStream_t s) {
+                              const double* thr3, const ReduceTarget& rt, hipStream_t s) {
   if (H < 1 || H > score_small_cap(A.dtype, exact) || rt.rows < 1 || (!h_poses == !d_poses)) return hipErrorInvalidValue;
   const int cap = 2048;   // workgroups (grid-stride beyond)
   if (A.dtype) {

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 evidence on one MI355X box (through gpurun):   gpurun --timeout 3000 -- 'bash scripts/collect_evidence_r04.sh r04e'
+# Round-5 evidence on one MI355X box (through gpurun):   gpurun --timeout 4500 -- 'bash scripts/collect_evidence_r05.sh r05e'
 # GPU tests, the bench line (default and the DRIVER'S command), rocprofv3 --kernel-trace --stats and the two --pmc passes (separate
 # runs, counters only) on the driver's command / the 2000-step default / the bandwidth-bound launches / the reference-API kernels, the
-# step budget from the stamps build, the SQ counters of the streaming kernels, a fuzz campaign.  Summarised by profile_summary_r04.py.
-tag=${1:-r04e}
+# step budget from the stamps build, the SQ counters of the streaming kernels, a fuzz campaign.  Summarised by profile_summary_r05.py.
+tag=${1:-r05e}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -47,9 +47,33 @@ rm -f $root/rgbd_pose_estimation_amd/lib/*stamps*
 # SQ counters of the streaming kernels at 1 M
 bash $root/scripts/sq_pmc.sh $tag/sq > /dev/null 2>&1
 # streaming kernels by flavour, and the examples' tuned / untuned loop
-bash $root/scripts/r04_streaming_ab.sh $tag/streaming_ab > $out/streaming_ab.txt 2>&1
+bash $root/scripts/streaming_ab.sh $tag/streaming_ab > $out/streaming_ab.txt 2>&1
 $root/examples/gn_refine_main 20 50 > $out/gn_refine_main_20.txt 2>&1
 $root/examples/gn_refine_main 2000 10 > $out/gn_refine_main_2000.txt 2>&1
+# ---- this round's additions
+# the world = 1 RCCL step beside the resident step (bench line + its kernel stats)
+RPE_BENCH_FORCE_DIST=1 RPE_BENCH_EXTRAS=$out/bench_rccl_world1_extras.json timeout 600 python3 $root/bench.py $drv > $out/bench_rccl_world1.json 2>> $out/bench_stderr.txt
+RPE_BENCH_FORCE_DIST=1 RPE_BENCH_EXTRAS=$out/tmp_extras.json timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_rccl -- python3 $root/bench.py $drv --no-extras --no-cpu-baseline --no-hbm > /dev/null 2>&1
+f=$(ls $out/prof_rccl/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/prof_rccl_kernel_stats.csv; rm -rf $out/prof_rccl $out/tmp_extras.json
+# joint kernels: event-timed by size, and their SQ counters
+timeout 600 python3 $root/scripts/kernel_roofline.py --sizes 307200,1000000,10000000 --kernels J_p2p_bearing,J_p2plane_bearing,J_p2p_bearing_normal,J_p2p_bearing_mask,K3_bearing,K2_p2plane,K4b_mask_33,K4b_mask_33_23,K4b_mask_nn_33_23 --launches 40 --out $out/kernel_roofline.jsonl --tag r05 > /dev/null 2>&1
+timeout 600 python3 $root/scripts/joint_ab.py --out $out/joint_ab.jsonl --tag r05 > /dev/null 2>&1
+bash $root/scripts/dev/joint_sq.sh $tag/joint_sq > /dev/null 2>&1
+# autonomous loops (solving workgroup on / off)
+timeout 600 python3 $root/scripts/device_loop_time.py > $out/device_loop_solver.jsonl 2>/dev/null
+RPE_AUTO_SOLVER=0 timeout 600 python3 $root/scripts/device_loop_time.py > $out/device_loop_nosolver.jsonl 2>/dev/null
+# scoring: kernel stats of 512 x 307 200 passes, the band filter's fall-through counter, the session
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_score -- python3 $root/scripts/score_pmc_probe.py > $out/score_probe.json 2>/dev/null
+f=$(ls $out/prof_score/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/prof_score_kernel_stats.csv; rm -rf $out/prof_score
+(cd $root && python3 -c "from rgbd_pose_estimation_amd import build; print(build.build_score_stats())") > $out/build_score_stats.txt 2>&1
+RPE_LIBRARY=$root/rgbd_pose_estimation_amd/lib/librgbdpose_hip_scorestats.so timeout 600 python3 $root/scripts/score_filter_stats.py > $out/score_filter_stats.jsonl 2>/dev/null
+rm -f $root/rgbd_pose_estimation_amd/lib/*scorestats* $root/rgbd_pose_estimation_amd/lib/rpe_score_stats.o
+timeout 300 python3 $root/scripts/dev/session_time.py 307200 > $out/session_time.json 2>/dev/null
+RPE_QUIET=1 timeout 120 $root/examples/engine_profile 307200 totals > $out/engine_session_on.txt 2>&1
+RPE_SCORE_SESSION=0 RPE_QUIET=1 timeout 120 $root/examples/engine_profile 307200 totals > $out/engine_session_off.txt 2>&1
+RPE_QUIET=1 timeout 120 $root/examples/engine_profile 307200 > $out/engine_session_phases.txt 2>&1
+# soak of the cross-workgroup protocols
+timeout 900 python3 $root/scripts/soak.py ${RPE_SOAK_S:-300} > $out/soak.json 2> $out/soak.err
 # randomised campaign against the oracle on this tree
 RPE_FUZZ_SEEDS=${RPE_FUZZ_SEEDS:-1200} timeout 2400 python3 -m pytest $root/tests/test_gpu_fuzz.py -q > $out/fuzz_campaign.txt 2>&1
 tail -3 $out/fuzz_campaign.txt

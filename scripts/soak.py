@@ -1,6 +1,6 @@
 """Soak of the cross-workgroup protocols (development aid, run on the GPU box): the host-driven resident loop, the collecting launches and
 the one-launch device loop (granules + double-buffered run records, no host in the loop) must give BITWISE the same result every time (fixed summation order whichever workgroup finishes first) and never lose a granule.
-  python scripts/soak.py [seconds]      (total, shared by the fifteen legs)"""
+  python scripts/soak.py [seconds]      (total: every leg runs for a fifteenth of it)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -56,3 +56,41 @@ for n in (307200, 20000):
     out3[f"lost_grids_{n}"] = ctx.resident_state()["lost"]
     ctx.close()
 print(json.dumps({"round3": out3}), flush=True)
+
+# ---- round 5: the resident scoring session (batches through the control block, the winner's masks as its last message, verified at
+# the next call) and the autonomous loops that hand their sums to the solving workgroup (single kind and joint)
+out5 = {}
+for n in (307200, 20000):
+    sc = util.scene_full(1900 + n, n, np.float32, n2d=2.0, n3d=0.03, nan_frac=0.02, outliers=0.2)
+    p = api.pose12(*util.perturbed_pose(np.random.default_rng(n), sc.R, sc.t, 0.01, 0.03))
+    ctx = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    rng = np.random.default_rng(5)
+    q = np.tile(api.pose7_from_Rt(sc.R, sc.t), (24, 1))
+    q[1:, 4:] += 0.02 * rng.standard_normal((23, 3))
+    q = np.ascontiguousarray(q.astype(np.float32).astype(np.float64))
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=2.0)
+    want_votes = ctx.score(L.VOTE_33_23, q, **thr)
+    ctx.inlier_mask(L.VOTE_33_23, q[3], **thr)
+    want_masks = [ctx.download_mask(L.MOD_23).copy(), ctx.download_mask(L.MOD_33).copy()]
+    t0, runs, bad = time.perf_counter(), 0, 0
+    while time.perf_counter() - t0 < seconds / 15:
+        assert ctx.score_session_begin(L.VOTE_33_23, **thr)
+        v = np.concatenate([ctx.score(L.VOTE_33_23, q[:8], **thr), ctx.score(L.VOTE_33_23, q[8:], **thr)])
+        ctx.inlier_mask(L.VOTE_33_23, q[3], **thr)            # not waited for
+        bad += int(not np.array_equal(v, want_votes))
+        if runs % 16 == 0:
+            bad += int(not (np.array_equal(ctx.download_mask(L.MOD_23), want_masks[0]) and np.array_equal(ctx.download_mask(L.MOD_33), want_masks[1])))
+        runs += 1
+    out5[f"score_session_{n}"] = dict(runs=runs, changed=bad)
+    terms2 = [(L.RES_P2P, 1.0, 0, 1.0), (L.RES_BEARING, 4.0, 0, 1.0)]
+    legs = {"p2p_device_loop_solver": lambda: ctx.gn_refine_device([(L.RES_P2P, 1.0)], p, 0, 300, 0.0)[0],
+            "joint_device_loop_solver": lambda: ctx.gn_refine_device(terms2, p, 0, 300, 0.0)[0]}
+    for name, f in legs.items():
+        first = f()
+        t0, calls, bad = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < seconds / 15:
+            bad += int(not np.array_equal(f(), first)); calls += 1
+        out5[f"{name}_{n}"] = dict(calls=calls, iterations=300 * calls, pose_changed=bad)
+    out5[f"lost_grids_{n}"] = ctx.resident_state()["lost"]
+    ctx.close()
+print(json.dumps({"round5": out5}), flush=True)
