@@ -232,7 +232,8 @@ int rpe_debug_loop_profile(rpe_context* ctx, int enable, double* wait_us, double
  * unit, and fewer than two lost grids so far; lost: refinements whose grid lost a workgroup's sums (another process on the GPU, a
  * partition smaller than the occupancy query promised) and that were FINISHED with one launch per iteration -- such a call still
  * succeeds, a context that sees it twice stops using resident loops; cap: workgroups of a resident kernel the device holds at once
- * (occupancy x compute units, at most 256; RPE_RESIDENT_CAP lowers it). */
+ * (occupancy x compute units, at most 256; RPE_RESIDENT_CAP lowers it).  enabled is a bit set: 1 resident loops, 2 host-driven ones
+ * (large BAR), 4 the autonomous loops still ask for their solving workgroup (cleared once the two kernels did not meet). */
 int rpe_debug_resident_state(rpe_context* ctx, int* enabled, int* lost, int* cap);
 /* Test hook, per context: the last workgroup of the next host-driven resident loops withholds its sums of `iteration` (> 0), and the
  * workgroups wait `pose_wait_s` seconds (0.5 .. 60; 0 = default 2 s) for the next pose.  (0, 0) = off.  Nothing in the library reads

@@ -320,7 +320,7 @@ class Context:
         """enabled / lost grids / co-residency cap of this context's resident loops (rpe_debug_resident_state)."""
         en, lost, cap = C.c_int(0), C.c_int(0), C.c_int(0)
         L.check(L.lib().rpe_debug_resident_state(self._h, C.byref(en), C.byref(lost), C.byref(cap)))
-        return {"enabled": bool(en.value), "host_driven": bool(en.value & 2), "lost": lost.value, "cap": cap.value}
+        return {"enabled": bool(en.value), "host_driven": bool(en.value & 2), "solver": bool(en.value & 4), "lost": lost.value, "cap": cap.value}
 
     def inject_resident_fault(self, iteration: int = 0, pose_wait_s: float = 0.0):
         """Test hook (rpe_debug_inject_resident_fault): the last workgroup of the next host-driven resident loops withholds its sums of

@@ -1331,7 +1331,16 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
       return RPE_OK;
     }
     // a workgroup's sums never arrived (the grid was not all resident at once): once more from the start pose, one launch per iteration
-    if (rt.solver) { c->auto_solver = false; (void)hipStreamSynchronize(c->stream2); }   // (the solving workgroup and its workers did not meet)
+    if (rt.solver) {   // (the solving workgroup and its workers did not meet)
+      c->auto_solver = false;
+      (void)hipStreamSynchronize(c->stream2);
+      (void)fail(RPE_ERR_HIP, "autonomous loop: the solving workgroup missed the sums of %d of %d workers (workgroups %d .. %d) at iteration %d; finished with one launch per iteration",
+                 (int)c->h_out[17], grid, (int)c->h_out[18], (int)c->h_out[19], (int)c->h_out[14]);
+#ifdef RPE_SOLVER_DEBUG
+      (void)fail(RPE_ERR_HIP, "DBG missing %d of %d (wg %d..%d) it %d | workers started %d, first %+.1f us, last %+.1f us after the solver; scan at %+.1f us", (int)c->h_out[17], grid,
+                 (int)c->h_out[18], (int)c->h_out[19], (int)c->h_out[14], (int)c->h_out[20], c->h_out[21], c->h_out[22], c->h_out[23]);
+#endif
+    }
     else note_lost_grid(c);
     rt.solver = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1385,7 +1394,7 @@ int rpe_debug_device_gn_update(rpe_context* c, const double* ne32, double* pose1
 // finished with one launch per iteration after their grid was lost, and the co-residency cap of the device.
 int rpe_debug_resident_state(rpe_context* c, int* enabled, int* lost, int* cap) {
   if (!c) return fail(RPE_ERR_ARG, "null context");
-  if (enabled) *enabled = c->resident ? (c->host_resident ? 3 : 1) : 0;
+  if (enabled) *enabled = (c->resident ? (c->host_resident ? 3 : 1) : 0) | (c->resident && c->auto_solver ? 4 : 0);
   if (lost) *lost = c->resident_lost;
   if (cap) *cap = c->resident_cap;
   return RPE_OK;

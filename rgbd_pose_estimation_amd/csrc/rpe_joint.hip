@@ -685,7 +685,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_joint_resident_kernel(JointArra
     if (STAGED) q.template get_first<TERMS, BLK>(j_lds, pl);   // in flight while the workgroup waits for its pose (a thread without a group reads its own unused slot)
     // stop requested or no host
     if (!AUTO && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go, fin.pose_wait_ticks) != 1) return;
-    if (with_solver && it > 1 && solver_wait_pose<BLK>(solver_pose_area(fin, workers, 29), first_tag + (unsigned long long)it, s_pose, &s_go) != 0) return;
+    if (with_solver && it > 1 && solver_wait_pose<BLK>(solver_pose_area(fin, workers, 29), first_tag + (unsigned long long)it, s_pose, &s_go, it == 2 ? kSolverMeetTicks : 200000000ull) != 0) return;
     PoseK<double> pose;
 #pragma unroll
     for (int k = 0; k < 9; k++) pose.R[k] = uniform_f64(s_pose[k]);

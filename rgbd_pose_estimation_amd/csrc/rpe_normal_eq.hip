@@ -158,6 +158,9 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     rpresent = g0 < full ? P : (int)(n - full * P);
   }
   // autonomous form (fin.gn set): the first pose comes from HBM, every later one from this workgroup's own solve (resident_auto_stage)
+#ifdef RPE_SOLVER_DEBUG
+  if (with_solver && threadIdx.x == 0) __hip_atomic_store(solver_pose_area(fin, workers, NACC) + 32 + blockIdx.x, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   constexpr bool autonomous = AUTO != 0;   // a template parameter: the host-driven instances carry no call to the solve (registers, scratch)
   double tol = 0.0;
   if (autonomous) {
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
     // stop requested or no host: uniform for the workgroup
     if (!autonomous && resident_wait_pose<BLK>(ctl, first_tag + (unsigned long long)it, s_pose, &s_go,
         fin.pose_wait_ticks) != 1) return;
-    if (with_solver && it > 1 && solver_wait_pose<BLK>(solver_pose_area(fin, workers, NACC), first_tag + (unsigned long long)it, s_pose, &s_go) != 0) return;
+    if (with_solver && it > 1 && solver_wait_pose<BLK>(solver_pose_area(fin, workers, NACC), first_tag + (unsigned long long)it, s_pose, &s_go, it == 2 ? kSolverMeetTicks : 200000000ull) != 0) return;
 #ifdef RPE_STAMPS
     const bool stamp_it = it == 1000;
     if (stamp_it) RPE_STAMP(0);
@@ -374,7 +377,19 @@ __global__ __launch_bounds__(512) void auto_solver_kernel(int workers, unsigned 
   solver_loop<NACC, 512>(fin, workers, first_tag, max_iters);
 }
 int auto_solver_workers(int grid) { return auto_solver_grid(grid, std::max(1, resident_cap_device())) ? grid : 0; }
-int auto_solver_cap() { return std::max(1, resident_cap_device()) - 1; }
+// Workers beside a solving workgroup: ONE COMPUTE UNIT PER SHADER ENGINE stays free (7 of 8: 224 workers on a whole MI355X).  The
+// dispatcher assigns a workgroup to a shader engine when it takes it off the queue, not when a compute unit is free: with more than 7
+// heavy workers per engine (one workgroup fills a compute unit, and only the lightest point-to-point instance can share one with the
+// solver) the engine that also holds the solving workgroup is one compute unit short, its last worker starts only when another
+// workgroup of that engine leaves -- and they all wait for its sums.  Measured: 225-255 workers lose a loop within ten refinements
+// of >= 1 M point-to-plane correspondences (the late worker's start stamp coincides with the others' bounded wait running out), 224
+// and fewer never in 360; profiles/r05_solver_room.txt.  RPE_AUTO_SOLVER_ROOM overrides the number of compute units left free.
+int auto_solver_cap() {
+  const int cap = std::max(1, resident_cap_device());
+  static const int env_room = getenv("RPE_AUTO_SOLVER_ROOM") ? atoi(getenv("RPE_AUTO_SOLVER_ROOM")) : 0;
+  const int room = env_room >= 1 ? env_room : std::max(1, cap / 8);
+  return std::max(1, cap - room);
+}
 hipError_t launch_auto_solver(int nacc, int workers, unsigned long long first_tag, int max_iters, const ReduceTarget& rt, hipStream_t s) {
   const Finish fin = make_finish(rt);
   if (nacc == 17) hipLaunchKernelGGL((auto_solver_kernel<17>), dim3(1), dim3(512), 0, s, workers, first_tag, max_iters, fin);

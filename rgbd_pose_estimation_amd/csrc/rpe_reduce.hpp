@@ -578,7 +578,8 @@ __device__ __forceinline__ void sum_records(const double* __restrict__ partials,
 // until every tag is this launch's), added in increasing row order into part[r][j].  Returns true if a granule never arrived (2 s).
 template <int NACC, int BLK, int CH = 4>
 __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gran, int G, int leader, int rows, unsigned long long tag,
-                                             double (*part)[NACC], int step = 1) {   // row k of the run = workgroup leader + k * step
+                                             double (*part)[NACC], int step = 1,   // row k of the run = workgroup leader + k * step
+                                             unsigned long long wait_ticks = 200000000ull) {   // 2 s of the 100 MHz clock
   constexpr int RGN = BLK / NACC;
   const int j = threadIdx.x % NACC, r = threadIdx.x / NACC;
   bool lost = false;
@@ -590,7 +591,7 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
       for (unsigned int spins = 1;; spins++) {
         q = load_granule16(src);
         if ((((unsigned long long)q.w << 32) | q.z) == tag) break;
-        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
+        if ((spins & 63u) == 0 && wall_clock64() - t0 > wait_ticks) { lost = true; break; }   // (2 s by default): a workgroup never delivered
       }
       part[r][j] = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
     }
@@ -614,7 +615,7 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
           if (row < rows && (((unsigned long long)q[u].w << 32) | q[u].z) != tag) pending = true;
         }
         if (!pending) break;
-        if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { lost = true; break; }   // 2 s: a workgroup never delivered
+        if ((spins & 63u) == 0 && wall_clock64() - t0 > wait_ticks) { lost = true; break; }   // (2 s by default): a workgroup never delivered
       }
 #pragma unroll
       for (int u = 0; u < CH; u++) {

@@ -647,13 +647,20 @@ __device__ __forceinline__ int resident_auto_stage(const double (&acc)[NACC], co
 // worker's sums of iteration i, i.e. after every worker has read pose i; a worker overwrites its granules of iteration i after it has
 // read pose i + 1, which was written after they were read.
 constexpr int kSolverPoseGranules = 14;
+// The solving workgroup and its workers are two kernels that must run TOGETHER.  Should a platform run them one after the other (two
+// streams that share a hardware queue), each waits for the other in vain: the first meetings -- the workers' wait for their first pose
+// from the solver, the solver's waits for the sums of iterations 1 and 2 -- are bounded by 0.25 s instead of the 2 s of every other
+// wait, the loop is reported lost, and the context finishes the refinement with one launch per iteration and never asks for a solving
+// workgroup again.  (0.25 s: far beyond one iteration over any slice that fits a GPU, and beyond a host thread's hiccup between the
+// two launches.)
+constexpr unsigned long long kSolverMeetTicks = 25000000ull;
 __device__ __forceinline__ unsigned long long* solver_pose_area(const Finish& fin, int workers, int nacc) {
   return reinterpret_cast<unsigned long long*>(fin.partials) + 2 * ((size_t)(workers + 8) * nacc);
 }
 // worker: wait for the pose record tagged `want`; returns the code (0 go on -- pose in s_pose --, 1 / 2 leave, 3 timed out)
 template <int BLK>
 __device__ __forceinline__ int solver_wait_pose(const unsigned long long* __restrict__ area, unsigned long long want, double* __restrict__ s_pose,
-                                                int* __restrict__ s_go) {
+                                                int* __restrict__ s_go, unsigned long long wait_ticks = 200000000ull) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -666,7 +673,7 @@ __device__ __forceinline__ int solver_wait_pose(const unsigned long long* __rest
         have = (((unsigned long long)q.w << 32) | q.z) == want;
       }
       if (__builtin_amdgcn_ballot_w64(!have) == 0) { go = 0; break; }
-      if ((spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { go = 3; break; }   // 2 s: the solving workgroup went away
+      if ((spins & 63u) == 0 && wall_clock64() - t0 > wait_ticks) { go = 3; break; }   // (2 s by default): the solving workgroup went away
       __builtin_amdgcn_s_sleep(1);
     }
     const double v = __longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x));
@@ -705,6 +712,9 @@ __device__ __forceinline__ void solver_loop(const Finish& fin, int workers, unsi
   __shared__ int v_code;
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);
   unsigned long long* area = solver_pose_area(fin, workers, NACC);
+#ifdef RPE_SOLVER_DEBUG
+  const unsigned long long dbg_start = wall_clock64();
+#endif
   if (threadIdx.x < 12) v_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
   const double tol = fin.gn->tol;
   __syncthreads();
@@ -712,8 +722,32 @@ __device__ __forceinline__ void solver_loop(const Finish& fin, int workers, unsi
     const unsigned long long tag = first_tag + (unsigned long long)it;
     if (threadIdx.x < NACC) v_part[0][threadIdx.x] = 0.0;   // "row 0" of collect_rows is the collector's own record: none here
     __syncthreads();
-    bool lost = collect_rows<NACC, BLK, 12>(gran, workers, -1, workers + 1, tag, v_part, 1);   // rows 1 .. workers = workgroups 0 .. workers - 1 (up to twelve granules in flight per thread: ONE sweep for a frame-sized grid of either record size)
+    // (the first two iterations wait kSolverMeetTicks only: a platform that runs the two kernels one after the other shows there)
+    bool lost = collect_rows<NACC, BLK, 12>(gran, workers, -1, workers + 1, tag, v_part, 1, it <= 2 ? kSolverMeetTicks : 200000000ull);   // rows 1 .. workers = workgroups 0 .. workers - 1 (up to twelve granules in flight per thread: ONE sweep for a frame-sized grid of either record size)
     lost = __syncthreads_or(lost);
+    if (lost && threadIdx.x == 0 && fin.out_host) {   // diagnostics for the host's error text: which workers' sums are missing
+      int missing = 0, lo = workers, hi = -1;
+      for (int w = 0; w < workers; w++) {
+        const granule_t q = load_granule16(gran + 2 * ((size_t)w * NACC + NACC - 1));
+        if ((((unsigned long long)q.w << 32) | q.z) != tag) { missing++; lo = w < lo ? w : lo; hi = w; }
+      }
+#ifdef RPE_SOLVER_DEBUG   // (diagnostic build: when did the workers start, relative to this workgroup?  profiles/r05_solver_room.txt)
+      {
+        unsigned long long mn = ~0ull, mx = 0; int started = 0;
+        for (int w = 0; w < workers; w++) {
+          const unsigned long long v = __hip_atomic_load(area + 32 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v > dbg_start - 100000000ull) { started++; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        }
+        __hip_atomic_store(fin.out_host + 20, (double)started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 21, started ? ((double)mn - (double)dbg_start) * 0.01 : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 22, started ? ((double)mx - (double)dbg_start) * 0.01 : -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fin.out_host + 23, ((double)wall_clock64() - (double)dbg_start) * 0.01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+#endif
+      __hip_atomic_store(fin.out_host + 17, (double)missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(fin.out_host + 18, (double)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(fin.out_host + 19, (double)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const double t = sum_rows<NACC, BLK>(v_part, workers + 1 < RGN ? workers + 1 : RGN);
     if (threadIdx.x < 64) {
       if (threadIdx.x < 32) v_tot[threadIdx.x] = threadIdx.x < NACC ? t : 0.0;

@@ -30,7 +30,7 @@ for n, kind in ((307200, 0), (1000000, 1), (20000, 0)):
     while time.perf_counter() - t2 < seconds / 15:
         q = ctx.gn_refine_device([(kind, 1.0)], p, 0, 500, 0.0)[0]
         dbad += int(not np.array_equal(q, first_dev)); dcalls += 1
-    out[f"{n}_{kind}"] = dict(resident_calls=calls, resident_iterations=iters, resident_pose_changed=bad, collect_calls=ncalls, collect_record_changed=nbad,
+    out[f"{n}_{kind}"] = dict(state=ctx.resident_state(), resident_calls=calls, resident_iterations=iters, resident_pose_changed=bad, collect_calls=ncalls, collect_record_changed=nbad,
                               device_loop_calls=dcalls, device_loop_iterations=500 * dcalls, device_loop_pose_changed=dbad)
     ctx.close()
 print(json.dumps(out), flush=True)
@@ -92,5 +92,6 @@ for n in (307200, 20000):
             bad += int(not np.array_equal(f(), first)); calls += 1
         out5[f"{name}_{n}"] = dict(calls=calls, iterations=300 * calls, pose_changed=bad)
     out5[f"lost_grids_{n}"] = ctx.resident_state()["lost"]
+    out5[f"solver_still_on_{n}"] = ctx.resident_state()["solver"]
     ctx.close()
 print(json.dumps({"round5": out5}), flush=True)
