@@ -1191,6 +1191,33 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
                                             "hbm_amortised_frac": BYTES[kname] * n / dts / 1e9 / HBM_PEAK_GBS, "bytes_per_pass": BYTES[kname] * n}
                 if mode == L.SCORE_EXACT and kname == "33":
                     v_exact = v
+        # (4b) a RANSAC-shaped sequence on the resident arrays -- one batch of 8 hypotheses, then the winner's masks -- served by ONE
+        # resident launch (scoring session, kernel K4r) against a launch each; wall time of the whole sequence, median of 200
+        sess = {}
+        try:
+            p8s = np.ascontiguousarray(poses[:8])
+
+            def run_seq(session):
+                if session and not sctx.score_session_begin(L.VOTE_33, thre_3d=THRE_3D):
+                    return None
+                vs = sctx.score(L.VOTE_33, p8s, THRE_3D)
+                sctx.inlier_mask(L.VOTE_33, p8s[int(np.argmax(vs))], thre_3d=THRE_3D)
+                if session:
+                    sctx.score_session_end()
+                return vs
+            for label, flag in (("launch_each", False), ("session", True)):
+                ref = run_seq(flag)
+                if ref is None:
+                    sess[label] = None
+                    continue
+                tsq = []
+                for _ in range(200):
+                    t0s = time.perf_counter(); run_seq(flag); tsq.append(time.perf_counter() - t0s)
+                tsq.sort()
+                sess[label] = {"us_per_run": tsq[len(tsq) // 2] * 1e6, "us_min": tsq[0] * 1e6, "votes_of_first": int(ref[0])}
+            sess["what"] = "score 8 hypotheses (exact 3D vote) + winner's masks over 307 200 resident correspondences, through the Python binding"
+        except Exception as e:  # noqa: BLE001
+            sess = {"error": repr(e)}
         sctx.close()
         cpu = None
         if not args.no_cpu_baseline:
@@ -1205,7 +1232,7 @@ def extras(out, args, ctx, sc, n, R0, t0, pose, local_rank):
             cpu = {"corr_hyp_per_s": n * 8 / dtc, "cores": 1, "sample": "8 hypotheses through the oracle's vote loop",
                    "votes_equal_exact_mode": bool(np.array_equal(votes_cpu, v_exact[:8]))}
         out["ransac_scoring"] = {"hypotheses": H, "kinds": "3D-3D (V1/V2) and 3D-3D + 2D-3D (V4), a bearing for every correspondence", "passes": res, "roofline": roof,
-                                 "cpu_port": cpu, "peaks": {"fp32_vector_TFLOPs": 157.3, "hbm_GBs": HBM_PEAK_GBS},
+                                 "ransac_run": sess, "cpu_port": cpu, "peaks": {"fp32_vector_TFLOPs": 157.3, "hbm_GBs": HBM_PEAK_GBS},
                                  "note": "wall time per rpe_score call incl. pose upload and vote read-out (median of 30); beside, not instead of, the headline"}
     except Exception as e:  # noqa: BLE001
         out["ransac_scoring"] = {"error": repr(e)}

@@ -140,3 +140,33 @@ def test_two_threads_two_contexts_one_gpu(gpu_ctx_factory):
         t.join(timeout=120)
     assert not any(t.is_alive() for t in ts)
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("kind", [L.RES_P2PLANE, L.RES_P2P])
+def test_the_solving_workgroup_and_its_workers_always_meet(gpu_ctx_factory, kind):
+    """Beyond a frame the autonomous loop's grid is capped so that every shader engine keeps a compute unit free for the solving
+    workgroup (rpe_normal_eq.hip auto_solver_cap).  With 225-255 heavy workers one of them started only when the others' bounded wait
+    had run out: a lost loop (0.25 s, finished with one launch per iteration) within ten refinements, after which the context stops
+    asking for a solving workgroup.  Forty refinements over 1.5 M correspondences with masks and weights: none may lose the loop."""
+    import time
+    n = 1_500_000
+    sc, mask, w, p0 = _scene(n, np.float32)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, nc=sc.N, nw=sc.M)
+    ctx.upload_mask(L.MOD_33, mask); ctx.upload_weight(L.MOD_33, w)
+    ctx.gn_refine([kind], p0, None, L.USE_MASK | L.USE_WEIGHT, 3, 0.0)           # (the arrays are verified finite: CLEAN flavour from here on)
+    if not ctx.resident_state().get("solver"):
+        pytest.skip("no solving workgroup on this device")
+    first, slow = None, []
+    for flags in (0, L.USE_MASK | L.USE_WEIGHT):
+        first = None
+        for i in range(20):
+            t0 = time.perf_counter()
+            p, it, *_ = ctx.gn_refine_device([(kind, 1.0)], p0, flags, 100, 0.0)
+            dt = time.perf_counter() - t0
+            assert it == 100
+            if dt > 0.1:
+                slow.append((flags, i, round(dt, 3), L.lib().rpe_last_error().decode()[:160]))
+            first = p if first is None else first
+            assert np.array_equal(p, first)
+    st = ctx.resident_state()
+    assert not slow and st["solver"] and st["lost"] == 0, (slow, st)
