@@ -1,4 +1,5 @@
 // K4: batched RANSAC hypothesis scoring (the eight vote loops) and K4b: the winner's inlier masks.
+#include <type_traits>
 #include "rpe_residuals.hpp"   // (the resident scoring kernel shares the resident loops' control block and collecting stage)
 
 namespace rpe {
@@ -284,7 +285,16 @@ template <class T> struct DeferQ {
 // on pairs of correspondences as 2-vectors (packed fp32 instructions), the 2D test (a square root and three divisions) stays scalar.
 // DEFER: queue the undecided 2D votes in `defer` (score_kernel's deferred-exact queue; the other callers pass a dummy and DEFER = false);
 // slot = where the hypothesis' deferred votes go (< 0: a padding hypothesis whose count is dropped -- nothing is queued for it)
-template <class T, int KIND, bool EXACT, bool DEFER = false>
+template <int P> __device__ __forceinline__ bool any_bearing(const wave_mask_t (&present)[P]) {
+  wave_mask_t m = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) m |= present[i];
+  return m != 0;
+}
+// W23 (fast mode; wave-uniform, decided ONCE per group by the caller -- any_bearing() -- not per correspondence: four scalar branches
+// per hypothesis cut the fast loops' straight-line code into pieces and cost the all-bearing scenes 12-20 %): false = no lane of the
+// wave has a bearing, the 2D test is left out altogether.  The exact kinds keep their per-pair test (always W23 = true).
+template <class T, int KIND, bool EXACT, bool DEFER = false, bool W23 = true>
 __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
                                                  const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
                                                  const wave_mask_t (&present)[Pk<T>::P], const wave_mask_t (&valid)[Pk<T>::P], T thr33, T cthr, T cnl,
@@ -343,7 +353,7 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
       if (MD::m33) {
         cnt += votes_of(valid[i], hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33));
       }
-      if (MD::m23 && present[i] != 0) {
+      if (MD::m23 && W23) {
         cnt += votes_of(present[i], hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX));
       }
     }
@@ -392,6 +402,8 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
       present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
       valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
     }
+    auto score_list = [&](auto w23) {
+    constexpr bool W23 = decltype(w23)::value;
     for (int h0 = 0; h0 < hcnt; h0 += 64) {
       const int hmax = min(64, hcnt - h0);
       int mine = 0;
@@ -408,13 +420,18 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
           hyp[u].load(hp + (size_t)(hl + u < hmax ? hl + u : hmax - 1) * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
 #pragma unroll
         for (int u = 0; u < HU; u++) {
-          const int cnt = count_group_votes<T, KIND, EXACT, DEFER>(hyp[u], vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, dq,
-                                                                   hl + u < hmax ? h0 + hl + u : -1);
+          const int cnt = count_group_votes<T, KIND, EXACT, DEFER, W23>(hyp[u], vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, dq,
+                                                                        hl + u < hmax ? h0 + hl + u : -1);
           mine = (lane == hl + u) ? cnt : mine;   // every hypothesis once per block of 64, `mine` starts at 0: a select, not an add
         }
       }
       if (lane < hmax && mine != 0) atomicAdd(&lds_votes[h0 + lane], mine);
     }
+    };
+    // The whole list with or without the 2D test: a wave none of whose lanes holds a bearing -- configs[2] has 2 000 among 307 200
+    // correspondences -- never enters it.  Fast mode only: the exact kinds, heavier in registers, keep their per-pair test (with the
+    // loop duplicated, NN + 3D + 2D exact took 324 instead of 297 us per 512 x 307 200 pass).
+    if (!EXACT && MD::m23 && !any_bearing<P>(present)) score_list(std::false_type{}); else score_list(std::true_type{});
     if (DEFER && dq.n > 0) dq.drain(cthr);   // what is left of the tile's undecided 2D votes
   }
   __syncthreads();
@@ -461,12 +478,14 @@ __global__ __launch_bounds__(kBlock) void score_small_kernel(const T* __restrict
       present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
       valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
     }
+    const bool w23 = EXACT || !MD::m23 || any_bearing<P>(present);
     for (int hl = copy; hl < H; hl += hs) {
       Hyp<T, EXACT> hyp;
       if (dposes) hyp.load(dposes + (size_t)hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);   // a list generated on the device
       else hyp.load(sp.v + hl * Hyp<T, EXACT>::STRIDE, KIND == VOTE_23_MATRIX);
       DeferQ<T> none;   // (no queue here: the in-place filter)
-      const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none);
+      const int cnt = w23 ? count_group_votes<T, KIND, EXACT, false, true>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none)
+                          : count_group_votes<T, KIND, EXACT, false, false>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none);
       mine += (lane == hl) ? cnt : 0;
     }
   }
@@ -673,6 +692,7 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
     present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
     valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
   }
+  const bool w23 = EXACT || !MD::m23 || any_bearing<P>(present);
   for (unsigned long long b = 1;; b++) {
     const unsigned long long want = first_tag + b;
     // ---- wait for batch b (both tags), bounded like the Gauss-Newton loops' wait for a pose
@@ -715,7 +735,8 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
         Hyp<T, EXACT> hyp;
         hyp.load(batch + h * STRIDE, KIND == VOTE_23_MATRIX);
         DeferQ<T> none;   // (no queue here: the in-place filter)
-        const int cnt = count_group_votes<T, KIND, EXACT>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none);
+        const int cnt = w23 ? count_group_votes<T, KIND, EXACT, false, true>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none)
+                            : count_group_votes<T, KIND, EXACT, false, false>(hyp, vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, none);
         mine = (lane == h) ? cnt : mine;
       }
       if (lane < HB) red[wave][lane] = (double)mine;

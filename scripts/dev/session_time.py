@@ -1,13 +1,14 @@
 """Per-call cost inside a resident scoring session (K4r): begin, then batches of 8 / 32 hypotheses and the masks, after a pause (the
 kernel is resident and warm) -- against the same calls outside a session."""
 import ctypes as C
+import os
 import json
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rgbd_pose_estimation_amd import _lib as L, api
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 307200
