@@ -63,6 +63,34 @@ template <class T> struct Hyp<T, false> {
     rot(nwx, nwy, nwz, rx, ry, rz);
     return fma(ncx, rx, fma(ncy, ry, ncz * rz)) > cnl;
   }
+  // The same predicates on a PAIR of correspondences as 2-vectors -- element by element the operations above in the same order (the
+  // same bits), written out so that the packed instructions do not depend on the auto-vectoriser's choice of pairs: left to it, the
+  // hypothesis loop of the kinds with a 2D test carried 13-17 register moves per hypothesis to re-pair its operands.
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ V2 fma2(T a, V2 b, V2 c) { return __builtin_elementwise_fma(V2(a), b, c); }
+  __device__ __forceinline__ void xform2(V2 x, V2 y, V2 z, V2& px, V2& py, V2& pz) const {
+    px = fma2(R[0], x, fma2(R[1], y, fma2(R[2], z, V2(t[0]))));
+    py = fma2(R[3], x, fma2(R[4], y, fma2(R[5], z, V2(t[1]))));
+    pz = fma2(R[6], x, fma2(R[7], y, fma2(R[8], z, V2(t[2]))));
+  }
+  static __device__ __forceinline__ void in33_p2(V2 px, V2 py, V2 pz, V2 cx, V2 cy, V2 cz, T thr_sq, bool& a, bool& b) {
+    const V2 ex = px - cx, ey = py - cy, ez = pz - cz;
+    const V2 s = __builtin_elementwise_fma(ex, ex, __builtin_elementwise_fma(ey, ey, ez * ez));
+    a = s.x < thr_sq; b = s.y < thr_sq;
+  }
+  static __device__ __forceinline__ void in23_p2(V2 px, V2 py, V2 pz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b) {
+    const V2 d = __builtin_elementwise_fma(px, bx, __builtin_elementwise_fma(py, by, pz * bz));
+    const V2 n2 = __builtin_elementwise_fma(px, px, __builtin_elementwise_fma(py, py, pz * pz));
+    const V2 rhs = V2(c * fabs(c)) * n2;
+    a = d.x * fabs(d.x) > rhs.x; b = d.y * fabs(d.y) > rhs.y;
+  }
+  __device__ __forceinline__ void innn2(V2 nwx, V2 nwy, V2 nwz, V2 ncx, V2 ncy, V2 ncz, T cnl, bool& a, bool& b) const {
+    const V2 rx = fma2(R[0], nwx, fma2(R[1], nwy, V2(R[2]) * nwz));
+    const V2 ry = fma2(R[3], nwx, fma2(R[4], nwy, V2(R[5]) * nwz));
+    const V2 rz = fma2(R[6], nwx, fma2(R[7], nwy, V2(R[8]) * nwz));
+    const V2 s = __builtin_elementwise_fma(ncx, rx, __builtin_elementwise_fma(ncy, ry, ncz * rz));
+    a = s.x > cnl; b = s.y > cnl;
+  }
 };
 // exact form: the reference's own operation sequence in Tp, no FMA contraction.
 //   R*x     = Eigen _transformVector (sophus/so3.hpp:238-240): uv = 2 (u x v); v + w uv + u x uv
@@ -344,17 +372,32 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
       }
     }
   } else {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    static_assert(P % 2 == 0, "pairs");
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-      const T x = vw[3 * i], y = vw[3 * i + 1], z = vw[3 * i + 2];
+    for (int j = 0; j < P / 2; j++) {
+      const int a = 2 * j, b = 2 * j + 1;
+      bool va, vb2;
       if (MD::mnn) {
-        cnt += votes_of(valid[i], hyp.innn(vnw[3 * i], vnw[3 * i + 1], vnw[3 * i + 2], vnc[3 * i], vnc[3 * i + 1], vnc[3 * i + 2], cnl));
+        const V2 nwx = {vnw[3 * a], vnw[3 * b]}, nwy = {vnw[3 * a + 1], vnw[3 * b + 1]}, nwz = {vnw[3 * a + 2], vnw[3 * b + 2]};
+        const V2 ncx = {vnc[3 * a], vnc[3 * b]}, ncy = {vnc[3 * a + 1], vnc[3 * b + 1]}, ncz = {vnc[3 * a + 2], vnc[3 * b + 2]};
+        hyp.innn2(nwx, nwy, nwz, ncx, ncy, ncz, cnl, va, vb2);
+        cnt += votes_of(valid[a], va) + votes_of(valid[b], vb2);
       }
-      if (MD::m33) {
-        cnt += votes_of(valid[i], hyp.in33(x, y, z, vc[3 * i], vc[3 * i + 1], vc[3 * i + 2], thr33));
-      }
-      if (MD::m23 && W23) {
-        cnt += votes_of(present[i], hyp.in23(x, y, z, vb[3 * i], vb[3 * i + 1], vb[3 * i + 2], cthr, KIND == VOTE_23_MATRIX));
+      if (MD::m33 || (MD::m23 && W23)) {
+        const V2 x = {vw[3 * a], vw[3 * b]}, y = {vw[3 * a + 1], vw[3 * b + 1]}, z = {vw[3 * a + 2], vw[3 * b + 2]};
+        V2 px, py, pz;
+        hyp.xform2(x, y, z, px, py, pz);   // one transform for the 3D and the 2D test
+        if (MD::m33) {
+          const V2 cx = {vc[3 * a], vc[3 * b]}, cy = {vc[3 * a + 1], vc[3 * b + 1]}, cz = {vc[3 * a + 2], vc[3 * b + 2]};
+          Hyp<T, false>::in33_p2(px, py, pz, cx, cy, cz, thr33, va, vb2);
+          cnt += votes_of(valid[a], va) + votes_of(valid[b], vb2);
+        }
+        if (MD::m23 && W23) {
+          const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
+          Hyp<T, false>::in23_p2(px, py, pz, bx, by, bz, cthr, va, vb2);
+          cnt += votes_of(present[a], va) + votes_of(present[b], vb2);
+        }
       }
     }
   }
