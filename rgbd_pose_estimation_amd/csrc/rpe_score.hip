@@ -762,14 +762,13 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
     __syncthreads();
     const int go = s_go;
     if (go != 1 && go != 4) return;
-    // the header again, now that the tags are known good (the copy above may predate them)
+    // header and payload, now that the tags are known good (the header copy above may predate them): ONE round of loads -- thread 0
+    // the header, threads 1 .. PAYLOAD_WORDS the largest payload a batch can have (what lies beyond this batch's is stale and unused)
     if (threadIdx.x == 0) s_hdr = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if ((int)threadIdx.x <= PAYLOAD_WORDS) s_words[threadIdx.x - 1] = __hip_atomic_load(ctl + 1 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     const int count = (int)(unsigned int)s_hdr, op = (int)(s_hdr >> 32);
     if (go == 4 && op != 1) return;   // a plain stop; with op 1: "write these masks, send their record, and leave"
-    const int words = (count * STRIDE * (int)sizeof(T) + 7) / 8;
-    if ((int)threadIdx.x < words) s_words[threadIdx.x] = __hip_atomic_load(ctl + 2 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __syncthreads();
     const T* batch = reinterpret_cast<const T*>(s_words);
     double own = 0.0;
     if (op == 0) {
