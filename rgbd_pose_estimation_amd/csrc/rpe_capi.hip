@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <limits>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -91,7 +93,7 @@ struct rpe_context {
   hipStream_t stream = nullptr;
   // resident scoring session (rpe_score_session_begin ... _end): the grid of score_resident_kernel waits for batches in c->ctl
   struct { bool active = false; int kind = 0, mode = 0, grid = 0, runs = 0, batches = 0; double thre_3d = 0, cos_thr = 0, cos_nl = 0;
-           unsigned long long base = 0;
+           unsigned long long base = 0, id = 0;
            // every hypothesis the session has scored (pose as the caller gave it -> votes): the winner's total is known without
            // waiting for the masks' own record
            std::vector<double> seen_pose; std::vector<int> seen_votes;
@@ -525,8 +527,17 @@ template <class T> static T sqrt_cut(T thr) {
 // One resident loop per GPU at a time within this process: two resident grids launched together (two contexts, two threads) could each
 // get only part of their workgroups onto the CUs and then wait for workgroups that cannot start (the bounded waits would end both with
 // an error).  Other PROCESSES on the same GPU are the caller's to serialise.
-static std::mutex& resident_mutex(int device) {
-  static std::mutex m[64];
+// (a lock that may be given back by another thread than the one that took it: a scoring session holds the device's resident slot
+// from rpe_score_session_begin to whatever call ends it, and a context may be handed from one thread to the next in between --
+// std::mutex forbids that)
+struct ResidentSlot {
+  std::mutex m; std::condition_variable cv; bool busy = false;
+  void lock() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return !busy; }); busy = true; }
+  bool try_lock() { std::lock_guard<std::mutex> lk(m); if (busy) return false; busy = true; return true; }
+  void unlock() { { std::lock_guard<std::mutex> lk(m); busy = false; } cv.notify_one(); }
+};
+static ResidentSlot& resident_mutex(int device) {
+  static ResidentSlot m[64];
   return m[device >= 0 && device < 64 ? device : 0];
 }
 
@@ -653,7 +664,37 @@ bool pin_calling_thread(int cpu) {
 }  // namespace
 
 // ---- resident scoring session (K4r, rpe_score.hip): ONE launch serves the batches of a RANSAC run and the winner's masks.
-static thread_local rpe_context* t_session = nullptr;   // the context whose session this thread holds open (at most one per thread)
+// Which session did THIS thread open?  By number, not by pointer: a context may be handed to another thread, which may end the session
+// (or destroy the context) without this thread hearing of it.  The open session of a device -- there is at most one: it holds the
+// resident slot -- is registered with its number; a thread that finds its own number still registered knows the context is alive.
+struct OpenSession { std::mutex m; rpe_context* ctx = nullptr; unsigned long long id = 0; };
+static OpenSession& open_session(int device) {
+  static OpenSession o[64];
+  return o[device >= 0 && device < 64 ? device : 0];
+}
+static std::atomic<unsigned long long> g_session_ids{0};
+static thread_local unsigned long long t_session_id = 0;
+static thread_local int t_session_dev = -1;
+static void session_close(rpe_context* c);
+// the session this thread holds open on `device`, if it still is one (and forgets it otherwise)
+static rpe_context* my_open_session(int device) {
+  if (t_session_id == 0 || t_session_dev != device) return nullptr;
+  OpenSession& o = open_session(device);
+  rpe_context* ctx = nullptr;
+  { std::lock_guard<std::mutex> lk(o.m); if (o.id == t_session_id) ctx = o.ctx; }
+  if (!ctx) t_session_id = 0;
+  return ctx;
+}
+static void session_registered(rpe_context* c, unsigned long long id) {
+  OpenSession& o = open_session(c->device);
+  { std::lock_guard<std::mutex> lk(o.m); o.ctx = c; o.id = id; }
+  t_session_id = id; t_session_dev = c->device;
+}
+static void session_unregistered(rpe_context* c, unsigned long long id) {
+  OpenSession& o = open_session(c->device);
+  { std::lock_guard<std::mutex> lk(o.m); if (o.id == id) { o.ctx = nullptr; o.id = 0; } }
+  if (t_session_id == id) t_session_id = 0;
+}
 static int mask_by_launch(rpe_context* c, int kind, int mode, const double* pose7, double thre_3d, double cos_thr, double cos_nl, int* votes_out);
 static void session_message(rpe_context* c, int op, const void* staged, int count, size_t bytes, unsigned long long tag) {
   const size_t words = (bytes + 7) / 8;
@@ -668,7 +709,7 @@ static void session_message(rpe_context* c, int op, const void* staged, int coun
 // Closes a session that is open (idempotent): the stop message releases the grid, the per-device resident slot is given back.
 static void session_close(rpe_context* c) {
   if (!c || !c->sess.active) return;
-  if (t_session == c) t_session = nullptr;
+  session_unregistered(c, c->sess.id);
   c->sess.active = false;
   session_message(c, 2, nullptr, 0, 0, (c->sess.base + (unsigned long long)c->sess.batches + 1) | rpe::kResidentStopBit);
   c->seq = c->sess.base + (unsigned long long)c->sess.batches + 2;   // stays ahead of every tag / sequence value the launch could use
@@ -694,7 +735,7 @@ static void session_verify(rpe_context* c) {
 static void session_end(rpe_context* c) {
   // (a session of ANOTHER context of this thread on the same GPU holds the device's resident slot: a resident loop of `c` would wait
   // for it forever)
-  if (c && t_session && t_session != c && t_session->device == c->device) session_close(t_session);
+  if (c) { rpe_context* mine = my_open_session(c->device); if (mine && mine != c) session_close(mine); }
   session_close(c);
   session_verify(c);
 }
@@ -716,7 +757,7 @@ static void session_final_masks(rpe_context* c, const void* staged, size_t bytes
   const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
   session_message(c, 1, staged, 1, bytes, tag | rpe::kResidentStopBit);
   c->sess.batches++;
-  if (t_session == c) t_session = nullptr;
+  session_unregistered(c, c->sess.id);
   c->sess.active = false;
   c->sess.pending = true; c->sess.pend_tag = tag; c->sess.pend_votes = votes;
   std::memcpy(c->sess.pend_pose, pose7, sizeof c->sess.pend_pose);
@@ -1196,7 +1237,7 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
         return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk,
                                                     (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream);
       };
-      { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+      { std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));
         rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight,
             "normal equations", clean, &verified); }
       if (clean && rc == kResidentDirty) note_clean_terms(c, sp.bits, false);
@@ -1305,7 +1346,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
-    std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
+    std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
     rt.clean = single ? take_clean(c, terms[0].kind, false) : joint_clean;   // no host in this loop: CLEAN only over verified arrays
     if (use_solver) {
       rt.solver = 1;
@@ -1483,7 +1524,7 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     for (int attempt = 0; attempt < 2; attempt++) {
       const bool clean = take_clean(c, kind, true);   // CLEAN flavour first; its first record is checked
       bool verified = false;
-      { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+      { std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));
         rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight,
             "normal equations", clean, &verified); }
       // promoted to "verified finite" only by a first record that was received and finite: a launch error, a wait that timed out or a
@@ -2088,7 +2129,7 @@ int rpe_inlier_mask(rpe_context* c, int kind, int mode, const double* pose7, dou
 int rpe_score_session_begin(rpe_context* c, int kind, int mode, double thre_3d, double cos_thr, double cos_nl) {
   if (!c) return fail(RPE_ERR_ARG, "null context");
   session_end(c);
-  if (t_session) session_close(t_session);   // one session per thread
+  if (t_session_id) { rpe_context* mine = my_open_session(t_session_dev); if (mine) session_close(mine); }   // one session per thread
   int rc = vote_arrays(c, kind);
   if (rc) return rc;
   static const bool off = getenv("RPE_SCORE_SESSION") && atoi(getenv("RPE_SCORE_SESSION")) == 0;
@@ -2121,7 +2162,8 @@ int rpe_score_session_begin(rpe_context* c, int kind, int mode, double thre_3d, 
   c->sess.active = true; c->sess.kind = kind; c->sess.mode = mode; c->sess.grid = grid; c->sess.runs = runs; c->sess.batches = 0;
   c->sess.thre_3d = thre_3d; c->sess.cos_thr = cos_thr; c->sess.cos_nl = cos_nl; c->sess.base = base;
   c->sess.seen_pose.clear(); c->sess.seen_votes.clear();
-  t_session = c;
+  c->sess.id = ++g_session_ids;
+  session_registered(c, c->sess.id);
   return RPE_OK;
 }
 int rpe_score_session_end(rpe_context* c) {
@@ -2385,7 +2427,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     rpe::ReduceTarget rt = host_target(c);
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
     static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
-    std::unique_lock<std::mutex> one_resident_grid(resident_mutex(c->device), std::defer_lock);
+    std::unique_lock<ResidentSlot> one_resident_grid(resident_mutex(c->device), std::defer_lock);
     bool one_launch = false;
     if (auto_on && c->resident && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm
         && c->p2p_world < 1) {
@@ -2432,7 +2474,7 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
           (float)o->cos_thr, o->use_normals,
                                       o->kind, (const unsigned long long*)c->ctl, base, o->max_iter, rt, c->stream);
     };
-    { std::lock_guard<std::mutex> one_resident_grid(resident_mutex(c->device));
+    { std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));
       rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs,
           "ICP: normal equations"); }
     if (rc != RPE_OK && rc != kResidentLost) { if (iters_out) *iters_out = it; return rc; }

@@ -196,3 +196,40 @@ def test_a_problem_beyond_a_frame_is_refused_and_scored_by_launches(gpu_ctx_fact
     assert not ctx.score_session_begin(L.VOTE_33, thre_3d=0.05)
     q = np.array([[1.0, 0, 0, 0, 0.01, 0.01, 0.01]])
     assert ctx.score(L.VOTE_33, q, thre_3d=0.05)[0] == n
+
+
+def test_a_session_may_be_continued_and_ended_by_another_thread(gpu_ctx_factory, oracle):
+    """A context handed from one thread to the next with its session open: the second thread scores through it, ends it (giving the
+    device's resident slot back -- which the first thread took), and the first thread's next calls on ANOTHER context do not touch the
+    session it no longer holds."""
+    import threading
+    sc = _scene(30000, np.float32, 10)
+    a = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    b = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    prob = oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    q = _poses(oracle, sc, False, 24, 12)
+    vo = oracle.votes(prob, oracle.V_33, q, thre_3d=0.05)
+    pose = api.pose12(sc.R, sc.t)
+    out = {}
+
+    def opener():
+        out["begun"] = a.score_session_begin(L.VOTE_33, thre_3d=0.05)
+        out["v0"] = a.score(L.VOTE_33, q[:8], thre_3d=0.05)
+    t = threading.Thread(target=opener); t.start(); t.join()
+    assert out["begun"] and np.array_equal(out["v0"], vo[:8])
+    assert np.array_equal(a.score(L.VOTE_33, q[8:], thre_3d=0.05), vo[8:])           # this thread, inside the other thread's session
+    assert a.inlier_mask(L.VOTE_33, q[2], thre_3d=0.05) == vo[2]
+    a.gn_refine([L.RES_P2P], pose, max_iter=3)                                       # ends it; takes and returns the resident slot
+    b.gn_refine([L.RES_P2P], pose, max_iter=3)                                       # the slot is free for another context
+
+    def closer():
+        out["v1"] = a.score(L.VOTE_33, q[:8], thre_3d=0.05)
+        a.score_session_end()
+        out["refined"] = b.gn_refine([L.RES_P2P], pose, max_iter=3)[1]
+    assert a.score_session_begin(L.VOTE_33, thre_3d=0.05)                            # opened here ...
+    t = threading.Thread(target=closer); t.start(); t.join(timeout=60)
+    assert not t.is_alive() and np.array_equal(out["v1"], vo[:8]) and out["refined"] == 3   # ... ended there
+    assert b.score_session_begin(L.VOTE_33, thre_3d=0.05)                            # this thread no longer holds a's
+    assert np.array_equal(b.score(L.VOTE_33, q, thre_3d=0.05), vo)
+    b.score_session_end()
+    assert np.array_equal(a.score(L.VOTE_33, q, thre_3d=0.05), vo)
