@@ -729,6 +729,7 @@ static void session_verify(rpe_context* c) {
   if (rc == RPE_OK && (int)tot[0] == c->sess.pend_votes) return;
   if (rc == kResidentLost) note_lost_grid(c);
   int votes = 0;
+  (void)hipSetDevice(c->device);   // (the callers set the device after their session_end)
   (void)mask_by_launch(c, c->sess.kind, c->sess.mode, c->sess.pend_pose, c->sess.thre_3d, c->sess.cos_thr, c->sess.cos_nl, &votes);
 }
 // Every entry point that queues work behind the context's stream, reads the masks or reuses the host-side record area calls this first.
