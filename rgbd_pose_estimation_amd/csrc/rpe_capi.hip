@@ -94,6 +94,8 @@ struct rpe_context {
   // resident scoring session (rpe_score_session_begin ... _end): the grid of score_resident_kernel waits for batches in c->ctl
   struct { bool active = false; int kind = 0, mode = 0, grid = 0, runs = 0, batches = 0; double thre_3d = 0, cos_thr = 0, cos_nl = 0;
            unsigned long long base = 0, id = 0;
+           double last_us = 0, wait_us = 2e6;   // host clock of the last message / the grid's bounded wait: a message that comes later
+           bool pend_late = false;              // than that finds no grid -- the caller's pause, not a lost grid (nothing is counted)
            // every hypothesis the session has scored (pose as the caller gave it -> votes): the winner's total is known without
            // waiting for the masks' own record
            std::vector<double> seen_pose; std::vector<int> seen_votes;
@@ -727,7 +729,7 @@ static void session_verify(rpe_context* c) {
   const int rc = wait_host_partials(c, c->sess.runs, rpe::kSessionHypsMax, tot, 0, true);
   c->seq = keep;
   if (rc == RPE_OK && (int)tot[0] == c->sess.pend_votes) return;
-  if (rc == kResidentLost) note_lost_grid(c);
+  if (rc == kResidentLost && !c->sess.pend_late) note_lost_grid(c);
   int votes = 0;
   (void)hipSetDevice(c->device);   // (the callers set the device after their session_end)
   (void)mask_by_launch(c, c->sess.kind, c->sess.mode, c->sess.pend_pose, c->sess.thre_3d, c->sess.cos_thr, c->sess.cos_nl, &votes);
@@ -744,11 +746,14 @@ static void session_end(rpe_context* c) {
 // the masks of one; totals = the 32 sums of the batch.  On a failure the session is closed and the caller takes the launch path.
 static int session_batch(rpe_context* c, int op, const void* staged, int count, size_t bytes, double* totals) {
   const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
+  const double now = clock_us();
+  const bool late = now - c->sess.last_us > 0.8 * c->sess.wait_us;
+  c->sess.last_us = now;
   session_message(c, op, staged, count, bytes, tag);
   c->sess.batches++;
   c->seq = tag;
   const int rc = wait_host_partials(c, c->sess.runs, rpe::kSessionHypsMax, totals, 0, true);
-  if (rc != RPE_OK) { if (rc == kResidentLost) note_lost_grid(c); session_close(c); return rc == kResidentLost ? RPE_ERR_HIP : rc; }
+  if (rc != RPE_OK) { if (rc == kResidentLost && !late) note_lost_grid(c); session_close(c); return rc == kResidentLost ? RPE_ERR_HIP : rc; }
   return RPE_OK;
 }
 // The session's LAST message: the masks of a hypothesis whose vote total is already known (it was scored in this session), together
@@ -756,6 +761,7 @@ static int session_batch(rpe_context* c, int op, const void* staged, int count, 
 // orders every later reader behind it, and session_verify looks at the record at the next call.
 static void session_final_masks(rpe_context* c, const void* staged, size_t bytes, const double* pose7, int votes) {
   const unsigned long long tag = c->sess.base + (unsigned long long)(c->sess.batches + 1);
+  c->sess.pend_late = clock_us() - c->sess.last_us > 0.8 * c->sess.wait_us;
   session_message(c, 1, staged, 1, bytes, tag | rpe::kResidentStopBit);
   c->sess.batches++;
   session_unregistered(c, c->sess.id);
@@ -2153,6 +2159,9 @@ int rpe_score_session_begin(rpe_context* c, int kind, int mode, double thre_3d, 
   rpe::ReduceTarget rt = host_target(c);
   rt.seq = base;
   rt.h_out = c->h_big;
+  if (c->test_pose_wait_s > 0) rt.pose_wait_ticks = (unsigned long long)(c->test_pose_wait_s * 1e8);   // tests: a grid that gives up soon
+  c->sess.wait_us = (double)rt.pose_wait_ticks * 0.01;   // (100 MHz clock)
+  c->sess.last_us = clock_us();
   const int nacc = rpe::kSessionHypsMax, rgn = 512 / nacc;
   int mult = (grid + rgn * 8 - 1) / (rgn * 8);
   mult = mult < 1 ? 1 : (mult > 4 ? 4 : mult);

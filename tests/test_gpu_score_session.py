@@ -233,3 +233,36 @@ def test_a_session_may_be_continued_and_ended_by_another_thread(gpu_ctx_factory,
     assert np.array_equal(b.score(L.VOTE_33, q, thre_3d=0.05), vo)
     b.score_session_end()
     assert np.array_equal(a.score(L.VOTE_33, q, thre_3d=0.05), vo)
+
+
+def test_a_session_whose_grid_has_gone_away_still_gives_the_right_answers(gpu_ctx_factory, oracle):
+    """The session's grid waits a bounded time for its next message (2 s; 0.5 s here through the test hook).  A host that comes back
+    later finds no grid: a batch is then scored by a launch, and masks that were sent as the session's last message without being
+    waited for are written by the one-launch kernel when their record turns out to be missing -- either way the oracle's results."""
+    import time
+    sc = _scene(30000, np.float32, 13)
+    ctx = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    prob = oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=2.0)
+    q = _poses(oracle, sc, False, 16, 14)
+    vo = oracle.votes(prob, oracle.V_33_23, q, **thr)
+    ctx.inject_resident_fault(0, 0.5)
+    # (1) the next batch comes too late
+    assert ctx.score_session_begin(L.VOTE_33_23, **thr)
+    assert np.array_equal(ctx.score(L.VOTE_33_23, q[:8], **thr), vo[:8])
+    time.sleep(0.9)
+    assert np.array_equal(ctx.score(L.VOTE_33_23, q[8:], **thr), vo[8:])
+    # (2) the masks come too late: sent as the last message (their total is known), found missing at the next call
+    assert ctx.score_session_begin(L.VOTE_33_23, **thr)
+    assert np.array_equal(ctx.score(L.VOTE_33_23, q[:8], **thr), vo[:8])
+    time.sleep(0.9)
+    assert ctx.inlier_mask(L.VOTE_33_23, q[5], **thr) == vo[5]
+    _, mo = oracle.votes(prob, oracle.V_33_23, q[5:6], mask_for=0, **thr)
+    assert np.array_equal(ctx.download_mask(L.MOD_33), mo[L.MOD_33]) and np.array_equal(ctx.download_mask(L.MOD_23), mo[L.MOD_23])
+    ctx.inject_resident_fault(0, 0.0)
+    # a caller's pause is not a lost grid: nothing was counted, and sessions go on working
+    st = ctx.resident_state()
+    assert st["lost"] == 0 and st["enabled"]
+    assert ctx.score_session_begin(L.VOTE_33_23, **thr)
+    assert np.array_equal(ctx.score(L.VOTE_33_23, q, **thr), vo)
+    ctx.score_session_end()
