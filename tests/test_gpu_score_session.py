@@ -266,3 +266,42 @@ def test_a_session_whose_grid_has_gone_away_still_gives_the_right_answers(gpu_ct
     assert ctx.score_session_begin(L.VOTE_33_23, **thr)
     assert np.array_equal(ctx.score(L.VOTE_33_23, q, **thr), vo)
     ctx.score_session_end()
+
+
+def test_sessions_of_two_threads_on_one_gpu_take_turns(gpu_ctx_factory, oracle):
+    """One resident grid per GPU at a time: a second thread's session (or resident loop) waits for the first one's to end.  Two threads,
+    a context each, 150 RANSAC-shaped runs each, a Gauss-Newton loop in between: every result the oracle's, nobody starves."""
+    import threading
+    sc = _scene(30000, np.float32, 15)
+    prob = oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    q = _poses(oracle, sc, False, 8, 16)
+    vo = oracle.votes(prob, oracle.V_33, q, thre_3d=0.05)
+    _, mo = oracle.votes(prob, oracle.V_33, q[:1], mask_for=0, thre_3d=0.05)
+    pose = api.pose12(sc.R, sc.t)
+    ctxs = [gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N) for _ in range(2)]
+    bad = []
+
+    def worker(ctx, k):
+        try:
+            for i in range(150):
+                assert ctx.score_session_begin(L.VOTE_33, thre_3d=0.05)
+                v = ctx.score(L.VOTE_33, q, thre_3d=0.05)
+                tot = ctx.inlier_mask(L.VOTE_33, q[0], thre_3d=0.05)
+                ctx.score_session_end()
+                if not np.array_equal(v, vo) or tot != vo[0]:
+                    bad.append((k, i, "votes"))
+                if i % 10 == k:
+                    if not np.array_equal(ctx.download_mask(L.MOD_33), mo[L.MOD_33]):
+                        bad.append((k, i, "mask"))
+                    ctx.gn_refine([L.RES_P2P], pose, flags=L.USE_MASK, max_iter=3)
+        except Exception as e:  # noqa: BLE001
+            bad.append((k, repr(e)))
+    ts = [threading.Thread(target=worker, args=(c, k)) for k, c in enumerate(ctxs)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts) and not bad, bad[:5]
+    for c in ctxs:
+        st = c.resident_state()
+        assert st["enabled"] and st["lost"] == 0
