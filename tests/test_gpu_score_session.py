@@ -305,3 +305,28 @@ def test_sessions_of_two_threads_on_one_gpu_take_turns(gpu_ctx_factory, oracle):
     for c in ctxs:
         st = c.resident_state()
         assert st["enabled"] and st["lost"] == 0
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 2049, 131073])
+def test_sessions_on_tiny_and_ragged_problems(gpu_ctx_factory, oracle, n, f64):
+    """one correspondence, a partial group, one workgroup and a bit, ... : the session's grid is one group per thread whatever n is"""
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(40 + n % 7, max(n, 8), np.float64, n2d=1.5 / 585.0, n3d=0.02, nnl_deg=2.0, outliers=0.3)
+    sc.Q, sc.P, sc.U, sc.M, sc.N = (a[:n] for a in (sc.Q, sc.P, sc.U, sc.M, sc.N))
+    if n > 4:
+        sc.P[n // 2] = np.nan
+    sc = sc.astype(dt)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    thr = dict(thre_3d=0.05, cos_thr=float(np.cos(np.arctan(4.0 / 585.0))), cos_nl=float(np.cos(np.radians(5.0))))
+    q = _poses(oracle, sc, f64, 40, 3)
+    for kind in (L.VOTE_33, L.VOTE_NN_33_23):
+        vo, mo = oracle.votes(prob, _okind(oracle, kind), q, mask_for=1, **thr)
+        assert ctx.score_session_begin(kind, **thr)
+        assert np.array_equal(ctx.score(kind, q, **thr), vo)
+        assert ctx.inlier_mask(kind, q[1], **thr) == vo[1]
+        ctx.score_session_end()
+        assert np.array_equal(ctx.download_mask(L.MOD_33), mo[L.MOD_33])
+        if kind == L.VOTE_NN_33_23:
+            assert np.array_equal(ctx.download_mask(L.MOD_23), mo[L.MOD_23]) and np.array_equal(ctx.download_mask(L.MOD_NN), mo[L.MOD_NN])
