@@ -164,7 +164,7 @@ def test_the_solving_workgroup_and_its_workers_always_meet(gpu_ctx_factory, kind
             p, it, *_ = ctx.gn_refine_device([(kind, 1.0)], p0, flags, 100, 0.0)
             dt = time.perf_counter() - t0
             assert it == 100
-            if dt > 0.1:
+            if dt > 0.2:   # (a lost loop costs 0.25 s: the meeting timeout)
                 slow.append((flags, i, round(dt, 3), L.lib().rpe_last_error().decode()[:160]))
             first = p if first is None else first
             assert np.array_equal(p, first)
