@@ -107,6 +107,14 @@ int rpe_p2p_moments(rpe_context* ctx, int flags, double* out18);
 /* Closed-form pose from the moments (host: 3x3 SVD, det fix, t = Cc - R*Cw; AbsoluteOrientation.hpp:75-95). */
 int rpe_pose_from_moments(const double* m18, double* R9, double* t3);
 
+/* ---- R1 lsq_pnp (P3P.hpp:472-502): the sum over ALL correspondences of the sine of the angle between predicted and observed
+ * bearing, sum_i | normalize(R*Xw_i + t) x bv_i | (what PnPPoseAdapter::getError(i) returns, PnPPoseAdapter.hpp:204-210).
+ * pose7 = unit quaternion (w, x, y, z) | t, rounded to the array dtype; every term is evaluated in the array dtype by the
+ * reference's own operation sequence (the reference's bits), the terms are added in fp64 -- the reference adds them one after
+ * the other in Tp, so its printed total differs from *sum_out by its own accumulated rounding only.  Arrays XW, BV (24 B/corr fp32).
+ * count_out (optional): the number of terms. */
+int rpe_sine_error_sum(rpe_context* ctx, const double* pose7, double* sum_out, int64_t* count_out);
+
 /* ---- K1/K2/K3 Gauss-Newton normal equations (new formulation; objective of K1 == shinji()).
  * kind: residual.  pose12 = R row-major (9) | t (3).  out32: H upper triangle row-major (21) | g (6) |
  * sum w r^2 | sum w | 3 pad.  Tangent order (upsilon, omega), update T <- exp(delta)*T (sophus/se3.hpp:314-342).

@@ -285,6 +285,22 @@ void orc_cos_nn(int is_f64, const void* nw, const void* nc, int n, const double*
     for (int i = 0; i < n; i++) out[i] = (double)dot(b.col3(i), s.R * a.col3(i)); }
 }
 
+// R1 lsq_pnp (P3P.hpp:472-502) through the PnPPoseAdapter at pose q7: out2[0] = the reference's total (the terms added one after the other
+// in Tp), out2[1] = the SAME Tp terms added in double (what the device kernel adds); terms (optional, n doubles) = every getError(i)
+void orc_lsq_pnp(int is_f64, const void* xw, const void* bv, int n, const double* q7, double* out2, double* terms) {
+  if (is_f64) {
+    MatX<double> a = load3<double>(xw, n), b = load3<double>(bv, n); SE3<double> s = pose7<double>(q7);
+    PnPPoseAdapter<double> ad(b, a); ad.setRcw(s.R); ad.sett(s.t);
+    out2[0] = lsq_pnp<double>(ad); out2[1] = 0;
+    for (int i = 0; i < n; i++) { const double e = ad.getError(i); out2[1] += e; if (terms) terms[i] = e; }
+  } else {
+    MatX<float> a = load3<float>(xw, n), b = load3<float>(bv, n); SE3<float> s = pose7<float>(q7);
+    PnPPoseAdapter<float> ad(b, a); ad.setRcw(s.R); ad.sett(s.t);
+    out2[0] = (double)lsq_pnp<float>(ad); out2[1] = 0;
+    for (int i = 0; i < n; i++) { const float e = ad.getError(i); out2[1] += (double)e; if (terms) terms[i] = (double)e; }
+  }
+}
+
 // ---- U1, samplers -------------------------------------------------------------------------------
 int orc_ransac_update_num_iters(int is_f64, double p, double ep, int modelPoints, int maxIters) {
   return is_f64 ? RANSACUpdateNumIters<double>(p, ep, modelPoints, maxIters) : RANSACUpdateNumIters<float>((float)p, (float)ep, modelPoints, maxIters);

@@ -123,6 +123,14 @@ class Context:
         L.check(L.lib().rpe_p2p_moments(self._h, flags, _p(out)))
         return out
 
+    def sine_error_sum(self, pose7):
+        """lsq_pnp (reference P3P.hpp:472-502): sum over all correspondences of |normalize(R Xw + t) x bv| at pose7 = (qw, qx, qy, qz, t);
+        returns (sum, number of terms)."""
+        q = np.ascontiguousarray(pose7, np.float64).reshape(7)
+        out, cnt = np.zeros(1), np.zeros(1, np.int64)
+        L.check(L.lib().rpe_sine_error_sum(self._h, _p(q), _p(out), _p(cnt)))
+        return float(out[0]), int(cnt[0])
+
     def normal_eq(self, kind: int, pose, flags: int = 0):
         """Returns (record32, pose_used12)."""
         p = np.array(pose, np.float64).reshape(12).copy()

@@ -4,9 +4,10 @@ hipcc cross-compiles without a GPU.  Kernel units (shared device code in csrc/rp
 csrc/rpe_normal_eq.hip (K1-K3 Gauss-Newton normal equations + the resident form), csrc/rpe_icp.hip (fused ICP rounds),
 csrc/rpe_joint.hip (joint normal equations), csrc/rpe_score.hip (K4 scoring, K4b masks), csrc/rpe_nl.hip (K1' moments, K5, publish
 kernels), csrc/rpe_frontend.hip (depth-frame front end), csrc/rpe_hypotheses.hip (batched hypothesis generation),
-csrc/rpe_prosac.hip (PROSAC order: top-k select + sort); csrc/rpe_capi.hip (C-ABI shim), csrc/library.cpp (reference-compatible
-ao / ao_ransac / py2c and the adapter-level pipelines), csrc/rpe_hostex.cpp (host-side all-reduce between the rank processes of
-one node).  The units compile in parallel (RPE_BUILD_JOBS, default 6)."""
+csrc/rpe_prosac.hip (PROSAC order: top-k select + sort); the host units behind include/rgbd_pose_hip.h Part 2 / 3 (csrc/rpe_host.hpp
+lists them: rpe_context.hip, rpe_receive.hip, rpe_capi.hip = the thin C-ABI shim, rpe_refine.hip, rpe_session.hip, rpe_dist.hip,
+rpe_frontend_api.hip), csrc/library.cpp (reference-compatible ao / ao_ransac / py2c and the adapter-level pipelines),
+csrc/rpe_hostex.cpp (host-side all-reduce between the rank processes of one node).  The units compile in parallel (RPE_BUILD_JOBS, default 6)."""
 from __future__ import annotations
 
 import os
@@ -18,7 +19,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librgbdpose_hip.so")
-SOURCES = ["rpe_normal_eq.hip", "rpe_icp.hip", "rpe_joint.hip", "rpe_score.hip", "rpe_nl.hip", "rpe_frontend.hip", "rpe_hypotheses.hip", "rpe_prosac.hip", "rpe_capi.hip", "library.cpp", "rpe_hostex.cpp"]
+SOURCES = ["rpe_normal_eq.hip", "rpe_icp.hip", "rpe_joint.hip", "rpe_score.hip", "rpe_nl.hip", "rpe_frontend.hip", "rpe_hypotheses.hip", "rpe_prosac.hip", "rpe_context.hip", "rpe_receive.hip", "rpe_capi.hip", "rpe_refine.hip", "rpe_session.hip", "rpe_dist.hip", "rpe_frontend_api.hip", "library.cpp", "rpe_hostex.cpp"]
 ARCH = "gfx950"
 LINK_RT = "--rtlib=libgcc"
 

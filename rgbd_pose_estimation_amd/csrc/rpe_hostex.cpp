@@ -1,7 +1,7 @@
 // Host-side all-reduce between the rank processes of ONE node (include/rgbd_pose_hip.h, rpe_host_exchange_* / rpe_hostex_*).
 //
 // Why it exists: on one GPU the cross-workgroup sums of a reduction already end on the HOST (collecting workgroups send a few run
-// records as tagged pairs; the thread that owns the 6x6 solve adds them, rpe_capi.hip wait_collect).  With the correspondences sharded
+// records as tagged pairs; the thread that owns the 6x6 solve adds them, rpe_receive.hip wait_collect).  With the correspondences sharded
 // over the GPUs of a node every rank's host thread therefore holds its shard's 32-double record a few microseconds after its kernel's
 // last workgroup -- and the rank processes share the node's memory.  Exchanging 256 bytes between host threads through a POSIX
 // shared-memory segment costs a cache-line transfer per peer (well under a microsecond), where a collective on the GPUs costs two more

@@ -150,7 +150,7 @@ template <class T> struct StructSums {
     t.cost += (cost_xy.x + cost_xy.y) + cost_z; t.weight += weight;
   }
 };
-// CLEAN flavour (rpe_capi.hip clean-first protocol): "a NaN or an infinity anywhere in the arrays makes at least one sum non-finite".
+// CLEAN flavour (rpe_receive.hip clean-first protocol): "a NaN or an infinity anywhere in the arrays makes at least one sum non-finite".
 // Where a term's own logic would keep such a value out of the sums (the reprojection validity test), the values are multiplied into the
 // cost by hand: 0 x finite = +0 (the sum of squares keeps its bits), 0 x NaN = 0 x inf = NaN.
 template <class T> __device__ __forceinline__ void clean_poison(T a, T b, T c, T d, T e, T f, T& cost) {

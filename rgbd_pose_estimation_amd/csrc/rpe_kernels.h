@@ -1,4 +1,4 @@
-// Internal launcher interface between the C-ABI shim (rpe_capi.hip) and the gfx950 kernel units (rpe_normal_eq.hip,
+// Internal launcher interface between the host units (rpe_host.hpp: rpe_capi.hip, rpe_refine.hip ...) and the gfx950 kernel units (rpe_normal_eq.hip,
 // rpe_icp.hip, rpe_joint.hip, rpe_score.hip, rpe_nl.hip; shared device code: rpe_reduce.hpp, rpe_residuals.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -66,7 +66,7 @@ struct ReduceTarget {
   int rows = 0;
   // normal-equation kernels (one launch and resident): the flavour WITHOUT NaN guards.  Only for arrays known or about to be verified
   // to hold finite values: the shim launches it first and repeats the launch in the guarded flavour if the record comes back
-  // non-finite (rpe_capi.hip clean_first); results nobody on the host inspects use it only for arrays already verified
+  // non-finite (rpe_receive.hip clean-first protocol); results nobody on the host inspects use it only for arrays already verified
   bool clean = false;
   int solver = 0;              // autonomous resident loops: 1 = launch_auto_solver's workgroup sums, solves and hands the poses out
   int stride = 0;              // resident kernels: > 1 = strided runs (see Finish)
@@ -118,6 +118,9 @@ hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags,
 hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, double pivot_floor, hipStream_t s);
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr,
                           hipEvent_t ev_end = nullptr);
+// R1 lsq_pnp: sum of the sine residuals at pose7 (quaternion | t), arrays XW and BV; record = sum | count
+hipError_t launch_sine_error(const DeviceArrays& A, const double* pose7, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr,
+                             hipEvent_t ev_end = nullptr);
 // fused joint normal equations: terms = bit set over residual kinds (1 << kind); scale / robust / robust_k indexed by kind
 hipError_t launch_normal_eq_joint(const DeviceArrays& A, int terms, int flags, const double* pose12, const double* scale4,
                                   const int* robust4, const double* robust_k4, const ReduceTarget& rt, hipStream_t s,

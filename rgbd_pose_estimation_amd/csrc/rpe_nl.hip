@@ -89,6 +89,65 @@ __global__ __launch_bounds__(BLK) void moments_kernel(const T* __restrict__ xw, 
 }
 
 // ================================================================================================
+// R1 : lsq_pnp (P3P.hpp:472-502) -- sum over ALL correspondences of the sine of the angle between the predicted and the observed
+// bearing, err_i = | normalize(R Xw_i + t) x bv_i |, every err_i evaluated in the array dtype by the reference's own operation
+// sequence (SO3 * v = Eigen _transformVector, sophus/so3.hpp:238-240; normalize() = division by the square root of the squared
+// norm; cross; norm), contraction off: the terms are the reference's values bit for bit.  The reference adds them one after the
+// other in Tp; here they are added in fp64 (per-thread, then the fixed-order two-stage reduction), so the total differs from the
+// reference's only by its own accumulated rounding.  record: sum err | count
+// ================================================================================================
+template <class T> struct SinePose { T qw, qx, qy, qz, t[3]; };
+template <class T>
+__device__ __forceinline__ T sine_error(const SinePose<T>& q, T x, T y, T z, T bx, T by, T bz) {
+#pragma clang fp contract(off)
+  T ux = q.qy * z - q.qz * y, uy = q.qz * x - q.qx * z, uz = q.qx * y - q.qy * x;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const T cx = q.qy * uz - q.qz * uy, cy = q.qz * ux - q.qx * uz, cz = q.qx * uy - q.qy * ux;
+  T px = ((x + q.qw * ux) + cx) + q.t[0], py = ((y + q.qw * uy) + cy) + q.t[1], pz = ((z + q.qw * uz) + cz) + q.t[2];
+  const T len = sqrt(px * px + py * py + pz * pz);
+  px = px / len; py = py / len; pz = pz / len;
+  const T ex = py * bz - pz * by, ey = pz * bx - px * bz, ez = px * by - py * bx;
+  return sqrt(ex * ex + ey * ey + ez * ez);
+}
+template <class T, int BLK>
+__global__ __launch_bounds__(BLK) void sine_error_kernel(const T* __restrict__ xw, const T* __restrict__ bv, int64_t n, SinePose<T> q, Finish fin) {
+  constexpr int P = Pk<T>::P;
+  typedef typename Pk<T>::V V;
+  double acc[2] = {0.0, 0.0};
+  const int64_t full = n / P;
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  const V* __restrict__ xw4 = reinterpret_cast<const V*>(xw);
+  const V* __restrict__ bv4 = reinterpret_cast<const V*>(bv);
+  int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  V a0, a1, a2, b0, b1, b2;
+  if (g < full) { a0 = xw4[3 * g]; a1 = xw4[3 * g + 1]; a2 = xw4[3 * g + 2]; b0 = bv4[3 * g]; b1 = bv4[3 * g + 1]; b2 = bv4[3 * g + 2]; }
+  while (g < full) {   // the streaming pipeline of moments_kernel: the next group's loads are in flight while this one is evaluated
+    const int64_t gn = g + stride;
+    const int64_t gl = gn < full ? gn : g;
+    const V na0 = xw4[3 * gl], na1 = xw4[3 * gl + 1], na2 = xw4[3 * gl + 2];
+    const V nb0 = bv4[3 * gl], nb1 = bv4[3 * gl + 1], nb2 = bv4[3 * gl + 2];
+    T vw[3 * P], vb[3 * P];
+    unpack3(a0, a1, a2, vw);
+    unpack3(b0, b1, b2, vb);
+#pragma unroll
+    for (int i = 0; i < P; i++) acc[0] += (double)sine_error<T>(q, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], vb[3 * i], vb[3 * i + 1], vb[3 * i + 2]);
+    acc[1] += (double)P;
+    a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
+    g = gn;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && full * P < n) {
+    T vw[3 * P], vb[3 * P];
+    load_group<T>(xw, full, n, vw);
+    load_group<T>(bv, full, n, vb);
+    for (int i = 0; i < (int)(n - full * P); i++) {
+      acc[0] += (double)sine_error<T>(q, vw[3 * i], vw[3 * i + 1], vw[3 * i + 2], vb[3 * i], vb[3 * i + 1], vb[3 * i + 2]);
+      acc[1] += 1.0;
+    }
+  }
+  reduce_and_finish<2, kNeLd, 0, BLK>(acc, fin);
+}
+
+// ================================================================================================
 // K5 : one round of nl_shinji_kneip_ls + find_opt_cc  (AbsoluteOrientationNormal.hpp:484-505, :24-39)
 // record (44): M23 (9) TW K | M33 (9) sigma | MNN (9) TL M | AA xx xy xz yy yz zz | bb (3) | pad
 // ================================================================================================
@@ -446,6 +505,19 @@ static hipError_t moments_t(const DeviceArrays& A, int flags, const ReduceTarget
 }
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   return A.dtype ? moments_t<double>(A, flags, rt, s, e0, e1) : moments_t<float>(A, flags, rt, s, e0, e1);
+}
+
+template <class T>
+static hipError_t sine_error_t(const DeviceArrays& A, const double* pose7, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  SinePose<T> q;
+  q.qw = (T)pose7[0]; q.qx = (T)pose7[1]; q.qy = (T)pose7[2]; q.qz = (T)pose7[3];
+  for (int i = 0; i < 3; i++) q.t[i] = (T)pose7[4 + i];
+  const int G = reduce_grid(A.n, Pk<T>::P, rt.max_blocks, 256);
+  RPE_LAUNCH_EV((sine_error_kernel<T, 256>), dim3(G), dim3(256), 0, s, e0, e1, (const T*)A.a[0], (const T*)A.a[2], A.n, q, make_finish(rt));
+  return hipGetLastError();
+}
+hipError_t launch_sine_error(const DeviceArrays& A, const double* pose7, const ReduceTarget& rt, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  return A.dtype ? sine_error_t<double>(A, pose7, rt, s, e0, e1) : sine_error_t<float>(A, pose7, rt, s, e0, e1);
 }
 
 template <class T, int BLK>

@@ -331,7 +331,7 @@ static hipError_t resident_t(const DeviceArrays& A, int kind, int flags, const u
 // smaller part has fewer than 256 -- and never more than one workgroup per compute unit, whatever a light instance would allow (the
 // occupancy query is known to come out one block too high at some SGPR counts: MI355X_MICROARCH.md, correctness boundaries).  What
 // cannot be known here is another process on the same GPU; that case is caught at run time (a run whose granules never arrive tells
-// the host, which finishes the refinement with one launch per iteration: rpe_capi.hip resident_host_loop).
+// the host, which finishes the refinement with one launch per iteration: rpe_host.hpp resident_host_loop).
 int resident_cap_device() {
   static int cap[64];
   static bool known[64];

@@ -664,7 +664,7 @@ __device__ __forceinline__ double sum_rows(const double (*part)[NACC], int nr) {
 // sequence number} (one sc1 store per lane; no drain, no arrival counter) and are done; the collecting workgroup reads its run's
 // granules (collect_rows), adds the rows in a fixed order and sends the run's NACC sums to pinned host memory as tagged 16-byte pairs
 // (slot 1 + run * NACC + j; slot 0 = a header pair from workgroup 0 that tells the host how many runs of how many sums to expect).
-// The host adds the runs in run order and expands the record (rpe_capi.hip wait_collect).  R = BLK / NACC rows (one granule per
+// The host adds the runs in run order and expands the record (rpe_receive.hip wait_collect).  R = BLK / NACC rows (one granule per
 // collecting thread) times 1..4, aiming at <= 8 runs; longer still if the runs would not fit in ~512 pairs. One hand-off hop of ~1 us
 // replaces the arrival counters + the last
 // workgroup's re-read of all G records + the drain before the flag (profiles/r02_tail_timeline.jsonl); the sums are a fixed function

@@ -270,7 +270,7 @@ __device__ __forceinline__ void p2p_pair(const PoseK<double>& T, const C (&x)[2]
 // caller decides how many groups share one widening into the fp64 accumulators -- flush_pairs).
 // CLEAN: the caller vouches that every value of the arrays is finite (the C-ABI shim launches the CLEAN flavour of a kernel first and
 // looks at the record it reads anyway: a NaN or an infinity anywhere in the arrays makes at least one sum non-finite -- 0 x NaN = NaN --
-// and the launch is repeated in the guarded flavour, rpe_capi.hip clean_first).  No NaN guards and no selects: a correspondence is
+// and the launch is repeated in the guarded flavour, rpe_receive.hip clean-first protocol).  No NaN guards and no selects: a correspondence is
 // switched off by its weight alone (0 x finite = 0: the same bits the guarded form adds); entries past the end of the arrays were
 // loaded as zeros and get weight 0.  17 % of the guarded group's instructions.
 template <class T, int KIND, bool MASK, bool WEIGHT, bool CLEAN, int NS>
@@ -313,7 +313,7 @@ __device__ __forceinline__ void pair_group(const PoseK<double>& pose, const T (&
     else if constexpr (KIND == KIND_BEARING) bearing_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
     else {
       reproj_pair<T>(pose, x, y, z, bx, by, bz, wi, s2);
-      // CLEAN promises "a NaN or an infinity anywhere in the arrays makes at least one sum non-finite" (rpe_capi.hip clean-first protocol).
+      // CLEAN promises "a NaN or an infinity anywhere in the arrays makes at least one sum non-finite" (rpe_receive.hip clean-first protocol).
       // reproj_prepare switches a correspondence with p_z or bv_z not above kReprojMinZ off -- which a NaN is -- and hands harmless
       // geometry on, so the inputs are multiplied into the cost slot by hand: 0 x finite = +0 (the sum of squares keeps its bits),
       // 0 x NaN = 0 x inf = NaN

@@ -120,7 +120,7 @@ template <class T> struct Hyp<T, true> {
     const T cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
     ox = (x + qw * ux) + cx; oy = (y + qw * uy) + cy; oz = (z + qw * uz) + cz;
   }
-  // `cut` = the smallest value whose correctly rounded square root reaches thre_3d (computed on the host, rpe_capi.hip sqrt_cut):
+  // `cut` = the smallest value whose correctly rounded square root reaches thre_3d (computed on the host, rpe_host.hpp sqrt_cut):
   // sqrt is monotonic, so  sqrt(s) < thre_3d  <=>  s < cut  for every s -- the reference's test, bit for bit, without the square root
   // (a third of the instructions of this predicate).  s is formed exactly as Eigen's squaredNorm() forms it.
   __device__ __forceinline__ bool in33(T x, T y, T z, T cx, T cy, T cz, T cut) const {

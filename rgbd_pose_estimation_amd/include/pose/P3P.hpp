@@ -226,13 +226,21 @@ void kneip_prosac(PnPPoseAdapter<Tp>& adapter, const Tp thre_2d_, int& Iter, Tp 
   rpe::kneip_sac<Tp>(adapter, thre_2d_, Iter, confidence, true, opt);
 }
 
-// Sum of the per-correspondence sine residuals at the adapter's pose (reference :472-502 prints it; returned here).
-// O(N) on the host through the virtual getters, as in the reference -- the GPU form of this residual is K3 (GaussNewton.hpp).
+// Sum of the per-correspondence sine residuals at the adapter's pose (reference :472-502 prints it; returned here): ONE pass of the
+// device kernel over the adapter's HBM-resident arrays (rpe_sine_error_sum, csrc/rpe_nl.hip sine_error_kernel).  Every term is
+// getError(i) bit for bit -- the reference's operation sequence in Tp; the terms are added in fp64 on the device, so the total differs
+// from the reference's sequential Tp sum only by that sum's own accumulated rounding.
 template <typename Tp>
 Tp lsq_pnp(PnPPoseAdapter<Tp>& adapter) {
-  Tp total_err = 0;
-  for (int i = 0; i < adapter.getNumberCorrespondences(); i++) total_err += adapter.getError(i);
-  return total_err;
+  const int N = adapter.getNumberCorrespondences();
+  if (N <= 0) return Tp(0);
+  rpe::DeviceSet& dev = adapter.device();
+  dev.template ensure<Tp>(RPE_XW, adapter.pointsGlobData(), N);
+  dev.template ensure<Tp>(RPE_BV, adapter.bearingData(), N);
+  double q7[7], total = 0;
+  rpe::pose7<Tp>(rpe::SE3<Tp>(adapter.getRcw(), adapter.gettw()), q7);
+  rpe::check(rpe_sine_error_sum(dev.ctx(), q7, &total, nullptr), "rpe_sine_error_sum");
+  return (Tp)total;
 }
 
 #endif

@@ -82,6 +82,14 @@ int main() {
     const int v23 = a.getMaxVotes();
     CHECK(v23 > N / 2 && count23(a, N) == v23 && (int)a23->getInlierIdx().size() == v23);
     CHECK(count33(a, N) == (int)a33->getInlierIdx().size());
+    // ---- lsq_pnp (reference P3P.hpp:472-502) at the pose kneip_ransac left: ONE device pass; its terms are getError(i) bit for bit and
+    // are added in double, so the total equals the host's double sum of the same float terms to the last few bits
+    {
+      double host = 0;
+      for (int i = 0; i < N; i++) host += (double)a23->getError(i);
+      const T dev = lsq_pnp<T>(*a23);
+      CHECK(std::fabs((double)dev - host) <= 2e-7 * host && host > 0);
+    }
     // ---- all three modalities
     it = 500;
     nl_shinji_kneip_ransac<T>(a, 0.15f, 8.0f, 0.1f, it, 0.99f);

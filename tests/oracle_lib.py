@@ -179,6 +179,16 @@ def cos_23(xw, bv, pose7, is_f64):
     return out
 
 
+def lsq_pnp(xw, bv, pose7, is_f64, with_terms=False):
+    """(the reference's sequential Tp total, the same Tp terms added in double[, the terms])"""
+    dt = _dt(is_f64)
+    xw, bv = _arr(xw, dt), _arr(bv, dt)
+    q = np.ascontiguousarray(pose7, np.float64)
+    out, terms = np.zeros(2), np.zeros(len(xw))
+    lib().orc_lsq_pnp(int(is_f64), _p(xw), _p(bv), len(xw), _p(q), _p(out), _p(terms))
+    return (out[0], out[1], terms) if with_terms else (out[0], out[1])
+
+
 def cos_nn(nw, nc, pose7, is_f64):
     dt = _dt(is_f64)
     nw, nc = _arr(nw, dt), _arr(nc, dt)

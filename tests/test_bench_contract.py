@@ -66,10 +66,38 @@ def test_missing_legs_and_odd_values_still_give_a_valid_line():
     assert j["valid"] is False and len(j["invalid_reason"]) <= 160
 
 
-def test_a_line_over_the_limit_is_refused(monkeypatch):
-    monkeypatch.setattr(bench, "LINE_LIMIT", 500)
+def test_a_line_over_the_limit_degrades_and_only_the_strict_form_refuses(monkeypatch):
+    """After a whole measurement the driver must get ONE valid line whatever was added to the record: over the limit the emitter drops the
+    optional scalars, shortens the strings and, last, keeps the contract's own members only; strict=True (this test) refuses instead."""
+    full = canned()
+    full["cpu_baseline"]["cpu_model"] = "a very long CPU model string " * 40
+    full["cpu_baseline"]["sample_short"] = "s" * 4000
+    monkeypatch.setattr(bench, "LINE_LIMIT", 1400)
     with pytest.raises(RuntimeError):
-        bench.contract_line(canned())
+        bench.contract_line(full, strict=True)
+    text = bench.contract_line(full)
+    assert len(text) < 1400 and "\n" not in text
+    j = json.loads(text)
+    assert j["truncated"] is True
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in j
+    assert j["config"]["workload"] and j["roofline"]["bound"] == "hbm" and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["cores"] == 1
+    monkeypatch.setattr(bench, "LINE_LIMIT", 700)            # even the last resort fits
+    j = json.loads(bench.contract_line(full))
+    assert len(bench.contract_line(full)) < 700 and j["value"] >= 1e9 and set(j["roofline"]) == {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_file_derived_traffic_names_its_source_and_goes_null_when_the_kernel_changed():
+    """roofline.traffic comes from a committed PMC profile: the line says which file and which kernel-source hash, and bench.py keeps it
+    only while that hash is the hash of the sources this build was compiled from."""
+    idx = bench.profile_entries()
+    assert idx.get("kernel_src_sha256"), "the profile index must record the kernel sources its PMC passes were taken on"
+    assert bench.kernel_source_hash() and len(bench.kernel_source_hash()) == 16
+    full = canned()
+    full["roofline"]["traffic_source"] = "profiles/x.json (PMC passes of this command; kernel sources abc = this build)"
+    assert json.loads(bench.contract_line(full))["roofline"]["traffic_source"].startswith("profiles/x.json")
+    full["roofline"].pop("traffic_source")
+    assert json.loads(bench.contract_line(full))["roofline"]["traffic_source"] == "none"
 
 
 def test_extras_file_holds_the_full_record(tmp_path, monkeypatch):

@@ -11,10 +11,10 @@ import pytest
 
 from bench_util import run_bench
 
-# Several processes share the ONE GPU of the test box here and wait for each other inside kernels: on request only
-# (RPE_TEST_MULTIPROC=1); the smallest peer-to-peer exchange case is part of the default suite (tests/test_gpu_p2p.py).
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1",
-                                                  reason="multi-process-on-one-GPU tests run with RPE_TEST_MULTIPROC=1")]
+# Several processes share the ONE GPU of the test box here and wait for each other inside kernels (every wait bounded): part of the
+# default suite, RPE_TEST_MULTIPROC=0 switches it off.
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") == "0",
+                                                  reason="RPE_TEST_MULTIPROC=0: multi-process-on-one-GPU tests are switched off")]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

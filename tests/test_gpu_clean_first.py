@@ -1,4 +1,4 @@
-"""-m gpu: the CLEAN-first protocol of the normal-equation kernels (rpe_capi.hip clean_first): the flavour without NaN guards is
+"""-m gpu: the CLEAN-first protocol of the normal-equation kernels (rpe_receive.hip clean-first protocol): the flavour without NaN guards is
 launched first, a non-finite record sends the launch through the guarded flavour, and from then on the arrays are known to need
 the guards.  RPE_GUARD_ALWAYS=1 (read at rpe_create) pins a context to the guarded flavour: on finite arrays the two flavours add the
 same bits, on NaN-marked arrays (the reference's "invalid measurement" columns, AOPoseAdapter.hpp:147-152) the protocol must hand back

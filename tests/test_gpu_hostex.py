@@ -12,8 +12,8 @@ import pytest
 
 pytestmark = [pytest.mark.gpu]
 # the cases in which kernels of different processes must run on the one GPU AT THE SAME TIME (two resident grids that wait for each
-# other's hosts), and the 4-rank frame-sized case, run on request like the other multi-process-on-one-GPU tests
-multiproc = pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1", reason="the larger multi-process-on-one-GPU cases run with RPE_TEST_MULTIPROC=1")
+# other's hosts), and the 4-rank frame-sized case: default on, RPE_TEST_MULTIPROC=0 switches them off
+multiproc = pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") == "0", reason="RPE_TEST_MULTIPROC=0: the larger multi-process-on-one-GPU cases are switched off")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -401,3 +401,23 @@ def test_rccl_communicator_one_rank_and_timing_hooks():
     assert 0 <= mn2 <= avg and mn2 < 0.1
     ctx.timing_enable(0, 1)
     ctx.close(); ref.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 257, 4099, 307200])
+@pytest.mark.parametrize("f64", [False, True])
+def test_lsq_pnp_sum_of_sine_residuals(gpu_ctx_factory, oracle, n, f64):
+    """R1 lsq_pnp (reference P3P.hpp:472-502): the device sum against the oracle's -- the same Tp terms (getError(i), the reference's
+    operation sequence) added in double: 1e-13 relative (only the order of the double additions differs); against the reference's own
+    sequential Tp total: within that total's accumulated rounding (n u for float)."""
+    dt = np.float64 if f64 else np.float32
+    sc = util.scene_full(31 + n, n, dt)
+    rng = np.random.default_rng(n)
+    Rp, tp = util.perturbed_pose(rng, sc.R, sc.t)
+    q7 = api.pose7_from_Rt(Rp, tp, f64)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, bv=sc.U)
+    total, count = ctx.sine_error_sum(q7)
+    ref_tp, ref_f64, terms = oracle.lsq_pnp(sc.Q, sc.U, q7, f64, with_terms=True)
+    assert count == n and np.all(terms >= 0) and ref_f64 > 0
+    assert abs(total - ref_f64) <= 1e-13 * ref_f64
+    u = 2.0 ** -53 if f64 else 2.0 ** -24
+    assert abs(total - ref_tp) <= max(4, n) * u * ref_tp

@@ -46,5 +46,12 @@ def test_kernel_counts_and_library_size():
 
 def test_units_without_device_code_have_none():
     _built()
-    for u in ("library", "rpe_hostex", "rpe_capi"):
+    for u in ("library", "rpe_hostex", "rpe_capi", "rpe_context", "rpe_receive", "rpe_refine", "rpe_session", "rpe_dist", "rpe_frontend_api"):
         assert T.kernel_resources(os.path.join(LIB, u + ".o")) == []
+
+
+def test_no_host_unit_outgrows_its_job():
+    """The C-ABI side is split by job (rpe_host.hpp lists the units); none of them may grow back into a catch-all file."""
+    csrc = os.path.join(os.path.dirname(LIB), "csrc")
+    for u in ("rpe_capi.hip", "rpe_context.hip", "rpe_receive.hip", "rpe_refine.hip", "rpe_session.hip", "rpe_dist.hip", "rpe_frontend_api.hip", "rpe_host.hpp"):
+        assert os.path.getsize(os.path.join(csrc, u)) < 40 * 1024, u
