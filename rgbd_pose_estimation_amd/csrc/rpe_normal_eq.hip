@@ -131,16 +131,23 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   reduce_and_finish<NACC, kNeLd, KIND == KIND_P2P ? 1 : 0, BLK>(acc, fin);
 }
 
-// IN_REGS: the grid covers all groups with one group per thread (frame-sized problems): each thread loads its group ONCE, before the
-// loop, and keeps it in registers for the whole refinement.  Otherwise the slice is re-read every iteration (it stays cache resident).
+// NREG: > 0 = the grid covers all groups with NREG groups per thread (frame-sized problems): each thread loads its groups ONCE, before
+// the loop, and keeps them in registers for the whole refinement; 0 = the slice is re-read every iteration (it stays cache resident).
+// A workgroup's slice is BLK x NREG consecutive groups, thread t holding groups t, t + BLK, ... of it.  The in-register instances run
+// 256 threads x 2 groups: an iteration of a frame-sized problem is bound by VECTOR INSTRUCTION ISSUE, not by memory (about 230
+// instructions of arithmetic per group and 180 for the wave's reduce-scatter of the sums, four cycles each), and the 512-thread x 1
+// form put two waves on every SIMD of the 150 compute units it used -- 2 x (230 + 180) instructions per SIMD and iteration; one wave
+// per SIMD with two groups issues 2 x 230 + 180.
 // AUTO: 0 = host-driven; 1 = autonomous, every workgroup adds the run records and solves (resident_auto_stage: grids too small for
-// 2, always one group per thread); 2 = autonomous with a solving workgroup beside the grid (auto_solver_kernel, solver_loop)
-template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, bool IN_REGS, int AUTO, bool CLEAN>
+// 2, always in registers); 2 = autonomous with a solving workgroup beside the grid (auto_solver_kernel, solver_loop)
+template <class T, int KIND, int BLK, bool MASK, bool WEIGHT, int NREG, int AUTO, bool CLEAN>
 __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __restrict__ xw, const T* __restrict__ b, const T* __restrict__ c,
                              const short* __restrict__ mask, const T* __restrict__ weight, int64_t n,
                              const unsigned long long* __restrict__ ctl, unsigned long long first_tag, int max_iters, Finish fin) {
   constexpr int P = Pk<T>::P;
   constexpr int NACC = KIND == KIND_P2P ? 17 : 29;
+  constexpr bool IN_REGS = NREG > 0;
+  constexpr int GPT = IN_REGS ? NREG : 1;
   __shared__ double s_pose[12];
   __shared__ int s_go;
   const int64_t full = n / P, groups = (n + P - 1) / P;
@@ -148,14 +155,19 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
   constexpr bool with_solver = AUTO == 2;
   const int workers = (int)gridDim.x;
   const int64_t stride = (int64_t)workers * BLK;
-  const int64_t g0 = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  T rw[3 * P], rb[3 * P], rc[3 * P];
-  short rm[P];
-  T rwv[P];
-  int rpresent = 0;
-  if (IN_REGS && g0 < groups) {
-    load_any_group<T, KIND, MASK, WEIGHT>(xw, b, c, mask, weight, g0, full, n, rw, rb, rc, rm, rwv);
-    rpresent = g0 < full ? P : (int)(n - full * P);
+  const int64_t g0 = (int64_t)blockIdx.x * (BLK * GPT) + threadIdx.x;
+  T rw[GPT][3 * P], rb[GPT][3 * P], rc[GPT][3 * P];
+  short rm[GPT][P];
+  T rwv[GPT][P];
+  int rpresent[GPT];
+#pragma unroll
+  for (int r = 0; r < GPT; r++) {
+    rpresent[r] = 0;
+    const int64_t g = g0 + (int64_t)r * BLK;
+    if (IN_REGS && g < groups) {
+      load_any_group<T, KIND, MASK, WEIGHT>(xw, b, c, mask, weight, g, full, n, rw[r], rb[r], rc[r], rm[r], rwv[r]);
+      rpresent[r] = g < full ? P : (int)(n - full * P);
+    }
   }
   // autonomous form (fin.gn set): the first pose comes from HBM, every later one from this workgroup's own solve (resident_auto_stage)
 #ifdef RPE_SOLVER_DEBUG
@@ -186,7 +198,9 @@ __global__ __launch_bounds__(BLK) void normal_eq_resident_kernel(const T* __rest
 #pragma unroll
     for (int k = 0; k < NACC; k++) acc[k] = 0.0;
     if (IN_REGS) {
-      if (rpresent > 0) normal_eq_group<T, KIND, MASK, WEIGHT, NACC, CLEAN>(pose, rw, rb, rc, rm, rwv, rpresent, acc);
+#pragma unroll
+      for (int r = 0; r < GPT; r++)
+        if (rpresent[r] > 0) normal_eq_group<T, KIND, MASK, WEIGHT, NACC, CLEAN>(pose, rw[r], rb[r], rc[r], rm[r], rwv[r], rpresent[r], acc);
     } else {
       for (int64_t g = g0; g < groups; g += stride) {
         T vw[3 * P], vb[3 * P], vc[3 * P];
@@ -299,9 +313,12 @@ static void resident_launch(const DeviceArrays& A, int flags, const unsigned lon
   if (fin.rows > kMaxRows) fin.rows = kMaxRows;
   if (fin.rows < 1) fin.rows = 1;
   if (fin.gn == nullptr) fin.solver = 0;
-#define RPE_RES_LAUNCH4(M, W, R, AU, C) RPE_LAUNCH_EV((normal_eq_resident_kernel<T, KIND, BLK, M, W, R, AU, C>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin)
+  // in registers (R): 256 threads x 2 groups per workgroup -- the same BLK-group slice per workgroup, one wave per SIMD; streaming: BLK
+  // threads, one group per thread and trip
+#define RPE_RES_LAUNCH4(M, W, R, AU, C) do { if constexpr (R) RPE_LAUNCH_EV((normal_eq_resident_kernel<T, KIND, BLK / kResidentGroupsPerThread, M, W, kResidentGroupsPerThread, AU, C>), dim3(G), dim3(BLK / kResidentGroupsPerThread), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); \
+                                             else RPE_LAUNCH_EV((normal_eq_resident_kernel<T, KIND, BLK, M, W, 0, AU, C>), dim3(G), dim3(BLK), 0, s, ev0, ev1, xw, b, c, mask, weight, A.n, ctl, first_tag, max_iters, fin); } while (0)
 #define RPE_RES_LAUNCH3(M, W, R, AU) do { if constexpr (sizeof(T) == 4) { if (rt.clean) { RPE_RES_LAUNCH4(M, W, R, AU, true); break; } } RPE_RES_LAUNCH4(M, W, R, AU, false); } while (0)
-  // (autonomous without a solving workgroup: only grids of fewer than 8 workgroups -- always one group per thread)
+  // (autonomous without a solving workgroup: only grids of fewer than 8 workgroups -- always in registers)
 #define RPE_RES_LAUNCH2(M, W, R) do { if (fin.gn != nullptr) { if (fin.solver) RPE_RES_LAUNCH3(M, W, R, 2); else if constexpr (R) RPE_RES_LAUNCH3(M, W, R, 1); } \
                                       else RPE_RES_LAUNCH3(M, W, R, 0); } while (0)
   // (fp64 arrays, the two-row 2D-3D kinds, more than one group per thread: no instance -- it spilled 7-45 registers; the callers ask
@@ -341,12 +358,14 @@ int resident_cap_device() {
   int cus = 0, c = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
   int per_cu = 1;
-  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, false, 0, false>,
-                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, 512, true, false, true, 1, false>,
-                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, 512, true, true, true, 0, false>};
-  for (const void* k : heavy) {
+  constexpr int kRegBlk = 512 / kResidentGroupsPerThread;
+  const void* heavy[] = {(const void*)normal_eq_resident_kernel<float, KIND_P2PLANE, 512, true, true, 0, 0, false>,
+                         (const void*)normal_eq_resident_kernel<float, KIND_P2P, kRegBlk, true, false, kResidentGroupsPerThread, 1, false>,
+                         (const void*)normal_eq_resident_kernel<double, KIND_BEARING, kRegBlk, true, true, kResidentGroupsPerThread, 0, false>};
+  const int heavy_blk[] = {512, kRegBlk, kRegBlk};
+  for (int i = 0; i < 3; i++) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 512, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, heavy[i], heavy_blk[i], 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
     if (nb < per_cu) per_cu = nb;
   }
   c = per_cu >= 1 ? cus : 0;

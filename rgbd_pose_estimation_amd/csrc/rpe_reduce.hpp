@@ -188,8 +188,16 @@ template <class V> __device__ __forceinline__ bool group_dirty(const V& a0, cons
 // then row_bcast:15 / row_bcast:31 fold the four rows; the total lands in lane 63.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_move(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  // The lanes a DPP move does not write keep the destination's OLD value.  With all rows enabled and a control whose source lane always
+  // exists (quad_perm, row_ror, row_half_mirror) every lane is written, so the old value is never seen: it is left undefined (an
+  // output-only empty asm: a register, no instruction) instead of the "v_mov_b32 v, 0" per half that a zero would cost -- 2 of the 5
+  // instructions of an fp64 step of the wave reductions, which are bound by instruction issue.  The row_bcast
+  // steps write two rows only and add the rest as zeros: they keep the zero.
+  constexpr bool all_written = ROW_MASK == 0xf && (CTRL < 0x100 || (CTRL >= 0x121 && CTRL <= 0x12f) || CTRL == 0x140 || CTRL == 0x141);
+  int old_lo = 0, old_hi = 0;
+  if (all_written) { asm("" : "=v"(old_lo)); asm("" : "=v"(old_hi)); }
+  const int lo = __builtin_amdgcn_update_dpp(old_lo, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(old_hi, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum_to_lane63(double v) {
@@ -628,6 +636,28 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
   return lost;
 }
 
+// Fixed-order sum over the nr (<= RGN) rows of part[..][NACC] (LDS) by the threads j < NACC alone, behind the ONE workgroup barrier that
+// says every granule has arrived: two interleaved chains (even rows, odd rows: the LDS reads are all in flight at once, the dependent
+// fp64 additions are half as deep), added at the end.  Replaces sum_rows -- one thread per (block of six rows, value), a second
+// workgroup barrier, the block sums -- on the critical path of every resident iteration and of every one-launch reduction: the second
+// barrier and the second LDS round cost more than the 15 - 30 additions they spread (0.24 us from "all granules read" to "run record
+// stored" at 150 workgroups, profiles/r05_resident_timeline.jsonl).  The order is a fixed function of nr.
+template <int NACC, int RGN>
+__device__ __forceinline__ double sum_rows_lane(const double (*part)[NACC], int nr, int j) {
+  // every row of the array is read, unconditionally and at once (rows past nr hold older values: selected away) -- a read behind a test
+  // of nr would wait for the one before it
+  double v[RGN];
+#pragma unroll
+  for (int k = 0; k < RGN; k++) v[k] = part[k][j];
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int k = 0; k < RGN; k += 2) {
+    a += k < nr ? v[k] : 0.0;
+    if (k + 1 < RGN) b += k + 1 < nr ? v[k + 1] : 0.0;
+  }
+  return a + b;
+}
+
 // Fixed-order sum over the nr (<= RGN) rows of part[..][NACC] (LDS), for every value j, by the whole collecting workgroup: blocks of
 // six
 // rows first -- one thread per (block, value), six LDS reads in flight -- a workgroup barrier, then the block sums in block order.  A
@@ -708,8 +738,8 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   RPE_STAMP(7);
   if (__syncthreads_or(lost)) return;   // nothing published: the host reports the kernel as having finished without its result
   RPE_STAMP(8);
-  const double t = sum_rows<NACC, BLK>(c_part, rows < RGN ? rows : RGN);
-  if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x, t, fin.seq);
+  if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x,
+      sum_rows_lane<NACC, RGN>(c_part, rows < RGN ? rows : RGN, threadIdx.x), fin.seq);
   if (blockIdx.x == 0 && threadIdx.x == 64) {   // header: runs | sums per run << 16 | record layout << 24
     const unsigned long long hdr = (unsigned long long)nruns | ((unsigned long long)NACC << 16) | ((unsigned long long)MODE << 24);
     store_tagged_pair(fin.out_host, 0, __longlong_as_double((long long)hdr), fin.seq);

@@ -472,35 +472,35 @@ __device__ __forceinline__ bool resident_cross_own(double own, const Finish& fin
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(fin.partials);   // [workgroup][NACC] granules of 2 words
   const RunShape rs = run_shape(fin, (int)gridDim.x);
   const int run = rs.run, leader = rs.leader;
-  if (threadIdx.x < NACC) {
+  if ((int)blockIdx.x != leader) {
     // test hook: a granule that never comes
     const bool withheld = fin.fault_tag != 0 && tag == fin.fault_tag && blockIdx.x + 1 == gridDim.x;
-    if ((int)blockIdx.x != leader) { if (!withheld) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag); }
-    else g_part[0][threadIdx.x] = own;
+    if (threadIdx.x < NACC && !withheld) store_granule16(gran + 2 * ((size_t)blockIdx.x * NACC + threadIdx.x), own, tag);
+#ifdef RPE_STAMPS
+    if (stamp_it) RPE_STAMP(2);
+#endif
+    return true;
   }
+  if (threadIdx.x < NACC) g_part[0][threadIdx.x] = own;
 #ifdef RPE_STAMPS
   if (stamp_it) RPE_STAMP(2);
 #endif
-  bool ok = true;
-  if ((int)blockIdx.x == leader) {
-    const int rows = rs.rows;
-    const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part, rs.step);
+  const int rows = rs.rows;
+  const bool lost = collect_rows<NACC, BLK>(gran, (int)gridDim.x, leader, rows, tag, g_part, rs.step);
 #ifdef RPE_STAMPS
-    if (stamp_it) RPE_STAMP(3);
+  if (stamp_it) RPE_STAMP(3);
 #endif
-    if (__syncthreads_or(lost)) ok = false;
+  const bool ok = !__syncthreads_or(lost);   // every granule of the run has arrived (or one never will)
 #ifdef RPE_STAMPS
-    if (stamp_it) RPE_STAMP(4);
+  if (stamp_it) RPE_STAMP(4);
 #endif
-    const double t = sum_rows<NACC, BLK>(g_part, rows < RGN ? rows : RGN);
-    // a run with a missing granule tells the host so (it releases the grid and finishes with one launch per iteration)
-    if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, run * NACC + threadIdx.x,
-        ok ? t : __longlong_as_double((long long)kLostMarker), seq);
+  // the run's sums by the threads that send them (sum_rows_lane: no second barrier); a run with a missing granule tells the host so (it
+  // releases the grid and finishes with one launch per iteration).  g_part is rewritten only behind the next wait's workgroup barrier.
+  if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, run * NACC + threadIdx.x,
+      ok ? sum_rows_lane<NACC, RGN>(g_part, rows < RGN ? rows : RGN, threadIdx.x) : __longlong_as_double((long long)kLostMarker), seq);
 #ifdef RPE_STAMPS
-    if (stamp_it) RPE_STAMP(5);
+  if (stamp_it) RPE_STAMP(5);
 #endif
-  }
-  __syncthreads();   // g_part is reused by the next iteration
   return ok;
 }
 template <int NACC, int BLK>
@@ -801,5 +801,8 @@ static inline bool auto_solver_grid(int workers, int cap) {
 // per step at 307 200 points, 46 vs 39 us at 10 M -- although they win for the one-launch kernels: twice the workgroups poll the
 // control block and twice the granules cross the hop every iteration.  The largest grid: resident_cap_device() (rpe_kernels.h).
 static inline int resident_block() { return 512; }
+// ... of which the in-register instances of the normal-equation kernel run 512 / kResidentGroupsPerThread threads, each holding that
+// many groups of its workgroup's 512-group slice (one wave per SIMD: rpe_normal_eq.hip normal_eq_resident_kernel)
+constexpr int kResidentGroupsPerThread = 2;
 
 }  // namespace rpe
