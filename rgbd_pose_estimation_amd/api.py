@@ -2,6 +2,7 @@
 multi-GPU driver.  All computation happens in librgbdpose_hip.so on the GPU; nothing here computes."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -367,6 +368,18 @@ class Context:
 
     def score_session_end(self):
         L.check(L.lib().rpe_score_session_end(self._h))
+
+    @contextlib.contextmanager
+    def score_session(self, kind: int, thre_3d=0.0, cos_thr=2.0, cos_nl=2.0, mode=L.SCORE_EXACT):
+        """`with ctx.score_session(kind, ...) as resident:` -- the session is ended on the way out whatever happens inside (an exception
+        between _begin and _end would otherwise leave the device's resident slot to the session until its grid's bounded wait has run
+        out: other contexts then run without resident grids for up to 2 s).  `resident` = whether a session could be opened."""
+        opened = self.score_session_begin(kind, thre_3d, cos_thr, cos_nl, mode)
+        try:
+            yield opened
+        finally:
+            if opened and self._h:
+                self.score_session_end()
 
     def nl_round(self, c_opt, Cw, Cc, Rwc) -> np.ndarray:
         a = [np.ascontiguousarray(x, np.float64) for x in (c_opt, Cw, Cc, Rwc)]

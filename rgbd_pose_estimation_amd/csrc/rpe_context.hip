@@ -104,7 +104,9 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_partials, partial_doubles * sizeof(double));
   // granule tags start below every sequence value
   if (e == hipSuccess) e = hipMemset(c->d_partials, 0, partial_doubles * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, 64 * sizeof(double));
+  // 64 doubles (a record for a collective, the solve probe) + the run records of a sharded step (rpe_dist.hip), zero between steps
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, (64 + rpe::kRunSlots * rpe::kRunLd) * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(c->d_out, 0, (64 + rpe::kRunSlots * rpe::kRunLd) * sizeof(double));
   c->h_big_pairs = 8192 + 64;
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_big, c->h_big_pairs * 16, hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) std::memset(c->h_big, 0, c->h_big_pairs * 16);
@@ -312,6 +314,7 @@ int rpe_timing_enable(rpe_context* c, int max_records, int stride) {
 }
 
 int rpe_timing_collect(rpe_context* c, int* count, double* total_ms, double* min_ms) {
+  session_end(c);   // (the synchronise below would otherwise sit behind an open session's grid for its whole bounded wait)
   if (!c) return fail(RPE_ERR_ARG, "null context");
   HIP_TRY(hipStreamSynchronize(c->stream));
   double tot = 0, mn = 1e30;

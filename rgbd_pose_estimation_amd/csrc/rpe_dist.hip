@@ -221,13 +221,31 @@ int rpe_gn_step_dist(rpe_context* c, int kind, int flags, double* pose12, double
     rt.clean = take_clean(c, kind, false);   // the record is summed with the peers' inside the kernel
     HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
   } else {
-    if ((rc = normal_eq_launch(c, kind, flags, pose12, c->d_out, take_clean(c, kind, false)))) return rc;
-    NCCL_TRY(rccl().AllReduce(c->d_out, c->d_out, 32, ncclFloat64, ncclSum, c->comm, c->stream));
+    // RCCL: ONE launch whose collecting stage leaves its run records in device memory (<= 8 per launch, as the single-GPU launch sends
+    // to the host: one hop on the device, no arrival counters), ONE in-place all-reduce of the kRunSlots x kRunLd doubles -- the
+    // ranks' run records added slot by slot --, and a one-workgroup kernel that sends them to the host as tagged pairs; every rank's
+    // host adds the all-reduced run records in run order (identical sums on every rank) and expands the record.
+    if (kind == RPE_RES_NORMAL) return fail(RPE_ERR_ARG, "RPE_RES_NORMAL is not served by the sharded step");
+    if ((rc = kind_arrays(c, kind))) return rc;
+    if (!pose12) return fail(RPE_ERR_ARG, "null argument");
+    if ((rc = check_flags(c, kind, flags))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    timing_pair(c, &e0, &e1);
+    rpe::ReduceTarget rt = device_runs_target(c);
+    rt.clean = take_clean(c, kind, false);   // nobody on the host sees this rank's own record
+    HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
+    double* runs = c->d_out + 64;
+    constexpr int kRunDoubles = rpe::kRunSlots * rpe::kRunLd;
+    NCCL_TRY(rccl().AllReduce(runs, runs, kRunDoubles, ncclFloat64, ncclSum, c->comm, c->stream));
     const unsigned long long seq = ++c->seq;
-    HIP_TRY(rpe::launch_publish_f64(c->d_out, 32, c->h_out, reinterpret_cast<unsigned long long*>(c->h_out + rpe::kNeLd), seq,
-        c->stream));
+    HIP_TRY(rpe::launch_publish_pairs(runs, kRunDoubles, c->h_big, seq, c->stream));
+    double tot[rpe::kRunLd];
+    if ((rc = wait_host_partials(c, rpe::kRunSlots, rpe::kRunLd, tot))) return rc;
+    if (kind == RPE_RES_P2P) expand_p2p17(tot, c->h_out);
+    else { for (int i = 0; i < 32; i++) c->h_out[i] = i < 29 ? tot[i] : 0.0; }
   }
-  if ((rc = wait_host(c, rpe::kNeLd))) return rc;
+  if (c->p2p_world >= 1 && (rc = wait_host(c, rpe::kNeLd))) return rc;
   double ne[32], d[6];
   for (int i = 0; i < 32; i++) ne[i] = c->h_out[i];
   if (c->p2p_world >= 1 && ne[31] != 0.0) return fail(RPE_ERR_HIP,

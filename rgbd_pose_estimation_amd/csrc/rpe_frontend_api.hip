@@ -1,6 +1,7 @@
 // Part 3 of include/rgbd_pose_hip.h: the depth-frame front end (back-projection, normals, projective association: kernels in
 // rpe_frontend.hip) and ICP over it (fused rounds / resident grids: rpe_icp.hip).  No reference counterpart.
 #include "rpe_host.hpp"
+#include <memory>
 using namespace rpeh;
 
 extern "C" {
@@ -205,13 +206,13 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
     rpe::ReduceTarget rt = host_target(c);
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
     static const bool auto_on = !(getenv("RPE_DEVICE_LOOP_RESIDENT") && atoi(getenv("RPE_DEVICE_LOOP_RESIDENT")) == 0);
-    std::unique_lock<ResidentSlot> one_resident_grid(resident_mutex(c->device), std::defer_lock);
+    const bool want_auto = auto_on && c->resident && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm && c->p2p_world < 1;
+    // the device's resident slot until the result has arrived (end of this block's scope); a session in the slot: one launch per round
+    std::unique_ptr<SlotHold> one_resident_grid(want_auto ? new SlotHold(resident_mutex(c->device)) : nullptr);
     bool one_launch = false;
-    if (auto_on && c->resident && o->fused && o->max_iter >= 2 && !c->hostex && !c->comm
-        && c->p2p_world < 1) {
+    if (want_auto && *one_resident_grid) {
       // ONE launch: the resident grid pairs, sums, solves and updates by itself (icp_resident_kernel with resident_auto_stage)
       one_launch = true;
-      one_resident_grid.lock();   // until the result has arrived (end of this block's scope)
       int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
       rpe::icp_resident_geometry(n, o->kind, c->max_blocks, &grid, &nacc, &max_rows, &rows_auto);
       const unsigned long long base = c->seq;
@@ -252,11 +253,12 @@ int rpe_icp(rpe_context* c, const rpe_icp_options* o, double* pose12, int* iters
           (float)o->cos_thr, o->use_normals,
                                       o->kind, (const unsigned long long*)c->ctl, base, o->max_iter, rt, c->stream);
     };
-    { std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));
-      rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs,
+    { SlotHold one_resident_grid(resident_mutex(c->device));
+      if (!one_resident_grid) rc = kResidentBusy;   // (a session holds the slot: every round a launch)
+      else rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, o->max_iter, o->tol, &it, &step, &cost, &pairs,
           "ICP: normal equations"); }
-    if (rc != RPE_OK && rc != kResidentLost) { if (iters_out) *iters_out = it; return rc; }
-    host_rounds = rc == kResidentLost;   // the grid was lost after `it` whole rounds: the rest one launch per round
+    if (rc != RPE_OK && rc != kResidentLost && rc != kResidentBusy) { if (iters_out) *iters_out = it; return rc; }
+    host_rounds = rc == kResidentLost || rc == kResidentBusy;   // the grid was lost after `it` whole rounds (or never launched): the rest one launch per round
   } else host_rounds = true;
   if (host_rounds) {
     for (; it < o->max_iter; it++) {

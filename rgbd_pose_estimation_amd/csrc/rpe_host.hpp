@@ -22,6 +22,7 @@
 #include <cmath>
 #include <limits>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -36,7 +37,7 @@ struct rpe_context {
   hipStream_t stream = nullptr;
   // resident scoring session (rpe_score_session_begin ... _end): the grid of score_resident_kernel waits for batches in c->ctl
   struct { bool active = false; int kind = 0, mode = 0, grid = 0, runs = 0, batches = 0; double thre_3d = 0, cos_thr = 0, cos_nl = 0;
-           unsigned long long base = 0, id = 0;
+           unsigned long long base = 0, id = 0, slot_token = 0;   // slot_token: this session's hold on the device's resident slot
            double last_us = 0, wait_us = 2e6;   // host clock of the last message / the grid's bounded wait: a message that comes later
            bool pend_late = false;              // than that finds no grid -- the caller's pause, not a lost grid (nothing is counted)
            // every hypothesis the session has scored (pose as the caller gave it -> votes): the winner's total is known without
@@ -44,6 +45,9 @@ struct rpe_context {
            std::vector<double> seen_pose; std::vector<int> seen_votes;
            // the session's LAST message was "write these masks and leave" and its record has not been looked at yet (session_verify)
            bool pending = false; unsigned long long pend_tag = 0; int pend_votes = 0; double pend_pose[7] = {0, 0, 0, 0, 0, 0, 0}; } sess;
+  // guards sess and the control block against the one other party that may touch them: the thread that opened a session and handed
+  // the context on, when it closes "its" session from a call on another context (rpe_session.hip close_session_of_this_thread)
+  std::recursive_mutex sess_m;
   hipStream_t stream2 = nullptr;   // the solving workgroup of the autonomous resident loops runs beside its workers (created on first use)
   hipEvent_t ev_stream2 = nullptr; // ... behind the uploads of the start pose / loop state on `stream`
   bool auto_solver = true;         // ... until the two kernels once failed to meet (a platform that serialises them)
@@ -74,7 +78,7 @@ struct rpe_context {
   int host_cpu_request = -2;     // RPE_HOST_CPU at rpe_create: -2 none, -1 auto (rpe_tune_host_thread at the first resident refinement), >= 0 that CPU
   bool host_cpu_done = false;
   double* d_partials = nullptr;  // max_blocks * kNlLd doubles
-  double* d_out = nullptr;       // 64 doubles
+  double* d_out = nullptr;       // 64 doubles + kRunSlots x kRunLd doubles of run records (rpe_dist.hip)
   double* h_out = nullptr;       // pinned + device-mapped, 64 doubles + sequence word: kernels publish straight into it
   unsigned int* d_ticket = nullptr;
   unsigned long long seq = 0;
@@ -197,11 +201,13 @@ void timing_pair(rpe_context* c, hipEvent_t* e0, hipEvent_t* e1);   // the event
 // ---- rpe_receive.hip: launch targets, the host's side of the result hand-off, clean-first protocol
 constexpr int kResidentLost = -1000;   // internal (never returned through the C ABI): the resident grid lost a granule or ended early
 constexpr int kResidentDirty = -1001;  // internal: the CLEAN flavour's first record was not finite -- the arrays need the guarded flavour
+constexpr int kResidentBusy = -1002;   // internal: a scoring session of another context holds the device's resident slot -- no resident grid now
 enum { kArrUnknown = 0, kArrClean = 1, kArrDirty = 2 };
 int run_stride_from_env();
 rpe::ReduceTarget host_target(rpe_context* c);
 rpe::ReduceTarget collect_target(rpe_context* c);
 rpe::ReduceTarget device_target(rpe_context* c, double* d_out);
+rpe::ReduceTarget device_runs_target(rpe_context* c);   // collecting launch whose run records stay on the device (c->d_out + 64)
 int wait_host(rpe_context* c, int ld);
 int wait_collect(rpe_context* c, int ld);
 int wait_host_partials(rpe_context* c, int grid, int nacc, double* totals, int first_slot = 0, bool resident = false);
@@ -245,14 +251,49 @@ int mask_by_launch(rpe_context* c, int kind, int mode, const double* pose7, doub
 // One resident loop per GPU at a time within this process: two resident grids launched together (two contexts, two threads) could each
 // get only part of their workgroups onto the CUs and then wait for workgroups that cannot start (the bounded waits would end both with
 // an error).  Other PROCESSES on the same GPU are the caller's to serialise.
-// (a lock that may be given back by another thread than the one that took it: a scoring session holds the device's resident slot
-// from rpe_score_session_begin to whatever call ends it, and a context may be handed from one thread to the next in between --
-// std::mutex forbids that)
+// The slot is held by a TOKEN, not by a thread: a scoring session holds it from rpe_score_session_begin to whatever call ends it, and
+// a context may be handed from one thread to the next in between.  Nobody ever blocks on a session: a resident LOOP holds the slot
+// within one call and all its waits are bounded, so a second loop waits for it; a SESSION holds it across calls, so whoever finds one
+// in the slot either takes the slot over -- if the session's grid has provably left: no message for longer than the grid's bounded
+// wait; the session's owner then finds its token revoked at its next message and goes on with ordinary launches -- or gets no slot
+// at all (acquire returns 0: a loop) and runs without a resident grid, one launch per iteration -- or waits its turn (another
+// session), at most until the holder's grid would have left.  (Round 5 blocked there without a time-out: a session left open by an
+// exception, or an owner waiting for the blocked thread, hung the process.)
 struct ResidentSlot {
-  std::mutex m; std::condition_variable cv; bool busy = false;
-  void lock() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return !busy; }); busy = true; }
-  bool try_lock() { std::lock_guard<std::mutex> lk(m); if (busy) return false; busy = true; return true; }
-  void unlock() { { std::lock_guard<std::mutex> lk(m); busy = false; } cv.notify_one(); }
+  std::mutex m; std::condition_variable cv;
+  unsigned long long owner = 0, tokens = 0;   // token of the holder (0 = free)
+  bool session = false;                       // the holder is a scoring session ...
+  double sess_last_us = 0, sess_wait_us = 0;  // ... whose grid leaves by itself sess_wait_us after its last message (host clock)
+  unsigned long long acquire(bool as_session, double wait_us = 0) {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      if (owner == 0) break;
+      if (session) {
+        const double left_us = sess_last_us + sess_wait_us + 5e4 - clock_us();
+        if (left_us <= 0) break;      // its grid has left: the slot changes hands
+        if (!as_session) return 0;    // a loop does not wait for a session: it runs without a resident grid
+        cv.wait_for(lk, std::chrono::microseconds((long long)left_us + 1));   // a session waits its turn -- at most until then
+        continue;
+      }
+      cv.wait(lk);
+    }
+    owner = ++tokens; session = as_session; sess_last_us = clock_us(); sess_wait_us = wait_us;
+    return owner;
+  }
+  // session holder, before every message: still mine?  (and the grid's wait starts anew)
+  bool touch(unsigned long long token) { std::lock_guard<std::mutex> lk(m); if (owner != token) return false; sess_last_us = clock_us(); return true; }
+  void release(unsigned long long token) {
+    { std::lock_guard<std::mutex> lk(m); if (owner != token || token == 0) return; owner = 0; session = false; }
+    cv.notify_all();
+  }
+};
+// a resident loop's hold on the slot for the length of a scope; false = a session is in the slot: run without a resident grid
+struct SlotHold {
+  ResidentSlot& slot; unsigned long long token;
+  explicit SlotHold(ResidentSlot& s) : slot(s), token(s.acquire(false)) {}
+  ~SlotHold() { slot.release(token); }
+  SlotHold(const SlotHold&) = delete; SlotHold& operator=(const SlotHold&) = delete;
+  explicit operator bool() const { return token != 0; }
 };
 ResidentSlot& resident_mutex(int device);
 int resident_run_shape(int grid, int nacc, int max_rows, int rows_auto, rpe::ReduceTarget* rt);

@@ -10,6 +10,10 @@ constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kNeLd = 32;            // doubles per normal-equation / moment partial record
 constexpr int kNlLd = 64;            // doubles per nl_round partial record
 constexpr int kMaxScoreH = 8192;     // hypotheses per scoring launch (LDS vote table = 32 KiB)
+// run records of a collecting launch kept on the device for a collective (ReduceTarget: rows > 0 with d_out set): kRunSlots slots of
+// kRunLd doubles; a launch of <= 256 workgroups has at most 8 runs (rpe_reduce.hpp collect_and_send), absent ones are zero
+constexpr int kRunSlots = 8;
+constexpr int kRunLd = 32;
 
 // Correspondence arrays resident in HBM.  3 x n column-major (xyz interleaved), dtype 0 = f32, 1 = f64.
 struct DeviceArrays {
@@ -164,8 +168,7 @@ hipError_t launch_nl_round(const DeviceArrays& A, const double* params24, const 
                            hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 
 // copy `count` reduced values from HBM to pinned host memory and then store `seq` to *h_flag (the host spins on it)
-hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq,
-    hipStream_t s);
+hipError_t launch_publish_pairs(const double* d_src, int count, double* h_pairs, unsigned long long seq, hipStream_t s);   // {value, seq} pairs, no flag
 // sharded scoring: exchange the `count` vote counters with the peers (same mailbox protocol as the records, one word per
 // hypothesis), add them in rank order, publish the totals, zero the counters.  *h_status is set to 1 if a peer timed out.
 hipError_t launch_publish_votes_p2p(int* d_votes, int count, const P2PDesc* p2p, unsigned long long step, int* h_dst, int* h_status,

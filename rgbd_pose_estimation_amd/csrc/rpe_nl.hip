@@ -407,9 +407,13 @@ __global__ void publish_kernel(const E* __restrict__ src, int count, E* __restri
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-hipError_t launch_publish_f64(const double* d_src, int count, double* h_dst, unsigned long long* h_flag, unsigned long long seq,
-    hipStream_t s) {
-  hipLaunchKernelGGL((publish_kernel<double>), dim3(1), dim3(64), 0, s, d_src, count, h_dst, h_flag, seq);
+// ... as tagged 16-byte pairs {value, sequence} (store_tagged_pair: one system-scope store each, the tag travels with the value): no
+// drain of the PCIe writes in front of a flag -- the host waits until every pair carries the sequence value (wait_host_partials)
+__global__ void publish_pairs_kernel(const double* __restrict__ src, int count, double* __restrict__ h_pairs, unsigned long long seq) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) store_tagged_pair(h_pairs, i, src[i], seq);
+}
+hipError_t launch_publish_pairs(const double* d_src, int count, double* h_pairs, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(publish_pairs_kernel, dim3(1), dim3(256), 0, s, d_src, count, h_pairs, seq);
   return hipGetLastError();
 }
 hipError_t launch_publish_i32(const int* d_src, int count, int* h_dst, unsigned long long* h_flag, unsigned long long seq,

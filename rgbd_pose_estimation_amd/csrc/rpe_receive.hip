@@ -41,6 +41,14 @@ rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
   c->collecting = false;
   return rt;
 }
+// sharded step behind a collective: the collecting stage of the host-consumed launches, its run records left in device memory
+// (kRunSlots x kRunLd doubles at c->d_out + 64) for the collective to add across the ranks -- one hop on the device, as on one GPU
+rpe::ReduceTarget device_runs_target(rpe_context* c) {
+  rpe::ReduceTarget rt = device_target(c, c->d_out + 64);
+  rt.rows = 1 << 20; rt.stride = 8;
+  rt.seq = ++c->seq;   // the granules of the collecting stage carry the launch's sequence number as their tag
+  return rt;
+}
 // Spin on the sequence word the kernel's last workgroup stores after the record (pinned, coherent host memory).
 int wait_host(rpe_context* c, int ld) {
   if (c->collecting) { c->collecting = false; return wait_collect(c, ld); }

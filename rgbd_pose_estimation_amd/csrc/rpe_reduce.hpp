@@ -738,6 +738,16 @@ __device__ __forceinline__ void collect_and_send(const double (*red)[NACC], cons
   RPE_STAMP(7);
   if (__syncthreads_or(lost)) return;   // nothing published: the host reports the kernel as having finished without its result
   RPE_STAMP(8);
+  if (fin.out_dev != nullptr) {
+    // sharded step behind a collective (rpe_dist.hip): the run records stay on the DEVICE, kRunSlots slots of kRunLd doubles that the
+    // collective then adds element by element across the ranks (every rank's host adds the all-reduced run records in run order
+    // afterwards: no second hop on the device, no arrival counters).  Plain stores: the collective is a later kernel on the stream.
+    // Slots of runs this grid does not have are cleared by workgroup 0 (the buffer is all-reduced in place: they hold the peers' sums
+    // of the step before).
+    if (threadIdx.x < NACC) fin.out_dev[run * kRunLd + threadIdx.x] = sum_rows_lane<NACC, RGN>(c_part, rows < RGN ? rows : RGN, threadIdx.x);
+    if (blockIdx.x == 0) for (int i = nruns * kRunLd + (int)threadIdx.x; i < kRunSlots * kRunLd; i += BLK) fin.out_dev[i] = 0.0;
+    return;
+  }
   if (threadIdx.x < NACC) store_tagged_pair(fin.out_host, 1 + run * NACC + threadIdx.x,
       sum_rows_lane<NACC, RGN>(c_part, rows < RGN ? rows : RGN, threadIdx.x), fin.seq);
   if (blockIdx.x == 0 && threadIdx.x == 64) {   // header: runs | sums per run << 16 | record layout << 24

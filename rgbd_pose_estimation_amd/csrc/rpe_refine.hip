@@ -4,6 +4,7 @@
 // each with its one-launch-per-iteration form for what does not fit a resident grid; the per-device resident slot; tuning of the host
 // thread that spins in the loop.
 #include "rpe_host.hpp"
+#include <memory>
 using namespace rpeh;
 
 namespace rpeh {
@@ -91,7 +92,8 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
         return rpe::launch_normal_eq_joint_resident(c->arrays(), sp.bits, flags, sp.scale, sp.robust, sp.rk,
                                                     (const unsigned long long*)c->ctl, base, max_iter, rt, c->stream);
       };
-      { std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));
+      { SlotHold one_resident_grid(resident_mutex(c->device));
+        if (!one_resident_grid) { rc = kResidentBusy; it = 0; break; }   // (a session holds the slot: one launch per iteration below)
         rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, 1.0, pose12, max_iter, tol, &it, &step, &cost, &weight,
             "normal equations", clean, &verified); }
       if (clean && rc == kResidentDirty) note_clean_terms(c, sp.bits, false);
@@ -100,14 +102,14 @@ int rpe_gn_refine_joint(rpe_context* c, int nterms, const rpe_term* terms, int f
       std::memcpy(pose12, start, sizeof(start));
       it = 0;
     }
-    if (rc != kResidentLost) {
+    if (rc != kResidentLost && rc != kResidentBusy) {
       if (iters_out) *iters_out = it;
       if (rc != RPE_OK) return rc;
       if (last_step) *last_step = step;
       if (final_cost) *final_cost = cost;
       return RPE_OK;
     }
-    // the resident grid was lost after `it` whole iterations: carry on below, one launch per iteration
+    // the resident grid was lost after `it` whole iterations (or never launched): carry on below, one launch per iteration
   }
   for (; it < max_iter; it++) {
     double ne[32], d[6];
@@ -185,9 +187,12 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
       if (c->stream2) { use_solver = true; auto_blocks = capped; }
     }
   }
-  if (auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2 &&
+  const bool want_auto = auto_on && c->resident && !sharded && !c->comm && !c->hostex && max_iter >= 2 &&
       (single ? rpe::normal_eq_resident_fits(c->arrays(), terms[0].kind, auto_blocks, !use_solver)
-              : (use_solver && rpe::joint_resident_fits(c->arrays(), bits, flags, auto_blocks, true, joint_clean)))) {
+              : (use_solver && rpe::joint_resident_fits(c->arrays(), bits, flags, auto_blocks, true, joint_clean)));
+  // the device's resident slot, until the result has arrived (a session in the slot: no resident grid, one launch per iteration below)
+  std::unique_ptr<SlotHold> one_resident_grid(want_auto ? new SlotHold(resident_mutex(c->device)) : nullptr);
+  if (want_auto && *one_resident_grid) {
     // a single plain kind: the dedicated kernel (17 structured sums for point-to-point); anything else: the joint kernel (29 sums)
     int grid = 0, nacc = 0, max_rows = 1, rows_auto = 1;
     rpe::resident_geometry(c->arrays(), single ? terms[0].kind : RPE_RES_P2PLANE, auto_blocks, &grid, &nacc, &max_rows, &rows_auto);
@@ -200,7 +205,6 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing && c->ev_used < c->ev0.size() && (c->timing_calls++ % c->timing_stride) == 0) { e0 = c->ev0[c->ev_used];
         e1 = c->ev1[c->ev_used]; c->ev_used++; }
-    std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));   // until the result has arrived
     rt.clean = single ? take_clean(c, terms[0].kind, false) : joint_clean;   // no host in this loop: CLEAN only over verified arrays
     if (use_solver) {
       rt.solver = 1;
@@ -244,6 +248,7 @@ int rpe_gn_refine_device(rpe_context* c, int nterms, const rpe_term* terms, int 
     rt = host_target(c);
     rt.gn_pose = c->d_gn_pose; rt.gn = c->d_gn_state;
   }
+  one_resident_grid.reset();
   for (int it = 0; it < max_iter; it++) {
     if (sharded) { rt.p2p = c->d_p2p; rt.p2p_step = c->p2p_step++; }
     rt.clean = single ? take_clean(c, terms[0].kind, false) : joint_clean;
@@ -343,7 +348,8 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
     for (int attempt = 0; attempt < 2; attempt++) {
       const bool clean = take_clean(c, kind, true);   // CLEAN flavour first; its first record is checked
       bool verified = false;
-      { std::lock_guard<ResidentSlot> one_resident_grid(resident_mutex(c->device));
+      { SlotHold one_resident_grid(resident_mutex(c->device));
+        if (!one_resident_grid) { rc = kResidentBusy; it = 0; break; }   // (a session holds the slot: one launch per iteration below)
         rc = resident_host_loop(c, launch, grid, nacc, max_rows, rows_auto, sc, pose12, max_iter, tol, &it, &step, &cost, &weight,
             "normal equations", clean, &verified); }
       // promoted to "verified finite" only by a first record that was received and finite: a launch error, a wait that timed out or a
@@ -353,14 +359,14 @@ int rpe_gn_refine(rpe_context* c, int nterms, const int* kinds, const double* sc
       if (rc != kResidentDirty) break;   // else: NaN-marked arrays -- once more, guarded, from the untouched start pose
       it = 0;
     }
-    if (rc != kResidentLost) {
+    if (rc != kResidentLost && rc != kResidentBusy) {
       if (iters_out) *iters_out = it;
       if (rc != RPE_OK) return rc;
       if (last_step) *last_step = step;
       if (final_cost) *final_cost = cost;
       return RPE_OK;
     }
-    // the resident grid was lost after `it` whole iterations: carry on from pose12 below, one launch per iteration
+    // the resident grid was lost after `it` whole iterations (or never launched): carry on from pose12 below, one launch per iteration
   }
   for (; it < max_iter; it++) {
     double ne[32], d[6];

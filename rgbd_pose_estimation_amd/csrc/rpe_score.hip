@@ -769,6 +769,9 @@ __global__ __launch_bounds__(512) void score_resident_kernel(const T* __restrict
     __syncthreads();
     const int count = (int)(unsigned int)s_hdr, op = (int)(s_hdr >> 32);
     if (go == 4 && op != 1) return;   // a plain stop; with op 1: "write these masks, send their record, and leave"
+    // a header that is neither "score" nor "masks", or a count beyond a batch (a torn or raced message): leave as a lost grid would --
+    // the host recovers through its bounded wait and the launch path -- rather than write masks from a stale payload
+    if (op < 0 || op > 1 || count < 0 || count > HB) return;
     const T* batch = reinterpret_cast<const T*>(s_words);
     double own = 0.0;
     if (op == 0) {

@@ -330,3 +330,54 @@ def test_sessions_on_tiny_and_ragged_problems(gpu_ctx_factory, oracle, n, f64):
         assert np.array_equal(ctx.download_mask(L.MOD_33), mo[L.MOD_33])
         if kind == L.VOTE_NN_33_23:
             assert np.array_equal(ctx.download_mask(L.MOD_23), mo[L.MOD_23]) and np.array_equal(ctx.download_mask(L.MOD_NN), mo[L.MOD_NN])
+
+
+def test_nobody_blocks_on_a_session_that_was_left_open(gpu_ctx_factory, oracle):
+    """Round-5 advisor finding: a session held the device's resident slot until some call ended it, and every other resident loop or
+    session of the process blocked on it without a time-out -- for ever if the owner never came back (an exception between _begin and
+    _end), a deadlock if the owner waited for the blocked thread.  Now: a resident LOOP of another context never waits for a session
+    (it runs with one launch per iteration, at once); another SESSION waits its turn at most until the holder's grid has left by itself
+    and then takes the slot over; the abandoned session's owner finds out at its next call and goes on with ordinary launches."""
+    import threading
+    import time
+    sc = _scene(30000, np.float32, 21)
+    a = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    b = gpu_ctx_factory().load(L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    prob = oracle.Problem(False, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    q = _poses(oracle, sc, False, 16, 22)
+    vo = oracle.votes(prob, oracle.V_33, q, thre_3d=0.05)
+    pose = api.pose12(sc.R, sc.t)
+    ref = b.gn_refine([L.RES_P2P], pose, max_iter=4, tol=0.0)
+    a.inject_resident_fault(0, 0.5)                                  # a's grids give up after 0.5 s without a message
+    assert a.score_session_begin(L.VOTE_33, thre_3d=0.05)            # ... and a's owner "forgets" the session
+    assert np.array_equal(a.score(L.VOTE_33, q[:8], thre_3d=0.05), vo[:8])
+    out = {}
+
+    def other_thread():
+        t0 = time.perf_counter()
+        out["refined"] = b.gn_refine([L.RES_P2P], pose, max_iter=4, tol=0.0)     # a loop: no resident grid now, but no waiting either
+        out["loop_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out["begun"] = b.score_session_begin(L.VOTE_33, thre_3d=0.05)            # a session: waits until a's grid has left, then takes over
+        out["begin_s"] = time.perf_counter() - t0
+        out["votes"] = b.score(L.VOTE_33, q, thre_3d=0.05)
+        b.score_session_end()
+    t = threading.Thread(target=other_thread); t.start(); t.join(timeout=30)
+    assert not t.is_alive()
+    assert out["loop_s"] < 0.2 and out["refined"][1] == 4 and np.abs(out["refined"][0] - ref[0]).max() < 1e-9
+    assert out["begun"] and out["begin_s"] < 2.0 and np.array_equal(out["votes"], vo)
+    # the abandoned session's owner comes back: its grid and its slot are gone, the answers are the oracle's all the same
+    assert np.array_equal(a.score(L.VOTE_33, q[8:], thre_3d=0.05), vo[8:])
+    assert a.inlier_mask(L.VOTE_33, q[3], thre_3d=0.05) == vo[3]
+    a.inject_resident_fault(0, 0.0)
+    for c in (a, b):
+        st = c.resident_state()
+        assert st["enabled"] and st["lost"] == 0
+    # and the context manager of the Python binding ends a session on the way out of an exception
+    with pytest.raises(RuntimeError):
+        with a.score_session(L.VOTE_33, thre_3d=0.05) as resident:
+            assert resident
+            raise RuntimeError("caller's bug")
+    t0 = time.perf_counter()
+    assert b.score_session_begin(L.VOTE_33, thre_3d=0.05) and time.perf_counter() - t0 < 0.2    # the slot was given back at once
+    b.score_session_end()
