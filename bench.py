@@ -657,7 +657,7 @@ def worker(args, affinity):
                     ctx.comm_destroy()
                     rccl_ok = False
             if rccl_ok:
-                coll_times["rccl_us"] = timed(400) * 1e6   # rpe_gn_steps_dist = kernel + ncclAllReduce + publish kernel per step
+                coll_times["rccl_us"] = timed(400) * 1e6   # rpe_gn_steps_dist = kernel + ncclAllReduce of its run records + publish kernel per step
         # (2) the in-kernel peer-to-peer exchange (only on request: it has never run on real xGMI)
         if dist_path and ("p2p" in plan["timed_beside"] or plan["headline"] == "p2p"):
             p2p = init_p2p(ctx)
@@ -723,7 +723,7 @@ def worker(args, affinity):
         collective = "none" if not dist_path else (
             "host-side exchange: every rank's host thread adds the peers' 32 fp64 records (shared memory, rank order) each iteration" if hostex else
             "peer-to-peer exchange of 32 fp64 per step inside the kernel (xGMI, HIP IPC mailboxes)" if p2p else
-            "rccl: all-reduce(sum) of 32 fp64 per step over RCCL, " + ("library-owned communicator" if native else "torch.distributed"))
+            ("rccl: one all-reduce(sum) per step of the launch's run records (8 x 32 fp64: the 17 / 29 sums per run), " if native else "rccl: all-reduce(sum) of 32 fp64 per step over RCCL, ") + ("library-owned communicator" if native else "torch.distributed"))
 
         # The host side of the loop (wait for the record, 6x6 solve, SE(3) exp-map update, next pose out) is C++ inside the library:
         # rpe_gn_refine / rpe_gn_steps_dist with tol = 0 run exactly k iterations, so the timed region contains no Python per step.
@@ -951,7 +951,7 @@ def worker(args, affinity):
                        "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
                        "streamed_corr_per_s": float(total_n) * args.steps / elapsed, "accumulate": "fp64", "collective": collective,
                        "collective_step_us": ({"rccl_us": coll_times.get("rccl_us"), "host_us": coll_times.get("host_us"), "p2p_us": coll_times.get("p2p_us")} if dist_path else None),
-                       "collective_step_us_note": "same run, same shards, 400 steps each: rccl = kernel + ncclAllReduce + publish kernel per step; host = resident kernel per rank + records added by the host threads; p2p = in-kernel mailboxes (timed on request only: RPE_BENCH_COLLECTIVE=auto_p2p)" if dist_path else None,
+                       "collective_step_us_note": "same run, same shards, 400 steps each: rccl = kernel (run records left on the device) + ncclAllReduce of the run records + one-workgroup kernel that sends them to the host as tagged pairs, per step; host = resident kernel per rank + records added by the host threads; p2p = in-kernel mailboxes (timed on request only: RPE_BENCH_COLLECTIVE=auto_p2p)" if dist_path else None,
                        "rccl_ranks": rccl_ranks, "rccl_ranks_source": "ncclCommCount on the library's communicator after one verified all-reduce" if rccl_ranks else None,
                        "resident_state": {"before": res_state0, "after": res_state1, "lost_in_run": resident_lost_in_run, "resident_loop_ran": resident_ran},
                        "rccl_verified": rccl_verified, "pci_bus_ids": bus_ids or None, "collective_plan": plan if dist_path else None,

@@ -153,15 +153,23 @@ template <class T> struct Hyp<T, true> {
     a = ss.x < cut; b = ss.y < cut;
   }
   // The reference's 2D test -- normalise by three IEEE divisions behind a square root, dot, compare (AbsoluteOrientation.hpp:413-418)
-  // --
-  // costs five times the 3D test.  Its value cos_ref differs from the exact cosine c* = p.bv / |p| by at most 6.5 u (u = unit
-  // roundoff of Tp: |p|^2 carries 3 roundings, the root and each quotient one more, products and the two sums one each; sum |p^_i bv_i|
-  // <= 1), and a cheap estimate  ct = (p.bv) * rsqrt(|p|^2)  -- same |p|^2, hardware reciprocal square root to 1 ulp (fp64: fp32
-  // estimate + two Newton steps), no division -- differs from c* by at most 7.5 u.  So |ct - cos_ref| <= 14 u: outside a band of 24 u
-  // around the threshold the cheap estimate DECIDES the reference's comparison; inside it (and for |p|^2 outside the normal range,
-  // NaN, infinity) the reference's own operation sequence runs.  The branch is wave-uniform (one ballot): a wave none of whose lanes is
-  // within the band -- almost all of them, the band is 1.4e-6 wide in cosine -- never divides.  Votes stay the reference's, bit for bit
-  // (tests/test_gpu_kernels.py test_score_exact_votes_bit_identical, and the near-threshold case of tests/test_gpu_score_filter.py).
+  // -- costs five times the 3D test.  A cheap estimate DECIDES it outside a band around the threshold; inside the band (and for |p|^2
+  // outside the normal range, NaN, infinity, non-unit bearings) the reference's own operation sequence runs.  The band (round 6: 14 u,
+  // u = unit roundoff of Tp; 24 u before) follows from what the two computations SHARE: both start from the same N = fl(|p|^2) -- the
+  // same three products and two sums, the same bits -- so its roundings cancel; with s = sqrt(N), a_i = p_i bv_i / s, c' = sum a_i and
+  // A = sum |a_i| <= (1 + 2u) |bv| <= 1.0006 (bearings within 1e-3 of unit length, checked per lane):
+  //   reference  L = fl(s) (1 rounding), q_i = fl(p_i / L) (1), t_i = fl(q_i bv_i) (1), d = fl(fl(t_x + t_y) + t_z) (2 on x and y, 1 on z):
+  //              every a_i carries at most 5 roundings  ->  |d - c'| <= 5.02 u A
+  //   estimate   D = fma(p_x, bv_x, fma(p_y, bv_y, fl(p_z bv_z)))  (at most 3 roundings per term: |D - p.bv| <= 3.01 u |p| |bv|),
+  //              Y = v_rsq_f32(N) (1 ulp: |Y s - 1| <= 2 u; fp64: fp32 estimate + two Newton steps, whose last step's three roundings
+  //              leave |Y s - 1| <= 3 u), ct = fl(D Y) (1 rounding):  |ct - c'| <= 3.01 u |c'| + 3.02 u A <= 6.04 u A  (fp64: 7.05 u A)
+  // so |ct - d| <= 11.1 u (fp64: 12.1 u): outside a band of 14 u the estimate decides the reference's comparison.  The branch is wave-uniform (one
+  // ballot): a wave none of whose lanes is within the band never divides.  Votes stay the reference's, bit for bit (tests/
+  // test_gpu_kernels.py test_score_exact_votes_bit_identical, the on-threshold cases of tests/test_gpu_score_filter.py, the fuzz campaign).
+  static constexpr T kBand23 = T(14) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 14 u
+  static __device__ __forceinline__ V2 dot_fma2(V2 px, V2 py, V2 pz, V2 bx, V2 by, V2 bz) {
+    return __builtin_elementwise_fma(px, bx, __builtin_elementwise_fma(py, by, pz * bz));
+  }
   __device__ __forceinline__ void in23_rot_x2(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b) const {
 #pragma clang fp contract(off)
     V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
@@ -169,15 +177,15 @@ template <class T> struct Hyp<T, true> {
     RPE_SCORE_STAT(0);
 #ifndef RPE_NO_23_FILTER
     {
-      const V2 dt = px * bx + py * by + pz * bz;
+      const V2 dt = dot_fma2(px, py, pz, bx, by, bz);
       const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
-      const T band = T(24) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 24 u
+      const T band = kBand23;
       const T hi = c + band, lo = c - band;
       // |p|^2 in metres^2; also the range in which the fp32 estimate behind the fp64 form is finite
       const T tiny = T(1e-30), huge = T(1e30);
       const bool in0 = ct.x > hi, in1 = ct.y > hi;
-      // the bound above holds for UNIT bearings (sum |p^_i bv_i| <= |bv|): both errors scale with |bv|, so a lane counts as decided only
-      // if |bv|^2 is within 1e-3 of 1 (24 u still covers 14 u x 1.0005); any other bearing -- the API does not normalise them -- takes
+      // the bound above holds for UNIT bearings (A <= |bv| (1 + 2u)): both errors scale with |bv|, so a lane counts as decided only
+      // if |bv|^2 is within 1e-3 of 1 (14 u covers the 11.1 u / 12.1 u, in which A <= 1.0006 is already counted); any other bearing -- the API does not normalise them -- takes
       // the reference's own sequence.  Hypothesis-independent: hoisted out of the hypothesis loop.
       const V2 b2 = bx * bx + by * by + bz * bz;
       const bool unit0 = (b2.x > T(0.999)) & (b2.x < T(1.001)), unit1 = (b2.y > T(0.999)) & (b2.y < T(1.001));
@@ -201,9 +209,9 @@ template <class T> struct Hyp<T, true> {
 #pragma clang fp contract(off)
     const V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
     const V2 n2 = px * px + py * py + pz * pz;
-    const V2 dt = px * bx + py * by + pz * bz;
+    const V2 dt = dot_fma2(px, py, pz, bx, by, bz);
     const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
-    const T band = T(24) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 24 u
+    const T band = kBand23;
     const T hi = c + band, lo = c - band;
     const T tiny = T(1e-30), huge = T(1e30);
     a = ct.x > hi; b = ct.y > hi;
