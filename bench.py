@@ -629,9 +629,10 @@ def worker(args, affinity):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1
 
-        def timed(k, refine=False):
+        def timed(k, refine=False, device=False):
             q = pose12(R0, t0)
-            run = (lambda kk: ctx.gn_refine([L.RES_P2P], q, None, L.USE_MASK, kk, 0.0)) if refine else (lambda kk: ctx.gn_steps_dist(L.RES_P2P, q, kk, L.USE_MASK))
+            run = (lambda kk: ctx.gn_refine([L.RES_P2P], q, None, L.USE_MASK, kk, 0.0)) if refine else (
+                  (lambda kk: ctx.gn_steps_dist_device(L.RES_P2P, q, kk, L.USE_MASK)) if device else (lambda kk: ctx.gn_steps_dist(L.RES_P2P, q, kk, L.USE_MASK)))
             run(200)
             dist.barrier()
             t0_ = time.perf_counter()
@@ -658,6 +659,12 @@ def worker(args, affinity):
                     rccl_ok = False
             if rccl_ok:
                 coll_times["rccl_us"] = timed(400) * 1e6   # rpe_gn_steps_dist = kernel + ncclAllReduce of its run records + publish kernel per step
+                # ... and the same steps chained on the device (rpe_gn_steps_dist_device: solve + exp-map in the kernels, the host enqueues
+                # 400 x {kernel, ncclAllReduce} and waits once) -- timed beside: the headline keeps the exp-map on the host (north star)
+                try:
+                    coll_times["rccl_device_us"] = timed(400, device=True) * 1e6
+                except L.RpeError as e:
+                    print(f"[bench] rank {rank}: chained sharded steps failed: {e}", file=sys.stderr, flush=True)
         # (2) the in-kernel peer-to-peer exchange (only on request: it has never run on real xGMI)
         if dist_path and ("p2p" in plan["timed_beside"] or plan["headline"] == "p2p"):
             p2p = init_p2p(ctx)
@@ -950,8 +957,8 @@ def worker(args, affinity):
             "config": {"workload": workload, "workload_short": workload_short, "corr_rank0": n, "global_corr": total_n, "valid_corr_per_step": inl_total,
                        "value_counts": "valid correspondences = rows that pass the RANSAC inlier mask (SURVEY 8d); every row is streamed",
                        "streamed_corr_per_s": float(total_n) * args.steps / elapsed, "accumulate": "fp64", "collective": collective,
-                       "collective_step_us": ({"rccl_us": coll_times.get("rccl_us"), "host_us": coll_times.get("host_us"), "p2p_us": coll_times.get("p2p_us")} if dist_path else None),
-                       "collective_step_us_note": "same run, same shards, 400 steps each: rccl = kernel (run records left on the device) + ncclAllReduce of the run records + one-workgroup kernel that sends them to the host as tagged pairs, per step; host = resident kernel per rank + records added by the host threads; p2p = in-kernel mailboxes (timed on request only: RPE_BENCH_COLLECTIVE=auto_p2p)" if dist_path else None,
+                       "collective_step_us": ({"rccl_us": coll_times.get("rccl_us"), "rccl_device_us": coll_times.get("rccl_device_us"), "host_us": coll_times.get("host_us"), "p2p_us": coll_times.get("p2p_us")} if dist_path else None),
+                       "collective_step_us_note": "same run, same shards, 400 steps each: rccl = kernel (run records left on the device) + ncclAllReduce of the run records + one-workgroup kernel that sends them to the host as tagged pairs, per step; rccl_device = the same steps chained on the device (rpe_gn_steps_dist_device: every launch solves for its own pose, the host enqueues all of them and waits once); host = resident kernel per rank + records added by the host threads; p2p = in-kernel mailboxes (timed on request only: RPE_BENCH_COLLECTIVE=auto_p2p)" if dist_path else None,
                        "rccl_ranks": rccl_ranks, "rccl_ranks_source": "ncclCommCount on the library's communicator after one verified all-reduce" if rccl_ranks else None,
                        "resident_state": {"before": res_state0, "after": res_state1, "lost_in_run": resident_lost_in_run, "resident_loop_ran": resident_ran},
                        "rccl_verified": rccl_verified, "pci_bus_ids": bus_ids or None, "collective_plan": plan if dist_path else None,

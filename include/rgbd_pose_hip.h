@@ -187,6 +187,13 @@ int rpe_device_bus_id(rpe_context* ctx, char* buf, int len);
 int rpe_gn_step_dist(rpe_context* ctx, int kind, int flags, double* pose12, double* ne32_out, double* step_norm);
 /* `steps` such steps in one call (every rank passes the same count). */
 int rpe_gn_steps_dist(rpe_context* ctx, int kind, int flags, double* pose12, int steps, double* last_step_norm);
+/* The same `steps` steps over the RCCL communicator with the HOST OUT OF THE LOOP: every launch takes its pose from the launch before
+ * it (each workgroup adds that step's all-reduced run records, solves the 6x6 system and applies the exp-map itself), so the calling
+ * thread enqueues steps x {kernel, ncclAllReduce} plus one finishing kernel and waits once -- a launch's latency overlaps the kernels
+ * in front of it instead of adding to every step.  The SE(3) update runs on the device (the device-resident loops' solve, equal to the
+ * host's to 1e-13); rpe_gn_steps_dist is the form with the exp-map on the host.  Needs rpe_comm_init; every rank passes the same
+ * arguments and ends with the same pose.  RPE_ERR_DEGENERATE if a step's normal equations are not positive definite. */
+int rpe_gn_steps_dist_device(rpe_context* ctx, int kind, int flags, double* pose12, int steps, double* last_step_norm);
 /* Peer-to-peer variant of the collective for ONE node (<= 8 ranks): instead of RCCL, the normal-equation kernel's last
  * workgroup writes the 32-double record straight into a mailbox of every peer over xGMI (HIP IPC mappings, flag-in-data
  * words), waits for the peers' records in its own mailbox, adds them in rank order and publishes the sum -- the whole sharded

@@ -28,7 +28,7 @@ SYMBOLS = [
     "rpe_abi_version", "rpe_last_error", "rpe_device_count", "rpe_create", "rpe_destroy", "rpe_synchronize",
     "rpe_set_problem", "rpe_upload", "rpe_download", "rpe_bind", "rpe_upload_mask", "rpe_upload_weight", "rpe_download_mask",
     "rpe_p2p_moments", "rpe_pose_from_moments", "rpe_sine_error_sum", "rpe_normal_eq", "rpe_normal_eq_device", "rpe_gn_solve", "rpe_gn_apply",
-    "rpe_normal_eq_joint", "rpe_gn_refine_joint", "rpe_gn_refine_device", "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_comm_count", "rpe_device_bus_id", "rpe_gn_step_dist", "rpe_gn_steps_dist", "rpe_p2p_export", "rpe_p2p_init", "rpe_p2p_pause", "rpe_p2p_destroy", "rpe_host_sqrt_cut", "rpe_hostex_init", "rpe_hostex_destroy", "rpe_host_exchange_open", "rpe_host_exchange_allreduce_f64", "rpe_host_exchange_allreduce_i32", "rpe_host_exchange_set_label", "rpe_host_exchange_labels_collide", "rpe_host_exchange_unlink", "rpe_host_exchange_close", "rpe_gn_refine", "rpe_debug_loop_profile", "rpe_debug_resident_state", "rpe_debug_inject_resident_fault", "rpe_debug_device_gn_update", "rpe_tune_host_thread", "rpe_timing_enable", "rpe_timing_collect", "rpe_timing_calibrate", "rpe_score", "rpe_ransac33_batch", "rpe_ransac_p3p_batch", "rpe_inlier_mask", "rpe_score_session_begin", "rpe_score_session_end", "rpe_prosac_order", "rpe_nl_round", "rpe_run", "rpe_host_hypotheses", "rpe_run_replay",
+    "rpe_normal_eq_joint", "rpe_gn_refine_joint", "rpe_gn_refine_device", "rpe_gn_step", "rpe_comm_unique_id", "rpe_comm_init", "rpe_comm_destroy", "rpe_comm_count", "rpe_device_bus_id", "rpe_gn_step_dist", "rpe_gn_steps_dist", "rpe_gn_steps_dist_device", "rpe_p2p_export", "rpe_p2p_init", "rpe_p2p_pause", "rpe_p2p_destroy", "rpe_host_sqrt_cut", "rpe_hostex_init", "rpe_hostex_destroy", "rpe_host_exchange_open", "rpe_host_exchange_allreduce_f64", "rpe_host_exchange_allreduce_i32", "rpe_host_exchange_set_label", "rpe_host_exchange_labels_collide", "rpe_host_exchange_unlink", "rpe_host_exchange_close", "rpe_gn_refine", "rpe_debug_loop_profile", "rpe_debug_resident_state", "rpe_debug_inject_resident_fault", "rpe_debug_device_gn_update", "rpe_tune_host_thread", "rpe_timing_enable", "rpe_timing_collect", "rpe_timing_calibrate", "rpe_score", "rpe_ransac33_batch", "rpe_ransac_p3p_batch", "rpe_inlier_mask", "rpe_score_session_begin", "rpe_score_session_end", "rpe_prosac_order", "rpe_nl_round", "rpe_run", "rpe_host_hypotheses", "rpe_run_replay",
     "rpe_frame_set_depth", "rpe_frame_download", "rpe_model_from_frame", "rpe_model_upload", "rpe_associate", "rpe_icp",
     "rpe_host_random_elements", "rpe_host_prosac_samples", "rpe_host_update_num_iters", "rpe_host_sort_indexes", "rpe_host_kneip_main",
     "rpe_host_kneip", "rpe_host_nl_2p", "rpe_host_shinji", "rpe_host_se3_exp", "rpe_host_svd3", "rpe_host_calc_err",
@@ -135,6 +135,7 @@ def lib():
         L.rpe_host_exchange_close.restype = None
         L.rpe_gn_step_dist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_gn_steps_dist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.rpe_gn_steps_dist_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.rpe_debug_device_gn_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_debug_loop_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpe_debug_resident_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -262,6 +262,13 @@ class Context:
         L.check(L.lib().rpe_gn_steps_dist(self._h, kind, flags, _p(pose12_inout), steps, C.byref(step)))
         return step.value
 
+    def gn_steps_dist_device(self, kind: int, pose12_inout: np.ndarray, steps: int, flags: int = 0) -> float:
+        """`steps` sharded GN steps over the RCCL communicator chained on the device (rpe_gn_steps_dist_device: solve + exp-map in the
+        kernels, the host enqueues everything and waits once); returns the last |delta|."""
+        step = C.c_double(0)
+        L.check(L.lib().rpe_gn_steps_dist_device(self._h, kind, flags, _p(pose12_inout), steps, C.byref(step)))
+        return step.value
+
     def comm_init(self, world: int, rank: int, id128: bytes):
         buf = (C.c_char * 128).from_buffer_copy(id128)
         L.check(L.lib().rpe_comm_init(self._h, world, rank, buf))

@@ -105,15 +105,15 @@ int rpe_create(rpe_context** out, int device, void* stream) {
   // granule tags start below every sequence value
   if (e == hipSuccess) e = hipMemset(c->d_partials, 0, partial_doubles * sizeof(double));
   // 64 doubles (a record for a collective, the solve probe) + the run records of a sharded step (rpe_dist.hip), zero between steps
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, (64 + rpe::kRunSlots * rpe::kRunLd) * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(c->d_out, 0, (64 + rpe::kRunSlots * rpe::kRunLd) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_out, (64 + 2 * rpe::kRunSlots * rpe::kRunLd) * sizeof(double));   // (two sets: chained steps alternate)
+  if (e == hipSuccess) e = hipMemset(c->d_out, 0, (64 + 2 * rpe::kRunSlots * rpe::kRunLd) * sizeof(double));
   c->h_big_pairs = 8192 + 64;
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_big, c->h_big_pairs * 16, hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) std::memset(c->h_big, 0, c->h_big_pairs * 16);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { std::memset(c->h_out, 0, 80 * sizeof(double)); e = hipMalloc((void**)&c->d_ticket, 9 * 128); }
   if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * 128);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_pose, 16 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_pose, 32 * sizeof(double));   // 12 (+ a second 12 at 16: chained steps alternate)
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_gn_state, sizeof(rpe::GnState));
   if (e == hipSuccess) e = hipMalloc(&c->d_poses, (size_t)rpe::kMaxScoreH * 12 * sizeof(double));
   // staging for pose uploads; also written directly by the hypothesis generator

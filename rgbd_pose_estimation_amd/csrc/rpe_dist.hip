@@ -272,4 +272,51 @@ int rpe_gn_steps_dist(rpe_context* c, int kind, int flags, double* pose12, int s
   return RPE_OK;
 }
 
+// `steps` sharded steps CHAINED ON THE DEVICE: every launch takes its pose from the launch before it -- each workgroup adds that step's
+// all-reduced run records, solves and applies the exp-map itself (chained_pose, rpe_reduce.hpp) -- so the host is not in the loop: it
+// enqueues steps x {kernel, ncclAllReduce} and one finishing kernel, and waits once.  A launch's own latency (6.7 us on this stack for
+// an empty kernel, scripts/ubench/stream_signal.hip) then overlaps the kernels in front of it instead of adding to every step, and no
+// result has to reach the host between steps: what is left per step is the kernel, the collective and two kernel boundaries.  The SE(3)
+// update runs on the device here (the device-resident loops' solve: gn_solve_update, checked against the host's to 1e-13); the
+// host-side form is rpe_gn_steps_dist.  Identical poses on every rank (identical all-reduced records, identical arithmetic).
+int rpe_gn_steps_dist_device(rpe_context* c, int kind, int flags, double* pose12, int steps, double* last_step_norm) {
+  session_end(c);
+  if (!c || !pose12 || steps < 1) return fail(RPE_ERR_ARG, "rpe_gn_steps_dist_device: bad argument");
+  if (!c->comm) return fail(RPE_ERR_STATE, "rpe_gn_steps_dist_device: rpe_comm_init was not called");
+  if (kind == RPE_RES_NORMAL) return fail(RPE_ERR_ARG, "RPE_RES_NORMAL is not served by the sharded step");
+  int rc = kind_arrays(c, kind);
+  if (rc) return rc;
+  if ((rc = check_flags(c, kind, flags))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  rpe::GnState st;
+  st.tol = 0; st.step = 0; st.cost = 0; st.max_iters = steps; st.iters = 0; st.done = 0; st.status = 0;
+  HIP_TRY(hipMemcpyAsync(c->d_gn_pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_gn_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+  constexpr int kRunDoubles = rpe::kRunSlots * rpe::kRunLd;
+  const bool clean = take_clean(c, kind, false);   // nobody on the host sees a record: CLEAN only over verified arrays
+  for (int i = 0; i < steps; i++) {
+    rpe::ReduceTarget rt = device_runs_target(c);
+    rt.d_out = c->d_out + 64 + (size_t)(i & 1) * kRunDoubles;              // this step's run records ...
+    rt.gn = c->d_gn_state;
+    rt.gn_pose = c->d_gn_pose + 16 * (size_t)((i + 1) & 1);                // ... its pose: of the step before, updated by ...
+    if (i == 0) rt.gn_pose = c->d_gn_pose;                                 // (the first launch: the uploaded pose as it stands)
+    else { rt.chain_runs = c->d_out + 64 + (size_t)((i - 1) & 1) * kRunDoubles;   // ... that step's all-reduced run records,
+           rt.chain_pose_out = c->d_gn_pose + 16 * (size_t)(i & 1); }             // and kept for the next launch
+    rt.clean = clean;
+    hipEvent_t e0, e1;
+    timing_pair(c, &e0, &e1);
+    HIP_TRY(rpe::launch_normal_eq(c->arrays(), kind, flags, pose12, rt, c->stream, e0, e1));
+    NCCL_TRY(rccl().AllReduce(rt.d_out, rt.d_out, kRunDoubles, ncclFloat64, ncclSum, c->comm, c->stream));
+  }
+  const unsigned long long seq = ++c->seq;
+  HIP_TRY(rpe::launch_chain_finish(kind, c->d_out + 64 + (size_t)((steps - 1) & 1) * kRunDoubles, c->d_gn_pose + 16 * (size_t)((steps - 1) & 1),
+      c->d_gn_state, rpe::pivot_floor(c->dtype == RPE_F64), c->h_big, seq, c->stream));
+  double out[16];
+  if ((rc = wait_host_partials(c, 1, 16, out))) return rc;
+  if (out[15] != 0.0) return fail(RPE_ERR_DEGENERATE, "normal equations are not positive definite at step %d", (int)out[14] - 1);
+  for (int i = 0; i < 12; i++) pose12[i] = out[i];
+  if (last_step_norm) *last_step_norm = out[12];
+  return RPE_OK;
+}
+
 }  // extern "C"

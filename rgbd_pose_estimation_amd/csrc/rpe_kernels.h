@@ -73,6 +73,8 @@ struct ReduceTarget {
   // non-finite (rpe_receive.hip clean-first protocol); results nobody on the host inspects use it only for arrays already verified
   bool clean = false;
   int solver = 0;              // autonomous resident loops: 1 = launch_auto_solver's workgroup sums, solves and hands the poses out
+  const double* chain_runs = nullptr;   // chained sharded steps: see Finish (rpe_reduce.hpp)
+  double* chain_pose_out = nullptr;
   int stride = 0;              // resident kernels: > 1 = strided runs (see Finish)
                                // the run, the run records go to h_out as tagged pairs (ordinary kernels: behind a header pair; h_out
                                // must hold
@@ -122,6 +124,10 @@ hipError_t launch_normal_eq_resident(const DeviceArrays& A, int kind, int flags,
 hipError_t launch_gn_update_probe(const double* d_rec32, double* d_pose12, double* d_step_ok, double pivot_floor, hipStream_t s);
 hipError_t launch_moments(const DeviceArrays& A, int flags, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr,
                           hipEvent_t ev_end = nullptr);
+// chained sharded steps: the LAST solve + update (all-reduced run records of the final step, its pose) and the result to the host as
+// tagged pairs: pose (12) | |delta| | cost | iterations | status
+hipError_t launch_chain_finish(int kind, const double* d_runs, const double* d_pose, GnState* d_state, double pivot_floor, double* h_pairs,
+                               unsigned long long seq, hipStream_t s);
 // R1 lsq_pnp: sum of the sine residuals at pose7 (quaternion | t), arrays XW and BV; record = sum | count
 hipError_t launch_sine_error(const DeviceArrays& A, const double* pose7, const ReduceTarget& rt, hipStream_t s, hipEvent_t ev_begin = nullptr,
                              hipEvent_t ev_end = nullptr);

@@ -38,10 +38,14 @@ __global__ __launch_bounds__(BLK) void normal_eq_kernel(const T* __restrict__ xw
   typedef typename Pk<T>::V V;
   if (fin.gn != nullptr) {  // device-resident Gauss-Newton: finished loops cost an empty launch; the pose lives in HBM
     if (fin.gn->done) return;
+    if (fin.chain_runs != nullptr) {   // chained sharded step: this launch's pose from the step before (chained_pose, rpe_reduce.hpp)
+      if (!chained_pose<KIND == KIND_P2P ? 1 : 0>(fin, pose)) return;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 9; k++) pose.R[k] = fin.gn_pose[k];
+      for (int k = 0; k < 9; k++) pose.R[k] = fin.gn_pose[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
+      for (int k = 0; k < 3; k++) pose.t[k] = fin.gn_pose[9 + k];
+    }
   }
   RPE_STAMP(0);
   double acc[NACC];
@@ -239,6 +243,39 @@ extern "C" int rpe_debug_read_stamps(unsigned long long* out, int nwords) {
 }
 namespace rpe {
 #endif
+
+// the end of a chain of sharded steps: one workgroup adds the last step's all-reduced run records, solves, updates and sends the result
+template <int MODE>
+__global__ __launch_bounds__(64) void chain_finish_kernel(const double* __restrict__ runs, const double* __restrict__ pose_in, GnState* st,
+                                                          double rel_floor, double* __restrict__ h_pairs, unsigned long long seq) {
+  __shared__ double f_tot[32];
+  __shared__ double f_pose[12];
+  __shared__ double f_out[16];
+  if (threadIdx.x < 12) f_pose[threadIdx.x] = pose_in[threadIdx.x];
+  if (threadIdx.x < 32) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < kRunSlots; r++) t += runs[r * kRunLd + threadIdx.x];
+    f_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double step = st->step;
+    bool ok = st->status == 0;
+    if (!st->done) ok = gn_solve_update<MODE>(f_tot, f_pose, &step, rel_floor);
+    for (int k = 0; k < 12; k++) f_out[k] = f_pose[k];
+    f_out[12] = step; f_out[13] = st->done ? st->cost : record_entry<MODE>(f_tot, 27); f_out[14] = (double)(st->iters + (st->done ? 0 : 1));
+    f_out[15] = ok ? 0.0 : 1.0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) store_tagged_pair(h_pairs, threadIdx.x, f_out[threadIdx.x], seq);
+}
+hipError_t launch_chain_finish(int kind, const double* d_runs, const double* d_pose, GnState* d_state, double pivot_floor, double* h_pairs,
+                               unsigned long long seq, hipStream_t s) {
+  if (kind == KIND_P2P) hipLaunchKernelGGL((chain_finish_kernel<1>), dim3(1), dim3(64), 0, s, d_runs, d_pose, d_state, pivot_floor, h_pairs, seq);
+  else hipLaunchKernelGGL((chain_finish_kernel<0>), dim3(1), dim3(64), 0, s, d_runs, d_pose, d_state, pivot_floor, h_pairs, seq);
+  return hipGetLastError();
+}
 
 template <class T, int KIND, int BLK>
 static void normal_eq_launch(const DeviceArrays& A, int flags, const PoseK<double>& pose, const ReduceTarget& rt, hipStream_t s,

@@ -322,6 +322,10 @@ struct Finish {
   unsigned long long fault_tag;         // test hook (0 = off): the LAST workgroup withholds its granules of the iteration with this tag
   double pivot_floor;                   // device-side 6x6 solves: relative pivot floor (rpe::pivot_floor, rpe/linalg.hpp)
   int solver;                           // autonomous resident loops: 1 = a solving workgroup (auto_solver_kernel, its own launch) plays the host
+  // chained sharded steps (rpe_gn_steps_dist_device): the all-reduced run records of the step before (kRunSlots x kRunLd doubles; null
+  // = first step: the pose is gn_pose as it stands) and where workgroup 0 leaves the pose this launch works with (for the next one)
+  const double* chain_runs;
+  double* chain_pose_out;
 };
 // what a collecting workgroup sends to the host in place of its run's sums when a granule of the run never arrived: a quiet NaN with a
 // payload no arithmetic produces; the host then releases the grid and finishes the refinement with one launch per iteration
@@ -508,6 +512,43 @@ static __device__ __noinline__ bool gn_solve_update(const double* __restrict__ t
 #pragma unroll
   for (int k = 0; k < 12; k++) pose[k] = Pn[k];
   return true;
+}
+
+// ---- chained sharded steps (rpe_dist.hip rpe_gn_steps_dist_device): the pose a launch works with comes from the launch BEFORE it --
+// every workgroup adds the all-reduced run records of that step in run order (the order the host uses: identical sums in every
+// workgroup and on every rank), solves and applies the exp-map to the pose of that step, all redundantly: no hop, no host.  Workgroup
+// 0 leaves the pose (for the next launch) and the loop state.  Returns false -- uniformly -- where the solve refused the system
+// (state.done is then set: the later launches of the chain return at once).
+template <int MODE>
+__device__ __forceinline__ bool chained_pose(const Finish& fin, PoseK<double>& pose) {
+  __shared__ double c_tot[32];
+  __shared__ double c_pose[12];
+  __shared__ int c_ok;
+  if (threadIdx.x < 12) c_pose[threadIdx.x] = fin.gn_pose[threadIdx.x];
+  if (threadIdx.x < 32) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < kRunSlots; r++) t += fin.chain_runs[r * kRunLd + threadIdx.x];
+    c_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double step = 0.0;
+    const bool ok = gn_solve_update<MODE>(c_tot, c_pose, &step, fin.pivot_floor);
+    c_ok = ok ? 1 : 0;
+    if (blockIdx.x == 0) {
+      GnState* st = fin.gn;
+      st->iters = st->iters + 1; st->step = step; st->cost = record_entry<MODE>(c_tot, 27);
+      if (!ok) { st->status = 1; st->done = 1; }
+      if (ok) { for (int k = 0; k < 12; k++) fin.chain_pose_out[k] = c_pose[k]; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 9; k++) pose.R[k] = c_pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pose.t[k] = c_pose[9 + k];
+  return c_ok != 0;
 }
 
 // one value to the host WITH the sequence number in ONE 16-byte SYSTEM-scope store (sc0 sc1: straight out over PCIe); the host waits
@@ -970,6 +1011,7 @@ static Finish make_finish(const ReduceTarget& rt) {
   f.stride = rt.stride > 1 ? rt.stride : 0;
   f.pose_wait_ticks = rt.pose_wait_ticks; f.fault_tag = rt.fault_tag; f.pivot_floor = rt.pivot_floor;
   f.solver = rt.solver;
+  f.chain_runs = rt.chain_runs; f.chain_pose_out = rt.chain_pose_out;
   return f;
 }
 // Launch geometry of the reduction kernels.  The tail (arrival count + fixed-order sum of one record per workgroup)

@@ -389,6 +389,28 @@ def test_rccl_communicator_one_rank_and_timing_hooks():
         assert s1 == s2
     assert np.array_equal(p1, p2)
     assert ctx.gn_steps_dist(L.RES_P2P, p1, 3) >= 0.0
+    # the same steps chained on the device (rpe_gn_steps_dist_device: every launch solves for its own pose from the launch before it):
+    # the device's solve and exp-map agree with the host's to rounding, so do the poses after 6 steps; an odd and an even count (the
+    # run records and the pose alternate between two buffers), point-to-point (17 structured sums) and point-to-plane (29)
+    for kind, arrs in ((L.RES_P2P, {}), (L.RES_P2PLANE, dict(nc=util.scene_full(6, 50000, np.float32).N))):
+        if arrs:
+            ctx.close(); ref.close()
+            ctx = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P, **arrs)
+            ctx.comm_init(1, 0, api.comm_unique_id())
+            ref = api.Context(0).load(L.F32, xw=sc.Q, xc=sc.P, **arrs)
+        for steps in (1, 6, 7):
+            pa, pb = api.pose12(np.eye(3), np.zeros(3)), api.pose12(np.eye(3), np.zeros(3))
+            sa = ctx.gn_steps_dist_device(kind, pa, steps)
+            sb = 0.0
+            for _ in range(steps):
+                sb = ref.gn_step(kind, pb)
+            assert np.abs(pa - pb).max() < 1e-10 and abs(sa - sb) <= 1e-9 * max(sb, 1e-12), (kind, steps, sa, sb)
+    # a degenerate problem is refused by the device's solve as by the host's
+    flat = api.Context(0).load(L.F32, xw=np.zeros((64, 3), np.float32), xc=np.zeros((64, 3), np.float32))
+    flat.comm_init(1, 0, api.comm_unique_id())
+    with pytest.raises(L.RpeError):
+        flat.gn_steps_dist_device(L.RES_P2P, api.pose12(np.eye(3), np.zeros(3)), 3)
+    flat.close()
     v = ctx.score(L.VOTE_33, np.array([api.pose7_from_Rt(sc.R, sc.t, L.F32)]), 0.2)     # votes all-reduced over the one rank
     assert v[0] == ref.score(L.VOTE_33, np.array([api.pose7_from_Rt(sc.R, sc.t, L.F32)]), 0.2)[0]
     ctx.comm_destroy()
