@@ -38,7 +38,7 @@ N_SHARDED = 10_000_000       # configs[4]
 BYTES_PER_CORR = 24 + 2      # Xw 12 + Xc 12 + short inlier mask 2 (p2p fp32 + mask)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 THRE_3D = 0.2                # Parameters.yml thre_3d
-PROFILE_INDEX = "profiles/r05_bench_profiles.json"   # rocprofv3 / PMC summaries of THIS command, one entry per steps-per-launch
+PROFILE_INDEX = "profiles/r06_bench_profiles.json"   # rocprofv3 / PMC summaries of THIS command, one entry per steps-per-launch
 
 
 # ------------------------------------------------------------------------------------------------ launcher (no GPU, no torch)
@@ -926,7 +926,7 @@ def worker(args, affinity):
         k_avg_s = (k_total_ms / max(k_cnt, 1)) * 1e-3
         bytes_per_launch = BYTES_PER_CORR * n * steps_per_launch
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else None
-        kernel_name = "rpe::normal_eq_resident_kernel<float, 0, 512, true, false, true, 0, true>" if resident else "rpe::normal_eq_kernel<float, 0, 512, true, false, true>"
+        kernel_name = "rpe::normal_eq_resident_kernel<float, 0, 256, true, false, 2, 0, true>" if resident else "rpe::normal_eq_kernel<float, 0, 512, true, false, true>"
         # profiles/ evidence of this command (rocprofv3 --kernel-trace --stats; two --pmc passes), recorded per steps-per-launch.  A
         # per-launch value from a file stands in the line ONLY if the file's launches served the same number of steps as this run's;
         # otherwise the line carries the file's per-step values with the file's own steps_per_launch beside them.

@@ -1,18 +1,18 @@
-"""Summarise the round-5 evidence run (scripts/collect_evidence_r05.sh) into profiles/:   python scripts/profile_summary_r05.py gpurun_out/r05e
- * r05_bench_driver_cmd.json, r05_bench_default_2000steps.json            the bench lines themselves
- * r05_bench_driver_{cmd,noextras}_rocprofv3_kernel_stats.csv, r05_bench_2000steps_rocprofv3_kernel_stats.csv
- * r05_pmc_{fetch,write}_{20,2000}_counters.csv                           per-dispatch counters of the resident kernel (separate passes)
- * r05_hbm_stream_*                                                       the bandwidth-bound launches of roofline_hbm
- * r05_reference_api_{n}_*                                                K1' moments / K5 nl_round / K4b mask at three sizes
- * r05_bench_profiles.json    the index bench.py reads (PROFILE_INDEX): per kernel and size, rocprofv3 average launch and PMC traffic per launch
- * r05_resident_timeline.jsonl, r05_sq_counters_1M.json, r05_streaming_ab.jsonl, r05_fuzz_campaign.txt, r05_pytest_gpu.txt
+"""Summarise the round-6 evidence run (scripts/collect_evidence_r06.sh) into profiles/:   python scripts/profile_summary_r06.py gpurun_out/r06e
+ * r06_bench_driver_cmd.json, r06_bench_default_2000steps.json            the bench lines themselves
+ * r06_bench_driver_{cmd,noextras}_rocprofv3_kernel_stats.csv, r06_bench_2000steps_rocprofv3_kernel_stats.csv
+ * r06_pmc_{fetch,write}_{20,2000}_counters.csv                           per-dispatch counters of the resident kernel (separate passes)
+ * r06_hbm_stream_*                                                       the bandwidth-bound launches of roofline_hbm
+ * r06_reference_api_{n}_*                                                K1' moments / K5 nl_round / K4b mask at three sizes
+ * r06_bench_profiles.json    the index bench.py reads (PROFILE_INDEX): per kernel and size, rocprofv3 average launch and PMC traffic per launch
+ * r06_resident_timeline.jsonl, r06_sq_counters_1M.json, r06_streaming_ab.jsonl, r06_fuzz_campaign.txt, r06_pytest_gpu.txt
 PMC correction (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE reads half the bytes of a 16-B/lane coalesced stream; both counters are
 in KiB.  traffic = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024."""
 import csv, glob, json, os, shutil, statistics, sys
 src = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
-RES = "normal_eq_resident_kernel<float, 0, 512, true, false, true, 0"
+RES = "normal_eq_resident_kernel<float, 0, 256, true, false, 2, 0"
 CORR = "gfx950: traffic = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (FETCH_SIZE reads half the bytes of a 16-B/lane stream; separate --pmc passes)"
 
 
@@ -48,14 +48,17 @@ def counters(name, counter_name, dst, needle, keep_lines=60):
     return {"median_KiB": vals[len(vals) // 2], "dispatches": len(vals), "file": ("profiles/" + dst) if dst else None, "grid": rows[0].get("Grid_Size"), "vgpr": rows[0].get("VGPR_Count")}
 
 
-index = {}
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_source_hash: the sources these profiles were taken on)
+index = {"kernel_src_sha256": bench.kernel_source_hash(), "kernel_src_sha256_note": "sha256[:16] over " + ", ".join(bench.KERNEL_SOURCES) + " (name NUL content) of the tree the passes below were taken on; bench.py carries a file-derived traffic only while its own hash equals this one",
+         "library_sha256": bench.library_hash()}
 # ---- the headline's resident kernel, per steps-per-launch
 entries = []
-for steps, st_name, st_dst, tagn in ((20, "prof_driver_noextras", "r05_bench_driver_noextras_rocprofv3_kernel_stats.csv", "20"),
-                                     (2000, "prof_2000", "r05_bench_2000steps_rocprofv3_kernel_stats.csv", "2000")):
+for steps, st_name, st_dst, tagn in ((20, "prof_driver_noextras", "r06_bench_driver_noextras_rocprofv3_kernel_stats.csv", "20"),
+                                     (2000, "prof_2000", "r06_bench_2000steps_rocprofv3_kernel_stats.csv", "2000")):
     st = pick(stats_rows(st_name, st_dst), RES)
-    fe = counters(f"pmc_fetch_{tagn}", "FETCH_SIZE", f"r05_pmc_fetch_{tagn}_counters.csv", RES)
-    wr = counters(f"pmc_write_{tagn}", "WRITE_SIZE", f"r05_pmc_write_{tagn}_counters.csv", RES)
+    fe = counters(f"pmc_fetch_{tagn}", "FETCH_SIZE", f"r06_pmc_fetch_{tagn}_counters.csv", RES)
+    wr = counters(f"pmc_write_{tagn}", "WRITE_SIZE", f"r06_pmc_write_{tagn}_counters.csv", RES)
     e = {"steps_per_launch": steps}
     if st:
         e.update(kernel=st["name"], rocprofv3_avg_launch_us=st["avg_ns"] * 1e-3, rocprofv3_us_per_step=st["avg_ns"] * 1e-3 / steps, rocprofv3_calls=st["calls"], rocprofv3_file=st["file"])
@@ -63,12 +66,12 @@ for steps, st_name, st_dst, tagn in ((20, "prof_driver_noextras", "r05_bench_dri
         traffic = 2 * fe["median_KiB"] * 1024 + wr["median_KiB"] * 1024
         e.update(traffic_bytes_per_launch=traffic, traffic_bytes_per_step=traffic / steps, FETCH_SIZE_KiB_median=fe["median_KiB"], WRITE_SIZE_KiB_median=wr["median_KiB"],
                  pmc_dispatches=[fe["dispatches"], wr["dispatches"]], pmc_files=[fe["file"], wr["file"]], grid_size=fe["grid"], correction=CORR)
-    e["source"] = "scripts/collect_evidence_r05.sh -> scripts/profile_summary_r05.py"
+    e["source"] = "scripts/collect_evidence_r06.sh -> scripts/profile_summary_r06.py"
     e["command"] = ("rocprofv3 ... -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-hbm" if steps == 20 else
                     "rocprofv3 ... -- python3 bench.py --steps 2000 --warmup 2000 --no-extras --no-cpu-baseline --no-hbm")
     entries.append(e)
 index["normal_eq_resident_p2p_f32"] = entries
-full = pick(stats_rows("prof_driver", "r05_bench_driver_cmd_rocprofv3_kernel_stats.csv"), RES)
+full = pick(stats_rows("prof_driver", "r06_bench_driver_cmd_rocprofv3_kernel_stats.csv"), RES)
 index["driver_command_with_extras"] = None if not full else {
     "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5", "rocprofv3_avg_launch_us": full["avg_ns"] * 1e-3, "calls": full["calls"],
     "file": full["file"], "note": "all launches of this kernel name in the run: pre-warm, host-thread tuning, timed (20 steps each), the --warmup launch (5) and the convergence leg's"}
@@ -78,7 +81,7 @@ try:
     live = json.loads(open(os.path.join(src, "hbm_stream_probe.json")).read().strip().splitlines()[-1])
 except Exception:
     live = {}
-stats_rows("prof_hbm", "r05_hbm_stream_rocprofv3_kernel_stats.csv")
+stats_rows("prof_hbm", "r06_hbm_stream_rocprofv3_kernel_stats.csv")
 f = os.path.join(src, "prof_hbm_kernel_trace.csv")
 trace = list(csv.DictReader(open(f))) if os.path.exists(f) else []
 
@@ -91,7 +94,7 @@ def by_case(rows, key_fn, val_fn):
 
 
 fe_f, wr_f = os.path.join(src, "pmc_fetch_hbm_counters.csv"), os.path.join(src, "pmc_write_hbm_counters.csv")
-for nm, dst in ((fe_f, "r05_hbm_stream_pmc_fetch_counters.csv"), (wr_f, "r05_hbm_stream_pmc_write_counters.csv")):
+for nm, dst in ((fe_f, "r06_hbm_stream_pmc_fetch_counters.csv"), (wr_f, "r06_hbm_stream_pmc_write_counters.csv")):
     if os.path.exists(nm):
         with open(nm) as fh, open(os.path.join(prof, dst), "w") as out:
             for i, line in enumerate(fh):
@@ -124,21 +127,21 @@ for case, alg, fv, wv in (("p2p_20M", 480e6, halves(fp2p)[0], halves(wp2p)[0]), 
                      "WRITE_SIZE_KiB_median": med(wv), "pmc_dispatches": [len(fv), len(wv)], "rocprofv3_median_launch_us": tdur.get(case),
                      "event_avg_launch_us_in_profiled_run": (live.get(case) or {}).get("avg_launch_us"), "correction": CORR}
 index["hbm_stream"] = hbm
-index["hbm_stream_source"] = "scripts/collect_evidence_r05.sh: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE over scripts/hbm_stream_probe.py"
+index["hbm_stream_source"] = "scripts/collect_evidence_r06.sh: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE over scripts/hbm_stream_probe.py"
 # ---- the reference-API kernels, one size per profiled process
 api = {}
 KN = {"K1p_moments": "moments_kernel", "K5_nl_round": "nl_round", "K4b_mask_33": "mask_kernel"}
 BPC = {"K1p_moments": 26, "K5_nl_round": 66, "K4b_mask_33": 26}
 for n in (307200, 1000000, 10000000):
-    rows = stats_rows(f"prof_api_{n}", f"r05_reference_api_{n}_rocprofv3_kernel_stats.csv")
+    rows = stats_rows(f"prof_api_{n}", f"r06_reference_api_{n}_rocprofv3_kernel_stats.csv")
     try:
         live = json.loads(open(os.path.join(src, f"reference_api_probe_{n}.json")).read().strip().splitlines()[-1])
     except Exception:
         live = {}
     for case, needle in KN.items():
         st = pick(rows, needle)
-        fe = counters(f"pmc_fetch_api_{n}", "FETCH_SIZE", f"r05_reference_api_{n}_pmc_fetch_counters.csv", needle, keep_lines=120)
-        wr = counters(f"pmc_write_api_{n}", "WRITE_SIZE", f"r05_reference_api_{n}_pmc_write_counters.csv", needle, keep_lines=120)
+        fe = counters(f"pmc_fetch_api_{n}", "FETCH_SIZE", f"r06_reference_api_{n}_pmc_fetch_counters.csv", needle, keep_lines=120)
+        wr = counters(f"pmc_write_api_{n}", "WRITE_SIZE", f"r06_reference_api_{n}_pmc_write_counters.csv", needle, keep_lines=120)
         e = {"n": n, "algorithmic_bytes_per_launch": BPC[case] * n}
         if st:
             e.update(kernel=st["name"], rocprofv3_avg_launch_us=st["avg_ns"] * 1e-3, rocprofv3_min_launch_us=st["min_ns"] * 1e-3, rocprofv3_calls=st["calls"], rocprofv3_file=st["file"],
@@ -151,22 +154,19 @@ for n in (307200, 1000000, 10000000):
             e["event_avg_launch_us_in_profiled_run"] = live[case]["avg_launch_us"]
         api["%s_%d" % (case, n)] = e
 index["reference_api_kernels"] = api
-index["reference_api_source"] = "scripts/collect_evidence_r05.sh: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE over scripts/reference_api_probe.py (RPE_PROBE_N = size; 35 steady launches per kernel)"
-json.dump(index, open(os.path.join(prof, "r05_bench_profiles.json"), "w"), indent=1)
+index["reference_api_source"] = "scripts/collect_evidence_r06.sh: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE over scripts/reference_api_probe.py (RPE_PROBE_N = size; 35 steady launches per kernel)"
+json.dump(index, open(os.path.join(prof, "r06_bench_profiles.json"), "w"), indent=1)
 for name in ("bench_driver_cmd.json", "bench_default_2000steps.json", "resident_timeline.jsonl", "pytest_gpu.txt", "fuzz_campaign.txt", "gn_refine_main_20.txt", "gn_refine_main_2000.txt",
-             "streaming_ab.jsonl"):
+             "stream_signal.jsonl"):
     f = os.path.join(src, name)
     if os.path.exists(f):
-        shutil.copy(f, os.path.join(prof, "r05_" + name))
-for name in ("bench_rccl_world1.json", "prof_rccl_kernel_stats.csv", "kernel_roofline.jsonl", "joint_ab.jsonl", "device_loop_solver.jsonl", "device_loop_nosolver.jsonl",
+        shutil.copy(f, os.path.join(prof, "r06_" + name))
+for name in ("bench_rccl_world1.json", "prof_rccl_kernel_stats.csv", "bench_rccl_world1_extras.json", "kernel_roofline.jsonl", "device_loop_solver.jsonl", "device_loop_nosolver.jsonl",
              "score_probe.json", "prof_score_kernel_stats.csv", "score_filter_stats.jsonl", "session_time.json", "engine_session_on.txt", "engine_session_off.txt",
              "engine_session_phases.txt", "soak.json"):
     f = os.path.join(src, name)
     if os.path.exists(f):
-        shutil.copy(f, os.path.join(prof, "r05_" + name.replace("prof_rccl_kernel_stats", "bench_rccl_world1_rocprofv3_kernel_stats").replace("prof_score_kernel_stats", "score_rocprofv3_kernel_stats")))
-f = os.path.join(src, "joint_sq", "summary.json")
-if os.path.exists(f):
-    shutil.copy(f, os.path.join(prof, "r05_joint_sq.json"))
+        shutil.copy(f, os.path.join(prof, "r06_" + name.replace("prof_rccl_kernel_stats", "bench_rccl_world1_rocprofv3_kernel_stats").replace("prof_score_kernel_stats", "score_rocprofv3_kernel_stats")))
 # SQ counters of the streaming kernels (medians per kernel kind)
 sq = {}
 for f in glob.glob(os.path.join(src, "sq", "counters_*.csv")):
@@ -178,12 +178,12 @@ for f in glob.glob(os.path.join(src, "sq", "counters_*.csv")):
             sq.setdefault(kind, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if sq:
     out = {"what": "SQ counters of normal_eq_kernel<float, kind, 256, false, false, CLEAN> at 1 000 000 correspondences (256 workgroups x 256 threads = 1024 waves, one per SIMD); rocprofv3 --pmc, "
-                   "separate passes of three counters, medians over the dispatches; scripts/sq_pmc.sh on the round-5 tree",
+                   "separate passes of three counters, medians over the dispatches; scripts/sq_pmc.sh on the round-6 tree",
            "note": "SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units of 4 cycles, summed over the waves"}
     for kind, d in sq.items():
         m = {c: statistics.median(v) for c, v in d.items()}
         w = m.get("SQ_WAVES", 1024.0)
         out[kind] = {"counters": m, "valu_instructions_per_wave": m.get("SQ_INSTS_VALU", 0) / w, "wave_life_cycles": 4 * m.get("SQ_WAVE_CYCLES", 0) / w,
                      "valu_active_fraction_of_wave_life": (m.get("SQ_ACTIVE_INST_VALU", 0) / m["SQ_WAVE_CYCLES"]) if m.get("SQ_WAVE_CYCLES") else None}
-    json.dump(out, open(os.path.join(prof, "r05_sq_counters_1M.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(prof, "r06_sq_counters_1M.json"), "w"), indent=1)
 print(json.dumps({k: (v if not isinstance(v, (dict, list)) else "...") for k, v in index.items()}, indent=1))

@@ -13,7 +13,7 @@ import pytest
 # the processes' queues concurrently; every wait is bounded (a missing peer ends in RPE_ERR_HIP after 10 s, never in a hang).  These
 # cases are part of the default -m gpu suite (world 2 / 3 / 8 on one GPU, the sharded device loop, sharded scoring, the missing-peer
 # time-out: ~25 s together); RPE_TEST_MULTIPROC=0 leaves only the smallest case, and the 20 000-exchange soak runs on request only
-# (RPE_TEST_MULTIPROC=1; scripts/collect_evidence.sh sets it).
+# (RPE_TEST_MULTIPROC=1).
 pytestmark = [pytest.mark.gpu]
 multiproc = pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") == "0", reason="RPE_TEST_MULTIPROC=0: the larger multi-process-on-one-GPU cases are switched off")
 soak = pytest.mark.skipif(os.environ.get("RPE_TEST_MULTIPROC") != "1", reason="the exchange soak runs with RPE_TEST_MULTIPROC=1")
