@@ -46,6 +46,7 @@ rpe::ReduceTarget device_target(rpe_context* c, double* d_out) {
 rpe::ReduceTarget device_runs_target(rpe_context* c) {
   rpe::ReduceTarget rt = device_target(c, c->d_out + 64);
   rt.rows = 1 << 20; rt.stride = 8;
+  if (rt.max_blocks > 256) rt.max_blocks = 256;   // at most kRunSlots = 8 runs (collect_and_send: one per XCD, or <= 8 of consecutive workgroups): RPE_MAX_BLOCKS cannot push a launch beyond the slots
   rt.seq = ++c->seq;   // the granules of the collecting stage carry the launch's sequence number as their tag
   return rt;
 }

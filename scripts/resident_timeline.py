@@ -67,6 +67,10 @@ def worker_auto(n, kind):
         names = ("iteration_starts", "slice_done", "granules_stored", "collected", "run_records_read", "record_expanded", "solved")
         row = dict(G=len(s))
         for c, nm in enumerate(names):
+            # with a solving workgroup beside the grid (frame-sized problems) the workers run only the first stages: a stage nobody stamped
+            # (all zeros) is left out instead of being reported relative to t0
+            if not (s[:, c] > 0).all():
+                continue
             row[nm + "_med"] = float(np.median(rel(c))); row[nm + "_last"] = float(rel(c).max())
         rows.append(row)
     keys = sorted({k for r in rows for k in r})

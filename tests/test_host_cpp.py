@@ -30,3 +30,16 @@ def test_lie_group_properties_cpp(tmp_path):
                            "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "lie_properties: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_resident_slot_policy_cpp(tmp_path):
+    """Who waits for whom on the GPU's one resident slot (round-5 advisor finding: sessions held it across calls and everybody else
+    blocked without a time-out): loops wait for loops, never for sessions; sessions wait for sessions at most until the holder's grid
+    has left, then take over; a revoked holder finds out and its release is a no-op.  hipcc-compiled host program, no HIP call."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "resident_slot")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-x", "hip",
+                           os.path.join(ROOT, "tests", "cpp", "resident_slot.cpp"), "-lpthread", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "resident_slot: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
