@@ -31,6 +31,7 @@
 #include <cctype>
 #include <sched.h>
 #include <unistd.h>
+#include <cstring>
 
 struct rpe_context {
   int device = 0;

@@ -685,16 +685,20 @@ __device__ __forceinline__ bool collect_rows(unsigned long long* __restrict__ gr
 // stored" at 150 workgroups, profiles/r05_resident_timeline.jsonl).  The order is a fixed function of nr.
 template <int NACC, int RGN>
 __device__ __forceinline__ double sum_rows_lane(const double (*part)[NACC], int nr, int j) {
-  // every row of the array is read, unconditionally and at once (rows past nr hold older values: selected away) -- a read behind a test
-  // of nr would wait for the one before it
-  double v[RGN];
-#pragma unroll
-  for (int k = 0; k < RGN; k++) v[k] = part[k][j];
+  // the rows are read unconditionally and sixteen at once (a read behind a test of nr would wait for the one before it; rows past nr
+  // hold older values: selected away), chunk after chunk while rows are left -- records of a few sums have hundreds of rows in the
+  // array (RGN = BLK / NACC) of which a launch fills a few dozen
+  constexpr int CH = RGN < 16 ? RGN : 16;
   double a = 0.0, b = 0.0;
+  for (int k0 = 0; k0 < nr; k0 += CH) {
+    double v[CH];
 #pragma unroll
-  for (int k = 0; k < RGN; k += 2) {
-    a += k < nr ? v[k] : 0.0;
-    if (k + 1 < RGN) b += k + 1 < nr ? v[k + 1] : 0.0;
+    for (int k = 0; k < CH; k++) v[k] = part[k0 + k < RGN ? k0 + k : RGN - 1][j];
+#pragma unroll
+    for (int k = 0; k < CH; k += 2) {
+      a += k0 + k < nr ? v[k] : 0.0;
+      if (k + 1 < CH) b += k0 + k + 1 < nr ? v[k + 1] : 0.0;
+    }
   }
   return a + b;
 }

@@ -13,8 +13,10 @@ namespace rpe {
 #ifdef RPE_SCORE_STATS
 static __device__ unsigned long long g_score_stats[4];
 #define RPE_SCORE_STAT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_score_stats[k], 1ull); } while (0)
+#define RPE_SCORE_STAT_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_score_stats[k], (unsigned long long)(v)); } while (0)
 #else
 #define RPE_SCORE_STAT(k) do {} while (0)
+#define RPE_SCORE_STAT_ADD(k, v) do {} while (0)
 #endif
 enum { VOTE_33 = 0, VOTE_23 = 1, VOTE_33_23 = 2, VOTE_NN_23 = 3, VOTE_NN_33 = 4, VOTE_NN_33_23 = 5, VOTE_23_MATRIX = 6 };
 template <int KIND> struct VoteMods {
@@ -305,7 +307,10 @@ template <class T> struct DeferQ {
   typedef T V2 __attribute__((ext_vector_type(2)));
   __device__ __forceinline__ void append(bool need_a, bool need_b, V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, int slot, T cthr) {
     const wave_mask_t ma = __builtin_amdgcn_ballot_w64(need_a), mb = __builtin_amdgcn_ballot_w64(need_b);
+    RPE_SCORE_STAT(0);                 // (diagnostic build: wave-pair evaluations of the batched kernel ...
     if ((ma | mb) == 0) return;
+    RPE_SCORE_STAT(1);                 // ... of which at least one lane sits inside the band ...
+    RPE_SCORE_STAT_ADD(2, __builtin_popcountll(ma) + __builtin_popcountll(mb));   // ... and how many elements that is)
     const int lane = threadIdx.x & 63;
     const wave_mask_t below = (1ull << lane) - 1ull;
     const int ca = __builtin_popcountll(ma);

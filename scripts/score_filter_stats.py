@@ -42,7 +42,7 @@ def main():
                     t0 = time.perf_counter(); ctx.score(kind, poses, 0.2, cthr, mode=mode); per.append(time.perf_counter() - t0)
                 ts[mname + "_us_per_call"] = round(sorted(per)[len(per) // 2] * 1e6, 1)
             if counters: lib.rpe_debug_read_score_stats(st)   # (the timed calls counted too: cleared)
-            row = dict(scene=name, kind=kname, hypotheses=H, wave_pair_evaluations=int(st[0]), fall_throughs=int(st[1]), share=(st[1] / st[0]) if st[0] else None,
+            row = dict(scene=name, kind=kname, hypotheses=H, wave_pair_evaluations=int(st[0]), fall_throughs=int(st[1]), share=(st[1] / st[0]) if st[0] else None, deferred_elements=int(st[2]), deferred_share_of_elements=(st[2] / (128.0 * st[0])) if st[0] else None,
                        votes_mean=float(np.mean(v)), votes_sum=int(np.sum(v)), defer=os.environ.get("RPE_SCORE_DEFER", "1"), **ts)
             line = json.dumps(row); print(line, flush=True)
             if out: out.write(line + "\n")

@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rgbd_pose_estimation_amd import _lib as L, api
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 307200
