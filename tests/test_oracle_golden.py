@@ -252,3 +252,29 @@ def test_pipelines_recover_pose(oracle):
                        iters=300, confidence=0.99999, seed=2, ls=ls)
         assert r["max_votes"] > 0 and r["iters"] <= 300
         assert util.rot_err(r["R"], sc.R) < 0.05 and np.linalg.norm(r["t"] - sc.t) < 0.5, m
+
+
+def test_lsq_pnp_is_the_sum_of_sines(oracle, G):
+    """R1 lsq_pnp (reference P3P.hpp:472-502): the oracle's total against numpy's sum of |normalize(R Xw + t) x bv| in fp64 -- 1e-12
+    for the double instantiation, the float one within its own accumulated rounding -- and term by term against getError(i)."""
+    sc = _scene(G)
+    xw, bv = sc["xw"], sc["bv"]
+    rng = np.random.default_rng(5)
+    R, t = util.perturbed_pose(rng, np.eye(3), np.array([0.1, -0.2, 0.3]), 0.3, 0.1)
+    q7 = oracle.pose7_from_Rt(R, t, True)
+    # (the quaternion the oracle rotates with, back to a matrix: exactly the rotation it applies)
+    w, x, y, z = q7[:4]
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    p = xw.astype(np.float64) @ Rq.T + q7[4:]
+    ph = p / np.linalg.norm(p, axis=1, keepdims=True)
+    terms_np = np.linalg.norm(np.cross(ph, bv.astype(np.float64)), axis=1)
+    tot64, tot64_again, terms = oracle.lsq_pnp(xw, bv, q7, True, with_terms=True)
+    assert abs(tot64 - terms_np.sum()) <= 1e-12 * terms_np.sum() and abs(tot64_again - tot64) <= 1e-13 * tot64
+    assert np.max(np.abs(terms - terms_np)) < 1e-13
+    q7f = oracle.pose7_from_Rt(R, t, False)
+    tot32, tot32_in_double, terms32 = oracle.lsq_pnp(xw, bv, q7f, False, with_terms=True)
+    n = len(xw)
+    assert abs(tot32 - terms_np.sum()) <= (n * 2.0 ** -24 + 1e-5) * terms_np.sum()
+    assert abs(tot32_in_double - terms32.sum()) <= 1e-12 * terms32.sum() and np.max(np.abs(terms32 - terms_np)) < 2e-6
