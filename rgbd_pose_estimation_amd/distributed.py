@@ -83,8 +83,10 @@ class ShardedScorer:
 def init_native_comm(ctx: "api.Context", group=None) -> bool:
     """Give `ctx` its own RCCL communicator (one per rank, same device as the context): rank 0 draws the 128-byte id,
     torch.distributed only ferries it to the other ranks.  After this, Context.gn_step_dist() runs the whole sharded step
-    -- kernel, in-place all-reduce of the 32-double record on the context's stream, publish, host solve -- inside
-    librgbdpose_hip.so, without a Python-side collective.  Returns False (and leaves ctx untouched) if RCCL cannot be set up."""
+    -- kernel, in-place all-reduce of the launch's run records (8 x 32 doubles) on the context's stream, publish, host solve --
+    inside librgbdpose_hip.so, without a Python-side collective; Context.gn_steps_dist(kind, pose, k) runs k of them, and
+    Context.gn_steps_dist_device(kind, pose, k) the same k with the solve and the exp-map in the kernels (the host enqueues
+    everything and waits once).  Returns False (and leaves ctx untouched) if RCCL cannot be set up."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
