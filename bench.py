@@ -1102,6 +1102,8 @@ def contract_line(full: dict, strict: bool = False) -> str:
                    "global_corr": cfg.get("global_corr"), "valid_corr_per_step": cfg.get("valid_corr_per_step"),
                    "collective": (cfg.get("collective") or "none")[:40], "rccl_ranks": cfg.get("rccl_ranks"), "rccl_verified": cfg.get("rccl_verified"),
                    "host_loop": "resident kernel, host exp-map" if resident else "launch per step, host exp-map",
+                   # N > 1: the same sharded step by the ways of adding the records, microseconds per iteration (400 steps each; flat keys)
+                   **({("step_" + k): _num(v) for k, v in cfg.get("collective_step_us").items() if v is not None} if isinstance(cfg.get("collective_step_us"), dict) else {}),
                    "repeats": tim.get("repeats"), "ms_per_step_p10": _num(tim.get("ms_per_step_p10")), "ms_per_step_p90": _num(tim.get("ms_per_step_p90"))},
         "roofline": {"bound": roof.get("bound"), "achieved": _num(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
                      "frac": _num(roof.get("frac")), "traffic": _num(roof.get("traffic"), 9), "traffic_source": (roof.get("traffic_source") or "none")[:150],
