@@ -144,3 +144,66 @@ def test_3d_votes_on_the_threshold_are_the_oracles_long_lists(gpu_ctx_factory, o
         assert len(set(v.tolist())) >= 3   # points do sit on the threshold: hypotheses a few ulps apart get different counts
     # the short-list kernel agrees hypothesis by hypothesis
     assert np.array_equal(ctx.score(kind, poses[:16], thre_3d, 2.0, 0.999, mode=L.SCORE_EXACT), vo[:16])
+
+
+# ---- correspondences ON the 3D and the normal threshold at once, with the hostile values of the cases above, RGB-D bearing coverage (a
+# bearing for the first few correspondences only) and full coverage, through all three scoring routes (short list, table kernel,
+# resident session) and the mask launch.  Written for a second attempt at deciding the exact 3D / normal votes from fused-multiply-add
+# estimates (round 6, measured and removed: profiles/r06_score_3d_filter_rejected.jsonl); kept for what they pin.
+def _near_both_thresholds_scene(n, dt, seed, thre_3d, cos_nl, bearings):
+    rng = np.random.default_rng(seed)
+    sc = _near_3d_threshold_scene(n, np.float64, seed, thre_3d)
+    # normals: Nc at an angle from R Nw whose cosine is cos_nl +- a few hundred ulps for a third of them
+    Nw = rng.standard_normal((n, 3)); Nw /= np.linalg.norm(Nw, axis=1, keepdims=True)
+    r = Nw @ sc.R.T
+    a = np.cross(r, rng.standard_normal((n, 3))); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    eps = np.finfo(dt).eps
+    target = np.where(np.arange(n) % 3 == 1, cos_nl + rng.integers(-300, 301, n) * eps * 0.5, np.where(np.arange(n) % 3 == 0, 0.99999, 0.9))
+    ang = np.arccos(np.clip(target, -1.0, 1.0))
+    sc.M = Nw
+    sc.N = r * np.cos(ang)[:, None] + a * np.sin(ang)[:, None]
+    sc.N[4] = np.nan            # an invalid normal on a valid point: no normal vote, the 3D vote unaffected
+    sc.M[5] = np.nan
+    sc.M[6] = 1e30
+    if bearings < n:            # RGB-D: a bearing for the first few correspondences only (F5: NaN elsewhere)
+        sc.U[bearings:] = np.nan
+    return sc.astype(dt)
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("kind", [L.VOTE_33, L.VOTE_NN_33, L.VOTE_33_23, L.VOTE_NN_23, L.VOTE_NN_33_23])
+@pytest.mark.parametrize("bearings", [300, 20000])
+def test_3d_and_normal_votes_on_both_thresholds_by_every_route(gpu_ctx_factory, oracle, kind, f64, bearings):
+    dt = np.float64 if f64 else np.float32
+    n, thre_3d = 20000, 0.2
+    cos_thr = float(np.cos(np.arctan(8.0 / 585.0)))
+    cos_nl = float(np.cos(np.radians(10.0)))
+    sc = _near_both_thresholds_scene(n, dt, 93, thre_3d, cos_nl, bearings)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    rng = np.random.default_rng(3)
+    q_true = oracle.pose7_from_Rt(sc.R, sc.t, f64)
+    H = 72
+    poses = np.tile(q_true, (H, 1))
+    poses[1:, :4] += 3e-8 * rng.standard_normal((H - 1, 4))
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    poses[36:, 4:] += 1e-7 * np.abs(poses[36:, 4:]).max() * rng.standard_normal((H - 36, 3))
+    poses[7, 4:] += 3e5          # a translation far beyond the scene
+    poses[9, :4] *= 1.2          # not a unit quaternion (the API does not renormalise)
+    poses[11, 5] = np.nan
+    poses = np.ascontiguousarray(poses.astype(dt).astype(np.float64))
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    okind = {L.VOTE_33: oracle.V_33, L.VOTE_NN_33: oracle.V_NN_33, L.VOTE_33_23: oracle.V_33_23, L.VOTE_NN_23: oracle.V_NN_23,
+             L.VOTE_NN_33_23: oracle.V_NN_33_23}[kind]
+    vo = oracle.votes(prob, okind, poses, thre_3d=thre_3d, cos_thr=cos_thr, cos_nl=cos_nl)
+    assert len(set(vo[:6].tolist()) | set(vo[12:].tolist())) >= 3          # the case is what it claims to be
+    v = ctx.score(kind, poses, thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT)                       # the table kernel
+    assert np.array_equal(v, vo), (v[:12], vo[:12])
+    assert np.array_equal(ctx.score(kind, poses[:16], thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT), vo[:16])   # the short-list kernel
+    with ctx.score_session(kind, thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT) as resident:       # the resident grid
+        assert resident                                     # (20 000 correspondences are frame-sized for the resident grid)
+        assert np.array_equal(ctx.score(kind, poses[:24], thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT), vo[:24])
+        assert np.array_equal(ctx.score(kind, poses[24:56], thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT), vo[24:56])
+        assert ctx.inlier_mask(kind, poses[0], thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT) == vo[0]
+    # the masks by launch are the oracle's, lane for lane
+    tot, mo = oracle.votes(prob, okind, poses[:1], thre_3d=thre_3d, cos_thr=cos_thr, cos_nl=cos_nl, mask_for=0)
+    assert ctx.inlier_mask(kind, poses[0], thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT) == tot[0]
