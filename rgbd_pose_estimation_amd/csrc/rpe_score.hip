@@ -26,6 +26,7 @@ template <int KIND> struct VoteMods {
   static constexpr bool need_xc = m33 || mnn;  // isValid() gates the N-N vote too
 };
 
+typedef unsigned long long wave_mask_t;   // one bit per lane of the wave
 // one hypothesis in registers (wave-uniform -> SGPRs)
 template <class T, bool EXACT> struct Hyp;
 template <class T> struct Hyp<T, false> {
@@ -156,19 +157,41 @@ template <class T> struct Hyp<T, true> {
   }
   // The reference's 2D test -- normalise by three IEEE divisions behind a square root, dot, compare (AbsoluteOrientation.hpp:413-418)
   // -- costs five times the 3D test.  A cheap estimate DECIDES it outside a band around the threshold; inside the band (and for |p|^2
-  // outside the normal range, NaN, infinity, non-unit bearings) the reference's own operation sequence runs.  The band (round 6: 14 u,
-  // u = unit roundoff of Tp; 24 u before) follows from what the two computations SHARE: both start from the same N = fl(|p|^2) -- the
-  // same three products and two sums, the same bits -- so its roundings cancel; with s = sqrt(N), a_i = p_i bv_i / s, c' = sum a_i and
-  // A = sum |a_i| <= (1 + 2u) |bv| <= 1.0006 (bearings within 1e-3 of unit length, checked per lane):
+  // outside the normal range, NaN, infinity, non-unit bearings, thresholds <= 0) the reference's own operation sequence runs.  The band
+  // (12 u, u = unit roundoff of Tp; 24 u until round 5) follows from what the two computations SHARE: both start from the same
+  // N = fl(|p|^2) -- the same three products and two sums, the same bits -- so its roundings cancel; with s = sqrt(N), a_i = p_i bv_i / s,
+  // c' = sum a_i and A = sum |a_i| <= (1 + 2u) |bv| <= 1.0006 (bearings within 1e-3 of unit length, checked per lane):
   //   reference  L = fl(s) (1 rounding), q_i = fl(p_i / L) (1), t_i = fl(q_i bv_i) (1), d = fl(fl(t_x + t_y) + t_z) (2 on x and y, 1 on z):
   //              every a_i carries at most 5 roundings  ->  |d - c'| <= 5.02 u A
-  //   estimate   D = fma(p_x, bv_x, fma(p_y, bv_y, fl(p_z bv_z)))  (at most 3 roundings per term: |D - p.bv| <= 3.01 u |p| |bv|),
-  //              Y = v_rsq_f32(N) (1 ulp: |Y s - 1| <= 2 u; fp64: fp32 estimate + two Newton steps, whose last step's three roundings
-  //              leave |Y s - 1| <= 3 u), ct = fl(D Y) (1 rounding):  |ct - c'| <= 3.01 u |c'| + 3.02 u A <= 6.04 u A  (fp64: 7.05 u A)
-  // so |ct - d| <= 11.1 u (fp64: 12.1 u): outside a band of 14 u the estimate decides the reference's comparison.  The branch is wave-uniform (one
-  // ballot): a wave none of whose lanes is within the band never divides.  Votes stay the reference's, bit for bit (tests/
-  // test_gpu_kernels.py test_score_exact_votes_bit_identical, the on-threshold cases of tests/test_gpu_score_filter.py, the fuzz campaign).
-  static constexpr T kBand23 = T(14) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 14 u
+  //   estimate   D = fma(p_x, bv_x, fma(p_y, bv_y, fl(p_z bv_z)))  (at most 3 roundings per term: |D - p.bv| <= 3.01 u |p| |bv|, i.e.
+  //              |D / s - c'| <= 3.02 u A), compared in SQUARES -- no reciprocal square root (a quarter-rate instruction per
+  //              element; in fp64 an fp32 estimate and two Newton steps), no product with it:
+  //                  fl(D |D|) > fl(N hi2),  hi2 = fl(hi hi),  hi = fl(c + band)   =>   D / s > (c + band) (1 - 2.5 u)
+  //              (one rounding each in D |D|, N hi2, hi2 and hi: the square root halves the first three), and with lo = fl(c - band)
+  //              the mirror image; D |D| carries D's sign, so a negative D is "below" without a comparison of its own
+  // so D / s > c + band - 2.5 u implies d > c + band - 10.6 u: outside a band of 12 u the estimate decides the reference's comparison.
+  // The branch is wave-uniform (one ballot): a wave none of whose lanes is within the band never divides.  Votes stay the reference's,
+  // bit for bit (tests/test_gpu_kernels.py test_score_exact_votes_bit_identical, the on-threshold cases of
+  // tests/test_gpu_score_filter.py, the fuzz campaign).
+  static constexpr T kBand23 = T(12) * (sizeof(T) == 4 ? T(5.9604644775390625e-08) : T(1.1102230246251565e-16));   // 12 u
+  // the estimate of a pair: in = "above the band", sure = "outside the band" with |p|^2 in the range the bound covers (1e-30 .. 1e30
+  // metres^2: no underflow in the squares, no overflow), per element
+  struct Est23 { bool in0, in1, sure0, sure1; };
+  static __device__ __forceinline__ Est23 estimate23(V2 px, V2 py, V2 pz, V2 n2, V2 bx, V2 by, V2 bz, T c) {
+    const V2 dt = dot_fma2(px, py, pz, bx, by, bz);
+    const T hi = c + kBand23, lo = c - kBand23;
+    // (wave-uniform, hypothesis-independent: formed once.  A threshold within the band of zero: nothing is above +inf |p|^2 or below
+    // -inf |p|^2 -- nothing is sure)
+    const T hi2 = lo > T(0) ? hi * hi : __builtin_inff(), lo2 = lo > T(0) ? lo * lo : -__builtin_inff();
+    const V2 d2 = {dt.x * fabs(dt.x), dt.y * fabs(dt.y)};
+    const V2 h = n2 * hi2, l = n2 * lo2;
+    const T tiny = T(1e-30), huge = T(1e30);
+    Est23 e;
+    e.in0 = d2.x > h.x; e.in1 = d2.y > h.y;
+    e.sure0 = (e.in0 | (d2.x < l.x)) & (n2.x > tiny) & (n2.x < huge);
+    e.sure1 = (e.in1 | (d2.y < l.y)) & (n2.y > tiny) & (n2.y < huge);
+    return e;
+  }
   static __device__ __forceinline__ V2 dot_fma2(V2 px, V2 py, V2 pz, V2 bx, V2 by, V2 bz) {
     return __builtin_elementwise_fma(px, bx, __builtin_elementwise_fma(py, by, pz * bz));
   }
@@ -179,21 +202,13 @@ template <class T> struct Hyp<T, true> {
     RPE_SCORE_STAT(0);
 #ifndef RPE_NO_23_FILTER
     {
-      const V2 dt = dot_fma2(px, py, pz, bx, by, bz);
-      const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
-      const T band = kBand23;
-      const T hi = c + band, lo = c - band;
-      // |p|^2 in metres^2; also the range in which the fp32 estimate behind the fp64 form is finite
-      const T tiny = T(1e-30), huge = T(1e30);
-      const bool in0 = ct.x > hi, in1 = ct.y > hi;
+      const Est23 e = estimate23(px, py, pz, n2, bx, by, bz, c);
       // the bound above holds for UNIT bearings (A <= |bv| (1 + 2u)): both errors scale with |bv|, so a lane counts as decided only
-      // if |bv|^2 is within 1e-3 of 1 (14 u covers the 11.1 u / 12.1 u, in which A <= 1.0006 is already counted); any other bearing -- the API does not normalise them -- takes
-      // the reference's own sequence.  Hypothesis-independent: hoisted out of the hypothesis loop.
+      // if |bv|^2 is within 1e-3 of 1 (in which A <= 1.0006 is already counted); any other bearing -- the API does not normalise them --
+      // takes the reference's own sequence.  Hypothesis-independent: hoisted out of the hypothesis loop.
       const V2 b2 = bx * bx + by * by + bz * bz;
       const bool unit0 = (b2.x > T(0.999)) & (b2.x < T(1.001)), unit1 = (b2.y > T(0.999)) & (b2.y < T(1.001));
-      const bool sure0 = (in0 | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge) & unit0,
-                 sure1 = (in1 | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge) & unit1;
-      if (__builtin_amdgcn_ballot_w64(!(sure0 & sure1)) == 0) { a = in0; b = in1; return; }
+      if (__builtin_amdgcn_ballot_w64(!((e.sure0 & unit0) & (e.sure1 & unit1))) == 0) { a = e.in0; b = e.in1; return; }
     }
 #endif
     RPE_SCORE_STAT(1);
@@ -202,26 +217,41 @@ template <class T> struct Hyp<T, true> {
     const V2 d = px * bx + py * by + pz * bz;
     a = d.x > c; b = d.y > c;
   }
-  // The same filter, DECIDING ONLY (the batched scoring kernel): a = b = the decided votes, need_a / need_b = this element is inside the
-  // band (or not a unit bearing, or |p|^2 out of range) and must be given the reference's own sequence -- by the caller, LATER: with
-  // realistic bearing noise 0.8 % of the elements sit inside the band, i.e. two waves in three hold one, and a wave that runs the square
-  // root and the six divisions for one lane pays them for all 128 elements (counted: profiles/r05_score_filter_stats.jsonl, 69 % of the
-  // wave evaluations fell through).  The caller queues those elements in LDS and evaluates them densely (score_kernel, DeferQ).
-  __device__ __forceinline__ void in23_rot_x2_decide(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b, bool& need_a, bool& need_b) const {
+  // The estimate of a pair as LANE MASKS (the batched scoring kernel's form: the comparisons ARE the ballots, everything after them is
+  // scalar -- as booleans the flags went through vector registers and back, two vector instructions per flag and pair): in = above the
+  // band, sure = outside the band with |p|^2 in range; lanes with a non-unit bearing are the caller's to exclude (a mask of its own,
+  // formed once per group).
+  __device__ __forceinline__ void in23_masks(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, wave_mask_t& in_a, wave_mask_t& in_b,
+                                             wave_mask_t& sure_a, wave_mask_t& sure_b) const {
 #pragma clang fp contract(off)
     const V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
     const V2 n2 = px * px + py * py + pz * pz;
     const V2 dt = dot_fma2(px, py, pz, bx, by, bz);
-    const V2 ct = dt * V2{rsqrt_est(n2.x), rsqrt_est(n2.y)};
-    const T band = kBand23;
-    const T hi = c + band, lo = c - band;
+    // (a threshold within the band of zero: nothing is above +inf |p|^2, nothing below -inf |p|^2 -- no flag, no select)
+    const T hi = c + kBand23, lo = c - kBand23;
+    const T hi2 = lo > T(0) ? hi * hi : __builtin_inff(), lo2 = lo > T(0) ? lo * lo : -__builtin_inff();
+    const V2 d2 = {dt.x * fabs(dt.x), dt.y * fabs(dt.y)};
+    const V2 h = n2 * hi2, l = n2 * lo2;
     const T tiny = T(1e-30), huge = T(1e30);
-    a = ct.x > hi; b = ct.y > hi;
+    in_a = __builtin_amdgcn_ballot_w64(d2.x > h.x); in_b = __builtin_amdgcn_ballot_w64(d2.y > h.y);
+    sure_a = (in_a | __builtin_amdgcn_ballot_w64(d2.x < l.x)) & __builtin_amdgcn_ballot_w64(n2.x > tiny) & __builtin_amdgcn_ballot_w64(n2.x < huge);
+    sure_b = (in_b | __builtin_amdgcn_ballot_w64(d2.y < l.y)) & __builtin_amdgcn_ballot_w64(n2.y > tiny) & __builtin_amdgcn_ballot_w64(n2.y < huge);
+  }
+  // The same filter, DECIDING ONLY (booleans; callers without a queue): a = b = the decided votes, need_a / need_b = this element is inside the
+  // band (or not a unit bearing, or |p|^2 out of range) and must be given the reference's own sequence -- by the caller, LATER: with
+  // realistic bearing noise 0.5 % of the elements sit inside the band, i.e. one wave in two holds one, and a wave that runs the square
+  // root and the six divisions for one lane pays them for all 128 elements (counted: profiles/r05_score_filter_stats.jsonl, 69 % of the
+  // wave evaluations fell through at 24 u).  The caller queues those elements in LDS and evaluates them densely (score_kernel, DeferQ).
+  __device__ __forceinline__ void in23_rot_x2_decide(V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, T c, bool& a, bool& b, bool& need_a, bool& need_b) const {
+#pragma clang fp contract(off)
+    const V2 px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+    const V2 n2 = px * px + py * py + pz * pz;
+    const Est23 e = estimate23(px, py, pz, n2, bx, by, bz, c);
     const V2 b2 = bx * bx + by * by + bz * bz;
     const bool unit0 = (b2.x > T(0.999)) & (b2.x < T(1.001)), unit1 = (b2.y > T(0.999)) & (b2.y < T(1.001));
-    need_a = !((a | (ct.x < lo)) & (n2.x > tiny) & (n2.x < huge) & unit0);
-    need_b = !((b | (ct.y < lo)) & (n2.y > tiny) & (n2.y < huge) & unit1);
-    a = a & !need_a; b = b & !need_b;
+    need_a = !(e.sure0 & unit0);
+    need_b = !(e.sure1 & unit1);
+    a = e.in0 & !need_a; b = e.in1 & !need_b;
   }
   // ... and the reference's sequence on ONE rotated point (what in23_rot_x2 runs behind its filter, element by element: the same bits)
   static __device__ __forceinline__ bool in23_reference(T rx, T ry, T rz, T t0, T t1, T t2, T bx, T by, T bz, T c) {
@@ -230,14 +260,6 @@ template <class T> struct Hyp<T, true> {
     const T len = sqrt(px * px + py * py + pz * pz);
     px = px / len; py = py / len; pz = pz / len;
     return (px * bx + py * by + pz * bz) > c;
-  }
-  static __device__ __forceinline__ float rsqrt_est(float x) { return __builtin_amdgcn_rsqf(x); }
-  static __device__ __forceinline__ double rsqrt_est(double x) {
-    double y = (double)__builtin_amdgcn_rsqf((float)x);
-    const double hx = 0.5 * x;
-    y = y * fma(-hx * y, y, 1.5);
-    y = y * fma(-hx * y, y, 1.5);
-    return y;
   }
   __device__ __forceinline__ void innnx2(V2 nwx, V2 nwy, V2 nwz, V2 ncx, V2 ncy, V2 ncz, T cnl, bool& a, bool& b) const {
 #pragma clang fp contract(off)
@@ -272,7 +294,6 @@ template <class T> struct Hyp<T, true> {
 // applied with one scalar AND, one s_bcnt1 counts.  __ballot(valid & pred) made the compiler materialise the combined predicate as
 // a 0 / 1 VGPR and compare it with zero again: two vector instructions per predicate, 8 of the 46 per hypothesis and group in the 3D
 // fast loop (profiles/r04_score_sq_counters.json).
-typedef unsigned long long wave_mask_t;
 __device__ __forceinline__ int votes_of(wave_mask_t mask, bool pred) {
   return __builtin_popcountll(__builtin_amdgcn_ballot_w64(pred) & mask);
 }
@@ -305,10 +326,10 @@ template <class T> struct DeferQ {
   }
   // the undecided elements of a PAIR (element a: *.x, element b: *.y)
   typedef T V2 __attribute__((ext_vector_type(2)));
-  __device__ __forceinline__ void append(bool need_a, bool need_b, V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, int slot, T cthr) {
-    const wave_mask_t ma = __builtin_amdgcn_ballot_w64(need_a), mb = __builtin_amdgcn_ballot_w64(need_b);
+  __device__ __forceinline__ void append(wave_mask_t ma, wave_mask_t mb, V2 rx, V2 ry, V2 rz, V2 bx, V2 by, V2 bz, int slot, T cthr) {
     RPE_SCORE_STAT(0);                 // (diagnostic build: wave-pair evaluations of the batched kernel ...
-    if ((ma | mb) == 0) return;
+    if ((ma | mb) == 0 || slot < 0) return;   // (slot < 0: a padding hypothesis queues nothing)
+    const bool need_a = (ma >> (threadIdx.x & 63)) & 1ull, need_b = (mb >> (threadIdx.x & 63)) & 1ull;
     RPE_SCORE_STAT(1);                 // ... of which at least one lane sits inside the band ...
     RPE_SCORE_STAT_ADD(2, __builtin_popcountll(ma) + __builtin_popcountll(mb));   // ... and how many elements that is)
     const int lane = threadIdx.x & 63;
@@ -316,7 +337,7 @@ template <class T> struct DeferQ {
     const int ca = __builtin_popcountll(ma);
     if (need_a) { T* e = entry + 8 * (n + __builtin_popcountll(ma & below)); e[0] = rx.x; e[1] = ry.x; e[2] = rz.x; e[3] = bx.x; e[4] = by.x; e[5] = bz.x; e[6] = (T)slot; }
     if (need_b) { T* e = entry + 8 * (n + ca + __builtin_popcountll(mb & below)); e[0] = rx.y; e[1] = ry.y; e[2] = rz.y; e[3] = bx.y; e[4] = by.y; e[5] = bz.y; e[6] = (T)slot; }
-    n += ca + __builtin_popcountll(mb);
+    n = __builtin_amdgcn_readfirstlane(n + ca + __builtin_popcountll(mb));   // (wave-uniform: kept in a scalar register)
     if (n >= 64) drain(cthr);
   }
 };
@@ -339,7 +360,8 @@ template <class T, int KIND, bool EXACT, bool DEFER = false, bool W23 = true>
 __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const T (&vw)[3 * Pk<T>::P], const T (&vc)[3 * Pk<T>::P],
                                                  const T (&vb)[3 * Pk<T>::P], const T (&vnw)[3 * Pk<T>::P], const T (&vnc)[3 * Pk<T>::P],
                                                  const wave_mask_t (&present)[Pk<T>::P], const wave_mask_t (&valid)[Pk<T>::P], T thr33, T cthr, T cnl,
-                                                 DeferQ<T>& defer, int slot = -1) {
+                                                 DeferQ<T>& defer, int slot = -1, const wave_mask_t* unit = nullptr) {
+  // (unit[], DEFER only: the lanes of present[] whose bearing is of unit length to 1e-3 -- what the 2D estimate's bound covers)
   // (present[] for the 2D test: lanes whose correspondence exists AND whose bearing holds no NaN -- a NaN bearing makes the reference's
   // comparison false whatever the hypothesis, so such a lane never votes, and a wave without any bearing at all -- configs[2] has 2 000
   // of them among 307 200 correspondences -- skips the test: the callers build the masks that way, once per group)
@@ -372,16 +394,15 @@ __device__ __forceinline__ int count_group_votes(const Hyp<T, EXACT>& hyp, const
         const V2 bx = {vb[3 * a], vb[3 * b]}, by = {vb[3 * a + 1], vb[3 * b + 1]}, bz = {vb[3 * a + 2], vb[3 * b + 2]};
         bool va, vb2;
         if constexpr (DEFER) {
-          bool na, nb;
-          hyp.in23_rot_x2_decide(rx, ry, rz, bx, by, bz, cthr, va, vb2, na, nb);
-          const int lane = threadIdx.x & 63;
-          na = na & (((present[a] >> lane) & 1ull) != 0) & (slot >= 0);
-          nb = nb & (((present[b] >> lane) & 1ull) != 0) & (slot >= 0);
-          defer.append(na, nb, rx, ry, rz, bx, by, bz, slot, cthr);
+          wave_mask_t ia, ib, sa, sb;
+          hyp.in23_masks(rx, ry, rz, bx, by, bz, cthr, ia, ib, sa, sb);
+          sa &= unit[a]; sb &= unit[b];                                   // decided: outside the band, in range, a present unit bearing
+          defer.append(present[a] & ~sa, present[b] & ~sb, rx, ry, rz, bx, by, bz, slot, cthr);
+          cnt += __builtin_popcountll(ia & sa) + __builtin_popcountll(ib & sb);
         } else {
           hyp.in23_rot_x2(rx, ry, rz, bx, by, bz, cthr, va, vb2);
+          cnt += votes_of(present[a], va) + votes_of(present[b], vb2);
         }
-        cnt += votes_of(present[a], va) + votes_of(present[b], vb2);
       }
     }
   } else {
@@ -446,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
   for (int64_t gb = (int64_t)blockIdx.x * kBlock; gb < groups; gb += stride) {
     const int64_t g = gb + threadIdx.x;
     T vw[3 * P], vc[3 * P], vb[3 * P], vnw[3 * P], vnc[3 * P];
-    wave_mask_t present[P], valid[P];   // hypothesis-independent: lane masks, once per group
+    wave_mask_t present[P], valid[P], unit[P];   // hypothesis-independent: lane masks, once per group
     load_group<T>(xw, g, n, vw);
     if (MD::need_xc) load_group<T>(xc, g, n, vc);
     if (MD::m23) load_group<T>(bv, g, n, vb);
@@ -457,6 +478,11 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
       // (only the 2D test reads present[]: lanes with a NaN in their bearing are left out -- see count_group_votes)
       present[i] = __builtin_amdgcn_ballot_w64(here & (!MD::m23 || !(vb[3 * i] != vb[3 * i] || vb[3 * i + 1] != vb[3 * i + 1] || vb[3 * i + 2] != vb[3 * i + 2])));
       valid[i] = __builtin_amdgcn_ballot_w64(here & (!MD::need_xc || !all_nan(vc[3 * i], vc[3 * i + 1], vc[3 * i + 2])));
+      unit[i] = 0;
+      if (DEFER) {
+        const T b2 = vb[3 * i] * vb[3 * i] + vb[3 * i + 1] * vb[3 * i + 1] + vb[3 * i + 2] * vb[3 * i + 2];
+        unit[i] = present[i] & __builtin_amdgcn_ballot_w64((b2 > T(0.999)) & (b2 < T(1.001)));
+      }
     }
     auto score_list = [&](auto w23) {
     constexpr bool W23 = decltype(w23)::value;
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void score_kernel(const T* __restrict__ xw,
 #pragma unroll
         for (int u = 0; u < HU; u++) {
           const int cnt = count_group_votes<T, KIND, EXACT, DEFER, W23>(hyp[u], vw, vc, vb, vnw, vnc, present, valid, thr33, cthr, cnl, dq,
-                                                                        hl + u < hmax ? h0 + hl + u : -1);
+                                                                        hl + u < hmax ? h0 + hl + u : -1, unit);
           mine = (lane == hl + u) ? cnt : mine;   // every hypothesis once per block of 64, `mine` starts at 0: a select, not an add
         }
       }
