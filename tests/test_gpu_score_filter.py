@@ -207,3 +207,32 @@ def test_3d_and_normal_votes_on_both_thresholds_by_every_route(gpu_ctx_factory, 
     # the masks by launch are the oracle's, lane for lane
     tot, mo = oracle.votes(prob, okind, poses[:1], thre_3d=thre_3d, cos_thr=cos_thr, cos_nl=cos_nl, mask_for=0)
     assert ctx.inlier_mask(kind, poses[0], thre_3d, cos_thr, cos_nl, mode=L.SCORE_EXACT) == tot[0]
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("cos_thr", [0.0, -0.3, 5e-7, 1.0])
+def test_2d_votes_at_thresholds_the_estimate_does_not_cover(gpu_ctx_factory, oracle, cos_thr, f64):
+    """The 2D estimate compares squares, which needs a threshold above its band of zero; at or below it (angles of 90 degrees and
+    more -- nobody's setting, but the API takes them) and at cos = 1 every present lane goes through the reference's own sequence.
+    Votes of the table kernel, the short-list kernel and the resident session against the oracle."""
+    dt = np.float64 if f64 else np.float32
+    n = 6000
+    sc = util.scene_full(21, n, dt, n2d=40.0, n3d=0.05, nnl_deg=2.0, outliers=0.3)
+    ctx = gpu_ctx_factory().load(L.F64 if f64 else L.F32, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    rng = np.random.default_rng(4)
+    H = 40
+    poses = np.tile(oracle.pose7_from_Rt(sc.R, sc.t, f64), (H, 1))
+    poses[1:, :4] += 0.3 * rng.standard_normal((H - 1, 4))           # wide: cosines all over [-1, 1]
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    poses[1:, 4:] += 2.0 * rng.standard_normal((H - 1, 3))
+    poses = np.ascontiguousarray(poses.astype(dt).astype(np.float64))
+    prob = oracle.Problem(f64, xw=sc.Q, xc=sc.P, bv=sc.U, nw=sc.M, nc=sc.N)
+    for kind, okind in ((L.VOTE_23, oracle.V_23), (L.VOTE_33_23, oracle.V_33_23)):
+        vo = oracle.votes(prob, okind, poses, thre_3d=0.2, cos_thr=cos_thr, cos_nl=0.9)
+        assert np.array_equal(ctx.score(kind, poses, 0.2, cos_thr, 0.9, mode=L.SCORE_EXACT), vo)
+        assert np.array_equal(ctx.score(kind, poses[:12], 0.2, cos_thr, 0.9, mode=L.SCORE_EXACT), vo[:12])
+        with ctx.score_session(kind, 0.2, cos_thr, 0.9, mode=L.SCORE_EXACT) as resident:
+            if resident:
+                assert np.array_equal(ctx.score(kind, poses[:20], 0.2, cos_thr, 0.9, mode=L.SCORE_EXACT), vo[:20])
+        if cos_thr <= 0.0:
+            assert vo.max() > 0.3 * n                                     # such thresholds let most correspondences vote
